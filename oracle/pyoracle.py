@@ -1,0 +1,322 @@
+"""oracle/pyoracle.py -- Python face of the CPU oracle (ctypes over oracle/liboracle.so + NumPy).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by bench.py's
+`cpu_baseline` leg.  The product package (rocco_amd/) never imports this module.
+
+Function names and return conventions mirror the reference so parity tests read like the
+reference's own tests:
+    rocco/dp.py:16-34    objective_value
+    rocco/dp.py:37-46    build_switch_costs
+    rocco/dp.py:49-86    solve_penalized_chain
+    rocco/dp.py:89-164   calibrate_selection_penalty
+    rocco/dp.py:167-228  solve_chrom_exact
+    rocco/rocco.py:74-95, 139-191, 194-240   BED record merge / per-chromosome BED / combine
+    rocco/rocco.py:243-304                   score_central_tendency_chrom (median branch)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_u8_p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class DeltaStats(ctypes.Structure):
+    _fields_ = [
+        ("count", ctypes.c_longlong),
+        ("uncertain", ctypes.c_longlong),
+        ("effect", ctypes.c_longlong),
+        ("max_run", ctypes.c_longlong),
+    ]
+
+
+class WindowStats(ctypes.Structure):
+    _fields_ = [
+        ("count_lo", ctypes.c_longlong),
+        ("count_hi", ctypes.c_longlong),
+        ("n_diff", ctypes.c_longlong),
+        ("first_diff", ctypes.c_longlong),
+        ("diff_adjacent", ctypes.c_int),
+        ("max_run", ctypes.c_longlong),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/liboracle.so (and oracle/_ref when the reference is mounted)."""
+    if force or not os.path.isfile(_LIB_PATH):
+        subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True, capture_output=True)
+    if os.path.isdir("/root/reference"):
+        subprocess.run(["make", "-C", _HERE, "ref"], check=False, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_solve_penalized_chain_f64.restype = ctypes.c_int
+        _lib.oracle_solve_penalized_chain_f64.argtypes = [
+            _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double,
+            _c_u8_p, _c_double_p, ctypes.POINTER(ctypes.c_longlong)]
+        _lib.oracle_calibrate_selection_penalty_f64.restype = ctypes.c_int
+        _lib.oracle_calibrate_selection_penalty_f64.argtypes = [
+            _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_longlong,
+            ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_double_p,
+            _c_u8_p, _c_double_p, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int)]
+        _lib.oracle_objective_value_f64.restype = ctypes.c_double
+        _lib.oracle_objective_value_f64.argtypes = [
+            _c_u8_p, _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t]
+        _lib.oracle_delta_chain_f64.restype = ctypes.c_int
+        _lib.oracle_delta_chain_f64.argtypes = [
+            _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double,
+            ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_u8_p,
+            ctypes.POINTER(DeltaStats)]
+        _lib.oracle_delta_window_f64.restype = ctypes.c_int
+        _lib.oracle_delta_window_f64.argtypes = [
+            _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double,
+            ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+            _c_u8_p, ctypes.POINTER(WindowStats)]
+        _lib.oracle_median_columns.restype = ctypes.c_int
+        _lib.oracle_median_columns.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_double_p]
+    return _lib
+
+
+def _dptr(a: Optional[np.ndarray]):
+    if a is None:
+        return ctypes.cast(None, _c_double_p)
+    return a.ctypes.data_as(_c_double_p)
+
+
+def _u8ptr(a: Optional[np.ndarray]):
+    if a is None:
+        return ctypes.cast(None, _c_u8_p)
+    return a.ctypes.data_as(_c_u8_p)
+
+
+def _check(rc: int) -> None:
+    if rc == -1:
+        raise MemoryError("oracle allocation failed")
+    if rc != 0:
+        raise ValueError(f"oracle rejected the arguments (status {rc})")
+
+
+# --------------------------------------------------------------------------------------------
+# dp.py surface
+# --------------------------------------------------------------------------------------------
+
+def objective_value(solution, scores, switch_costs) -> float:
+    """rocco/dp.py:16-34, restated with the same NumPy expressions (BLAS dot order)."""
+    solution_ = np.asarray(solution, dtype=np.float64)
+    scores_ = np.asarray(scores, dtype=np.float64)
+    if np.isscalar(switch_costs):
+        costs_ = np.full(max(solution_.shape[0] - 1, 0), float(switch_costs), dtype=np.float64)
+    else:
+        costs_ = np.asarray(switch_costs, dtype=np.float64)
+    penalty = 0.0
+    if solution_.shape[0] > 1:
+        penalty = float(costs_ @ np.abs(np.diff(solution_, 1)))
+    return float(-(scores_ @ solution_) + penalty)
+
+
+def build_switch_costs(scores, gamma: float = 1.0) -> np.ndarray:
+    """rocco/dp.py:37-46."""
+    scores_ = np.asarray(scores, dtype=np.float64)
+    if scores_.ndim != 1:
+        raise ValueError("`scores` must be a one-dimensional array")
+    if scores_.shape[0] <= 1:
+        return np.zeros(0, dtype=np.float64)
+    return np.full(scores_.shape[0] - 1, float(gamma), dtype=np.float64)
+
+
+def _prep(scores, switch_costs) -> Tuple[np.ndarray, np.ndarray]:
+    scores_ = np.ascontiguousarray(scores, dtype=np.float64)
+    costs_ = np.ascontiguousarray(switch_costs, dtype=np.float64)
+    if scores_.ndim != 1:
+        raise ValueError("`scores` must be one-dimensional")
+    if costs_.ndim != 1:
+        raise ValueError("`switch_costs` must be one-dimensional")
+    n = scores_.shape[0]
+    if n <= 0:
+        raise ValueError("`scores` cannot be empty")
+    if n > 1 and costs_.shape[0] != n - 1:
+        raise ValueError("`switch_costs` must have length len(scores) - 1")
+    return scores_, costs_
+
+
+def solve_penalized_chain(scores, switch_costs, selection_penalty: float):
+    """rocco/dp.py:49-86 -> rocco/_chain_dp.c:9-213.  Returns (uint8[n], value, count)."""
+    scores_, costs_ = _prep(scores, switch_costs)
+    n = scores_.shape[0]
+    solution = np.zeros(n, dtype=np.uint8)
+    value = ctypes.c_double(0.0)
+    count = ctypes.c_longlong(0)
+    _check(lib().oracle_solve_penalized_chain_f64(
+        _dptr(scores_), _dptr(costs_) if n > 1 else _dptr(None), 0.0, n, float(selection_penalty),
+        _u8ptr(solution), ctypes.byref(value), ctypes.byref(count)))
+    return solution, float(value.value), int(count.value)
+
+
+def calibrate_selection_penalty(scores, switch_costs, target_count: int, max_iter: int = 60,
+                                return_evaluations: bool = False):
+    """rocco/dp.py:89-164.  Returns (upper, best_solution, best_value, best_count)."""
+    scores_ = np.ascontiguousarray(scores, dtype=np.float64)
+    costs_ = np.ascontiguousarray(switch_costs, dtype=np.float64)
+    n = scores_.shape[0]
+    if n == 0:
+        raise ValueError("`scores` cannot be empty")
+    solution = np.zeros(n, dtype=np.uint8)
+    penalty = ctypes.c_double(0.0)
+    value = ctypes.c_double(0.0)
+    count = ctypes.c_longlong(0)
+    evals = ctypes.c_int(0)
+    # np.min / np.max / np.sum exactly as dp.py:110-111 calls them
+    _check(lib().oracle_calibrate_selection_penalty_f64(
+        _dptr(scores_), _dptr(costs_) if n > 1 else _dptr(None), 0.0, n, int(target_count),
+        int(max_iter), float(np.sum(costs_)), float(np.min(scores_)), float(np.max(scores_)),
+        ctypes.byref(penalty), _u8ptr(solution), ctypes.byref(value), ctypes.byref(count),
+        ctypes.byref(evals)))
+    out = (float(penalty.value), solution, float(value.value), int(count.value))
+    if return_evaluations:
+        return out + (int(evals.value),)
+    return out
+
+
+def solve_chrom_exact(scores, budget: Optional[float] = None, gamma: float = 1.0,
+                      selection_penalty: Optional[float] = None, return_details: bool = False):
+    """rocco/dp.py:167-228."""
+    scores_ = np.ascontiguousarray(scores, dtype=np.float64)
+    switch_costs = build_switch_costs(scores_, gamma=gamma)
+    if selection_penalty is None:
+        if budget is None:
+            penalty_ = 0.0
+            solution, penalized, count = solve_penalized_chain(scores_, switch_costs, penalty_)
+        else:
+            target_count = int(np.floor(len(scores_) * float(budget)))
+            penalty_, solution, penalized, count = calibrate_selection_penalty(
+                scores_, switch_costs, target_count=target_count)
+    else:
+        penalty_ = float(selection_penalty)
+        solution, penalized, count = solve_penalized_chain(scores_, switch_costs, penalty_)
+    objective = objective_value(solution, scores_, switch_costs)
+    if not return_details:
+        return solution.astype(np.uint8, copy=False), objective
+    return solution.astype(np.uint8, copy=False), objective, {
+        "penalized_objective": float(penalized),
+        "selected_count": int(count),
+        "selected_fraction": float(count / len(scores_)),
+        "selection_penalty": float(penalty_),
+    }
+
+
+# --------------------------------------------------------------------------------------------
+# delta-form recursion (sequential definition of the GPU fast path)
+# --------------------------------------------------------------------------------------------
+
+def delta_chain(scores, gamma_or_costs, selection_penalty: float, tau0: float, tau_step: float,
+                guard: float, m_cap: int, want_solution: bool = True):
+    scores_ = np.ascontiguousarray(scores, dtype=np.float64)
+    n = scores_.shape[0]
+    costs_ = None if np.isscalar(gamma_or_costs) else np.ascontiguousarray(gamma_or_costs, dtype=np.float64)
+    gamma = float(gamma_or_costs) if costs_ is None else 0.0
+    solution = np.zeros(n, dtype=np.uint8) if want_solution else None
+    stats = DeltaStats()
+    _check(lib().oracle_delta_chain_f64(_dptr(scores_), _dptr(costs_), gamma, n, float(selection_penalty),
+                                        float(tau0), float(tau_step), float(guard), int(m_cap),
+                                        _u8ptr(solution), ctypes.byref(stats)))
+    return solution, {"count": stats.count, "uncertain": stats.uncertain, "effect": stats.effect,
+                      "max_run": stats.max_run}
+
+
+def delta_window(scores, gamma_or_costs, lambda_lo: float, lambda_hi: float, tau0: float,
+                 tau_step: float, guard: float, m_cap: int):
+    scores_ = np.ascontiguousarray(scores, dtype=np.float64)
+    n = scores_.shape[0]
+    costs_ = None if np.isscalar(gamma_or_costs) else np.ascontiguousarray(gamma_or_costs, dtype=np.float64)
+    gamma = float(gamma_or_costs) if costs_ is None else 0.0
+    solution = np.zeros(n, dtype=np.uint8)
+    stats = WindowStats()
+    _check(lib().oracle_delta_window_f64(_dptr(scores_), _dptr(costs_), gamma, n, float(lambda_lo),
+                                         float(lambda_hi), float(tau0), float(tau_step), float(guard),
+                                         int(m_cap), _u8ptr(solution), ctypes.byref(stats)))
+    return solution, {"count_lo": stats.count_lo, "count_hi": stats.count_hi, "n_diff": stats.n_diff,
+                      "first_diff": stats.first_diff, "diff_adjacent": bool(stats.diff_adjacent),
+                      "max_run": stats.max_run}
+
+
+# --------------------------------------------------------------------------------------------
+# scoring and BED (rocco/rocco.py)
+# --------------------------------------------------------------------------------------------
+
+def score_central_tendency_chrom(chrom_matrix, method="quantile", quantile=0.50, tprop=0.05, power=1.0):
+    """rocco/rocco.py:243-304, median branch only (the branch rocco.py:983-991 reaches)."""
+    m = np.asarray(chrom_matrix)
+    if m.ndim != 2:
+        raise ValueError("`chrom_matrix` must be a 2D array.")
+    method_ = str(method).strip().lower().replace("-", "").replace("_", "")
+    if method_ != "quantile" or quantile != 0.50 or power != 1.0:
+        raise NotImplementedError("oracle restates the median branch only")
+    if m.shape[0] == 1:
+        return np.asarray(m[0, :], dtype=float)
+    is_f32 = m.dtype == np.float32
+    m_ = np.ascontiguousarray(m, dtype=np.float32 if is_f32 else np.float64)
+    out = np.empty(m_.shape[1], dtype=np.float64)
+    _check(lib().oracle_median_columns(m_.ctypes.data_as(ctypes.c_void_p), int(is_f32), m_.shape[0],
+                                       m_.shape[1], _dptr(out)))
+    return out
+
+
+Record = Tuple[str, int, int]
+
+
+def merge_bed_records(records: Sequence[Record], min_length_bp: Optional[int] = None) -> List[Record]:
+    """rocco/rocco.py:74-95: sort by (chrom string, start, end), merge when start <= previous end,
+    then drop records shorter than min_length_bp."""
+    out: List[List] = []
+    for chrom, start, end in sorted(records, key=lambda r: (r[0], r[1], r[2])):
+        if out and chrom == out[-1][0] and int(start) <= int(out[-1][2]):
+            out[-1][2] = max(int(out[-1][2]), int(end))
+        else:
+            out.append([chrom, int(start), int(end)])
+    return [(str(c), int(s), int(e)) for c, s, e in out
+            if min_length_bp is None or (int(e) - int(s)) >= int(min_length_bp)]
+
+
+def chrom_solution_records(chromosome, intervals, solution, check_gaps_intervals=True,
+                           min_length_bp=None) -> List[Record]:
+    """rocco/rocco.py:139-191 up to (not including) the file write: loci 0..n-2 with
+    solution > 0.5 become (intervals[i], intervals[i+1]); the last locus is never emitted."""
+    if len(intervals) != len(solution):
+        raise ValueError("Intervals and solution must have the same length")
+    if check_gaps_intervals and len(set(np.diff(intervals))) > 1:
+        raise ValueError("Intervals must be contiguous")
+    recs = [(str(chromosome), int(intervals[i]), int(intervals[i + 1]))
+            for i in range(len(intervals) - 1) if solution[i] > 0.50]
+    return merge_bed_records(recs, min_length_bp=min_length_bp)
+
+
+def bed_text(records: Sequence[Record], name_features: bool = False) -> str:
+    """rocco/rocco.py:98-110."""
+    if name_features:
+        return "".join(f"{c}\t{s}\t{e}\t{c}_{s}_{e}\n" for c, s, e in records)
+    return "".join(f"{c}\t{s}\t{e}\n" for c, s, e in records)
+
+
+def combine_records(per_chrom_records: Sequence[Sequence[Record]]) -> List[Record]:
+    """rocco/rocco.py:194-240 on in-memory records."""
+    allr: List[Record] = []
+    for recs in per_chrom_records:
+        allr.extend(recs)
+    return merge_bed_records(allr)
