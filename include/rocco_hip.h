@@ -1,0 +1,133 @@
+/*
+ * include/rocco_hip.h -- C ABI of librocco_hip.so, the MI355X (gfx950) implementation of ROCCO's
+ * per-chromosome solve path:  K x n signal matrix -> per-locus scores -> budgeted chain solve ->
+ * 0/1 vector -> merged runs (BED3 intervals).
+ *
+ * Convention (modelled on the reference's native backends, rocco/native/wls_backend.h:11-28 and
+ * rocco/native/baseline_backend.h:12-23): plain pointers and sizes, caller-owned buffers, `int`
+ * status -- 0 ok, -1 out of memory, -2 invalid argument, -3 HIP runtime error (see
+ * rocco_hip_last_error).  All `*_dev` pointers are DEVICE pointers (HBM); everything else is host
+ * memory.  `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ * synchronous with respect to their scalar outputs (they return after the needed readback) and
+ * re-entrant across different solver handles; one handle must not be used from two host threads
+ * at once.  There is no CPU fallback anywhere behind this interface.
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef ROCCO_HIP_H
+#define ROCCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ROCCO_HIP_OK 0
+#define ROCCO_HIP_ENOMEM (-1)
+#define ROCCO_HIP_EINVAL (-2)
+#define ROCCO_HIP_EHIP (-3)
+
+/* How a result was obtained (diagnostic; written to `path_out` / result.path). */
+#define ROCCO_HIP_PATH_CERTIFIED 1 /* parallel delta-form kernels, certified equal to the reference */
+#define ROCCO_HIP_PATH_EXACT 2     /* sequential exact emulation kernel (same IEEE op order)        */
+#define ROCCO_HIP_PATH_TRIVIAL 3   /* decided without a kernel launch (e.g. n == 1)                 */
+
+typedef struct rocco_hip_solver rocco_hip_solver;
+
+/* ABI version of this header (major * 1000 + minor). */
+int rocco_hip_abi_version(void);
+
+/* Last HIP/runtime error text for this thread ("" if none). */
+const char *rocco_hip_last_error(void);
+
+/* Create / destroy a solver handle bound to HIP device `device`.  The handle owns device scratch
+ * and pinned host staging that grow on demand. */
+int rocco_hip_solver_create(rocco_hip_solver **solver_out, int device);
+void rocco_hip_solver_destroy(rocco_hip_solver *solver);
+
+/* Tunables (speculation depth of the lambda search, force the exact kernel, ...).  Unknown keys
+ * return ROCCO_HIP_EINVAL.  Keys: "force_exact" (0/1), "spec_depth" (1..6), "m_cap". */
+int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long value);
+
+/* ---- scoring -------------------------------------------------------------------------------
+ * Replaces rocco/rocco.py:243-304 `score_central_tendency_chrom`, median branch (264-265), as
+ * reached from rocco/rocco.py:983-991.  `matrix_dev` is row-major [K][row_stride] (row_stride >= n,
+ * in elements); dtype 0 = float64, 1 = float32 (the --low_memory matrices, readtracks.py:621).
+ * K == 1 copies the row (rocco.py:254-255).  A NaN anywhere in a column gives NaN. */
+int rocco_hip_score_median(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K,
+                           size_t n, size_t row_stride, double *scores_dev, void *stream);
+
+/* ---- chain solve at a fixed selection penalty ----------------------------------------------
+ * Replaces rocco/_chain_dp.c:9-213 `solve_penalized_chain` (Python wrapper rocco/dp.py:49-86).
+ * `switch_costs_dev` has n-1 entries, or is NULL to use the scalar `gamma` at every boundary
+ * (what rocco/dp.py:37-46 materialises).  `solution_dev` (n bytes, 0/1) may be NULL.
+ * value/count are the reference's (best_val, best_count) (rocco/_chain_dp.c:194-198); the value is
+ * reproduced bit-for-bit only on the exact path, otherwise to ~1e-12 relative. */
+int rocco_hip_solve_penalized_chain_f64(rocco_hip_solver *solver, const double *scores_dev,
+                                        const double *switch_costs_dev, double gamma, size_t n,
+                                        double selection_penalty, uint8_t *solution_dev,
+                                        double *value_out, long long *count_out, int *path_out,
+                                        void *stream);
+
+/* ---- budgeted solve, one launch sequence for a batch of chromosomes -------------------------
+ * Replaces rocco/dp.py:89-164 `calibrate_selection_penalty` (bracket + exactly `max_iter`
+ * bisection steps on the selection penalty) for every task in the batch at once.  The caller
+ * supplies the bracket seeds exactly as the reference computes them on the host
+ * (rocco/dp.py:110-111: lower = min(s) - sum(c) - 1, upper = max(s) + sum(c) + 1, with NumPy's
+ * np.min / np.max / pairwise np.sum), because their last bits fix the midpoint sequence. */
+typedef struct {
+    const double *scores_dev;       /* n doubles                                        */
+    const double *switch_costs_dev; /* n-1 doubles or NULL (use gamma)                  */
+    double gamma;
+    size_t n;
+    long long target_count;         /* int(floor(n * budget)), rocco/dp.py:197          */
+    double lower0, upper0;          /* rocco/dp.py:110-111                              */
+    int max_iter;                   /* 60 in the reference (rocco/dp.py:93)             */
+    uint8_t *solution_dev;          /* n bytes out                                      */
+} rocco_hip_budget_task;
+
+typedef struct {
+    double selection_penalty; /* the returned `upper` (rocco/dp.py:164)                          */
+    double penalized_value;   /* best_value                                                      */
+    long long selected_count; /* best_count                                                      */
+    int evaluations;          /* chain evaluations the reference would have made (62 normally)   */
+    int path;                 /* ROCCO_HIP_PATH_*                                                */
+    int passes;               /* device passes over the scores actually made                     */
+} rocco_hip_budget_result;
+
+int rocco_hip_solve_budget_batch_f64(rocco_hip_solver *solver, size_t n_tasks,
+                                     const rocco_hip_budget_task *tasks,
+                                     rocco_hip_budget_result *results, void *stream);
+
+/* ---- objective ------------------------------------------------------------------------------
+ * Replaces rocco/dp.py:16-34 `objective_value`: -(s . z) + c . |diff z|  (fixed-order tree sum;
+ * the reference uses BLAS dot, so agreement is to relative 1e-12, not bitwise). */
+int rocco_hip_objective_value_f64(rocco_hip_solver *solver, const uint8_t *solution_dev,
+                                  const double *scores_dev, const double *switch_costs_dev,
+                                  double gamma, size_t n, double *objective_out, void *stream);
+
+/* ---- run-length decode ------------------------------------------------------------------------
+ * Replaces the per-locus Python loop + merge of rocco/rocco.py:180-190 (`chrom_solution_to_bed`)
+ * and rocco/rocco.py:74-95 (`_merge_bed_records`) for contiguous fixed-step loci: maximal runs of
+ * selected loci among loci 0..n-2 (the last locus is never emitted, rocco.py:180) are written as
+ * half-open locus index pairs [run_begin, run_end) in ascending order; the interval in base pairs
+ * is (intervals[run_begin], intervals[run_end]).  At most `capacity` runs are written;
+ * *n_runs_out is the total found. */
+int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev, size_t n,
+                          int64_t *run_begin_dev, int64_t *run_end_dev, size_t capacity,
+                          size_t *n_runs_out, void *stream);
+
+/* ---- synthetic signal matrices (benchmark / test support, device-resident) -------------------
+ * Fills a row-major [K][n] matrix with the counter-based synthetic tracks described in
+ * DESIGN.md section 7 (5-decimal background + planted peaks with per-sample dropout); the same
+ * integer arithmetic is restated in NumPy in rocco_amd/synth.py so any slice can be regenerated
+ * on the host bit-for-bit. */
+int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
+                           size_t row_stride, uint64_t seed, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROCCO_HIP_H */

@@ -1,0 +1,21 @@
+"""rocco_amd -- MI355X-native implementation of ROCCO's per-chromosome solve path.
+
+Re-exports the hot-path functions under the reference's own names (rocco/__init__.py:1-7 star-exports
+them from rocco/dp.py and rocco/rocco.py), so `from rocco_amd import solve_chrom_exact` replaces
+`from rocco import solve_chrom_exact`.
+"""
+from .dp import (  # noqa: F401
+    build_switch_costs,
+    calibrate_selection_penalty,
+    objective_value,
+    solve_chrom_exact,
+    solve_penalized_chain,
+)
+from .rocco import (  # noqa: F401
+    chrom_solution_to_bed,
+    combine_chrom_results,
+    score_central_tendency_chrom,
+    solve_cached_chromosomes,
+)
+
+__version__ = "0.1.0"

@@ -1,0 +1,153 @@
+"""ctypes binding of librocco_hip.so (C ABI declared in include/rocco_hip.h).
+
+This is the reference-side stub a ROCCO maintainer would add in place of `from . import _chain_dp`
+(rocco/dp.py:10-13): load the shared library, declare the prototypes, and raise the same
+RuntimeError the reference raises when its native extension is missing (rocco/dp.py:73-74).
+There is no CPU fallback: if the library or a GPU is missing, every call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librocco_hip.so")
+
+OK, ENOMEM, EINVAL, EHIP = 0, -1, -2, -3
+PATH_CERTIFIED, PATH_EXACT, PATH_TRIVIAL = 1, 2, 3
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_ll_p = ctypes.POINTER(ctypes.c_longlong)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_size_p = ctypes.POINTER(ctypes.c_size_t)
+
+
+class BudgetTask(ctypes.Structure):
+    _fields_ = [
+        ("scores_dev", ctypes.c_void_p),
+        ("switch_costs_dev", ctypes.c_void_p),
+        ("gamma", ctypes.c_double),
+        ("n", ctypes.c_size_t),
+        ("target_count", ctypes.c_longlong),
+        ("lower0", ctypes.c_double),
+        ("upper0", ctypes.c_double),
+        ("max_iter", ctypes.c_int),
+        ("solution_dev", ctypes.c_void_p),
+    ]
+
+
+class BudgetResult(ctypes.Structure):
+    _fields_ = [
+        ("selection_penalty", ctypes.c_double),
+        ("penalized_value", ctypes.c_double),
+        ("selected_count", ctypes.c_longlong),
+        ("evaluations", ctypes.c_int),
+        ("path", ctypes.c_int),
+        ("passes", ctypes.c_int),
+    ]
+
+
+# every symbol include/rocco_hip.h declares: (name, restype, argtypes)
+PROTOTYPES = [
+    ("rocco_hip_abi_version", ctypes.c_int, []),
+    ("rocco_hip_last_error", ctypes.c_char_p, []),
+    ("rocco_hip_solver_create", ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
+    ("rocco_hip_solver_destroy", None, [ctypes.c_void_p]),
+    ("rocco_hip_solver_set", ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong]),
+    ("rocco_hip_score_median", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+      ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_solve_penalized_chain_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t,
+      ctypes.c_double, ctypes.c_void_p, c_double_p, c_ll_p, c_int_p, ctypes.c_void_p]),
+    ("rocco_hip_solve_budget_batch_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(BudgetTask), ctypes.POINTER(BudgetResult),
+      ctypes.c_void_p]),
+    ("rocco_hip_objective_value_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
+      ctypes.c_size_t, c_double_p, ctypes.c_void_p]),
+    ("rocco_hip_decode_runs", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+      ctypes.c_size_t, c_size_p, ctypes.c_void_p]),
+    ("rocco_hip_synth_matrix", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
+      ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]),
+]
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """Load librocco_hip.so and bind every prototype.  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            "Make sure native HIP extension is built and available "
+            f"({LIB_PATH} missing; run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # missing ROCm runtime etc.
+        raise RuntimeError(f"Make sure native HIP extension is built and available: {exc}") from exc
+    for name, restype, argtypes in PROTOTYPES:
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().rocco_hip_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str) -> None:
+    if rc == OK:
+        return
+    if rc == ENOMEM:
+        raise MemoryError(f"{what}: device/host allocation failed ({last_error()})")
+    if rc == EINVAL:
+        raise ValueError(f"{what}: invalid argument ({last_error()})")
+    raise RuntimeError(f"{what}: HIP runtime error ({last_error()})")
+
+
+class Solver:
+    """Owns one `rocco_hip_solver*` bound to a HIP device."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        handle = ctypes.c_void_p()
+        check(self._lib.rocco_hip_solver_create(ctypes.byref(handle), int(device)),
+              "rocco_hip_solver_create")
+        self.handle = handle
+        self.device = int(device)
+
+    def set(self, key: str, value: int) -> None:
+        check(self._lib.rocco_hip_solver_set(self.handle, key.encode(), int(value)),
+              f"rocco_hip_solver_set({key})")
+
+    def close(self) -> None:
+        if getattr(self, "handle", None) is not None and self.handle:
+            self._lib.rocco_hip_solver_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_solvers: dict = {}
+
+
+def solver_for(device: int) -> Solver:
+    """Process-wide solver handle per device (scratch buffers are reused across calls)."""
+    s = _solvers.get(int(device))
+    if s is None:
+        s = Solver(int(device))
+        _solvers[int(device)] = s
+    return s

@@ -1,0 +1,246 @@
+// rocco_amd/csrc/api.hip -- C ABI entry points of librocco_hip.so (see include/rocco_hip.h).
+#include "kernels.h"
+#include "budget.h"
+
+#include <cmath>
+#include <new>
+
+namespace rocco {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+int DeviceBuffer::reserve(size_t want)
+{
+    if (want <= bytes) {
+        return ROCCO_HIP_OK;
+    }
+    size_t grow = bytes ? bytes * 2 : (size_t)1 << 16;
+    if (grow < want) {
+        grow = want;
+    }
+    void *p = nullptr;
+    ROCCO_HIP_TRY(hipMalloc(&p, grow));
+    if (ptr != nullptr) {
+        (void)hipFree(ptr);
+    }
+    ptr = p;
+    bytes = grow;
+    return ROCCO_HIP_OK;
+}
+
+void DeviceBuffer::release()
+{
+    if (ptr != nullptr) {
+        (void)hipFree(ptr);
+    }
+    ptr = nullptr;
+    bytes = 0;
+}
+
+int PinnedBuffer::reserve(size_t want)
+{
+    if (want <= bytes) {
+        return ROCCO_HIP_OK;
+    }
+    size_t grow = bytes ? bytes * 2 : (size_t)1 << 14;
+    if (grow < want) {
+        grow = want;
+    }
+    void *p = nullptr;
+    ROCCO_HIP_TRY(hipHostMalloc(&p, grow, hipHostMallocDefault));
+    if (ptr != nullptr) {
+        (void)hipHostFree(ptr);
+    }
+    ptr = p;
+    bytes = grow;
+    return ROCCO_HIP_OK;
+}
+
+void PinnedBuffer::release()
+{
+    if (ptr != nullptr) {
+        (void)hipHostFree(ptr);
+    }
+    ptr = nullptr;
+    bytes = 0;
+}
+
+}  // namespace rocco
+
+using namespace rocco;
+
+extern "C" {
+
+int rocco_hip_abi_version(void) { return 1000; }
+
+const char *rocco_hip_last_error(void) { return g_last_error.c_str(); }
+
+int rocco_hip_solver_create(rocco_hip_solver **solver_out, int device)
+{
+    if (solver_out == nullptr) {
+        return ROCCO_HIP_EINVAL;
+    }
+    *solver_out = nullptr;
+    int count = 0;
+    ROCCO_HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) {
+        set_last_error("rocco_hip_solver_create: no such HIP device");
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(device));
+    rocco_hip_solver *s = new (std::nothrow) rocco_hip_solver();
+    if (s == nullptr) {
+        return ROCCO_HIP_ENOMEM;
+    }
+    s->device = device;
+    *solver_out = s;
+    return ROCCO_HIP_OK;
+}
+
+void rocco_hip_solver_destroy(rocco_hip_solver *solver)
+{
+    if (solver == nullptr) {
+        return;
+    }
+    (void)hipSetDevice(solver->device);
+    solver->dev_tasks.release();
+    solver->dev_params.release();
+    solver->dev_results.release();
+    solver->dev_bits.release();
+    solver->dev_misc.release();
+    solver->host_stage.release();
+    solver->host_back.release();
+    delete solver;
+}
+
+int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long value)
+{
+    if (solver == nullptr || key == nullptr) {
+        return ROCCO_HIP_EINVAL;
+    }
+    const std::string k(key);
+    if (k == "force_exact") {
+        solver->force_exact = value ? 1 : 0;
+    } else if (k == "spec_depth") {
+        if (value < 1 || value > 6) {
+            return ROCCO_HIP_EINVAL;
+        }
+        solver->spec_depth = (int)value;
+    } else if (k == "m_cap") {
+        if (value < 1 || value > (1 << 20)) {
+            return ROCCO_HIP_EINVAL;
+        }
+        solver->m_cap = (int)value;
+    } else {
+        set_last_error("rocco_hip_solver_set: unknown key " + k);
+        return ROCCO_HIP_EINVAL;
+    }
+    return ROCCO_HIP_OK;
+}
+
+int rocco_hip_score_median(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K,
+                           size_t n, size_t row_stride, double *scores_dev, void *stream)
+{
+    if (solver == nullptr || matrix_dev == nullptr || scores_dev == nullptr || K == 0 ||
+        row_stride < n || (dtype != 0 && dtype != 1)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_median(matrix_dev, dtype, K, n, row_stride, scores_dev, (hipStream_t)stream);
+}
+
+int rocco_hip_solve_penalized_chain_f64(rocco_hip_solver *solver, const double *scores_dev,
+                                        const double *switch_costs_dev, double gamma, size_t n,
+                                        double selection_penalty, uint8_t *solution_dev,
+                                        double *value_out, long long *count_out, int *path_out,
+                                        void *stream)
+{
+    if (solver == nullptr || scores_dev == nullptr || n == 0 || n >= ((size_t)1 << 31)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return solve_fixed_penalty(solver, scores_dev, switch_costs_dev, gamma, n, selection_penalty,
+                               solution_dev, value_out, count_out, path_out, (hipStream_t)stream);
+}
+
+int rocco_hip_solve_budget_batch_f64(rocco_hip_solver *solver, size_t n_tasks,
+                                     const rocco_hip_budget_task *tasks,
+                                     rocco_hip_budget_result *results, void *stream)
+{
+    if (solver == nullptr || (n_tasks > 0 && (tasks == nullptr || results == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    for (size_t t = 0; t < n_tasks; ++t) {
+        if (tasks[t].scores_dev == nullptr || tasks[t].n == 0 || tasks[t].n >= ((size_t)1 << 31) ||
+            tasks[t].solution_dev == nullptr || tasks[t].max_iter < 0) {
+            return ROCCO_HIP_EINVAL;
+        }
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return solve_budget_batch(solver, n_tasks, tasks, results, (hipStream_t)stream);
+}
+
+int rocco_hip_objective_value_f64(rocco_hip_solver *solver, const uint8_t *solution_dev,
+                                  const double *scores_dev, const double *switch_costs_dev,
+                                  double gamma, size_t n, double *objective_out, void *stream)
+{
+    if (solver == nullptr || objective_out == nullptr || (n > 0 && (solution_dev == nullptr || scores_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc = solver->dev_misc.reserve(objective_scratch_bytes(n));
+    if (rc != ROCCO_HIP_OK) {
+        return rc;
+    }
+    rc = solver->host_back.reserve(64);
+    if (rc != ROCCO_HIP_OK) {
+        return rc;
+    }
+    double *back = (double *)solver->host_back.ptr;
+    rc = launch_objective(solution_dev, scores_dev, switch_costs_dev, gamma, n, solver->dev_misc.ptr,
+                          back, (hipStream_t)stream);
+    if (rc == ROCCO_HIP_OK) {
+        *objective_out = *back;
+    }
+    return rc;
+}
+
+int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev, size_t n,
+                          int64_t *run_begin_dev, int64_t *run_end_dev, size_t capacity,
+                          size_t *n_runs_out, void *stream)
+{
+    if (solver == nullptr || n_runs_out == nullptr || (n > 0 && solution_dev == nullptr) ||
+        (capacity > 0 && (run_begin_dev == nullptr || run_end_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc = solver->dev_misc.reserve(decode_scratch_bytes(n));
+    if (rc != ROCCO_HIP_OK) {
+        return rc;
+    }
+    rc = solver->host_back.reserve(64);
+    if (rc != ROCCO_HIP_OK) {
+        return rc;
+    }
+    unsigned long long *back = (unsigned long long *)solver->host_back.ptr;
+    rc = launch_decode_runs(solution_dev, n, run_begin_dev, run_end_dev, capacity, solver->dev_misc.ptr,
+                            back, (hipStream_t)stream);
+    if (rc == ROCCO_HIP_OK) {
+        *n_runs_out = (size_t)*back;
+    }
+    return rc;
+}
+
+int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
+                           size_t row_stride, uint64_t seed, void *stream)
+{
+    if (solver == nullptr || matrix_dev == nullptr || row_stride < n || (dtype != 0 && dtype != 1)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_synth(matrix_dev, dtype, K, n, row_stride, seed, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,16 @@
+// rocco_amd/csrc/budget.h -- host orchestration of the chain solves (fixed penalty and budgeted).
+#pragma once
+
+#include "kernels.h"
+
+namespace rocco {
+
+int solve_fixed_penalty(rocco_hip_solver *solver, const double *scores_dev,
+                        const double *switch_costs_dev, double gamma, size_t n, double lambda,
+                        uint8_t *solution_dev, double *value_out, long long *count_out, int *path_out,
+                        hipStream_t stream);
+
+int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip_budget_task *tasks,
+                       rocco_hip_budget_result *results, hipStream_t stream);
+
+}  // namespace rocco

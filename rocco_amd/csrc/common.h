@@ -1,0 +1,59 @@
+// rocco_amd/csrc/common.h -- shared host-side plumbing for librocco_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rocco_hip.h"
+
+namespace rocco {
+
+void set_last_error(const std::string &msg);
+
+#define ROCCO_HIP_TRY(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ::rocco::set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));      \
+            return (_e == hipErrorOutOfMemory) ? ROCCO_HIP_ENOMEM : ROCCO_HIP_EHIP;          \
+        }                                                                                    \
+    } while (0)
+
+// Growable device / pinned-host buffers owned by a solver handle.
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t want);
+    void release();
+};
+
+struct PinnedBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t want);
+    void release();
+};
+
+}  // namespace rocco
+
+struct rocco_hip_solver {
+    int device = 0;
+    // tunables
+    int force_exact = 0;
+    int spec_depth = 2;
+    int m_cap = 4096;
+    // scratch
+    rocco::DeviceBuffer dev_tasks;    // kernel task descriptors
+    rocco::DeviceBuffer dev_params;   // per-launch lambda lists etc.
+    rocco::DeviceBuffer dev_results;  // per-launch counters / values
+    rocco::DeviceBuffer dev_bits;     // exact-path decision bits
+    rocco::DeviceBuffer dev_misc;     // decode / reduction scratch
+    rocco::PinnedBuffer host_stage;   // pinned staging for uploads
+    rocco::PinnedBuffer host_back;    // pinned staging for readbacks
+};

@@ -1,0 +1,46 @@
+// rocco_amd/csrc/kernels.h -- device task descriptors and launchers shared by the .hip files.
+#pragma once
+
+#include "common.h"
+
+namespace rocco {
+
+// ---- chain_exact.hip ------------------------------------------------------------------------
+struct ExactTask {
+    const double *scores;         // n
+    const double *switch_costs;   // n-1 or nullptr
+    double gamma;
+    long long n;
+    const double *lambdas;        // n_lambda penalties (device)
+    int n_lambda;                 // 1..64
+    int record_lane;              // lane whose decisions are recorded + backtracked
+    double *values_out;           // n_lambda
+    long long *counts_out;        // n_lambda
+    unsigned long long *decision_words;  // ceil((n-1)/32) words or nullptr
+    uint8_t *solution;            // n bytes (used iff decision_words)
+};
+
+int launch_chain_exact(const ExactTask *tasks_dev, int n_tasks, hipStream_t stream);
+
+// ---- median.hip -----------------------------------------------------------------------------
+int launch_median(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride,
+                  double *scores_dev, hipStream_t stream);
+
+// ---- decode.hip -----------------------------------------------------------------------------
+// scratch: at least decode_scratch_bytes(n) bytes
+size_t decode_scratch_bytes(size_t n);
+int launch_decode_runs(const uint8_t *solution_dev, size_t n, int64_t *run_begin_dev,
+                       int64_t *run_end_dev, size_t capacity, void *scratch_dev,
+                       unsigned long long *n_runs_host_pinned, hipStream_t stream);
+
+// ---- objective.hip --------------------------------------------------------------------------
+size_t objective_scratch_bytes(size_t n);
+int launch_objective(const uint8_t *solution_dev, const double *scores_dev,
+                     const double *switch_costs_dev, double gamma, size_t n, void *scratch_dev,
+                     double *objective_host_pinned, hipStream_t stream);
+
+// ---- synth.hip ------------------------------------------------------------------------------
+int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
+                 hipStream_t stream);
+
+}  // namespace rocco

@@ -1,0 +1,199 @@
+// rocco_amd/csrc/median.hip -- column-wise median over K samples (K x n row-major -> n), gfx950.
+//
+// Replaces rocco/rocco.py:264-265 (np.median(chrom_matrix, axis=0) inside
+// score_central_tendency_chrom) as called from rocco/rocco.py:983-991.
+//
+// One lane owns one locus: it reads its K samples (row k is a coalesced 512-byte segment per
+// wavefront), keeps them in registers, and runs a Batcher merge-exchange network whose compare
+// indices are all compile-time constants.  Only the two middle outputs are consumed, so the
+// compiler prunes every min/max that cannot reach them (a selection network, not a full sort).
+// K is padded to a supported even size with -inf/+inf in equal numbers (one extra +inf for odd
+// K), which leaves the middle order statistics unchanged.  HBM-bound: 8K (or 4K) bytes read and
+// 8 bytes written per locus.
+#include "kernels.h"
+
+#include <limits>
+
+namespace rocco {
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ void select_middle(double (&v)[N])
+{
+    // Batcher's merge exchange for arbitrary N; every index below is a compile-time constant
+    // once the loops are fully unrolled.
+#pragma unroll
+    for (int p = 1; p < N; p <<= 1) {
+#pragma unroll
+        for (int k = p; k >= 1; k >>= 1) {
+#pragma unroll
+            for (int j = k % p; j <= N - 1 - k; j += 2 * k) {
+#pragma unroll
+                for (int i = 0; i <= ((k - 1 < N - j - k - 1) ? (k - 1) : (N - j - k - 1)); ++i) {
+                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+                        const double a = v[i + j];
+                        const double b = v[i + j + k];
+                        v[i + j] = fmin(a, b);
+                        v[i + j + k] = fmax(a, b);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int KP>
+__global__ __launch_bounds__(256) void median_kernel(const T *__restrict__ m, int K, long long n,
+                                                     long long stride, double *__restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) {
+        return;
+    }
+    const int pad = KP - K;
+    const int n_lo = pad / 2;  // -inf entries; the remaining pad entries are +inf
+    double v[KP];
+    bool has_nan = false;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        double x;
+        if (k < K) {
+            x = (double)m[(long long)k * stride + j];
+            has_nan |= (x != x);
+            x = (x != x) ? std::numeric_limits<double>::infinity() : x;
+        } else {
+            x = (k - K < n_lo) ? -std::numeric_limits<double>::infinity()
+                               : std::numeric_limits<double>::infinity();
+        }
+        v[k] = x;
+    }
+    select_middle<KP>(v);
+    double r;
+    if (K & 1) {
+        r = v[KP / 2 - 1];
+    } else {
+        r = (v[KP / 2 - 1] + v[KP / 2]) / 2.0;
+    }
+    out[j] = has_nan ? std::numeric_limits<double>::quiet_NaN() : r;
+}
+
+// K == 1: copy (rocco.py:254-255; power == 1.0 is the identity)
+template <typename T>
+__global__ __launch_bounds__(256) void copy_row_kernel(const T *__restrict__ m, long long n,
+                                                       double *__restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) {
+        out[j] = (double)m[j];
+    }
+}
+
+// Any K (used above the largest network): rank counting, O(K^2) reads served from L1/L2.
+template <typename T>
+__global__ __launch_bounds__(256) void median_rank_kernel(const T *__restrict__ m, int K, long long n,
+                                                          long long stride, double *__restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) {
+        return;
+    }
+    const int want_lo = (K - 1) / 2;  // 0-based order statistics wanted
+    const int want_hi = K / 2;
+    double lo = 0.0, hi = 0.0;
+    bool has_nan = false;
+    for (int a = 0; a < K; ++a) {
+        const double x = (double)m[(long long)a * stride + j];
+        if (x != x) {
+            has_nan = true;
+            continue;
+        }
+        int less = 0, equal = 0;
+        for (int b = 0; b < K; ++b) {
+            const double y = (double)m[(long long)b * stride + j];
+            less += (y < x);
+            equal += (y == x);
+        }
+        // x occupies sorted positions [less, less + equal)
+        if (want_lo >= less && want_lo < less + equal) {
+            lo = x;
+        }
+        if (want_hi >= less && want_hi < less + equal) {
+            hi = x;
+        }
+    }
+    out[j] = has_nan ? std::numeric_limits<double>::quiet_NaN() : ((K & 1) ? lo : (lo + hi) / 2.0);
+}
+
+template <typename T, int KP>
+void launch_kp(const T *m, int K, long long n, long long stride, double *out, hipStream_t stream)
+{
+    const int threads = 256;
+    const long long blocks = (n + threads - 1) / threads;
+    hipLaunchKernelGGL((median_kernel<T, KP>), dim3((unsigned)blocks), dim3(threads), 0, stream, m, K,
+                       n, stride, out);
+}
+
+template <typename T>
+int dispatch(const T *m, size_t K, size_t n, size_t stride, double *out, hipStream_t stream)
+{
+    const long long nn = (long long)n;
+    const long long st = (long long)stride;
+    const int threads = 256;
+    const long long blocks = (nn + threads - 1) / threads;
+    if (K == 1) {
+        hipLaunchKernelGGL((copy_row_kernel<T>), dim3((unsigned)blocks), dim3(threads), 0, stream, m,
+                           nn, out);
+    } else if (K <= 2) {
+        launch_kp<T, 2>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 4) {
+        launch_kp<T, 4>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 6) {
+        launch_kp<T, 6>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 8) {
+        launch_kp<T, 8>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 10) {
+        launch_kp<T, 10>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 12) {
+        launch_kp<T, 12>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 16) {
+        launch_kp<T, 16>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 20) {
+        launch_kp<T, 20>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 24) {
+        launch_kp<T, 24>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 32) {
+        launch_kp<T, 32>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 40) {
+        launch_kp<T, 40>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 50) {
+        launch_kp<T, 50>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 64) {
+        launch_kp<T, 64>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 80) {
+        launch_kp<T, 80>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 100) {
+        launch_kp<T, 100>(m, (int)K, nn, st, out, stream);
+    } else {
+        hipLaunchKernelGGL((median_rank_kernel<T>), dim3((unsigned)blocks), dim3(threads), 0, stream,
+                           m, (int)K, nn, st, out);
+    }
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+}  // namespace
+
+int launch_median(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride,
+                  double *scores_dev, hipStream_t stream)
+{
+    if (n == 0) {
+        return ROCCO_HIP_OK;
+    }
+    if (dtype == 0) {
+        return dispatch<double>((const double *)matrix_dev, K, n, row_stride, scores_dev, stream);
+    }
+    return dispatch<float>((const float *)matrix_dev, K, n, row_stride, scores_dev, stream);
+}
+
+}  // namespace rocco

@@ -1,0 +1,313 @@
+"""Scoring, solve driver and BED decode on MI355X -- drop-in for the hot-path functions of the
+reference's `rocco/rocco.py`:
+
+    score_central_tendency_chrom   rocco/rocco.py:243-304  (median branch 264-265; call-site 983-991)
+    chrom_solution_to_bed          rocco/rocco.py:139-191
+    _merge_bed_records             rocco/rocco.py:74-95
+    _write_bed_records             rocco/rocco.py:98-110
+    _read_bed_records              rocco/rocco.py:53-71
+    combine_chrom_results          rocco/rocco.py:194-240
+    solve_cached_chromosomes       rocco/rocco.py:890-930, 1146-1196 (one process per GPU, every
+                                   chromosome of the rank batched into the same device passes,
+                                   instead of a fork pool of <= 4 workers)
+
+The K x n -> n scoring, the chain solve and the run-length decode run in librocco_hip.so; text
+formatting / file writing of the (small) interval lists stays on the host as in the reference.
+"""
+from __future__ import annotations
+
+import ctypes
+import logging
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native
+from . import dp as _dp
+
+logger = logging.getLogger(__name__)
+
+Record = Tuple[str, int, int]
+
+
+# --------------------------------------------------------------------------------------------
+# BED record helpers (host; interval lists are ~1e5 records per genome)
+# --------------------------------------------------------------------------------------------
+
+def _read_bed_records(bed_file: str) -> Tuple[List[Record], bool]:
+    """rocco/rocco.py:53-71."""
+    records: List[Record] = []
+    extra = False
+    with open(bed_file, "r", encoding="utf-8") as handle:
+        for line_num, line in enumerate(handle, start=1):
+            text = line.strip()
+            if text == "":
+                continue
+            fields = text.split("\t")
+            if len(fields) < 3:
+                raise ValueError(f"BED row {line_num} in {bed_file} has fewer than 3 columns.")
+            if len(fields) > 3:
+                extra = True
+            records.append((str(fields[0]), int(fields[1]), int(fields[2])))
+    return records, extra
+
+
+def _merge_bed_records(records: Sequence[Record], min_length_bp: Optional[int] = None) -> List[Record]:
+    """rocco/rocco.py:74-95: order by (chromosome string, start, end) -- so chr10 sorts before
+    chr2 -- merge records whose start is <= the previous end, then apply the length filter."""
+    merged: List[List] = []
+    for chrom, start, end in sorted(records, key=lambda rec: (rec[0], rec[1], rec[2])):
+        if merged and merged[-1][0] == chrom and int(start) <= int(merged[-1][2]):
+            if int(end) > int(merged[-1][2]):
+                merged[-1][2] = int(end)
+            continue
+        merged.append([chrom, int(start), int(end)])
+    return [(str(c), int(s), int(e)) for c, s, e in merged
+            if min_length_bp is None or (int(e) - int(s)) >= int(min_length_bp)]
+
+
+def _write_bed_records(records: Sequence[Record], output_file: str, name_features: bool = False) -> str:
+    """rocco/rocco.py:98-110."""
+    with open(output_file, "w", encoding="utf-8") as handle:
+        for chrom, start, end in records:
+            if name_features:
+                handle.write(f"{chrom}\t{start}\t{end}\t{chrom}_{start}_{end}\n")
+            else:
+                handle.write(f"{chrom}\t{start}\t{end}\n")
+    return output_file
+
+
+def combine_chrom_results(chrom_bed_files: list, output_file: str, name_features: bool = False) -> str:
+    """Combine per-chromosome BED files into one sorted, merged BED file (rocco/rocco.py:194-240)."""
+    if os.path.exists(output_file):
+        logger.info("Removing existing output file: %s", output_file)
+        try:
+            os.remove(output_file)
+        except OSError:
+            logger.info("Could not remove existing output file: %s.", output_file)
+    combined: List[Record] = []
+    warned = False
+    for bed in chrom_bed_files:
+        if not os.path.exists(bed):
+            raise FileNotFoundError(f"File does not exist: {bed}")
+        records, extra = _read_bed_records(bed)
+        if extra and not warned:
+            logger.info("More than 3 columns detected in the input BED files. Extra columns will be ignored.")
+            warned = True
+        combined.extend(records)
+    return _write_bed_records(_merge_bed_records(combined), output_file, name_features=name_features)
+
+
+# --------------------------------------------------------------------------------------------
+# scoring
+# --------------------------------------------------------------------------------------------
+
+def score_central_tendency_chrom_device(matrix_t, out_t=None):
+    """Column-wise median of a [K, n] float64/float32 CUDA tensor -> float64 CUDA tensor [n]."""
+    import torch
+
+    if matrix_t.ndim != 2:
+        raise ValueError("`chrom_matrix` must be a 2D array.")
+    if matrix_t.dtype not in (torch.float64, torch.float32):
+        matrix_t = matrix_t.to(torch.float64)
+    if matrix_t.stride(1) != 1:
+        matrix_t = matrix_t.contiguous()
+    K, n = int(matrix_t.shape[0]), int(matrix_t.shape[1])
+    if out_t is None:
+        out_t = torch.empty(n, dtype=torch.float64, device=matrix_t.device)
+    if n == 0:
+        return out_t
+    solver = _native.solver_for(matrix_t.device.index)
+    row_stride = int(matrix_t.stride(0)) if K > 1 else n
+    _native.check(_native.load().rocco_hip_score_median(
+        solver.handle, matrix_t.data_ptr(), 0 if matrix_t.dtype == torch.float64 else 1, K, n,
+        max(row_stride, n), out_t.data_ptr(), _dp._stream_ptr(matrix_t)), "rocco_hip_score_median")
+    return out_t
+
+
+def score_central_tendency_chrom(chrom_matrix, method="quantile", quantile=0.50, tprop=0.05, power=1.0):
+    r"""Return a column-wise location summary across samples (rocco/rocco.py:243-304).
+
+    The median branch -- the only one the reference's driver reaches (rocco/rocco.py:983-991) --
+    runs on the GPU.  The other branches of the reference (nearest quantile, trimmed mean, mean,
+    and `power` != 1) are not on the accelerated path and raise NotImplementedError here.
+    """
+    import torch
+
+    _native.load()
+    if _dp._is_tensor(chrom_matrix):
+        matrix_t = chrom_matrix
+        if matrix_t.ndim != 2:
+            raise ValueError("`chrom_matrix` must be a 2D array.")
+    else:
+        arr = np.asarray(chrom_matrix)
+        if arr.dtype != np.float32:
+            arr = np.asarray(arr, dtype=float)
+        if arr.ndim != 2:
+            raise ValueError("`chrom_matrix` must be a 2D array.")
+        matrix_t = torch.from_numpy(np.ascontiguousarray(arr)).to(f"cuda:{_dp._device_index()}")
+    method_ = str(method).strip().lower().replace("-", "").replace("_", "")
+    if matrix_t.shape[0] > 1:
+        if method_ == "quantile":
+            if not 0.0 <= quantile <= 1.0:
+                logger.warning("`quantile` must be in [0, 1]. Using the median instead.")
+                quantile = 0.50
+            if quantile != 0.50:
+                raise NotImplementedError("only the median (quantile=0.5) runs on the accelerated path")
+        elif method_ in ("tmean", "mean"):
+            raise NotImplementedError(f"method {method!r} is not on the accelerated path")
+        else:
+            raise ValueError(f"Central tendency method not recognized: {method}")
+    if power != 1.0:
+        raise NotImplementedError("`power` != 1.0 is not on the accelerated path")
+    if not matrix_t.is_cuda:
+        matrix_t = matrix_t.to(f"cuda:{_dp._device_index()}")
+    out = score_central_tendency_chrom_device(matrix_t)
+    return out.cpu().numpy()
+
+
+# --------------------------------------------------------------------------------------------
+# decode
+# --------------------------------------------------------------------------------------------
+
+def decode_runs_device(solution_t, capacity: Optional[int] = None):
+    """Maximal runs of selected loci among loci 0..n-2 as two int64 CUDA tensors (begin, end)."""
+    import torch
+
+    n = int(solution_t.shape[0])
+    if solution_t.dtype != torch.uint8:
+        solution_t = (solution_t > 0.5).to(torch.uint8)
+    solution_t = solution_t.contiguous()
+    solver = _native.solver_for(solution_t.device.index)
+    lib = _native.load()
+    cap = int(capacity) if capacity is not None else max(1024, n // 64)
+    while True:
+        begin_t = torch.empty(cap, dtype=torch.int64, device=solution_t.device)
+        end_t = torch.empty(cap, dtype=torch.int64, device=solution_t.device)
+        n_runs = ctypes.c_size_t(0)
+        _native.check(lib.rocco_hip_decode_runs(solver.handle, solution_t.data_ptr(), n,
+                                                begin_t.data_ptr(), end_t.data_ptr(), cap,
+                                                ctypes.byref(n_runs), _dp._stream_ptr(solution_t)),
+                      "rocco_hip_decode_runs")
+        if n_runs.value <= cap:
+            return begin_t[: n_runs.value], end_t[: n_runs.value]
+        cap = int(n_runs.value)
+
+
+def chrom_solution_records(chromosome, intervals, solution, check_gaps_intervals=True,
+                           min_length_bp=None) -> List[Record]:
+    """The merged records chrom_solution_to_bed writes (rocco/rocco.py:165-190), as a list."""
+    import torch
+
+    n = len(intervals)
+    n_sol = int(solution.shape[0]) if hasattr(solution, "shape") else len(solution)
+    if n != n_sol:
+        raise ValueError(
+            f"Intervals and solution must have the same length at the pre-merge stage: {n} != {n_sol}")
+    intervals_ = np.asarray(intervals)
+    if check_gaps_intervals and n > 1:
+        diffs = np.diff(intervals_)
+        if np.any(diffs != diffs[0]):
+            raise ValueError(f"Intervals must be contiguous: {set(diffs.tolist())}")
+    if n > 2 and np.any(np.diff(intervals_) <= 0):
+        raise NotImplementedError("non-increasing `intervals` are not supported by the device decode")
+    if _dp._is_tensor(solution):
+        sol_t = solution
+        if not sol_t.is_cuda:
+            sol_t = sol_t.to(f"cuda:{_dp._device_index()}")
+    else:
+        sol_np = np.ascontiguousarray(np.asarray(solution) > 0.50, dtype=np.uint8)
+        sol_t = torch.from_numpy(sol_np).to(f"cuda:{_dp._device_index()}")
+    begin_t, end_t = decode_runs_device(sol_t)
+    begins = begin_t.cpu().numpy()
+    ends = end_t.cpu().numpy()
+    starts_bp = intervals_[begins] if len(begins) else np.zeros(0, dtype=np.int64)
+    ends_bp = intervals_[ends] if len(ends) else np.zeros(0, dtype=np.int64)
+    chrom = str(chromosome)
+    return [(chrom, int(s), int(e)) for s, e in zip(starts_bp, ends_bp)
+            if min_length_bp is None or (int(e) - int(s)) >= int(min_length_bp)]
+
+
+def chrom_solution_to_bed(chromosome, intervals, solution, ID=None, check_gaps_intervals=True,
+                          min_length_bp=None) -> str:
+    r"""Convert the vector of decision variables of one chromosome to a BED file
+    (rocco/rocco.py:139-191): loci 0..n-2 with solution > 0.5 become (intervals[i], intervals[i+1]),
+    touching records are merged, records shorter than `min_length_bp` are dropped, and the file
+    `rocco_{ID}_{chromosome}.bed` (or `rocco_{chromosome}.bed`) is written in the working directory.
+    """
+    records = chrom_solution_records(chromosome, intervals, solution,
+                                     check_gaps_intervals=check_gaps_intervals,
+                                     min_length_bp=min_length_bp)
+    output_file = f"rocco_{chromosome}.bed" if ID is None else f"rocco_{ID}_{chromosome}.bed"
+    return _write_bed_records(records, output_file)
+
+
+# --------------------------------------------------------------------------------------------
+# per-rank solve driver
+# --------------------------------------------------------------------------------------------
+
+def solve_cached_chromosomes(chrom_cache: Dict[str, dict], chrom_budgets: Dict[str, float],
+                             selection_penalty: Optional[float] = None,
+                             min_length_bp: Optional[int] = None,
+                             run_id: Optional[str] = None, write_files: bool = True):
+    """Solve every chromosome in `chrom_cache` on the current GPU (rocco/rocco.py:890-930 and
+    1146-1196).  `chrom_cache[chrom]` holds "scores" (NumPy or CUDA tensor), "intervals" and
+    "gamma" as in the reference's cache.  Returns a list of
+    (chrom, objective, details, bed_path_or_records) in cache order.
+    """
+    import torch
+
+    chroms = list(chrom_cache)
+    scores_list = []
+    gammas = []
+    targets = []
+    for chrom in chroms:
+        data = chrom_cache[chrom]
+        try:
+            budget = float(chrom_budgets[chrom])
+        except (TypeError, ValueError) as exc:
+            raise ValueError(f"{chrom} budget could not be read as a finite number") from exc
+        try:
+            gamma = float(data["gamma"])
+        except (TypeError, ValueError) as exc:
+            raise ValueError(f"{chrom} gamma could not be read as a finite number") from exc
+        if not np.isfinite(budget) or budget < 0.0:
+            raise ValueError(f"{chrom} budget must be finite and non-negative")
+        if not np.isfinite(gamma) or gamma < 0.0:
+            raise ValueError(f"{chrom} gamma must be finite and non-negative")
+        s_t = _dp._to_device_f64(data["scores"])
+        if not bool(torch.isfinite(s_t).all()):
+            raise ValueError(f"{chrom} scores contain non-finite values")
+        scores_list.append(s_t)
+        gammas.append(gamma)
+        targets.append(int(np.floor(int(s_t.shape[0]) * budget)))  # rocco/dp.py:197
+
+    results = []
+    if selection_penalty is None:
+        solved = _dp.calibrate_batch_device(scores_list, gammas, targets)
+    else:
+        solved = []
+        for s_t, gamma in zip(scores_list, gammas):
+            sol_t, value, count, path = _dp.solve_penalized_chain_device(s_t, gamma, float(selection_penalty))
+            solved.append((float(selection_penalty), sol_t, value, count, {"path": path}))
+    for chrom, s_t, gamma, (penalty, sol_t, value, count, info) in zip(chroms, scores_list, gammas, solved):
+        objective = _dp.objective_value(sol_t, s_t, gamma)
+        details = {
+            "penalized_objective": float(value),
+            "selected_count": int(count),
+            "selected_fraction": float(count / int(s_t.shape[0])),
+            "selection_penalty": float(penalty),
+        }
+        data = chrom_cache[chrom]
+        if write_files:
+            out = chrom_solution_to_bed(chrom, data["intervals"], sol_t, run_id,
+                                        check_gaps_intervals=True, min_length_bp=min_length_bp)
+        else:
+            out = chrom_solution_records(chrom, data["intervals"], sol_t, check_gaps_intervals=True,
+                                         min_length_bp=min_length_bp)
+        logger.info("%s solve: selected=%s (%.6f), selection_penalty=%.6f, objective=%.4f", chrom,
+                    details["selected_count"], details["selected_fraction"],
+                    details["selection_penalty"], objective)
+        results.append((chrom, float(objective), details, out))
+    return results

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import pyoracle
+
+    pyoracle.build()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    torch.cuda.set_device(0)
+    return torch.device("cuda:0")
