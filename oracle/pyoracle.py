@@ -43,9 +43,30 @@ class WindowStats(ctypes.Structure):
         ("count_lo", ctypes.c_longlong),
         ("count_hi", ctypes.c_longlong),
         ("n_diff", ctypes.c_longlong),
-        ("first_diff", ctypes.c_longlong),
         ("diff_adjacent", ctypes.c_int),
+        ("overflow", ctypes.c_int),
         ("max_run", ctypes.c_longlong),
+    ]
+
+
+class WindowDiff(ctypes.Structure):
+    _fields_ = [
+        ("locus", ctypes.c_longlong),
+        ("margin_lo", ctypes.c_double),
+        ("margin_hi", ctypes.c_double),
+        ("run", ctypes.c_longlong),
+        ("cls_lo", ctypes.c_int),
+        ("cls_hi", ctypes.c_int),
+    ]
+
+
+class Noise(ctypes.Structure):
+    _fields_ = [
+        ("p16", ctypes.c_longlong),
+        ("npos", ctypes.c_longlong),
+        ("tau0", ctypes.c_double),
+        ("tau_step", ctypes.c_double),
+        ("guard", ctypes.c_double),
     ]
 
 
@@ -78,16 +99,19 @@ def lib() -> ctypes.CDLL:
         _lib.oracle_objective_value_f64.restype = ctypes.c_double
         _lib.oracle_objective_value_f64.argtypes = [
             _c_u8_p, _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t]
+        _lib.oracle_noise_model.restype = None
+        _lib.oracle_noise_model.argtypes = [
+            _c_double_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+            ctypes.c_double, ctypes.c_int, ctypes.POINTER(Noise)]
         _lib.oracle_delta_chain_f64.restype = ctypes.c_int
         _lib.oracle_delta_chain_f64.argtypes = [
-            _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double,
-            ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_u8_p,
-            ctypes.POINTER(DeltaStats)]
+            _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
+            ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_u8_p, ctypes.POINTER(DeltaStats)]
         _lib.oracle_delta_window_f64.restype = ctypes.c_int
         _lib.oracle_delta_window_f64.argtypes = [
             _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double,
-            ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
-            _c_u8_p, ctypes.POINTER(WindowStats)]
+            ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_u8_p,
+            ctypes.POINTER(WindowStats), ctypes.POINTER(WindowDiff), ctypes.c_int]
         _lib.oracle_median_columns.restype = ctypes.c_int
         _lib.oracle_median_columns.argtypes = [
             ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_double_p]
@@ -225,35 +249,66 @@ def solve_chrom_exact(scores, budget: Optional[float] = None, gamma: float = 1.0
 # delta-form recursion (sequential definition of the GPU fast path)
 # --------------------------------------------------------------------------------------------
 
-def delta_chain(scores, gamma_or_costs, selection_penalty: float, tau0: float, tau_step: float,
-                guard: float, m_cap: int, want_solution: bool = True):
+def grid_exponent(cmax: float, smin: float, smax: float) -> int:
+    """qexp such that every value of magnitude <= 8 R is exact on the grid 2^qexp, with
+    R = cmax + (smax - smin) + 2 (penalties are evaluated within [smin - 1, smax + 1])."""
+    r = float(cmax) + (float(smax) - float(smin)) + 2.0
+    import math
+    return int(math.ceil(math.log2(8.0 * r))) - 52
+
+
+def _costs(gamma_or_costs):
+    if np.isscalar(gamma_or_costs):
+        return None, float(gamma_or_costs), float(gamma_or_costs)
+    c = np.ascontiguousarray(gamma_or_costs, dtype=np.float64)
+    return c, 0.0, float(c.max()) if c.size else 0.0
+
+
+def noise_model(scores, selection_penalty: float, qexp: int, cmax: float, m_cap: int = 1048576):
+    scores_ = np.ascontiguousarray(scores, dtype=np.float64)
+    out = Noise()
+    lib().oracle_noise_model(_dptr(scores_), scores_.shape[0], float(selection_penalty), int(qexp),
+                             float(cmax), float(np.max(np.abs(scores_))), int(m_cap), ctypes.byref(out))
+    return {"p16": out.p16, "npos": out.npos, "tau0": out.tau0, "tau_step": out.tau_step, "guard": out.guard}
+
+
+def delta_chain(scores, gamma_or_costs, selection_penalty: float, qexp: int = None, m_cap: int = 1048576,
+                want_solution: bool = True):
     scores_ = np.ascontiguousarray(scores, dtype=np.float64)
     n = scores_.shape[0]
-    costs_ = None if np.isscalar(gamma_or_costs) else np.ascontiguousarray(gamma_or_costs, dtype=np.float64)
-    gamma = float(gamma_or_costs) if costs_ is None else 0.0
+    costs_, gamma, cmax = _costs(gamma_or_costs)
+    if qexp is None:
+        qexp = grid_exponent(cmax, scores_.min(), scores_.max())
     solution = np.zeros(n, dtype=np.uint8) if want_solution else None
     stats = DeltaStats()
     _check(lib().oracle_delta_chain_f64(_dptr(scores_), _dptr(costs_), gamma, n, float(selection_penalty),
-                                        float(tau0), float(tau_step), float(guard), int(m_cap),
+                                        int(qexp), cmax, float(np.max(np.abs(scores_))), int(m_cap),
                                         _u8ptr(solution), ctypes.byref(stats)))
     return solution, {"count": stats.count, "uncertain": stats.uncertain, "effect": stats.effect,
                       "max_run": stats.max_run}
 
 
-def delta_window(scores, gamma_or_costs, lambda_lo: float, lambda_hi: float, tau0: float,
-                 tau_step: float, guard: float, m_cap: int):
+def delta_window(scores, gamma_or_costs, lambda_lo: float, lambda_hi: float, qexp: int = None,
+                 m_cap: int = 1048576, diff_capacity: int = 16):
     scores_ = np.ascontiguousarray(scores, dtype=np.float64)
     n = scores_.shape[0]
-    costs_ = None if np.isscalar(gamma_or_costs) else np.ascontiguousarray(gamma_or_costs, dtype=np.float64)
-    gamma = float(gamma_or_costs) if costs_ is None else 0.0
+    costs_, gamma, cmax = _costs(gamma_or_costs)
+    if qexp is None:
+        qexp = grid_exponent(cmax, scores_.min(), scores_.max())
     solution = np.zeros(n, dtype=np.uint8)
     stats = WindowStats()
+    diffs = (WindowDiff * max(1, diff_capacity))()
     _check(lib().oracle_delta_window_f64(_dptr(scores_), _dptr(costs_), gamma, n, float(lambda_lo),
-                                         float(lambda_hi), float(tau0), float(tau_step), float(guard),
-                                         int(m_cap), _u8ptr(solution), ctypes.byref(stats)))
+                                         float(lambda_hi), int(qexp), cmax,
+                                         float(np.max(np.abs(scores_))), int(m_cap), _u8ptr(solution),
+                                         ctypes.byref(stats), diffs, int(diff_capacity)))
+    listed = min(int(stats.n_diff), diff_capacity)
     return solution, {"count_lo": stats.count_lo, "count_hi": stats.count_hi, "n_diff": stats.n_diff,
-                      "first_diff": stats.first_diff, "diff_adjacent": bool(stats.diff_adjacent),
-                      "max_run": stats.max_run}
+                      "diff_adjacent": bool(stats.diff_adjacent), "overflow": bool(stats.overflow),
+                      "max_run": stats.max_run,
+                      "diffs": [{"locus": int(d.locus), "margin_lo": d.margin_lo, "margin_hi": d.margin_hi,
+                                 "run": int(d.run), "cls_lo": d.cls_lo, "cls_hi": d.cls_hi}
+                                for d in diffs[:listed]]}
 
 
 # --------------------------------------------------------------------------------------------

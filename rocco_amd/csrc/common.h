@@ -47,7 +47,7 @@ struct rocco_hip_solver {
     // tunables
     int force_exact = 0;
     int spec_depth = 2;
-    int m_cap = 4096;
+    int m_cap = 1 << 20;
     // scratch
     rocco::DeviceBuffer dev_tasks;    // kernel task descriptors
     rocco::DeviceBuffer dev_params;   // per-launch lambda lists etc.

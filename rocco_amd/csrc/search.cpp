@@ -1,0 +1,535 @@
+// rocco_amd/csrc/search.cpp -- see search.h.  Pure host logic, no HIP.
+#include "search.h"
+
+#include <algorithm>
+#include <cmath>
+
+#include "../../include/rocco_hip.h"
+
+namespace rocco {
+
+namespace {
+
+// Midpoints of `depth` levels of the reference's bisection tree below (lower, upper), breadth
+// first.  Node i has children 2i+1 (count <= target: upper = mid) and 2i+2 (count > target:
+// lower = mid).  The midpoint expression is the reference's own (rocco/dp.py:143).
+void build_tree(double lower, double upper, int depth, std::vector<double> &mids)
+{
+    const size_t nodes = ((size_t)1 << depth) - 1;
+    std::vector<double> lo(nodes), hi(nodes);
+    mids.assign(nodes, 0.0);
+    if (nodes == 0) {
+        return;
+    }
+    lo[0] = lower;
+    hi[0] = upper;
+    for (size_t i = 0; i < nodes; ++i) {
+        const double mid = (lo[i] + hi[i]) / 2.0;
+        mids[i] = mid;
+        const size_t l = 2 * i + 1, r = 2 * i + 2;
+        if (l < nodes) {
+            lo[l] = lo[i];
+            hi[l] = mid;
+        }
+        if (r < nodes) {
+            lo[r] = mid;
+            hi[r] = hi[i];
+        }
+    }
+}
+
+enum class Outcome { kGreater, kLessEqual, kUncertain };
+
+Outcome classify(const ProbeResult &r, long long target)
+{
+    if (r.count - r.effect > target) {
+        return Outcome::kGreater;
+    }
+    if (r.count + r.effect <= target) {
+        return Outcome::kLessEqual;
+    }
+    return Outcome::kUncertain;
+}
+
+struct State {
+    enum Phase {
+        kAll,           // target == n: single solve at penalty 0 (rocco/dp.py:102-108)
+        kLowerBracket,  // rocco/dp.py:113-125
+        kUpperBracket,  // rocco/dp.py:127-138
+        kBisect,        // rocco/dp.py:141-162
+        kZone,          // an uncertain probe was met: joint window over the current bracket
+        kFinalExact,    // exact solve at the final penalty (writes the solution)
+        kDone
+    } phase = kLowerBracket;
+    long long target = 0;
+    double lower = 0.0, upper = 0.0;
+    int iters_left = 0;
+    bool use_exact = false;
+    CalibrationResult out;
+    // request in flight
+    int tree_depth = 0;
+    std::vector<double> tree;
+};
+
+// Advance through bracket / bisection steps whose outcome is known without device work.
+void advance_analytic(const ChainProblem &p, State &s)
+{
+    long long c = 0;
+    for (;;) {
+        if (s.phase == State::kLowerBracket) {
+            if (!analytic_count(p, s.lower, &c)) {
+                return;
+            }
+            ++s.out.evaluations;
+            if (c <= s.target) {
+                s.lower -= std::max(1.0, std::fabs(s.lower));
+            } else {
+                s.phase = State::kUpperBracket;
+            }
+        } else if (s.phase == State::kUpperBracket) {
+            if (!analytic_count(p, s.upper, &c)) {
+                return;
+            }
+            ++s.out.evaluations;
+            if (c > s.target) {
+                s.upper += std::max(1.0, std::fabs(s.upper));
+            } else {
+                s.phase = State::kBisect;
+            }
+        } else if (s.phase == State::kBisect) {
+            if (s.iters_left <= 0) {
+                return;
+            }
+            const double mid = (s.lower + s.upper) / 2.0;
+            if (!analytic_count(p, mid, &c)) {
+                return;
+            }
+            ++s.out.evaluations;
+            --s.iters_left;
+            if (c > s.target) {
+                s.lower = mid;
+            } else {
+                s.upper = mid;
+            }
+        } else {
+            return;
+        }
+    }
+}
+
+// Replay the remaining bisection steps when count > target  <=>  mid < critical.
+void replay_with_critical(State &s, double critical)
+{
+    while (s.iters_left > 0) {
+        const double mid = (s.lower + s.upper) / 2.0;
+        if (mid < critical) {
+            s.lower = mid;
+        } else {
+            s.upper = mid;
+        }
+        ++s.out.evaluations;
+        --s.iters_left;
+    }
+}
+
+}  // namespace
+
+bool analytic_count(const ChainProblem &p, double lambda, long long *count_out)
+{
+    // every partial sum of the reference stays far below 2^50 so that a margin of 1 in every
+    // decision dwarfs the rounding of its running values
+    const double mag = (double)p.n * (std::fabs(lambda) + std::max(std::fabs(p.score_min), std::fabs(p.score_max)) + p.cost_max + 1.0);
+    if (!(mag < 1.0e15) || !(p.cost_min >= 0.0)) {
+        return false;
+    }
+    if (lambda >= p.score_max + 1.0) {
+        *count_out = 0;
+        return true;
+    }
+    if (lambda <= p.score_min - 1.0) {
+        *count_out = (long long)p.n;
+        return true;
+    }
+    return false;
+}
+
+bool fast_path_applicable(const ChainProblem &p)
+{
+    if (!(p.cost_min >= 1.0e-3) || !(p.cost_max <= 1.0e6)) {
+        return false;
+    }
+    if (!std::isfinite(p.score_min) || !std::isfinite(p.score_max)) {
+        return false;
+    }
+    if (!(p.score_max - p.score_min <= 1.0e9) || !(std::max(std::fabs(p.score_min), std::fabs(p.score_max)) <= 1.0e12)) {
+        return false;
+    }
+    return p.n >= 1;
+}
+
+int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
+                    const SearchOptions &opt, std::vector<CalibrationResult> &results)
+{
+    const size_t B = problems.size();
+    std::vector<State> st(B);
+    for (size_t b = 0; b < B; ++b) {
+        const ChainProblem &p = problems[b];
+        State &s = st[b];
+        s.target = std::max(0LL, std::min(p.target_count, (long long)p.n));  // rocco/dp.py:101
+        s.lower = p.score_min - p.sum_costs - 1.0;                            // rocco/dp.py:110
+        s.upper = p.score_max + p.sum_costs + 1.0;                            // rocco/dp.py:111
+        s.iters_left = p.max_iter;
+        s.use_exact = opt.force_exact || !fast_path_applicable(p);
+        s.phase = (s.target == (long long)p.n) ? State::kAll : State::kLowerBracket;
+        s.out.zone_iters = -1;
+    }
+
+    for (;;) {
+        std::vector<ProbeRequest> probes;
+        std::vector<WindowRequest> windows;
+        std::vector<ExactRequest> exacts;
+        std::vector<size_t> probe_owner, window_owner, exact_owner;
+
+        for (size_t b = 0; b < B; ++b) {
+            const ChainProblem &p = problems[b];
+            State &s = st[b];
+            if (s.phase == State::kDone) {
+                continue;
+            }
+            advance_analytic(p, s);
+            if (s.phase == State::kBisect && s.iters_left <= 0) {
+                // every step was decided with certainty: the final penalty is `upper`
+                if (s.use_exact) {
+                    s.phase = State::kFinalExact;
+                } else {
+                    s.phase = State::kZone;  // degenerate zone [upper, upper]: certify + materialise
+                    s.lower = s.upper;
+                }
+            }
+            s.tree.clear();
+            s.tree_depth = 0;
+            switch (s.phase) {
+            case State::kAll:
+                if (s.use_exact) {
+                    ExactRequest r;
+                    r.problem = b;
+                    r.lambdas = {0.0};
+                    r.write_solution = true;
+                    exacts.push_back(r);
+                    exact_owner.push_back(b);
+                } else {
+                    WindowRequest r;
+                    r.problem = b;
+                    r.lambda_lo = r.lambda_hi = 0.0;
+                    windows.push_back(r);
+                    window_owner.push_back(b);
+                }
+                break;
+            case State::kLowerBracket:
+            case State::kUpperBracket: {
+                const double lam = (s.phase == State::kLowerBracket) ? s.lower : s.upper;
+                if (s.use_exact) {
+                    ExactRequest r;
+                    r.problem = b;
+                    r.lambdas = {lam};
+                    exacts.push_back(r);
+                    exact_owner.push_back(b);
+                } else {
+                    ProbeRequest r;
+                    r.problem = b;
+                    r.lambdas = {lam};
+                    probes.push_back(r);
+                    probe_owner.push_back(b);
+                }
+                break;
+            }
+            case State::kBisect: {
+                s.tree_depth = std::min(s.use_exact ? opt.exact_depth : opt.spec_depth, s.iters_left);
+                build_tree(s.lower, s.upper, s.tree_depth, s.tree);
+                if (s.use_exact) {
+                    ExactRequest r;
+                    r.problem = b;
+                    r.lambdas = s.tree;
+                    exacts.push_back(r);
+                    exact_owner.push_back(b);
+                } else {
+                    ProbeRequest r;
+                    r.problem = b;
+                    r.lambdas = s.tree;
+                    probes.push_back(r);
+                    probe_owner.push_back(b);
+                }
+                break;
+            }
+            case State::kZone: {
+                WindowRequest r;
+                r.problem = b;
+                r.lambda_lo = s.lower;
+                r.lambda_hi = s.upper;
+                windows.push_back(r);
+                window_owner.push_back(b);
+                break;
+            }
+            case State::kFinalExact: {
+                ExactRequest r;
+                r.problem = b;
+                r.lambdas = {s.upper};
+                r.write_solution = true;
+                exacts.push_back(r);
+                exact_owner.push_back(b);
+                break;
+            }
+            case State::kDone:
+                break;
+            }
+        }
+        if (probes.empty() && windows.empty() && exacts.empty()) {
+            break;
+        }
+        int rc;
+        if (!probes.empty() && (rc = ev.probe(probes)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        if (!windows.empty() && (rc = ev.window(windows)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        if (!exacts.empty() && (rc = ev.exact(exacts)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+
+        // ---- consume probe results ----
+        for (size_t q = 0; q < probes.size(); ++q) {
+            State &s = st[probe_owner[q]];
+            const ProbeRequest &r = probes[q];
+            ++s.out.passes;
+            if (s.phase == State::kLowerBracket || s.phase == State::kUpperBracket) {
+                const Outcome o = classify(r.results[0], s.target);
+                if (o == Outcome::kUncertain) {
+                    s.use_exact = true;  // redo this bracket step exactly
+                    continue;
+                }
+                ++s.out.evaluations;
+                if (s.phase == State::kLowerBracket) {
+                    if (o == Outcome::kLessEqual) {
+                        s.lower -= std::max(1.0, std::fabs(s.lower));
+                    } else {
+                        s.phase = State::kUpperBracket;
+                    }
+                } else {
+                    if (o == Outcome::kGreater) {
+                        s.upper += std::max(1.0, std::fabs(s.upper));
+                    } else {
+                        s.phase = State::kBisect;
+                    }
+                }
+                continue;
+            }
+            // kBisect: walk the evaluated levels while the outcomes are certain
+            size_t i = 0;
+            for (int level = 0; level < s.tree_depth; ++level) {
+                const Outcome o = classify(r.results[i], s.target);
+                if (o == Outcome::kUncertain) {
+                    s.phase = State::kZone;
+                    s.out.zone_iters = s.iters_left;
+                    break;
+                }
+                ++s.out.evaluations;
+                --s.iters_left;
+                if (o == Outcome::kGreater) {
+                    s.lower = r.lambdas[i];
+                    i = 2 * i + 2;
+                } else {
+                    s.upper = r.lambdas[i];
+                    i = 2 * i + 1;
+                }
+            }
+        }
+
+        // ---- consume window results ----
+        for (size_t q = 0; q < windows.size(); ++q) {
+            State &s = st[window_owner[q]];
+            const WindowResult &w = windows[q].result;
+            ++s.out.passes;
+            s.out.n_diff = w.n_diff;
+            if (s.phase == State::kAll) {
+                if (w.n_diff == 0 && !w.overflow) {
+                    s.out.selected_count = w.count_lo;
+                    s.out.selection_penalty = 0.0;
+                    s.out.evaluations = 1;
+                    s.out.path = ROCCO_HIP_PATH_CERTIFIED;
+                    s.phase = State::kDone;
+                } else {
+                    s.use_exact = true;
+                }
+                continue;
+            }
+            // kZone
+            bool certified = false;
+            if (!w.overflow && w.n_diff == 0 && w.count_lo <= s.target) {
+                // every remaining probe selects count_lo <= target loci: upper = mid each step
+                replay_with_critical(s, -INFINITY);
+                certified = true;
+            } else if (!w.overflow && w.n_diff == 1 && w.diff_adjacent && w.count_lo <= s.target &&
+                       w.count_hi > s.target && !w.diffs.empty()) {
+                // exactly one decision separates the two candidates; the reference keeps the one
+                // within budget.  The reported penalty follows the crossing of that decision.
+                const WindowDiff &d = w.diffs[0];
+                double critical = s.upper;
+                const double span = d.margin_lo - d.margin_hi;
+                if (span > 0.0 && d.margin_lo > 0.0 && d.margin_hi <= 0.0) {
+                    critical = s.lower + (d.margin_lo / span) * (s.upper - s.lower);
+                }
+                replay_with_critical(s, critical);
+                certified = true;
+            }
+            if (certified) {
+                s.out.selected_count = w.count_lo;
+                s.out.selection_penalty = s.upper;
+                s.out.path = ROCCO_HIP_PATH_CERTIFIED;
+                s.phase = State::kDone;
+            } else {
+                // not separable by the window: finish the reference's own steps exactly
+                s.use_exact = true;
+                s.phase = (s.iters_left > 0) ? State::kBisect : State::kFinalExact;
+            }
+        }
+
+        // ---- consume exact results ----
+        for (size_t q = 0; q < exacts.size(); ++q) {
+            State &s = st[exact_owner[q]];
+            const ExactRequest &r = exacts[q];
+            ++s.out.passes;
+            if (s.phase == State::kAll) {
+                s.out.selection_penalty = 0.0;
+                s.out.penalized_value = r.results[0].value;
+                s.out.selected_count = r.results[0].count;
+                s.out.evaluations = 1;
+                s.out.path = ROCCO_HIP_PATH_EXACT;
+                s.phase = State::kDone;
+            } else if (s.phase == State::kFinalExact) {
+                s.out.selection_penalty = s.upper;
+                s.out.penalized_value = r.results[0].value;
+                s.out.selected_count = r.results[0].count;
+                s.out.path = ROCCO_HIP_PATH_EXACT;
+                s.phase = State::kDone;
+            } else if (s.phase == State::kLowerBracket) {
+                ++s.out.evaluations;
+                if (r.results[0].count <= s.target) {
+                    s.lower -= std::max(1.0, std::fabs(s.lower));
+                } else {
+                    s.phase = State::kUpperBracket;
+                }
+            } else if (s.phase == State::kUpperBracket) {
+                ++s.out.evaluations;
+                if (r.results[0].count > s.target) {
+                    s.upper += std::max(1.0, std::fabs(s.upper));
+                } else {
+                    s.phase = State::kBisect;
+                }
+            } else if (s.phase == State::kBisect) {
+                size_t i = 0;
+                for (int level = 0; level < s.tree_depth; ++level) {
+                    ++s.out.evaluations;
+                    --s.iters_left;
+                    if (r.results[i].count > s.target) {
+                        s.lower = r.lambdas[i];
+                        i = 2 * i + 2;
+                    } else {
+                        s.upper = r.lambdas[i];
+                        i = 2 * i + 1;
+                    }
+                }
+                if (s.iters_left <= 0) {
+                    s.phase = State::kFinalExact;
+                }
+            }
+        }
+    }
+
+    results.resize(B);
+    for (size_t b = 0; b < B; ++b) {
+        State &s = st[b];
+        if (s.out.path == ROCCO_HIP_PATH_CERTIFIED) {
+            const int rc = ev.penalized_value(b, s.out.selection_penalty, s.out.selected_count,
+                                              &s.out.penalized_value);
+            if (rc != ROCCO_HIP_OK) {
+                return rc;
+            }
+        }
+        results[b] = s.out;
+    }
+    return ROCCO_HIP_OK;
+}
+
+int solve_fixed_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
+                      const std::vector<double> &lambdas, const SearchOptions &opt,
+                      std::vector<CalibrationResult> &results)
+{
+    const size_t B = problems.size();
+    results.assign(B, CalibrationResult());
+    std::vector<WindowRequest> windows;
+    std::vector<size_t> owner;
+    std::vector<char> need_exact(B, 0);
+    for (size_t b = 0; b < B; ++b) {
+        results[b].selection_penalty = lambdas[b];
+        results[b].evaluations = 1;
+        results[b].zone_iters = -1;
+        if (opt.force_exact || !fast_path_applicable(problems[b])) {
+            need_exact[b] = 1;
+            continue;
+        }
+        WindowRequest r;
+        r.problem = b;
+        r.lambda_lo = r.lambda_hi = lambdas[b];
+        windows.push_back(r);
+        owner.push_back(b);
+    }
+    int rc;
+    if (!windows.empty()) {
+        if ((rc = ev.window(windows)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        for (size_t q = 0; q < windows.size(); ++q) {
+            const size_t b = owner[q];
+            const WindowResult &w = windows[q].result;
+            results[b].passes = 1;
+            results[b].n_diff = w.n_diff;
+            if (w.n_diff == 0 && !w.overflow) {
+                results[b].selected_count = w.count_lo;
+                results[b].path = ROCCO_HIP_PATH_CERTIFIED;
+                if ((rc = ev.penalized_value(b, lambdas[b], w.count_lo, &results[b].penalized_value)) != ROCCO_HIP_OK) {
+                    return rc;
+                }
+            } else {
+                need_exact[b] = 1;
+            }
+        }
+    }
+    std::vector<ExactRequest> exacts;
+    std::vector<size_t> exact_owner;
+    for (size_t b = 0; b < B; ++b) {
+        if (need_exact[b]) {
+            ExactRequest r;
+            r.problem = b;
+            r.lambdas = {lambdas[b]};
+            r.write_solution = true;
+            exacts.push_back(r);
+            exact_owner.push_back(b);
+        }
+    }
+    if (!exacts.empty()) {
+        if ((rc = ev.exact(exacts)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        for (size_t q = 0; q < exacts.size(); ++q) {
+            const size_t b = exact_owner[q];
+            results[b].penalized_value = exacts[q].results[0].value;
+            results[b].selected_count = exacts[q].results[0].count;
+            results[b].path = ROCCO_HIP_PATH_EXACT;
+            ++results[b].passes;
+        }
+    }
+    return ROCCO_HIP_OK;
+}
+
+}  // namespace rocco

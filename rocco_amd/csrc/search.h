@@ -1,0 +1,122 @@
+// rocco_amd/csrc/search.h -- host-side replay of the reference's penalty calibration with
+// certification.  Pure C++ (no HIP): the device work is behind the Evaluator interface, so the
+// same code is compiled into librocco_hip.so (HIP evaluator) and into the CPU test harness
+// tests/host_logic/ (evaluator backed by the CPU oracle) where it is checked against the reference.
+//
+// What is replayed: rocco/dp.py:89-164 (bracket, bracket expansion, exactly max_iter bisection
+// steps with midpoint (lower + upper) / 2.0).  What is certified: DESIGN.md section 4.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace rocco {
+
+struct ChainProblem {
+    size_t n = 0;
+    double gamma = 0.0;     // scalar switch cost (ignored by evaluators that hold a cost vector)
+    bool has_cost_vector = false;
+    double cost_min = 0.0;  // min / max switch cost (== gamma for the scalar case)
+    double cost_max = 0.0;
+    double score_min = 0.0, score_max = 0.0;
+    long long target_count = 0;
+    double sum_costs = 0.0;  // np.sum(switch_costs) as NumPy computes it (rocco/dp.py:110-111)
+    int max_iter = 60;
+};
+
+struct ProbeResult {
+    long long count = 0;      // selected loci under the exact-rule classes
+    long long uncertain = 0;  // loci whose class is not certified
+    long long effect = 0;     // bound on |count(reference) - count|
+    long long max_run = 0;
+};
+
+struct WindowDiff {
+    long long locus = 0;
+    double margin_lo = 0.0, margin_hi = 0.0;  // delta - decision boundary at lambda_lo / lambda_hi
+    long long run = 0;
+    int cls_lo = 0, cls_hi = 0;
+};
+
+struct WindowResult {
+    long long count_lo = 0, count_hi = 0;
+    long long n_diff = 0;
+    bool diff_adjacent = true;
+    bool overflow = false;
+    long long max_run = 0;
+    std::vector<WindowDiff> diffs;
+};
+
+struct ExactResult {
+    double value = 0.0;
+    long long count = 0;
+};
+
+// One batch round of device work.  Indices refer to the problems of the batch.
+struct ProbeRequest {
+    size_t problem = 0;
+    std::vector<double> lambdas;
+    std::vector<ProbeResult> results;  // filled by the evaluator
+};
+
+struct WindowRequest {
+    size_t problem = 0;
+    double lambda_lo = 0.0, lambda_hi = 0.0;
+    WindowResult result;  // filled by the evaluator; the solution buffer of the problem = fill(LO)
+};
+
+struct ExactRequest {
+    size_t problem = 0;
+    std::vector<double> lambdas;  // <= 64
+    bool write_solution = false;  // solution for lambdas[0]
+    std::vector<ExactResult> results;
+};
+
+class Evaluator {
+public:
+    virtual ~Evaluator() = default;
+    // delta-form evaluation of every (problem, lambda): count + certification statistics
+    virtual int probe(std::vector<ProbeRequest> &reqs) = 0;
+    // joint window evaluation, writes fill(LO) into the problem's solution buffer
+    virtual int window(std::vector<WindowRequest> &reqs) = 0;
+    // exact emulation of the reference (always correct)
+    virtual int exact(std::vector<ExactRequest> &reqs) = 0;
+    // penalised value  sum (s - lambda) z - sum c |dz|  of the solution currently in the buffer
+    virtual int penalized_value(size_t problem, double lambda, long long count, double *value_out) = 0;
+};
+
+struct CalibrationResult {
+    double selection_penalty = 0.0;
+    double penalized_value = 0.0;
+    long long selected_count = 0;
+    int evaluations = 0;   // chain evaluations the reference would have made
+    int path = 0;          // ROCCO_HIP_PATH_*
+    int passes = 0;        // device rounds this problem took part in
+    int zone_iters = 0;    // bisection steps left when the first uncertain probe was met (-1: none)
+    long long n_diff = -1; // window differences (-1: no window evaluated)
+};
+
+struct SearchOptions {
+    int spec_depth = 2;     // levels of the bisection tree evaluated per probe round
+    int exact_depth = 6;    // same for the exact kernel (63 lanes)
+    bool force_exact = false;
+};
+
+// Calibrate every problem of the batch; solutions are left in the evaluator's solution buffers.
+int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
+                    const SearchOptions &opt, std::vector<CalibrationResult> &results);
+
+// Fixed-penalty solve (rocco/dp.py:49-86) with certification, exact fallback.
+int solve_fixed_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
+                      const std::vector<double> &lambdas, const SearchOptions &opt,
+                      std::vector<CalibrationResult> &results);
+
+// Is the fast path applicable to this problem at all (cost not degenerate, sizes sane)?
+bool fast_path_applicable(const ChainProblem &p);
+
+// Penalties whose outcome is known without evaluation (rocco/_chain_dp.c semantics):
+// lambda >= score_max + 1 selects nothing, lambda <= score_min - 1 selects everything.
+bool analytic_count(const ChainProblem &p, double lambda, long long *count_out);
+
+}  // namespace rocco
