@@ -48,7 +48,7 @@ int rocco_hip_solver_create(rocco_hip_solver **solver_out, int device);
 void rocco_hip_solver_destroy(rocco_hip_solver *solver);
 
 /* Tunables (speculation depth of the lambda search, force the exact kernel, ...).  Unknown keys
- * return ROCCO_HIP_EINVAL.  Keys: "force_exact" (0/1), "spec_depth" (1..6), "m_cap". */
+ * return ROCCO_HIP_EINVAL.  Keys: "force_exact" (0/1), "spec_depth" (1..6). */
 int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long value);
 
 /* ---- scoring -------------------------------------------------------------------------------
@@ -73,17 +73,18 @@ int rocco_hip_solve_penalized_chain_f64(rocco_hip_solver *solver, const double *
 
 /* ---- budgeted solve, one launch sequence for a batch of chromosomes -------------------------
  * Replaces rocco/dp.py:89-164 `calibrate_selection_penalty` (bracket + exactly `max_iter`
- * bisection steps on the selection penalty) for every task in the batch at once.  The caller
- * supplies the bracket seeds exactly as the reference computes them on the host
- * (rocco/dp.py:110-111: lower = min(s) - sum(c) - 1, upper = max(s) + sum(c) + 1, with NumPy's
- * np.min / np.max / pairwise np.sum), because their last bits fix the midpoint sequence. */
+ * bisection steps on the selection penalty) for every task in the batch at once.  The bracket
+ * seeds are formed as the reference does (rocco/dp.py:110-111: lower = min(s) - sum(c) - 1,
+ * upper = max(s) + sum(c) + 1): min / max are computed on the device (exact), `sum_costs` must be
+ * supplied by the caller as NumPy's pairwise np.sum(switch_costs) gives it, because its last bits
+ * fix the midpoint sequence. */
 typedef struct {
     const double *scores_dev;       /* n doubles                                        */
     const double *switch_costs_dev; /* n-1 doubles or NULL (use gamma)                  */
     double gamma;
     size_t n;
     long long target_count;         /* int(floor(n * budget)), rocco/dp.py:197          */
-    double lower0, upper0;          /* rocco/dp.py:110-111                              */
+    double sum_costs;               /* np.sum(switch_costs), rocco/dp.py:110-111        */
     int max_iter;                   /* 60 in the reference (rocco/dp.py:93)             */
     uint8_t *solution_dev;          /* n bytes out                                      */
 } rocco_hip_budget_task;
@@ -94,12 +95,51 @@ typedef struct {
     long long selected_count; /* best_count                                                      */
     int evaluations;          /* chain evaluations the reference would have made (62 normally)   */
     int path;                 /* ROCCO_HIP_PATH_*                                                */
-    int passes;               /* device passes over the scores actually made                     */
+    int passes;               /* device rounds this task took part in                            */
+    int zone_iters;           /* bisection steps left at the first uncertain probe (-1: none)    */
+    long long n_diff;         /* decisions left open by the final window (-1: no window)         */
 } rocco_hip_budget_result;
 
 int rocco_hip_solve_budget_batch_f64(rocco_hip_solver *solver, size_t n_tasks,
                                      const rocco_hip_budget_task *tasks,
                                      rocco_hip_budget_result *results, void *stream);
+
+/* ---- delta-form evaluation (the parallel kernels behind the two solves above) ----------------
+ * Count-only evaluation of the chain at several penalties in one pass over the scores, with the
+ * certification statistics of DESIGN.md section 4, and the joint "window" evaluation over a
+ * penalty interval.  These are what rocco_hip_solve_budget_batch_f64 drives; they are exported so
+ * that the kernels can be checked bit-for-bit against their sequential definition
+ * (oracle/delta_oracle.c) and so that callers can run their own searches.  They stand where the
+ * reference calls rocco/_chain_dp.c once per penalty (rocco/dp.py:113-162). */
+typedef struct {
+    long long count;     /* selected loci under the exact-rule classes                          */
+    long long uncertain; /* loci whose class is not certified                                   */
+    long long effect;    /* bound on |count(reference) - count| (n + 1 if the model overflowed) */
+    long long max_run;   /* longest run without a provable clear clamp                          */
+} rocco_hip_probe_stats;
+
+int rocco_hip_delta_probe_f64(rocco_hip_solver *solver, const double *scores_dev,
+                              const double *switch_costs_dev, double gamma, size_t n,
+                              const double *lambdas, size_t n_lambdas,
+                              rocco_hip_probe_stats *stats_out, void *stream);
+
+typedef struct {
+    long long count_lo, count_hi; /* selected loci of fill(LO) / fill(HI)                 */
+    long long n_diff;             /* loci whose class differs between LO and HI           */
+    int diff_adjacent;            /* every difference is one class step                   */
+    int overflow;                 /* tolerance model exceeded somewhere                   */
+    long long max_run;
+    long long diff_locus[16];     /* first differences, ascending (-1 = unused)           */
+    double diff_margin_lo[16], diff_margin_hi[16];
+    long long diff_run[16];
+    int diff_cls_lo[16], diff_cls_hi[16];
+} rocco_hip_window_stats;
+
+/* Writes fill(LO) (n bytes) to solution_dev. */
+int rocco_hip_delta_window_f64(rocco_hip_solver *solver, const double *scores_dev,
+                               const double *switch_costs_dev, double gamma, size_t n,
+                               double lambda_lo, double lambda_hi, uint8_t *solution_dev,
+                               rocco_hip_window_stats *stats_out, void *stream);
 
 /* ---- objective ------------------------------------------------------------------------------
  * Replaces rocco/dp.py:16-34 `objective_value`: -(s . z) + c . |diff z|  (fixed-order tree sum;

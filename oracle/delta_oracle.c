@@ -15,12 +15,13 @@
  *    recursion is exactly associative, and any parallel decomposition gives identical bits.
  *  - noise model: P16 = sum floor(16 * max(a_i, 0)) and npos = #{a_i > 0} (exact integers);
  *    Pb = 2 * ((P16 + npos) / 16 + cmax + sabs + |lambda| + 1) bounds every intermediate of the
- *    reference's pass; h = 2^(ilogb(Pb) - 53); tau_step = 4h + q; tau0 = 9h + 2q;
- *    guard = tau0 + tau_step * m_cap.
+ *    reference's pass; h = 2^(ilogb(Pb) - 53); tau_step = 4h + q; tau0 = 9h + 2q.
+ *    guard = ORACLE_GUARD = 2^-16 (constant): a clamp is "clear" when |delta| - c > guard.
  *  - chunks of ORACLE_CHUNK = 32 loci: inside a chunk two extreme chains start from the clamp
  *    bounds (+c, -c); a locus is "known" once they agree; a known locus with |delta| - c > guard is a
  *    provable clear clamp; m_j = j - 1 - (last provable clear clamp before j).
- *  - tau_j = tau0 + tau_step * m_j; locus j is certain iff m_j <= m_cap and ||delta_j| - c_j| > tau_j.
+ *  - tau_j = tau0 + tau_step * m_j; locus j is certain iff tau_j <= guard and ||delta_j| - c_j| > tau_j
+ *    (tau_j > guard = "overflow": the tolerance model no longer covers that locus).
  */
 #include "oracle.h"
 
@@ -54,7 +55,7 @@ static void fill_backward(const uint8_t *cls, size_t n, uint8_t *solution, long 
 }
 
 void oracle_noise_model(const double *scores, size_t n, double lambda, int qexp, double cmax,
-                        double sabs, int m_cap, oracle_noise *out)
+                        double sabs, oracle_noise *out)
 {
     const double magic = ldexp(1.5, 52 + qexp);
     long long p16 = 0, npos = 0;
@@ -72,11 +73,11 @@ void oracle_noise_model(const double *scores, size_t n, double lambda, int qexp,
     out->npos = npos;
     out->tau_step = 4.0 * h + q;
     out->tau0 = 9.0 * h + 2.0 * q;
-    out->guard = out->tau0 + out->tau_step * (double)m_cap;
+    out->guard = ORACLE_GUARD;
 }
 
 int oracle_delta_chain_f64(const double *scores, const double *switch_costs, double gamma, size_t n,
-                           double selection_penalty, int qexp, double cmax, double sabs, int m_cap,
+                           double selection_penalty, int qexp, double cmax, double sabs,
                            uint8_t *solution, oracle_delta_stats *stats)
 {
     if (scores == NULL || n == 0 || stats == NULL) {
@@ -87,13 +88,14 @@ int oracle_delta_chain_f64(const double *scores, const double *switch_costs, dou
         return -1;
     }
     oracle_noise nz;
-    oracle_noise_model(scores, n, selection_penalty, qexp, cmax, sabs, m_cap, &nz);
+    oracle_noise_model(scores, n, selection_penalty, qexp, cmax, sabs, &nz);
     const double magic = ldexp(1.5, 52 + qexp);
     const double lam = selection_penalty;
     const double gq = grid_round(gamma, magic);
     double delta = 0.0, up = 0.0, dn = 0.0;
     long long last_clear = -1;
     long long uncertain = 0, effect = 0, max_run = 0;
+    int overflow = 0;
 
     for (size_t j = 0; j < n; ++j) {
         const double a = grid_round(scores[j] - lam, magic);
@@ -120,15 +122,18 @@ int oracle_delta_chain_f64(const double *scores, const double *switch_costs, dou
         if (j + 1 < n) {
             const double cj = (switch_costs != NULL) ? grid_round(switch_costs[j], magic) : gq;
             const double e = fabs(delta) - cj;
-            certain = (m <= m_cap) && (e > tau || e < -tau);
+            certain = (tau <= nz.guard) && (e > tau || e < -tau);
             k = (delta > cj) ? CLS_ONE : ((delta < -cj) ? CLS_ZERO : CLS_COPY);
             if (up == dn && e > nz.guard) {
                 last_clear = (long long)j;
             }
         } else {
             const double e = fabs(delta);
-            certain = (m <= m_cap) && (e > tau);
+            certain = (tau <= nz.guard) && (e > tau);
             k = (delta > 0.0) ? CLS_ONE : CLS_ZERO;
+        }
+        if (tau > nz.guard) {
+            overflow = 1;
         }
         if (!certain) {
             ++uncertain;
@@ -140,13 +145,14 @@ int oracle_delta_chain_f64(const double *scores, const double *switch_costs, dou
     stats->uncertain = uncertain;
     stats->effect = effect;
     stats->max_run = max_run;
+    stats->overflow = overflow;
     free(cls);
     return 0;
 }
 
 int oracle_delta_window_f64(const double *scores, const double *switch_costs, double gamma, size_t n,
                             double lambda_lo, double lambda_hi, int qexp, double cmax, double sabs,
-                            int m_cap, uint8_t *solution, oracle_window_stats *stats,
+                            uint8_t *solution, oracle_window_stats *stats,
                             oracle_window_diff *diffs, int diff_capacity)
 {
     if (scores == NULL || n == 0 || stats == NULL || !(lambda_lo <= lambda_hi)) {
@@ -160,7 +166,7 @@ int oracle_delta_window_f64(const double *scores, const double *switch_costs, do
         return -1;
     }
     oracle_noise nz;
-    oracle_noise_model(scores, n, lambda_lo, qexp, cmax, sabs, m_cap, &nz);
+    oracle_noise_model(scores, n, lambda_lo, qexp, cmax, sabs, &nz);
     const double magic = ldexp(1.5, 52 + qexp);
     const double gq = grid_round(gamma, magic);
     /* "lo" chain uses lambda_lo (larger delta), "hi" chain uses lambda_hi (smaller delta) */
@@ -224,7 +230,7 @@ int oracle_delta_window_f64(const double *scores, const double *switch_costs, do
             lo = (d_hi > tau) ? CLS_ONE : CLS_ZERO;
             hi = (d_lo > -tau) ? CLS_ONE : CLS_ZERO;
         }
-        if (m > m_cap) { /* tolerance model no longer valid */
+        if (tau > nz.guard) { /* tolerance model no longer valid */
             overflow = 1;
         }
         if (lo != hi) {

@@ -35,6 +35,7 @@ class DeltaStats(ctypes.Structure):
         ("uncertain", ctypes.c_longlong),
         ("effect", ctypes.c_longlong),
         ("max_run", ctypes.c_longlong),
+        ("overflow", ctypes.c_int),
     ]
 
 
@@ -102,15 +103,15 @@ def lib() -> ctypes.CDLL:
         _lib.oracle_noise_model.restype = None
         _lib.oracle_noise_model.argtypes = [
             _c_double_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_int, ctypes.c_double,
-            ctypes.c_double, ctypes.c_int, ctypes.POINTER(Noise)]
+            ctypes.c_double, ctypes.POINTER(Noise)]
         _lib.oracle_delta_chain_f64.restype = ctypes.c_int
         _lib.oracle_delta_chain_f64.argtypes = [
             _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
-            ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_u8_p, ctypes.POINTER(DeltaStats)]
+            ctypes.c_double, ctypes.c_double, _c_u8_p, ctypes.POINTER(DeltaStats)]
         _lib.oracle_delta_window_f64.restype = ctypes.c_int
         _lib.oracle_delta_window_f64.argtypes = [
             _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double,
-            ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_u8_p,
+            ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, _c_u8_p,
             ctypes.POINTER(WindowStats), ctypes.POINTER(WindowDiff), ctypes.c_int]
         _lib.oracle_median_columns.restype = ctypes.c_int
         _lib.oracle_median_columns.argtypes = [
@@ -264,15 +265,15 @@ def _costs(gamma_or_costs):
     return c, 0.0, float(c.max()) if c.size else 0.0
 
 
-def noise_model(scores, selection_penalty: float, qexp: int, cmax: float, m_cap: int = 1048576):
+def noise_model(scores, selection_penalty: float, qexp: int, cmax: float):
     scores_ = np.ascontiguousarray(scores, dtype=np.float64)
     out = Noise()
     lib().oracle_noise_model(_dptr(scores_), scores_.shape[0], float(selection_penalty), int(qexp),
-                             float(cmax), float(np.max(np.abs(scores_))), int(m_cap), ctypes.byref(out))
+                             float(cmax), float(np.max(np.abs(scores_))), ctypes.byref(out))
     return {"p16": out.p16, "npos": out.npos, "tau0": out.tau0, "tau_step": out.tau_step, "guard": out.guard}
 
 
-def delta_chain(scores, gamma_or_costs, selection_penalty: float, qexp: int = None, m_cap: int = 1048576,
+def delta_chain(scores, gamma_or_costs, selection_penalty: float, qexp: int = None,
                 want_solution: bool = True):
     scores_ = np.ascontiguousarray(scores, dtype=np.float64)
     n = scores_.shape[0]
@@ -282,14 +283,14 @@ def delta_chain(scores, gamma_or_costs, selection_penalty: float, qexp: int = No
     solution = np.zeros(n, dtype=np.uint8) if want_solution else None
     stats = DeltaStats()
     _check(lib().oracle_delta_chain_f64(_dptr(scores_), _dptr(costs_), gamma, n, float(selection_penalty),
-                                        int(qexp), cmax, float(np.max(np.abs(scores_))), int(m_cap),
+                                        int(qexp), cmax, float(np.max(np.abs(scores_))),
                                         _u8ptr(solution), ctypes.byref(stats)))
     return solution, {"count": stats.count, "uncertain": stats.uncertain, "effect": stats.effect,
-                      "max_run": stats.max_run}
+                      "max_run": stats.max_run, "overflow": bool(stats.overflow)}
 
 
 def delta_window(scores, gamma_or_costs, lambda_lo: float, lambda_hi: float, qexp: int = None,
-                 m_cap: int = 1048576, diff_capacity: int = 16):
+                 diff_capacity: int = 16):
     scores_ = np.ascontiguousarray(scores, dtype=np.float64)
     n = scores_.shape[0]
     costs_, gamma, cmax = _costs(gamma_or_costs)
@@ -300,7 +301,7 @@ def delta_window(scores, gamma_or_costs, lambda_lo: float, lambda_hi: float, qex
     diffs = (WindowDiff * max(1, diff_capacity))()
     _check(lib().oracle_delta_window_f64(_dptr(scores_), _dptr(costs_), gamma, n, float(lambda_lo),
                                          float(lambda_hi), int(qexp), cmax,
-                                         float(np.max(np.abs(scores_))), int(m_cap), _u8ptr(solution),
+                                         float(np.max(np.abs(scores_))), _u8ptr(solution),
                                          ctypes.byref(stats), diffs, int(diff_capacity)))
     listed = min(int(stats.n_diff), diff_capacity)
     return solution, {"count_lo": stats.count_lo, "count_hi": stats.count_hi, "n_diff": stats.n_diff,

@@ -30,8 +30,7 @@ class BudgetTask(ctypes.Structure):
         ("gamma", ctypes.c_double),
         ("n", ctypes.c_size_t),
         ("target_count", ctypes.c_longlong),
-        ("lower0", ctypes.c_double),
-        ("upper0", ctypes.c_double),
+        ("sum_costs", ctypes.c_double),
         ("max_iter", ctypes.c_int),
         ("solution_dev", ctypes.c_void_p),
     ]
@@ -45,6 +44,34 @@ class BudgetResult(ctypes.Structure):
         ("evaluations", ctypes.c_int),
         ("path", ctypes.c_int),
         ("passes", ctypes.c_int),
+        ("zone_iters", ctypes.c_int),
+        ("n_diff", ctypes.c_longlong),
+    ]
+
+
+class ProbeStats(ctypes.Structure):
+    _fields_ = [
+        ("count", ctypes.c_longlong),
+        ("uncertain", ctypes.c_longlong),
+        ("effect", ctypes.c_longlong),
+        ("max_run", ctypes.c_longlong),
+    ]
+
+
+class WindowStats(ctypes.Structure):
+    _fields_ = [
+        ("count_lo", ctypes.c_longlong),
+        ("count_hi", ctypes.c_longlong),
+        ("n_diff", ctypes.c_longlong),
+        ("diff_adjacent", ctypes.c_int),
+        ("overflow", ctypes.c_int),
+        ("max_run", ctypes.c_longlong),
+        ("diff_locus", ctypes.c_longlong * 16),
+        ("diff_margin_lo", ctypes.c_double * 16),
+        ("diff_margin_hi", ctypes.c_double * 16),
+        ("diff_run", ctypes.c_longlong * 16),
+        ("diff_cls_lo", ctypes.c_int * 16),
+        ("diff_cls_hi", ctypes.c_int * 16),
     ]
 
 
@@ -64,6 +91,12 @@ PROTOTYPES = [
     ("rocco_hip_solve_budget_batch_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(BudgetTask), ctypes.POINTER(BudgetResult),
       ctypes.c_void_p]),
+    ("rocco_hip_delta_probe_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t,
+      c_double_p, ctypes.c_size_t, ctypes.POINTER(ProbeStats), ctypes.c_void_p]),
+    ("rocco_hip_delta_window_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t,
+      ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.POINTER(WindowStats), ctypes.c_void_p]),
     ("rocco_hip_objective_value_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
       ctypes.c_size_t, c_double_p, ctypes.c_void_p]),

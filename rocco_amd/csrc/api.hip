@@ -110,6 +110,7 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->dev_results.release();
     solver->dev_bits.release();
     solver->dev_misc.release();
+    solver->dev_solution.release();
     solver->host_stage.release();
     solver->host_back.release();
     delete solver;
@@ -128,11 +129,6 @@ int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long va
             return ROCCO_HIP_EINVAL;
         }
         solver->spec_depth = (int)value;
-    } else if (k == "m_cap") {
-        if (value < 1 || value > (1 << 20)) {
-            return ROCCO_HIP_EINVAL;
-        }
-        solver->m_cap = (int)value;
     } else {
         set_last_error("rocco_hip_solver_set: unknown key " + k);
         return ROCCO_HIP_EINVAL;
@@ -180,6 +176,34 @@ int rocco_hip_solve_budget_batch_f64(rocco_hip_solver *solver, size_t n_tasks,
     }
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
     return solve_budget_batch(solver, n_tasks, tasks, results, (hipStream_t)stream);
+}
+
+int rocco_hip_delta_probe_f64(rocco_hip_solver *solver, const double *scores_dev,
+                              const double *switch_costs_dev, double gamma, size_t n,
+                              const double *lambdas, size_t n_lambdas,
+                              rocco_hip_probe_stats *stats_out, void *stream)
+{
+    if (solver == nullptr || scores_dev == nullptr || n == 0 || n >= ((size_t)1 << 31) ||
+        (n_lambdas > 0 && (lambdas == nullptr || stats_out == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return delta_probe(solver, scores_dev, switch_costs_dev, gamma, n, lambdas, n_lambdas, stats_out,
+                       (hipStream_t)stream);
+}
+
+int rocco_hip_delta_window_f64(rocco_hip_solver *solver, const double *scores_dev,
+                               const double *switch_costs_dev, double gamma, size_t n,
+                               double lambda_lo, double lambda_hi, uint8_t *solution_dev,
+                               rocco_hip_window_stats *stats_out, void *stream)
+{
+    if (solver == nullptr || scores_dev == nullptr || n == 0 || n >= ((size_t)1 << 31) ||
+        solution_dev == nullptr || stats_out == nullptr || !(lambda_lo <= lambda_hi)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return delta_window(solver, scores_dev, switch_costs_dev, gamma, n, lambda_lo, lambda_hi, solution_dev,
+                        stats_out, (hipStream_t)stream);
 }
 
 int rocco_hip_objective_value_f64(rocco_hip_solver *solver, const uint8_t *solution_dev,

@@ -1,145 +1,463 @@
-// rocco_amd/csrc/budget.hip -- host orchestration: replay of the reference's penalty calibration
-// (rocco/dp.py:89-164) over batches of chromosomes, with the device doing every chain evaluation.
+// rocco_amd/csrc/budget.hip -- device-side Evaluator for the host search logic (search.cpp) and the
+// two solve entry points built on it.
 //
-// The reference evaluates the chain 2 + 60 times strictly one after another.  Here several levels
-// of its bisection tree are evaluated speculatively in one device pass (the midpoints are formed
-// with the reference's own expression (lower + upper) / 2.0, rocco/dp.py:143, so the visited
-// penalties are bit-identical), and all chromosomes of a batch share each pass.
+// search.cpp replays the reference's calibration (rocco/dp.py:89-164) and asks for three kinds of
+// device work; this file turns each request batch into launches:
+//   probe  -> one fast round (chain_fast.hip) over every (chromosome, penalty) of the batch
+//   window -> one fast round in window mode (also materialises fill(LO) into the solution buffers)
+//   exact  -> the sequential emulation kernel (chain_exact.hip), one wavefront per chromosome
 #include "budget.h"
 
 #include <algorithm>
 #include <cmath>
 
+#include "chain_fast.h"
+#include "search.h"
+
 namespace rocco {
 
 namespace {
 
-struct EvalRequest {
-    size_t task = 0;
-    std::vector<double> lambdas;  // 1..64 penalties
-    bool record = false;          // write the 0/1 solution for lambdas[0]
-    std::vector<double> values;
-    std::vector<long long> counts;
+struct DevProblem {
+    const double *scores = nullptr;
+    const double *costs = nullptr;
+    double gamma = 0.0;
+    size_t n = 0;
+    uint8_t *solution = nullptr;
+    int qexp = 0;
+    double cmax = 0.0, sabs = 0.0;
 };
 
-// Evaluate every request with the exact kernel: one wavefront per request, one lane per penalty.
-int exact_evaluate(rocco_hip_solver *solver, const rocco_hip_budget_task *tasks,
-                   std::vector<EvalRequest> &reqs, hipStream_t stream)
+int grid_exponent(double cmax, double lo, double hi)
 {
-    const size_t R = reqs.size();
-    if (R == 0) {
+    const double r = cmax + (hi - lo) + 2.0;
+    return (int)std::ceil(std::log2(8.0 * r)) - 52;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+class HipEvaluator : public Evaluator {
+public:
+    HipEvaluator(rocco_hip_solver *solver, hipStream_t stream) : solver_(solver), stream_(stream) {}
+
+    std::vector<DevProblem> probs;
+
+    int probe(std::vector<ProbeRequest> &reqs) override
+    {
+        std::vector<RoundTask> tasks;
+        for (ProbeRequest &r : reqs) {
+            r.results.assign(r.lambdas.size(), ProbeResult());
+            if (r.lambdas.empty()) {
+                continue;
+            }
+            RoundTask t;
+            t.problem = r.problem;
+            t.window = false;
+            t.lambdas = r.lambdas;
+            t.probe = &r;
+            tasks.push_back(t);
+        }
+        return run_round(tasks);
+    }
+
+    int window(std::vector<WindowRequest> &reqs) override
+    {
+        std::vector<RoundTask> tasks;
+        for (WindowRequest &r : reqs) {
+            RoundTask t;
+            t.problem = r.problem;
+            t.window = true;
+            t.lambdas = {r.lambda_lo, r.lambda_hi};
+            t.win = &r;
+            tasks.push_back(t);
+        }
+        return run_round(tasks);
+    }
+
+    int exact(std::vector<ExactRequest> &reqs) override
+    {
+        const size_t R = reqs.size();
+        if (R == 0) {
+            return ROCCO_HIP_OK;
+        }
+        size_t words_total = 0;
+        for (const ExactRequest &r : reqs) {
+            if (r.lambdas.empty() || r.lambdas.size() > 64) {
+                return ROCCO_HIP_EINVAL;
+            }
+            if (r.write_solution) {
+                words_total += (probs[r.problem].n + 30) / 32 + 1;
+            }
+        }
+        int rc;
+        if ((rc = solver_->dev_tasks.reserve(R * sizeof(ExactTask))) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->dev_params.reserve(R * 64 * sizeof(double))) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->dev_results.reserve(R * 64 * (sizeof(double) + sizeof(long long)))) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->dev_bits.reserve(words_total * sizeof(unsigned long long) + 8)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_stage.reserve(R * sizeof(ExactTask) + R * 64 * sizeof(double))) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_back.reserve(R * 64 * (sizeof(double) + sizeof(long long)))) != ROCCO_HIP_OK) return rc;
+
+        ExactTask *h_tasks = (ExactTask *)solver_->host_stage.ptr;
+        double *h_lams = (double *)((char *)solver_->host_stage.ptr + R * sizeof(ExactTask));
+        double *d_lams = (double *)solver_->dev_params.ptr;
+        double *d_vals = (double *)solver_->dev_results.ptr;
+        long long *d_cnts = (long long *)((char *)solver_->dev_results.ptr + R * 64 * sizeof(double));
+        unsigned long long *d_words = (unsigned long long *)solver_->dev_bits.ptr;
+        size_t word_off = 0;
+        for (size_t r = 0; r < R; ++r) {
+            const DevProblem &p = probs[reqs[r].problem];
+            ExactTask &e = h_tasks[r];
+            e.scores = p.scores;
+            e.switch_costs = p.costs;
+            e.gamma = p.gamma;
+            e.n = (long long)p.n;
+            e.lambdas = d_lams + r * 64;
+            e.n_lambda = (int)reqs[r].lambdas.size();
+            e.record_lane = 0;
+            e.values_out = d_vals + r * 64;
+            e.counts_out = d_cnts + r * 64;
+            if (reqs[r].write_solution) {
+                e.decision_words = d_words + word_off;
+                e.solution = p.solution;
+                word_off += (p.n + 30) / 32 + 1;
+            } else {
+                e.decision_words = nullptr;
+                e.solution = nullptr;
+            }
+            for (size_t l = 0; l < 64; ++l) {
+                h_lams[r * 64 + l] = reqs[r].lambdas[l < reqs[r].lambdas.size() ? l : 0];
+            }
+        }
+        ROCCO_HIP_TRY(hipMemcpyAsync(solver_->dev_tasks.ptr, h_tasks, R * sizeof(ExactTask), hipMemcpyHostToDevice, stream_));
+        ROCCO_HIP_TRY(hipMemcpyAsync(d_lams, h_lams, R * 64 * sizeof(double), hipMemcpyHostToDevice, stream_));
+        if ((rc = launch_chain_exact((const ExactTask *)solver_->dev_tasks.ptr, (int)R, stream_)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        double *b_vals = (double *)solver_->host_back.ptr;
+        long long *b_cnts = (long long *)((char *)solver_->host_back.ptr + R * 64 * sizeof(double));
+        ROCCO_HIP_TRY(hipMemcpyAsync(b_vals, d_vals, R * 64 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        ROCCO_HIP_TRY(hipMemcpyAsync(b_cnts, d_cnts, R * 64 * sizeof(long long), hipMemcpyDeviceToHost, stream_));
+        ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        for (size_t r = 0; r < R; ++r) {
+            const size_t Lr = reqs[r].lambdas.size();
+            reqs[r].results.resize(Lr);
+            for (size_t l = 0; l < Lr; ++l) {
+                reqs[r].results[l].value = b_vals[r * 64 + l];
+                reqs[r].results[l].count = b_cnts[r * 64 + l];
+            }
+        }
         return ROCCO_HIP_OK;
     }
-    size_t words_total = 0;
-    for (const EvalRequest &r : reqs) {
-        if (r.lambdas.empty() || r.lambdas.size() > 64) {
-            return ROCCO_HIP_EINVAL;
-        }
-        if (r.record) {
-            words_total += (tasks[r.task].n + 30) / 32 + 1;
-        }
-    }
-    int rc;
-    if ((rc = solver->dev_tasks.reserve(R * sizeof(ExactTask))) != ROCCO_HIP_OK) return rc;
-    if ((rc = solver->dev_params.reserve(R * 64 * sizeof(double))) != ROCCO_HIP_OK) return rc;
-    if ((rc = solver->dev_results.reserve(R * 64 * (sizeof(double) + sizeof(long long)))) != ROCCO_HIP_OK) return rc;
-    if ((rc = solver->dev_bits.reserve(words_total * sizeof(unsigned long long) + 8)) != ROCCO_HIP_OK) return rc;
-    const size_t stage_bytes = R * sizeof(ExactTask) + R * 64 * sizeof(double);
-    if ((rc = solver->host_stage.reserve(stage_bytes)) != ROCCO_HIP_OK) return rc;
-    if ((rc = solver->host_back.reserve(R * 64 * (sizeof(double) + sizeof(long long)))) != ROCCO_HIP_OK) return rc;
 
-    ExactTask *h_tasks = (ExactTask *)solver->host_stage.ptr;
-    double *h_lams = (double *)((char *)solver->host_stage.ptr + R * sizeof(ExactTask));
-    double *d_lams = (double *)solver->dev_params.ptr;
-    double *d_vals = (double *)solver->dev_results.ptr;
-    long long *d_cnts = (long long *)((char *)solver->dev_results.ptr + R * 64 * sizeof(double));
-    unsigned long long *d_words = (unsigned long long *)solver->dev_bits.ptr;
-
-    size_t word_off = 0;
-    for (size_t r = 0; r < R; ++r) {
-        const rocco_hip_budget_task &t = tasks[reqs[r].task];
-        ExactTask &e = h_tasks[r];
-        e.scores = t.scores_dev;
-        e.switch_costs = t.switch_costs_dev;
-        e.gamma = t.gamma;
-        e.n = (long long)t.n;
-        e.lambdas = d_lams + r * 64;
-        e.n_lambda = (int)reqs[r].lambdas.size();
-        e.record_lane = 0;
-        e.values_out = d_vals + r * 64;
-        e.counts_out = d_cnts + r * 64;
-        if (reqs[r].record) {
-            e.decision_words = d_words + word_off;
-            e.solution = t.solution_dev;
-            word_off += (t.n + 30) / 32 + 1;
-        } else {
-            e.decision_words = nullptr;
-            e.solution = nullptr;
+    int penalized_value(size_t problem, double lambda, long long count, double *value_out) override
+    {
+        const DevProblem &p = probs[problem];
+        int rc;
+        if ((rc = solver_->dev_misc.reserve(objective_scratch_bytes(p.n))) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_back.reserve(64)) != ROCCO_HIP_OK) return rc;
+        double *back = (double *)solver_->host_back.ptr;
+        rc = launch_objective(p.solution, p.scores, p.costs, p.gamma, p.n, solver_->dev_misc.ptr, back, stream_);
+        if (rc != ROCCO_HIP_OK) {
+            return rc;
         }
-        for (size_t l = 0; l < 64; ++l) {
-            h_lams[r * 64 + l] = reqs[r].lambdas[l < reqs[r].lambdas.size() ? l : 0];
-        }
+        *value_out = -(*back) - lambda * (double)count;
+        return ROCCO_HIP_OK;
     }
-    ROCCO_HIP_TRY(hipMemcpyAsync(solver->dev_tasks.ptr, h_tasks, R * sizeof(ExactTask),
-                                 hipMemcpyHostToDevice, stream));
-    ROCCO_HIP_TRY(hipMemcpyAsync(d_lams, h_lams, R * 64 * sizeof(double), hipMemcpyHostToDevice, stream));
-    if ((rc = launch_chain_exact((const ExactTask *)solver->dev_tasks.ptr, (int)R, stream)) != ROCCO_HIP_OK) {
+
+    // smin, smax, cmin, cmax of every problem (one stats pass over the batch)
+    int compute_stats(std::vector<double> &out)
+    {
+        const size_t B = probs.size();
+        out.assign(4 * B, 0.0);
+        if (B == 0) {
+            return ROCCO_HIP_OK;
+        }
+        std::vector<int2> blockmap;
+        for (size_t b = 0; b < B; ++b) {
+            const int nb = (int)((probs[b].n + kFastBlockLoci - 1) / kFastBlockLoci);
+            for (int k = 0; k < nb; ++k) {
+                blockmap.push_back(make_int2((int)b, k));
+            }
+        }
+        const size_t nbt = blockmap.size();
+        const size_t bytes_tasks = align_up(B * sizeof(StatsTask), 256);
+        const size_t bytes_map = align_up(nbt * sizeof(int2), 256);
+        const size_t bytes_part = align_up(nbt * 4 * sizeof(double), 256);
+        const size_t bytes_out = align_up(B * 4 * sizeof(double), 256);
+        int rc;
+        if ((rc = solver_->dev_misc.reserve(bytes_tasks + bytes_map + bytes_part + bytes_out)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_stage.reserve(bytes_tasks + bytes_map)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_back.reserve(bytes_out)) != ROCCO_HIP_OK) return rc;
+        char *h = (char *)solver_->host_stage.ptr;
+        StatsTask *ht = (StatsTask *)h;
+        for (size_t b = 0; b < B; ++b) {
+            ht[b].scores = probs[b].scores;
+            ht[b].switch_costs = probs[b].costs;
+            ht[b].n = (long long)probs[b].n;
+        }
+        std::memcpy(h + bytes_tasks, blockmap.data(), nbt * sizeof(int2));
+        char *dv = (char *)solver_->dev_misc.ptr;
+        ROCCO_HIP_TRY(hipMemcpyAsync(dv, h, bytes_tasks + bytes_map, hipMemcpyHostToDevice, stream_));
+        double *d_part = (double *)(dv + bytes_tasks + bytes_map);
+        double *d_out = (double *)(dv + bytes_tasks + bytes_map + bytes_part);
+        if ((rc = launch_stats((const StatsTask *)dv, (int)B, (const int2 *)(dv + bytes_tasks), (int)nbt, d_part,
+                               d_out, stream_)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        ROCCO_HIP_TRY(hipMemcpyAsync(solver_->host_back.ptr, d_out, B * 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        std::memcpy(out.data(), solver_->host_back.ptr, B * 4 * sizeof(double));
+        return ROCCO_HIP_OK;
+    }
+
+    int rounds = 0;
+
+private:
+    struct RoundTask {
+        size_t problem = 0;
+        bool window = false;
+        std::vector<double> lambdas;
+        ProbeRequest *probe = nullptr;
+        WindowRequest *win = nullptr;
+    };
+
+    int run_round(std::vector<RoundTask> &rt)
+    {
+        const size_t T = rt.size();
+        if (T == 0) {
+            return ROCCO_HIP_OK;
+        }
+        ++rounds;
+        std::vector<FastTask> tasks(T);
+        std::vector<FastChain> chains;
+        std::vector<FastSlot> slots;
+        std::vector<int2> blockmap;
+        long long chain_chunks = 0, chain_blocks = 0, slot_chunks = 0, slot_blocks = 0;
+        bool any_costs = false, any_window = false;
+        for (size_t t = 0; t < T; ++t) {
+            const DevProblem &p = probs[rt[t].problem];
+            FastTask &ft = tasks[t];
+            const long long nchunks = (long long)((p.n + kChunk - 1) / kChunk);
+            const int nblocks = (int)((p.n + kFastBlockLoci - 1) / kFastBlockLoci);
+            ft.scores = p.scores;
+            ft.switch_costs = p.costs;
+            ft.gamma = p.gamma;
+            ft.n = (long long)p.n;
+            ft.magic = std::ldexp(1.5, 52 + p.qexp);
+            ft.big = std::ldexp(1.0, 50 + p.qexp);
+            ft.qstep = std::ldexp(1.0, p.qexp);
+            ft.cmax = p.cmax;
+            ft.sabs = p.sabs;
+            ft.n_blocks = nblocks;
+            ft.solution = p.solution;
+            ft.slot_begin = (int)slots.size();
+            any_costs = any_costs || (p.costs != nullptr);
+            if (rt[t].window) {
+                any_window = true;
+                FastSlot s;
+                s.task = (int)t;
+                s.mode = kModeWindow;
+                s.chain_a = (int)chains.size();
+                s.chain_b = s.chain_a + 1;
+                s.chunk_off = slot_chunks;
+                s.block_off = slot_blocks;
+                slot_chunks += nchunks;
+                slot_blocks += nblocks;
+                for (int k = 0; k < 2; ++k) {
+                    FastChain c;
+                    c.task = (int)t;
+                    c.lambda = rt[t].lambdas[k];
+                    c.chunk_off = chain_chunks;
+                    c.block_off = chain_blocks;
+                    chain_chunks += nchunks;
+                    chain_blocks += nblocks;
+                    chains.push_back(c);
+                }
+                slots.push_back(s);
+            } else {
+                for (double lam : rt[t].lambdas) {
+                    FastSlot s;
+                    s.task = (int)t;
+                    s.mode = kModeProbe;
+                    s.chain_a = s.chain_b = (int)chains.size();
+                    s.chunk_off = slot_chunks;
+                    s.block_off = slot_blocks;
+                    slot_chunks += nchunks;
+                    slot_blocks += nblocks;
+                    FastChain c;
+                    c.task = (int)t;
+                    c.lambda = lam;
+                    c.chunk_off = chain_chunks;
+                    c.block_off = chain_blocks;
+                    chain_chunks += nchunks;
+                    chain_blocks += nblocks;
+                    chains.push_back(c);
+                    slots.push_back(s);
+                }
+            }
+            ft.slot_count = (int)slots.size() - ft.slot_begin;
+            for (int k = 0; k < nblocks; ++k) {
+                blockmap.push_back(make_int2((int)t, k));
+            }
+        }
+        const size_t C = chains.size(), S = slots.size(), NB = blockmap.size();
+
+        // ---- descriptor upload ----
+        const size_t b_tasks = align_up(T * sizeof(FastTask), 256);
+        const size_t b_chains = align_up(C * sizeof(FastChain), 256);
+        const size_t b_slots = align_up(S * sizeof(FastSlot), 256);
+        const size_t b_map = align_up(NB * sizeof(int2), 256);
+        const size_t desc_bytes = b_tasks + b_chains + b_slots + b_map;
+        int rc;
+        if ((rc = solver_->dev_tasks.reserve(desc_bytes)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_stage.reserve(desc_bytes)) != ROCCO_HIP_OK) return rc;
+        char *h = (char *)solver_->host_stage.ptr;
+        std::memcpy(h, tasks.data(), T * sizeof(FastTask));
+        std::memcpy(h + b_tasks, chains.data(), C * sizeof(FastChain));
+        std::memcpy(h + b_tasks + b_chains, slots.data(), S * sizeof(FastSlot));
+        std::memcpy(h + b_tasks + b_chains + b_slots, blockmap.data(), NB * sizeof(int2));
+        char *dd = (char *)solver_->dev_tasks.ptr;
+        ROCCO_HIP_TRY(hipMemcpyAsync(dd, h, desc_bytes, hipMemcpyHostToDevice, stream_));
+
+        // ---- scratch carve ----
+        size_t off = 0;
+        auto carve = [&off](size_t bytes) {
+            const size_t at = off;
+            off += align_up(bytes, 256);
+            return at;
+        };
+        const size_t o_agg_a = carve((size_t)chain_chunks * 8), o_agg_lo = carve((size_t)chain_chunks * 8),
+                     o_agg_hi = carve((size_t)chain_chunks * 8), o_pstar = carve((size_t)chain_chunks);
+        const size_t o_blk_a = carve((size_t)chain_blocks * 8), o_blk_lo = carve((size_t)chain_blocks * 8),
+                     o_blk_hi = carve((size_t)chain_blocks * 8), o_din = carve((size_t)chain_blocks * 8);
+        const size_t o_lcc = carve((size_t)slot_chunks);
+        const size_t o_lcb = carve((size_t)slot_blocks * 4), o_lcin = carve((size_t)slot_blocks * 4);
+        const size_t o_fvlo = carve((size_t)slot_blocks), o_fvhi = carve((size_t)slot_blocks);
+        const size_t o_plo = carve((size_t)slot_blocks * 4), o_phi = carve((size_t)slot_blocks * 4);
+        const size_t o_blo = carve((size_t)slot_blocks * 4), o_bhi = carve((size_t)slot_blocks * 4);
+        const size_t o_rin = carve((size_t)slot_blocks);
+        const size_t o_res = carve(S * sizeof(FastSlotResult));
+        if ((rc = solver_->dev_params.reserve(off)) != ROCCO_HIP_OK) return rc;
+        char *sc = (char *)solver_->dev_params.ptr;
+
+        FastLaunch L;
+        L.tasks = (const FastTask *)dd;
+        L.chains = (const FastChain *)(dd + b_tasks);
+        L.slots = (const FastSlot *)(dd + b_tasks + b_chains);
+        L.blockmap = (const int2 *)(dd + b_tasks + b_chains + b_slots);
+        L.n_tasks = (int)T;
+        L.n_chains = (int)C;
+        L.n_slots = (int)S;
+        L.n_blocks_total = (int)NB;
+        L.any_costs = any_costs;
+        L.any_window = any_window;
+        L.buf.agg_a = (double *)(sc + o_agg_a);
+        L.buf.agg_lo = (double *)(sc + o_agg_lo);
+        L.buf.agg_hi = (double *)(sc + o_agg_hi);
+        L.buf.pstar = (uint8_t *)(sc + o_pstar);
+        L.buf.blk_a = (double *)(sc + o_blk_a);
+        L.buf.blk_lo = (double *)(sc + o_blk_lo);
+        L.buf.blk_hi = (double *)(sc + o_blk_hi);
+        L.buf.din = (double *)(sc + o_din);
+        L.buf.lc_chunk = (int8_t *)(sc + o_lcc);
+        L.buf.lc_block = (int *)(sc + o_lcb);
+        L.buf.lcin_block = (int *)(sc + o_lcin);
+        L.buf.bfv_lo = (uint8_t *)(sc + o_fvlo);
+        L.buf.bfv_hi = (uint8_t *)(sc + o_fvhi);
+        L.buf.bpend_lo = (unsigned *)(sc + o_plo);
+        L.buf.bpend_hi = (unsigned *)(sc + o_phi);
+        L.buf.bbase_lo = (unsigned *)(sc + o_blo);
+        L.buf.bbase_hi = (unsigned *)(sc + o_bhi);
+        L.buf.rin_lo = (uint8_t *)(sc + o_rin);
+        L.buf.results = (FastSlotResult *)(sc + o_res);
+        ROCCO_HIP_TRY(hipMemsetAsync(L.buf.results, 0, S * sizeof(FastSlotResult), stream_));
+        if ((rc = launch_fast_round(L, stream_)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        if ((rc = solver_->host_back.reserve(S * sizeof(FastSlotResult))) != ROCCO_HIP_OK) return rc;
+        ROCCO_HIP_TRY(hipMemcpyAsync(solver_->host_back.ptr, L.buf.results, S * sizeof(FastSlotResult),
+                                     hipMemcpyDeviceToHost, stream_));
+        ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        const FastSlotResult *hr = (const FastSlotResult *)solver_->host_back.ptr;
+
+        for (size_t t = 0; t < T; ++t) {
+            const FastTask &ft = tasks[t];
+            const DevProblem &p = probs[rt[t].problem];
+            if (rt[t].window) {
+                const FastSlotResult &r = hr[ft.slot_begin];
+                WindowResult &w = rt[t].win->result;
+                w.count_lo = r.count_lo;
+                w.count_hi = r.count_hi;
+                w.n_diff = r.n_diff;
+                w.diff_adjacent = (r.nonadjacent == 0);
+                w.overflow = (r.overflow != 0);
+                w.max_run = r.max_run;
+                w.diffs.clear();
+                const long long listed = std::min<long long>(r.n_diff, kMaxDiffs);
+                for (long long k = 0; k < listed; ++k) {
+                    WindowDiff d;
+                    d.locus = r.diffs[k].locus;
+                    d.margin_lo = r.diffs[k].margin_lo;
+                    d.margin_hi = r.diffs[k].margin_hi;
+                    d.run = r.diffs[k].run;
+                    d.cls_lo = r.diffs[k].cls_lo;
+                    d.cls_hi = r.diffs[k].cls_hi;
+                    w.diffs.push_back(d);
+                }
+                std::sort(w.diffs.begin(), w.diffs.end(),
+                          [](const WindowDiff &a, const WindowDiff &b) { return a.locus < b.locus; });
+            } else {
+                for (int k = 0; k < ft.slot_count; ++k) {
+                    const FastSlotResult &r = hr[ft.slot_begin + k];
+                    ProbeResult &o = rt[t].probe->results[k];
+                    o.count = r.count_lo;
+                    o.uncertain = r.uncertain;
+                    o.effect = r.overflow ? (long long)p.n + 1 : r.effect;
+                    o.max_run = r.max_run;
+                }
+            }
+        }
+        return ROCCO_HIP_OK;
+    }
+
+    rocco_hip_solver *solver_;
+    hipStream_t stream_;
+};
+
+// Fill ChainProblem / DevProblem statistics from one stats pass.
+int prepare(HipEvaluator &ev, std::vector<ChainProblem> &problems, const std::vector<double> *fixed_lambdas)
+{
+    std::vector<double> stats;
+    const int rc = ev.compute_stats(stats);
+    if (rc != ROCCO_HIP_OK) {
         return rc;
     }
-    double *b_vals = (double *)solver->host_back.ptr;
-    long long *b_cnts = (long long *)((char *)solver->host_back.ptr + R * 64 * sizeof(double));
-    ROCCO_HIP_TRY(hipMemcpyAsync(b_vals, d_vals, R * 64 * sizeof(double), hipMemcpyDeviceToHost, stream));
-    ROCCO_HIP_TRY(hipMemcpyAsync(b_cnts, d_cnts, R * 64 * sizeof(long long), hipMemcpyDeviceToHost, stream));
-    ROCCO_HIP_TRY(hipStreamSynchronize(stream));
-    for (size_t r = 0; r < R; ++r) {
-        const size_t L = reqs[r].lambdas.size();
-        reqs[r].values.assign(b_vals + r * 64, b_vals + r * 64 + L);
-        reqs[r].counts.assign(b_cnts + r * 64, b_cnts + r * 64 + L);
+    for (size_t b = 0; b < problems.size(); ++b) {
+        ChainProblem &p = problems[b];
+        DevProblem &d = ev.probs[b];
+        p.score_min = stats[4 * b + 0];
+        p.score_max = stats[4 * b + 1];
+        if (d.costs != nullptr && d.n > 1) {
+            p.cost_min = stats[4 * b + 2];
+            p.cost_max = stats[4 * b + 3];
+            p.has_cost_vector = true;
+        } else {
+            p.cost_min = p.cost_max = d.gamma;
+            p.has_cost_vector = false;
+        }
+        double lo = p.score_min, hi = p.score_max;
+        if (fixed_lambdas != nullptr) {
+            lo = std::min(lo, (*fixed_lambdas)[b]);
+            hi = std::max(hi, (*fixed_lambdas)[b]);
+        }
+        d.cmax = p.cost_max;
+        d.sabs = std::max(std::fabs(p.score_min), std::fabs(p.score_max));
+        d.qexp = (std::isfinite(lo) && std::isfinite(hi) && std::isfinite(p.cost_max))
+                     ? grid_exponent(std::max(p.cost_max, 0.0), lo, hi)
+                     : 0;
     }
     return ROCCO_HIP_OK;
 }
-
-// Midpoints of `depth` levels of the reference's bisection tree below (lower, upper), breadth first.
-// Node i has children 2i+1 (count <= target: upper = mid) and 2i+2 (count > target: lower = mid).
-void build_tree(double lower, double upper, int depth, std::vector<double> &mids)
-{
-    const size_t nodes = ((size_t)1 << depth) - 1;
-    std::vector<double> lo(nodes), hi(nodes);
-    mids.assign(nodes, 0.0);
-    if (nodes == 0) {
-        return;
-    }
-    lo[0] = lower;
-    hi[0] = upper;
-    for (size_t i = 0; i < nodes; ++i) {
-        const double mid = (lo[i] + hi[i]) / 2.0;  // rocco/dp.py:143
-        mids[i] = mid;
-        const size_t l = 2 * i + 1, r = 2 * i + 2;
-        if (l < nodes) {
-            lo[l] = lo[i];
-            hi[l] = mid;
-        }
-        if (r < nodes) {
-            lo[r] = mid;
-            hi[r] = hi[i];
-        }
-    }
-}
-
-struct Search {
-    enum Phase { kAll, kBrackets, kBisect, kFinal, kDone } phase = kBrackets;
-    long long target = 0;
-    double lower = 0.0, upper = 0.0;
-    bool lower_ok = false, upper_ok = false;
-    int iters_left = 0;
-    double best_lambda = 0.0, best_value = 0.0;
-    long long best_count = 0;
-    int evals = 0;
-    int passes = 0;
-    // bookkeeping for the request in flight
-    int tree_depth = 0;
-    size_t tree_offset = 0;  // index of the first tree node in the request's lambda list
-};
 
 }  // namespace
 
@@ -148,160 +466,146 @@ int solve_fixed_penalty(rocco_hip_solver *solver, const double *scores_dev,
                         uint8_t *solution_dev, double *value_out, long long *count_out, int *path_out,
                         hipStream_t stream)
 {
-    rocco_hip_budget_task t{};
-    t.scores_dev = scores_dev;
-    t.switch_costs_dev = switch_costs_dev;
-    t.gamma = gamma;
-    t.n = n;
-    t.solution_dev = solution_dev;
-    std::vector<EvalRequest> reqs(1);
-    reqs[0].task = 0;
-    reqs[0].lambdas = {lambda};
-    reqs[0].record = (solution_dev != nullptr);
-    const int rc = exact_evaluate(solver, &t, reqs, stream);
-    if (rc != ROCCO_HIP_OK) {
-        return rc;
+    HipEvaluator ev(solver, stream);
+    DevProblem d;
+    d.scores = scores_dev;
+    d.costs = (n > 1) ? switch_costs_dev : nullptr;
+    d.gamma = gamma;
+    d.n = n;
+    int rc;
+    if (solution_dev == nullptr) {  // the fast path always materialises; give it scratch
+        if ((rc = solver->dev_solution.reserve(n)) != ROCCO_HIP_OK) return rc;
+        d.solution = (uint8_t *)solver->dev_solution.ptr;
+    } else {
+        d.solution = solution_dev;
     }
-    if (value_out) *value_out = reqs[0].values[0];
-    if (count_out) *count_out = reqs[0].counts[0];
-    if (path_out) *path_out = ROCCO_HIP_PATH_EXACT;
+    ev.probs.push_back(d);
+    std::vector<ChainProblem> problems(1);
+    problems[0].n = n;
+    problems[0].gamma = gamma;
+    std::vector<double> lambdas = {lambda};
+    if ((rc = prepare(ev, problems, &lambdas)) != ROCCO_HIP_OK) return rc;
+    SearchOptions opt;
+    opt.force_exact = solver->force_exact != 0;
+    std::vector<CalibrationResult> res;
+    if ((rc = solve_fixed_batch(ev, problems, lambdas, opt, res)) != ROCCO_HIP_OK) return rc;
+    if (value_out) *value_out = res[0].penalized_value;
+    if (count_out) *count_out = res[0].selected_count;
+    if (path_out) *path_out = res[0].path;
+    return ROCCO_HIP_OK;
+}
+
+int delta_probe(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
+                double gamma, size_t n, const double *lambdas, size_t n_lambdas,
+                rocco_hip_probe_stats *stats_out, hipStream_t stream)
+{
+    HipEvaluator ev(solver, stream);
+    DevProblem d;
+    d.scores = scores_dev;
+    d.costs = (n > 1) ? switch_costs_dev : nullptr;
+    d.gamma = gamma;
+    d.n = n;
+    ev.probs.push_back(d);
+    std::vector<ChainProblem> problems(1);
+    problems[0].n = n;
+    problems[0].gamma = gamma;
+    int rc;
+    if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    std::vector<ProbeRequest> reqs(1);
+    reqs[0].problem = 0;
+    reqs[0].lambdas.assign(lambdas, lambdas + n_lambdas);
+    if ((rc = ev.probe(reqs)) != ROCCO_HIP_OK) return rc;
+    for (size_t i = 0; i < n_lambdas; ++i) {
+        stats_out[i].count = reqs[0].results[i].count;
+        stats_out[i].uncertain = reqs[0].results[i].uncertain;
+        stats_out[i].effect = reqs[0].results[i].effect;
+        stats_out[i].max_run = reqs[0].results[i].max_run;
+    }
+    return ROCCO_HIP_OK;
+}
+
+int delta_window(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
+                 double gamma, size_t n, double lambda_lo, double lambda_hi, uint8_t *solution_dev,
+                 rocco_hip_window_stats *stats_out, hipStream_t stream)
+{
+    HipEvaluator ev(solver, stream);
+    DevProblem d;
+    d.scores = scores_dev;
+    d.costs = (n > 1) ? switch_costs_dev : nullptr;
+    d.gamma = gamma;
+    d.n = n;
+    d.solution = solution_dev;
+    ev.probs.push_back(d);
+    std::vector<ChainProblem> problems(1);
+    problems[0].n = n;
+    problems[0].gamma = gamma;
+    int rc;
+    if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    std::vector<WindowRequest> reqs(1);
+    reqs[0].problem = 0;
+    reqs[0].lambda_lo = lambda_lo;
+    reqs[0].lambda_hi = lambda_hi;
+    if ((rc = ev.window(reqs)) != ROCCO_HIP_OK) return rc;
+    const WindowResult &w = reqs[0].result;
+    stats_out->count_lo = w.count_lo;
+    stats_out->count_hi = w.count_hi;
+    stats_out->n_diff = w.n_diff;
+    stats_out->diff_adjacent = w.diff_adjacent ? 1 : 0;
+    stats_out->overflow = w.overflow ? 1 : 0;
+    stats_out->max_run = w.max_run;
+    for (size_t k = 0; k < 16; ++k) {
+        if (k < w.diffs.size()) {
+            stats_out->diff_locus[k] = w.diffs[k].locus;
+            stats_out->diff_margin_lo[k] = w.diffs[k].margin_lo;
+            stats_out->diff_margin_hi[k] = w.diffs[k].margin_hi;
+            stats_out->diff_run[k] = w.diffs[k].run;
+            stats_out->diff_cls_lo[k] = w.diffs[k].cls_lo;
+            stats_out->diff_cls_hi[k] = w.diffs[k].cls_hi;
+        } else {
+            stats_out->diff_locus[k] = -1;
+            stats_out->diff_margin_lo[k] = stats_out->diff_margin_hi[k] = 0.0;
+            stats_out->diff_run[k] = 0;
+            stats_out->diff_cls_lo[k] = stats_out->diff_cls_hi[k] = 0;
+        }
+    }
     return ROCCO_HIP_OK;
 }
 
 int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip_budget_task *tasks,
                        rocco_hip_budget_result *results, hipStream_t stream)
 {
-    const int kExactDepth = 6;     // 63 speculative penalties per pass
-    const int kBracketDepth = 5;   // 2 bracket ends + 31 tree nodes in the first pass
-    std::vector<Search> st(n_tasks);
+    HipEvaluator ev(solver, stream);
+    std::vector<ChainProblem> problems(n_tasks);
     for (size_t t = 0; t < n_tasks; ++t) {
-        Search &s = st[t];
-        const long long n = (long long)tasks[t].n;
-        s.target = std::max(0LL, std::min(tasks[t].target_count, n));  // rocco/dp.py:101
-        s.lower = tasks[t].lower0;
-        s.upper = tasks[t].upper0;
-        s.iters_left = tasks[t].max_iter;
-        s.phase = (s.target == n) ? Search::kAll : Search::kBrackets;  // rocco/dp.py:102-108
+        DevProblem d;
+        d.scores = tasks[t].scores_dev;
+        d.costs = (tasks[t].n > 1) ? tasks[t].switch_costs_dev : nullptr;
+        d.gamma = tasks[t].gamma;
+        d.n = tasks[t].n;
+        d.solution = tasks[t].solution_dev;
+        ev.probs.push_back(d);
+        problems[t].n = tasks[t].n;
+        problems[t].gamma = tasks[t].gamma;
+        problems[t].target_count = tasks[t].target_count;
+        problems[t].sum_costs = tasks[t].sum_costs;
+        problems[t].max_iter = tasks[t].max_iter;
     }
-
-    for (;;) {
-        std::vector<EvalRequest> reqs;
-        std::vector<size_t> owner;
-        for (size_t t = 0; t < n_tasks; ++t) {
-            Search &s = st[t];
-            if (s.phase == Search::kDone) {
-                continue;
-            }
-            EvalRequest r;
-            r.task = t;
-            if (s.phase == Search::kAll) {
-                r.lambdas = {0.0};
-                r.record = true;
-            } else if (s.phase == Search::kBrackets) {
-                r.lambdas = {s.lower, s.upper};
-                s.tree_depth = std::min(kBracketDepth, s.iters_left);
-                s.tree_offset = 2;
-                std::vector<double> mids;
-                build_tree(s.lower, s.upper, s.tree_depth, mids);
-                r.lambdas.insert(r.lambdas.end(), mids.begin(), mids.end());
-            } else if (s.phase == Search::kBisect) {
-                s.tree_depth = std::min(kExactDepth, s.iters_left);
-                s.tree_offset = 0;
-                build_tree(s.lower, s.upper, s.tree_depth, r.lambdas);
-            } else {  // kFinal
-                r.lambdas = {s.best_lambda};
-                r.record = true;
-            }
-            reqs.push_back(std::move(r));
-            owner.push_back(t);
-        }
-        if (reqs.empty()) {
-            break;
-        }
-        const int rc = exact_evaluate(solver, tasks, reqs, stream);
-        if (rc != ROCCO_HIP_OK) {
-            return rc;
-        }
-        for (size_t q = 0; q < reqs.size(); ++q) {
-            Search &s = st[owner[q]];
-            const EvalRequest &r = reqs[q];
-            ++s.passes;
-            if (s.phase == Search::kAll) {
-                s.best_lambda = 0.0;
-                s.best_value = r.values[0];
-                s.best_count = r.counts[0];
-                s.evals = 1;
-                s.phase = Search::kDone;
-                continue;
-            }
-            if (s.phase == Search::kFinal) {
-                s.best_value = r.values[0];
-                s.best_count = r.counts[0];
-                s.phase = Search::kDone;
-                continue;
-            }
-            bool tree_valid = true;
-            if (s.phase == Search::kBrackets) {
-                if (!s.lower_ok) {  // rocco/dp.py:113-125
-                    ++s.evals;
-                    if (r.counts[0] <= s.target) {
-                        s.lower -= std::max(1.0, std::fabs(s.lower));
-                        tree_valid = false;
-                    } else {
-                        s.lower_ok = true;
-                    }
-                }
-                if (s.lower_ok && !s.upper_ok) {  // rocco/dp.py:127-138
-                    ++s.evals;
-                    if (r.counts[1] > s.target) {
-                        s.upper += std::max(1.0, std::fabs(s.upper));
-                        tree_valid = false;
-                    } else {
-                        s.upper_ok = true;
-                        s.best_lambda = r.lambdas[1];
-                        s.best_value = r.values[1];
-                        s.best_count = r.counts[1];
-                    }
-                }
-                if (!(s.lower_ok && s.upper_ok)) {
-                    continue;  // ask again with the expanded bracket
-                }
-                s.phase = Search::kBisect;
-                if (!tree_valid) {
-                    continue;  // brackets moved during this pass: the speculative tree is stale
-                }
-            }
-            // walk the evaluated levels (rocco/dp.py:141-162)
-            size_t i = 0;
-            for (int level = 0; level < s.tree_depth; ++level) {
-                const size_t idx = s.tree_offset + i;
-                const double mid = r.lambdas[idx];
-                ++s.evals;
-                if (r.counts[idx] > s.target) {
-                    s.lower = mid;
-                    i = 2 * i + 2;
-                } else {
-                    s.upper = mid;
-                    s.best_lambda = mid;
-                    s.best_value = r.values[idx];
-                    s.best_count = r.counts[idx];
-                    i = 2 * i + 1;
-                }
-            }
-            s.iters_left -= s.tree_depth;
-            if (s.iters_left <= 0) {
-                s.phase = Search::kFinal;
-            }
-        }
-    }
+    int rc;
+    if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    SearchOptions opt;
+    opt.force_exact = solver->force_exact != 0;
+    opt.spec_depth = solver->spec_depth;
+    std::vector<CalibrationResult> res;
+    if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
     for (size_t t = 0; t < n_tasks; ++t) {
-        const Search &s = st[t];
-        results[t].selection_penalty = (st[t].target == (long long)tasks[t].n) ? 0.0 : s.upper;
-        results[t].penalized_value = s.best_value;
-        results[t].selected_count = s.best_count;
-        results[t].evaluations = s.evals;
-        results[t].path = ROCCO_HIP_PATH_EXACT;
-        results[t].passes = s.passes;
+        results[t].selection_penalty = res[t].selection_penalty;
+        results[t].penalized_value = res[t].penalized_value;
+        results[t].selected_count = res[t].selected_count;
+        results[t].evaluations = res[t].evaluations;
+        results[t].path = res[t].path;
+        results[t].passes = res[t].passes;
+        results[t].zone_iters = res[t].zone_iters;
+        results[t].n_diff = res[t].n_diff;
     }
     return ROCCO_HIP_OK;
 }

@@ -1,0 +1,109 @@
+// rocco_amd/csrc/chain_fast.h -- device descriptors of the parallel delta-form ("fast path") kernels.
+//
+// SPEC: identical, bit for bit, to the sequential definition in oracle/delta_oracle.c (DESIGN.md
+// section 4): fixed-point grid q = 2^qexp, chunks of 32 loci, constant clear-clamp guard 2^-16,
+// integer noise bound (P16, npos), tolerance tau_j = tau0 + tau_step * m_j.
+#pragma once
+
+#include "common.h"
+
+namespace rocco {
+
+constexpr int kChunk = 32;                          // loci per lane (== ORACLE_CHUNK)
+constexpr int kFastThreads = 256;                   // lanes per workgroup
+constexpr int kFastBlockLoci = kChunk * kFastThreads;  // 8192 loci per workgroup
+constexpr double kGuard = 0x1p-16;                  // == ORACLE_GUARD
+constexpr int kMaxDiffs = 16;
+
+enum FastMode { kModeProbe = 0, kModeWindow = 1 };
+
+struct FastTask {
+    const double *scores;
+    const double *switch_costs;  // n-1 or nullptr
+    double gamma;
+    long long n;
+    double magic;  // 1.5 * 2^(52 + qexp)
+    double big;    // 2^(50 + qexp): saturation bound of the shift component
+    double qstep;  // 2^qexp
+    double cmax, sabs;
+    int slot_begin, slot_count;
+    int n_blocks;
+    uint8_t *solution;  // n bytes (window slots write fill(LO) here)
+};
+
+// One delta chain = (task, penalty).  A probe slot owns one chain, a window slot two
+// (chain_a = lambda_lo, the larger delta; chain_b = lambda_hi).
+struct FastChain {
+    int task;
+    double lambda;
+    long long chunk_off;  // offset of this chain in the per-chunk chain arrays
+    long long block_off;  // offset in the per-block chain arrays
+};
+
+struct FastSlot {
+    int task;
+    int mode;
+    int chain_a, chain_b;
+    long long chunk_off;  // per-chunk slot arrays
+    long long block_off;  // per-block slot arrays
+};
+
+struct FastDiff {
+    long long locus;
+    double margin_lo, margin_hi;
+    long long run;
+    int cls_lo, cls_hi;
+};
+
+struct FastSlotResult {
+    long long count_lo, count_hi;  // probe: count_lo == the exact-rule count
+    long long uncertain, effect;
+    long long max_run;
+    long long n_diff;
+    long long p16, npos;
+    double tau0, tau_step;
+    int overflow;
+    int nonadjacent;
+    FastDiff diffs[kMaxDiffs];
+};
+
+struct FastBuffers {
+    // per (chain, chunk)
+    double *agg_a, *agg_lo, *agg_hi;
+    uint8_t *pstar;
+    // per (chain, block)
+    double *blk_a, *blk_lo, *blk_hi, *din;
+    // per (slot, chunk)
+    int8_t *lc_chunk;
+    // per (slot, block)
+    int *lc_block, *lcin_block;
+    uint8_t *bfv_lo, *bfv_hi;
+    unsigned *bpend_lo, *bpend_hi, *bbase_lo, *bbase_hi;
+    uint8_t *rin_lo;
+    // per slot
+    FastSlotResult *results;
+};
+
+struct FastLaunch {
+    const FastTask *tasks;
+    const FastChain *chains;
+    const FastSlot *slots;
+    const int2 *blockmap;  // global workgroup -> (task, local block)
+    int n_tasks, n_chains, n_slots, n_blocks_total;
+    bool any_costs;
+    bool any_window;
+    FastBuffers buf;
+};
+
+int launch_fast_round(const FastLaunch &L, hipStream_t stream);
+
+// min / max of scores (and of switch costs) per task: out[4 * t + {0,1,2,3}] = smin, smax, cmin, cmax
+struct StatsTask {
+    const double *scores;
+    const double *switch_costs;
+    long long n;
+};
+int launch_stats(const StatsTask *tasks_dev, int n_tasks, const int2 *blockmap_dev, int n_blocks_total,
+                 double *partials_dev, double *out_dev, hipStream_t stream);
+
+}  // namespace rocco

@@ -1,0 +1,979 @@
+// rocco_amd/csrc/chain_fast.hip -- parallel delta-form evaluation of the chain solve on gfx950.
+//
+// What it computes (sequential definition: oracle/delta_oracle.c; derivation: DESIGN.md section 4):
+// the reference's two-state Viterbi pass (rocco/_chain_dp.c:115-186) collapses, in exact arithmetic,
+// to   delta_j = clamp(delta_{j-1}, -c, +c) + (s_j - lambda)   plus a backward fill over per-locus
+// classes ONE / ZERO / COPY.  x -> clamp(x + a, lo, hi) is closed under composition, and with
+// a_j, c_j rounded to a fixed-point grid every add/min/max is exact, so the composition is exactly
+// associative: the scan below returns the same bits as the sequential recursion.
+//
+// One round = five launches, all streaming / scan work (no MFMA; BLAS-1 class, HBM-bound):
+//   K1 aggregate : each lane owns a 32-locus chunk staged through LDS (coalesced 16-B loads),
+//                  builds its chunk function for every penalty of the task, workgroup-reduces it
+//   K2 blockscan : per chain, the (short) sequence of workgroup functions -> incoming delta per
+//                  workgroup; per slot, noise model (tau0, tau_step) and incoming clear-clamp index
+//   K3 apply     : re-stage the tile, in-workgroup scan -> exact incoming delta per lane, run the
+//                  recursion, classify, certify, per-chunk fill summaries, window: write fill(LO)
+//   K4 fillscan  : per slot, backward over workgroups: fill value entering from the right, counts
+//   K5 patch     : window slots only: trailing undetermined loci of a workgroup take that value
+// The scores are read twice per round (K1, K3): 16 B / locus for all penalties of the round.
+#include "chain_fast.h"
+
+#include <cmath>
+
+namespace rocco {
+
+namespace {
+
+constexpr int kLdsStride = kChunk + 2;  // doubles per chunk row in LDS (16-B aligned, conflict-free)
+constexpr int kTileDoubles = kFastThreads * kLdsStride;
+enum { kClsZero = 0, kClsCopy = 1, kClsOne = 2 };
+constexpr int kFvNone = 2;
+
+struct Fn {
+    double a, lo, hi;  // x -> min(max(x + a, lo), hi)
+};
+
+__device__ __forceinline__ double grid_round(double x, double magic) { return (x + magic) - magic; }
+
+__device__ __forceinline__ double clampc(double x, double c) { return fmin(fmax(x, -c), c); }
+
+// apply f, then g
+__device__ __forceinline__ Fn compose(const Fn &f, const Fn &g, double big)
+{
+    Fn r;
+    r.a = fmin(fmax(f.a + g.a, -big), big);
+    r.lo = fmin(fmax(f.lo + g.a, g.lo), g.hi);
+    r.hi = fmin(fmax(f.hi + g.a, g.lo), g.hi);
+    return r;
+}
+
+__device__ __forceinline__ double apply_fn(const Fn &f, double x) { return fmin(fmax(x + f.a, f.lo), f.hi); }
+
+__device__ __forceinline__ Fn shfl_down_fn(const Fn &f, int off)
+{
+    Fn r;
+    r.a = __shfl_down(f.a, off);
+    r.lo = __shfl_down(f.lo, off);
+    r.hi = __shfl_down(f.hi, off);
+    return r;
+}
+
+__device__ __forceinline__ Fn shfl_up_fn(const Fn &f, int off)
+{
+    Fn r;
+    r.a = __shfl_up(f.a, off);
+    r.lo = __shfl_up(f.lo, off);
+    r.hi = __shfl_up(f.hi, off);
+    return r;
+}
+
+// ---- tile staging -----------------------------------------------------------------------------
+// The workgroup's 8192 loci are loaded with coalesced 16-B accesses and laid out one 32-locus
+// chunk per LDS row (row stride 34 doubles), so that every lane then reads its own row with
+// 16-B LDS reads without bank conflicts.
+template <bool HAS_COSTS>
+__device__ __forceinline__ void stage_tile(const FastTask &task, int local_block, double *lds_s,
+                                           double *lds_c)
+{
+    const long long base = (long long)local_block * kFastBlockLoci;
+    const double *__restrict__ s = task.scores;
+    const double *__restrict__ cs = task.switch_costs;
+    const long long n = task.n;
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(s) & 15U) == 0);
+#pragma unroll 4
+    for (int r = 0; r < kChunk / 2; ++r) {
+        const int e = 2 * (r * kFastThreads + (int)threadIdx.x);  // even element index in the tile
+        const long long j = base + e;
+        double2 v = make_double2(0.0, 0.0);
+        if (j + 1 < n && aligned16) {
+            v = *reinterpret_cast<const double2 *>(s + j);
+        } else {
+            if (j < n) v.x = s[j];
+            if (j + 1 < n) v.y = s[j + 1];
+        }
+        *reinterpret_cast<double2 *>(lds_s + (e >> 5) * kLdsStride + (e & 31)) = v;
+        if (HAS_COSTS) {
+            double2 c = make_double2(0.0, 0.0);
+            if (j < n - 1) c.x = cs[j];
+            if (j + 1 < n - 1) c.y = cs[j + 1];
+            *reinterpret_cast<double2 *>(lds_c + (e >> 5) * kLdsStride + (e & 31)) = c;
+        }
+    }
+    __syncthreads();
+}
+
+// Per-lane view of its chunk on the grid: sv[i] raw scores, cv[i] = cost between loci j0+i and
+// j0+i+1, c_prev0 = cost between j0-1 and j0.
+template <bool HAS_COSTS>
+struct ChunkData {
+    double sv[kChunk];
+    double cv[HAS_COSTS ? kChunk : 1];
+    double c_prev0;
+    double gq;
+};
+
+template <bool HAS_COSTS>
+__device__ __forceinline__ void load_chunk(const FastTask &task, long long j0, const double *lds_s,
+                                           const double *lds_c, ChunkData<HAS_COSTS> &d)
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < kChunk; i += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(lds_s + t * kLdsStride + i);
+        d.sv[i] = v.x;
+        d.sv[i + 1] = v.y;
+    }
+    d.gq = grid_round(task.gamma, task.magic);
+    if (HAS_COSTS) {
+#pragma unroll
+        for (int i = 0; i < kChunk; i += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(lds_c + t * kLdsStride + i);
+            d.cv[i] = grid_round(v.x, task.magic);
+            d.cv[i + 1] = grid_round(v.y, task.magic);
+        }
+        double cp = 0.0;
+        if (j0 > 0 && j0 < task.n) {
+            cp = (t > 0) ? lds_c[(t - 1) * kLdsStride + (kChunk - 1)] : task.switch_costs[j0 - 1];
+        }
+        d.c_prev0 = grid_round(cp, task.magic);
+    } else {
+        d.c_prev0 = d.gq;
+    }
+}
+
+template <bool HAS_COSTS>
+__device__ __forceinline__ double cost_at(const ChunkData<HAS_COSTS> &d, int i)
+{
+    if (HAS_COSTS) {
+        return d.cv[i];
+    }
+    return d.gq;
+}
+
+// ---- K1: chunk functions, provable clear clamps, noise sums ------------------------------------
+template <int NCH, bool HAS_COSTS>
+__device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastSlot &slot, int slot_index,
+                                               const FastChain *chains, const FastBuffers &buf,
+                                               const ChunkData<HAS_COSTS> &d, long long chunk, long long j0,
+                                               int local_block, double *lds_red)
+{
+    const long long n = task.n;
+    const double magic = task.magic;
+    const double big = task.big;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const bool valid = j0 < n;
+
+    double lam[NCH];
+    lam[0] = chains[slot.chain_a].lambda;
+    if (NCH == 2) {
+        lam[NCH - 1] = chains[slot.chain_b].lambda;
+    }
+    Fn f[NCH];
+    int pstar[NCH];
+    bool known[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        f[k].a = 0.0;
+        f[k].lo = -big;
+        f[k].hi = big;
+        pstar[k] = kChunk;
+        known[k] = false;
+    }
+    int lc = -1;
+    long long p16 = 0;
+    long long npos = 0;
+
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            const long long j = j0 + i;
+            if (j < n) {
+                const double c_prev = (i == 0) ? d.c_prev0 : cost_at(d, i - 1);
+                const double cj = cost_at(d, i);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const double a = grid_round(d.sv[i] - lam[k], magic);
+                    if (j == 0) {
+                        f[k].a = 0.0;
+                        f[k].lo = a;
+                        f[k].hi = a;
+                    } else if (i == 0) {
+                        f[k].a = a;
+                        f[k].lo = -c_prev + a;
+                        f[k].hi = c_prev + a;
+                    } else {
+                        f[k].a = fmin(fmax(f[k].a + a, -big), big);
+                        f[k].lo = clampc(f[k].lo, c_prev) + a;
+                        f[k].hi = clampc(f[k].hi, c_prev) + a;
+                    }
+                    if (!known[k] && f[k].lo == f[k].hi) {
+                        known[k] = true;
+                        pstar[k] = i;
+                    }
+                    if (k == 0 && a > 0.0) {
+                        p16 += (long long)(16.0 * a);
+                        ++npos;
+                    }
+                }
+                if (j + 1 < n) {
+                    bool clear;
+                    if (NCH == 1) {
+                        clear = known[0] && (fabs(f[0].hi) - cj > kGuard);
+                    } else {
+                        clear = known[0] && known[NCH - 1] &&
+                                ((f[NCH - 1].hi - cj > kGuard) || (-f[0].hi - cj > kGuard));
+                    }
+                    if (clear) {
+                        lc = i;
+                    }
+                }
+            }
+        }
+    }
+
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const FastChain &ch = chains[k == 0 ? slot.chain_a : slot.chain_b];
+            buf.agg_a[ch.chunk_off + chunk] = f[k].a;
+            buf.agg_lo[ch.chunk_off + chunk] = f[k].lo;
+            buf.agg_hi[ch.chunk_off + chunk] = f[k].hi;
+            buf.pstar[ch.chunk_off + chunk] = (uint8_t)pstar[k];
+        }
+        buf.lc_chunk[slot.chunk_off + chunk] = (int8_t)lc;
+    }
+
+    // workgroup-ordered composition of the chunk functions (per chain)
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        Fn g = f[k];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const Fn p = shfl_down_fn(g, off);
+            if (lane + off < 64) {
+                g = compose(g, p, big);
+            }
+        }
+        if (lane == 0) {
+            lds_red[(k * 4 + wave) * 3 + 0] = g.a;
+            lds_red[(k * 4 + wave) * 3 + 1] = g.lo;
+            lds_red[(k * 4 + wave) * 3 + 2] = g.hi;
+        }
+    }
+    long long lcg = (lc >= 0) ? (j0 + lc) : -1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long o = __shfl_down(lcg, off);
+        lcg = (o > lcg) ? o : lcg;
+        p16 += __shfl_down(p16, off);
+        npos += __shfl_down(npos, off);
+    }
+    long long *lds_ll = reinterpret_cast<long long *>(lds_red + 24);
+    if (lane == 0) {
+        lds_ll[wave * 3 + 0] = lcg;
+        lds_ll[wave * 3 + 1] = p16;
+        lds_ll[wave * 3 + 2] = npos;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            Fn g;
+            g.a = lds_red[(k * 4) * 3 + 0];
+            g.lo = lds_red[(k * 4) * 3 + 1];
+            g.hi = lds_red[(k * 4) * 3 + 2];
+            for (int w = 1; w < 4; ++w) {
+                Fn p;
+                p.a = lds_red[(k * 4 + w) * 3 + 0];
+                p.lo = lds_red[(k * 4 + w) * 3 + 1];
+                p.hi = lds_red[(k * 4 + w) * 3 + 2];
+                g = compose(g, p, big);
+            }
+            const FastChain &ch = chains[k == 0 ? slot.chain_a : slot.chain_b];
+            buf.blk_a[ch.block_off + local_block] = g.a;
+            buf.blk_lo[ch.block_off + local_block] = g.lo;
+            buf.blk_hi[ch.block_off + local_block] = g.hi;
+        }
+        long long m = -1, sp = 0, sn = 0;
+        for (int w = 0; w < 4; ++w) {
+            m = (lds_ll[w * 3] > m) ? lds_ll[w * 3] : m;
+            sp += lds_ll[w * 3 + 1];
+            sn += lds_ll[w * 3 + 2];
+        }
+        buf.lc_block[slot.block_off + local_block] = (int)m;
+        if (sp != 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&buf.results[slot_index].p16),
+                      (unsigned long long)sp);
+        }
+        if (sn != 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&buf.results[slot_index].npos),
+                      (unsigned long long)sn);
+        }
+    }
+    __syncthreads();
+}
+
+template <bool HAS_COSTS>
+__global__ __launch_bounds__(kFastThreads) void fast_aggregate_kernel(FastLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *lds_s = smem;
+    double *lds_c = HAS_COSTS ? (smem + kTileDoubles) : smem;
+    double *lds_red = smem + (HAS_COSTS ? 2 : 1) * kTileDoubles;  // 24 doubles + 12 long long
+
+    const int2 bm = L.blockmap[blockIdx.x];
+    const FastTask task = L.tasks[bm.x];
+    if (HAS_COSTS != (task.switch_costs != nullptr)) {
+        return;
+    }
+    const int local_block = bm.y;
+    stage_tile<HAS_COSTS>(task, local_block, lds_s, lds_c);
+    const long long chunk = (long long)local_block * kFastThreads + threadIdx.x;
+    const long long j0 = chunk * kChunk;
+    ChunkData<HAS_COSTS> d;
+    load_chunk<HAS_COSTS>(task, j0, lds_s, lds_c, d);
+    for (int si = 0; si < task.slot_count; ++si) {
+        const int slot_index = task.slot_begin + si;
+        const FastSlot slot = L.slots[slot_index];
+        if (slot.mode == kModeProbe) {
+            aggregate_slot<1, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block,
+                                         lds_red);
+        } else {
+            aggregate_slot<2, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block,
+                                         lds_red);
+        }
+    }
+}
+
+// ---- K2: per chain incoming delta per workgroup; per slot noise model + incoming clear index ----
+__global__ __launch_bounds__(64) void fast_blockscan_kernel(FastLaunch L)
+{
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx < L.n_chains) {
+        const FastChain ch = L.chains[idx];
+        const FastTask &task = L.tasks[ch.task];
+        const int nb = task.n_blocks;
+        double v = 0.0;  // delta at the last locus of the previous workgroup (unused for block 0)
+        for (int b = 0; b < nb; ++b) {
+            L.buf.din[ch.block_off + b] = v;
+            Fn f;
+            f.a = L.buf.blk_a[ch.block_off + b];
+            f.lo = L.buf.blk_lo[ch.block_off + b];
+            f.hi = L.buf.blk_hi[ch.block_off + b];
+            v = apply_fn(f, v);
+        }
+    } else if (idx < L.n_chains + L.n_slots) {
+        const int si = idx - L.n_chains;
+        const FastSlot slot = L.slots[si];
+        const FastTask &task = L.tasks[slot.task];
+        const int nb = task.n_blocks;
+        int run = -1;
+        for (int b = 0; b < nb; ++b) {
+            L.buf.lcin_block[slot.block_off + b] = run;
+            const int x = L.buf.lc_block[slot.block_off + b];
+            run = (x > run) ? x : run;
+        }
+        // noise model (oracle_noise_model): Pb bounds every intermediate of the reference's pass
+        FastSlotResult &res = L.buf.results[si];
+        const double lam = L.chains[slot.chain_a].lambda;
+        const double pb = 2.0 * ((double)(res.p16 + res.npos) * 0.0625 + task.cmax + task.sabs + fabs(lam) + 1.0);
+        const double h = ldexp(1.0, ilogb(pb) - 53);
+        res.tau_step = 4.0 * h + task.qstep;
+        res.tau0 = 9.0 * h + 2.0 * task.qstep;
+    }
+}
+
+// ---- K3 helpers ---------------------------------------------------------------------------------
+// Within-chunk backward fill on bit masks: det = determined loci, val = class ONE among them.
+// Returns smeared masks: every locus below a determined one takes the nearest determined value
+// above it; loci above the highest determined one stay undetermined.
+__device__ __forceinline__ void smear_fill(unsigned &det, unsigned &val)
+{
+    val &= det;
+#pragma unroll
+    for (int k = 1; k < 32; k <<= 1) {
+        const unsigned take = ~det & (det >> k);
+        val |= take & (val >> k);
+        det |= take;
+    }
+}
+
+__device__ __forceinline__ unsigned long long spread_bits_to_bytes(unsigned x8)
+{
+    unsigned long long t = ((unsigned long long)(x8 & 0xFFU) * 0x0101010101010101ULL) & 0x8040201008040201ULL;
+    t = ((t + 0x7F7F7F7F7F7F7F7FULL) >> 7) & 0x0101010101010101ULL;
+    return t;
+}
+
+struct FillOut {
+    unsigned zbits;    // fill values of the chunk (pending loci as 0)
+    bool pending;      // the chunk's trailing undetermined loci wait for the value from the right
+    unsigned tailmask; // those loci
+};
+
+// Workgroup-level backward fill for one class variant.  D/V: determined / ONE masks of the lane's
+// chunk (already restricted to valid loci).  Writes the workgroup summary (fv, pend, base).
+__device__ __forceinline__ FillOut block_fill(unsigned D, unsigned V, unsigned validmask, uint8_t *bfv,
+                                              unsigned *bpend, unsigned *bbase, long long block_index,
+                                              unsigned *lds_u)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    unsigned det = D, val = V;
+    smear_fill(det, val);
+    const unsigned tailmask = ~det & validmask;
+    const int fv = (D != 0U) ? (int)((V >> (__ffs(D) - 1)) & 1U) : kFvNone;
+    const unsigned long long has = __ballot(fv != kFvNone);
+    const unsigned long long one = __ballot(fv == 1);
+    // nearest lane to the right (same wave) with a determined class
+    int r = kFvNone;
+    const unsigned long long right = (lane == 63) ? 0ULL : (has & (~0ULL << (lane + 1)));
+    if (right != 0ULL) {
+        const int u = __ffsll((long long)right) - 1;
+        r = (int)((one >> u) & 1ULL);
+    }
+    if (lane == 0) {
+        lds_u[wave * 2 + 0] = (has != 0ULL) ? 1U : 0U;
+        lds_u[wave * 2 + 1] = (has != 0ULL) ? (unsigned)((one >> (__ffsll((long long)has) - 1)) & 1ULL) : 0U;
+    }
+    __syncthreads();
+    if (r == kFvNone) {
+        for (int w = wave + 1; w < 4; ++w) {
+            if (lds_u[w * 2]) {
+                r = (int)lds_u[w * 2 + 1];
+                break;
+            }
+        }
+    }
+    int block_fv = kFvNone;
+    for (int w = 0; w < 4; ++w) {
+        if (lds_u[w * 2]) {
+            block_fv = (int)lds_u[w * 2 + 1];
+            break;
+        }
+    }
+    __syncthreads();
+    FillOut out;
+    out.tailmask = tailmask;
+    out.pending = (r == kFvNone) && (tailmask != 0U);
+    out.zbits = (val & det & validmask) | ((r == 1) ? tailmask : 0U);
+    unsigned base = (unsigned)__popc(out.zbits);
+    unsigned pend = out.pending ? (unsigned)__popc(tailmask) : 0U;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        base += __shfl_down(base, off);
+        pend += __shfl_down(pend, off);
+    }
+    if (lane == 0) {
+        lds_u[8 + wave * 2 + 0] = base;
+        lds_u[8 + wave * 2 + 1] = pend;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned b = 0, p = 0;
+        for (int w = 0; w < 4; ++w) {
+            b += lds_u[8 + w * 2];
+            p += lds_u[8 + w * 2 + 1];
+        }
+        bfv[block_index] = (uint8_t)block_fv;
+        bpend[block_index] = p;
+        bbase[block_index] = b;
+    }
+    __syncthreads();
+    return out;
+}
+
+// exclusive in-workgroup scan of the chunk functions of one chain, evaluated at the workgroup's
+// incoming delta: returns the delta entering this lane's chunk
+__device__ __forceinline__ double incoming_delta(const FastBuffers &buf, const FastChain &ch, long long chunk,
+                                                 bool valid, int local_block, double big, double *lds_red)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    Fn f;
+    f.a = 0.0;
+    f.lo = -big;
+    f.hi = big;
+    if (valid) {
+        f.a = buf.agg_a[ch.chunk_off + chunk];
+        f.lo = buf.agg_lo[ch.chunk_off + chunk];
+        f.hi = buf.agg_hi[ch.chunk_off + chunk];
+    }
+    Fn inc = f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Fn p = shfl_up_fn(inc, off);
+        if (lane >= off) {
+            inc = compose(p, inc, big);
+        }
+    }
+    if (lane == 63) {
+        lds_red[wave * 3 + 0] = inc.a;
+        lds_red[wave * 3 + 1] = inc.lo;
+        lds_red[wave * 3 + 2] = inc.hi;
+    }
+    __syncthreads();
+    Fn ex = shfl_up_fn(inc, 1);
+    if (lane == 0) {
+        ex.a = 0.0;
+        ex.lo = -big;
+        ex.hi = big;
+    }
+    Fn pre;
+    pre.a = 0.0;
+    pre.lo = -big;
+    pre.hi = big;
+    for (int w = 0; w < wave; ++w) {
+        Fn p;
+        p.a = lds_red[w * 3 + 0];
+        p.lo = lds_red[w * 3 + 1];
+        p.hi = lds_red[w * 3 + 2];
+        pre = compose(pre, p, big);
+    }
+    __syncthreads();
+    const Fn total = compose(pre, ex, big);
+    return apply_fn(total, buf.din[ch.block_off + local_block]);
+}
+
+// exclusive in-workgroup prefix max of the clear-clamp index (global locus index, -1 none)
+__device__ __forceinline__ long long incoming_clear(long long own, long long block_in, long long *lds_ll)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    long long inc = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long p = __shfl_up(inc, off);
+        if (lane >= off) {
+            inc = (p > inc) ? p : inc;
+        }
+    }
+    if (lane == 63) {
+        lds_ll[wave] = inc;
+    }
+    __syncthreads();
+    long long ex = __shfl_up(inc, 1);
+    if (lane == 0) {
+        ex = -1;
+    }
+    long long pre = block_in;
+    for (int w = 0; w < wave; ++w) {
+        pre = (lds_ll[w] > pre) ? lds_ll[w] : pre;
+    }
+    __syncthreads();
+    return (ex > pre) ? ex : pre;
+}
+
+// ---- K3: apply ------------------------------------------------------------------------------------
+template <int NCH, bool HAS_COSTS>
+__device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot &slot, int slot_index,
+                                           const FastChain *chains, const FastBuffers &buf,
+                                           const ChunkData<HAS_COSTS> &d, long long chunk, long long j0,
+                                           int local_block, double *lds_red)
+{
+    const long long n = task.n;
+    const double magic = task.magic;
+    const double big = task.big;
+    const bool valid = j0 < n;
+    const int lane = threadIdx.x & 63;
+    FastSlotResult &res = buf.results[slot_index];
+    const double tau0 = res.tau0;
+    const double tau_step = res.tau_step;
+    long long *lds_ll = reinterpret_cast<long long *>(lds_red + 24);
+    unsigned *lds_u = reinterpret_cast<unsigned *>(lds_red + 40);
+
+    double lam[NCH], delta[NCH];
+    int pstar = 0;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const FastChain &ch = chains[k == 0 ? slot.chain_a : slot.chain_b];
+        lam[k] = ch.lambda;
+        delta[k] = incoming_delta(buf, ch, chunk, valid, local_block, big, lds_red);
+        if (valid) {
+            const int p = (int)buf.pstar[ch.chunk_off + chunk];
+            pstar = (p > pstar) ? p : pstar;
+        }
+    }
+    const long long own_lc =
+        (valid && buf.lc_chunk[slot.chunk_off + chunk] >= 0) ? (j0 + buf.lc_chunk[slot.chunk_off + chunk]) : -1;
+    long long lc = incoming_clear(own_lc, (long long)buf.lcin_block[slot.block_off + local_block], lds_ll);
+
+    unsigned D_lo = 0, V_lo = 0, D_hi = 0, V_hi = 0;
+    long long uncertain = 0, effect = 0, max_run = 0;
+    int overflow = 0, nonadjacent = 0;
+    unsigned validmask = 0;
+
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            const long long j = j0 + i;
+            if (j < n) {
+                validmask |= 1U << i;
+                const double c_prev = (i == 0) ? d.c_prev0 : cost_at(d, i - 1);
+                const double cj = cost_at(d, i);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const double a = grid_round(d.sv[i] - lam[k], magic);
+                    delta[k] = (j == 0) ? a : (clampc(delta[k], c_prev) + a);
+                }
+                const long long m = j - 1 - lc;
+                max_run = (m > max_run) ? m : max_run;
+                const double tau = tau0 + tau_step * (double)m;
+                const bool over = tau > kGuard;
+                overflow |= over ? 1 : 0;
+                const bool last = (j + 1 >= n);
+                if (NCH == 1) {
+                    const double dl = delta[0];
+                    int cls;
+                    bool certain;
+                    if (!last) {
+                        const double e = fabs(dl) - cj;
+                        certain = !over && (e > tau || e < -tau);
+                        cls = (dl > cj) ? kClsOne : ((dl < -cj) ? kClsZero : kClsCopy);
+                        if (i >= pstar && e > kGuard) {
+                            lc = j;
+                        }
+                    } else {
+                        certain = !over && (fabs(dl) > tau);
+                        cls = (dl > 0.0) ? kClsOne : kClsZero;
+                    }
+                    if (!certain) {
+                        ++uncertain;
+                        effect += m + 1;
+                    }
+                    D_lo |= (cls != kClsCopy ? 1U : 0U) << i;
+                    V_lo |= (cls == kClsOne ? 1U : 0U) << i;
+                } else {
+                    const double dlo = delta[0];        // at lambda_lo (larger)
+                    const double dhi = delta[NCH - 1];  // at lambda_hi (smaller)
+                    int lo, hi;
+                    if (!last) {
+                        lo = (dhi + cj < tau) ? kClsZero : ((dhi - cj > tau) ? kClsOne : kClsCopy);
+                        hi = (dlo - cj > -tau) ? kClsOne : ((dlo + cj < -tau) ? kClsZero : kClsCopy);
+                        if (i >= pstar && ((dhi - cj > kGuard) || (-dlo - cj > kGuard))) {
+                            lc = j;
+                        }
+                    } else {
+                        lo = (dhi > tau) ? kClsOne : kClsZero;
+                        hi = (dlo > -tau) ? kClsOne : kClsZero;
+                    }
+                    if (lo != hi) {
+                        const double bound = !last ? ((hi == kClsOne) ? cj : -cj) : 0.0;
+                        if (!last && (hi - lo != 1)) {
+                            nonadjacent = 1;
+                        }
+                        const unsigned long long at =
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&res.n_diff), 1ULL);
+                        if (at < (unsigned long long)kMaxDiffs) {
+                            FastDiff &fd = res.diffs[at];
+                            fd.locus = j;
+                            fd.margin_lo = dlo - bound;
+                            fd.margin_hi = dhi - bound;
+                            fd.run = m;
+                            fd.cls_lo = lo;
+                            fd.cls_hi = hi;
+                        }
+                    }
+                    D_lo |= (lo != kClsCopy ? 1U : 0U) << i;
+                    V_lo |= (lo == kClsOne ? 1U : 0U) << i;
+                    D_hi |= (hi != kClsCopy ? 1U : 0U) << i;
+                    V_hi |= (hi == kClsOne ? 1U : 0U) << i;
+                }
+            }
+        }
+    }
+
+    // certification statistics
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uncertain += __shfl_down(uncertain, off);
+        effect += __shfl_down(effect, off);
+        const long long o = __shfl_down(max_run, off);
+        max_run = (o > max_run) ? o : max_run;
+        overflow |= __shfl_down(overflow, off);
+        nonadjacent |= __shfl_down(nonadjacent, off);
+    }
+    if (lane == 0) {
+        if (uncertain) atomicAdd(reinterpret_cast<unsigned long long *>(&res.uncertain), (unsigned long long)uncertain);
+        if (effect) atomicAdd(reinterpret_cast<unsigned long long *>(&res.effect), (unsigned long long)effect);
+        if (max_run > 0) atomicMax(reinterpret_cast<long long *>(&res.max_run), max_run);
+        if (overflow) atomicOr(&res.overflow, 1);
+        if (nonadjacent) atomicOr(&res.nonadjacent, 1);
+    }
+
+    // backward fill
+    const long long bidx = slot.block_off + local_block;
+    const FillOut f_lo = block_fill(D_lo, V_lo, validmask, buf.bfv_lo, buf.bpend_lo, buf.bbase_lo, bidx, lds_u);
+    if (NCH == 2) {
+        (void)block_fill(D_hi, V_hi, validmask, buf.bfv_hi, buf.bpend_hi, buf.bbase_hi, bidx, lds_u);
+        // materialise fill(LO); pending tails are written as 0 and patched by K5
+        if (valid) {
+            uint8_t *z = task.solution + j0;
+            const unsigned bits = f_lo.zbits;
+            if (j0 + kChunk <= n && ((reinterpret_cast<uintptr_t>(z) & 15U) == 0)) {
+                uint4 w0, w1;
+                unsigned long long q0 = spread_bits_to_bytes(bits);
+                unsigned long long q1 = spread_bits_to_bytes(bits >> 8);
+                unsigned long long q2 = spread_bits_to_bytes(bits >> 16);
+                unsigned long long q3 = spread_bits_to_bytes(bits >> 24);
+                w0.x = (unsigned)q0;
+                w0.y = (unsigned)(q0 >> 32);
+                w0.z = (unsigned)q1;
+                w0.w = (unsigned)(q1 >> 32);
+                w1.x = (unsigned)q2;
+                w1.y = (unsigned)(q2 >> 32);
+                w1.z = (unsigned)q3;
+                w1.w = (unsigned)(q3 >> 32);
+                reinterpret_cast<uint4 *>(z)[0] = w0;
+                reinterpret_cast<uint4 *>(z)[1] = w1;
+            } else {
+                for (int i = 0; i < kChunk && j0 + i < n; ++i) {
+                    z[i] = (uint8_t)((bits >> i) & 1U);
+                }
+            }
+        }
+    }
+}
+
+template <bool HAS_COSTS>
+__global__ __launch_bounds__(kFastThreads) void fast_apply_kernel(FastLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *lds_s = smem;
+    double *lds_c = HAS_COSTS ? (smem + kTileDoubles) : smem;
+    double *lds_red = smem + (HAS_COSTS ? 2 : 1) * kTileDoubles;  // 24 doubles + 16 long long + 16 unsigned
+
+    const int2 bm = L.blockmap[blockIdx.x];
+    const FastTask task = L.tasks[bm.x];
+    if (HAS_COSTS != (task.switch_costs != nullptr)) {
+        return;
+    }
+    const int local_block = bm.y;
+    stage_tile<HAS_COSTS>(task, local_block, lds_s, lds_c);
+    const long long chunk = (long long)local_block * kFastThreads + threadIdx.x;
+    const long long j0 = chunk * kChunk;
+    ChunkData<HAS_COSTS> d;
+    load_chunk<HAS_COSTS>(task, j0, lds_s, lds_c, d);
+    for (int si = 0; si < task.slot_count; ++si) {
+        const int slot_index = task.slot_begin + si;
+        const FastSlot slot = L.slots[slot_index];
+        if (slot.mode == kModeProbe) {
+            apply_slot<1, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block, lds_red);
+        } else {
+            apply_slot<2, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block, lds_red);
+        }
+    }
+}
+
+// ---- K4: backward over workgroups -------------------------------------------------------------------
+__global__ __launch_bounds__(64) void fast_fillscan_kernel(FastLaunch L)
+{
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= 2 * L.n_slots) {
+        return;
+    }
+    const int si = idx >> 1;
+    const int variant = idx & 1;  // 0 = LO (probe: the exact-rule classes), 1 = HI (window only)
+    const FastSlot slot = L.slots[si];
+    if (variant == 1 && slot.mode != kModeWindow) {
+        return;
+    }
+    const FastTask &task = L.tasks[slot.task];
+    const uint8_t *bfv = variant ? L.buf.bfv_hi : L.buf.bfv_lo;
+    const unsigned *bpend = variant ? L.buf.bpend_hi : L.buf.bpend_lo;
+    const unsigned *bbase = variant ? L.buf.bbase_hi : L.buf.bbase_lo;
+    long long count = 0;
+    int r = 0;  // the last workgroup never has pending loci (the terminal locus is determined)
+    for (int b = task.n_blocks - 1; b >= 0; --b) {
+        const long long at = slot.block_off + b;
+        if (variant == 0) {
+            L.buf.rin_lo[at] = (uint8_t)r;
+        }
+        count += (long long)bbase[at] + (r ? (long long)bpend[at] : 0LL);
+        if (bfv[at] != kFvNone) {
+            r = (int)bfv[at];
+        }
+    }
+    if (variant == 0) {
+        L.buf.results[si].count_lo = count;
+    } else {
+        L.buf.results[si].count_hi = count;
+    }
+}
+
+// ---- K5: patch pending tails of fill(LO) ------------------------------------------------------------
+__global__ __launch_bounds__(kFastThreads) void fast_patch_kernel(FastLaunch L)
+{
+    const int2 bm = L.blockmap[blockIdx.x];
+    const FastTask task = L.tasks[bm.x];
+    const int local_block = bm.y;
+    for (int si = 0; si < task.slot_count; ++si) {
+        const FastSlot slot = L.slots[task.slot_begin + si];
+        if (slot.mode != kModeWindow) {
+            continue;
+        }
+        const long long at = slot.block_off + local_block;
+        const unsigned pend = L.buf.bpend_lo[at];
+        if (pend == 0U || L.buf.rin_lo[at] == 0) {
+            continue;
+        }
+        long long end = (long long)(local_block + 1) * kFastBlockLoci;
+        end = (end < task.n) ? end : task.n;
+        for (long long j = end - pend + threadIdx.x; j < end; j += kFastThreads) {
+            task.solution[j] = 1;
+        }
+    }
+}
+
+// ---- stats: min / max of scores and costs --------------------------------------------------------
+__global__ __launch_bounds__(kFastThreads) void stats_partial_kernel(const StatsTask *tasks, const int2 *blockmap,
+                                                                   double *partials)
+{
+    __shared__ double red[4][4];
+    const int2 bm = blockmap[blockIdx.x];
+    const StatsTask t = tasks[bm.x];
+    const long long base = (long long)bm.y * kFastBlockLoci;
+    double smin = INFINITY, smax = -INFINITY, cmin = INFINITY, cmax = -INFINITY;
+    for (int r = 0; r < kChunk; ++r) {
+        const long long j = base + r * kFastThreads + threadIdx.x;
+        if (j < t.n) {
+            const double v = t.scores[j];
+            smin = fmin(smin, v);
+            smax = fmax(smax, v);
+            if (t.switch_costs != nullptr && j < t.n - 1) {
+                const double c = t.switch_costs[j];
+                cmin = fmin(cmin, c);
+                cmax = fmax(cmax, c);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        smin = fmin(smin, __shfl_down(smin, off));
+        smax = fmax(smax, __shfl_down(smax, off));
+        cmin = fmin(cmin, __shfl_down(cmin, off));
+        cmax = fmax(cmax, __shfl_down(cmax, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        red[w][0] = smin;
+        red[w][1] = smax;
+        red[w][2] = cmin;
+        red[w][3] = cmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            red[0][0] = fmin(red[0][0], red[w][0]);
+            red[0][1] = fmax(red[0][1], red[w][1]);
+            red[0][2] = fmin(red[0][2], red[w][2]);
+            red[0][3] = fmax(red[0][3], red[w][3]);
+        }
+        for (int k = 0; k < 4; ++k) {
+            partials[4LL * blockIdx.x + k] = red[0][k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kFastThreads) void stats_final_kernel(const int2 *blockmap, int n_blocks_total,
+                                                                 const double *partials, double *out)
+{
+    // one workgroup per task: reduce the partials of that task's workgroups
+    __shared__ double red[4][4];
+    const int task = blockIdx.x;
+    double smin = INFINITY, smax = -INFINITY, cmin = INFINITY, cmax = -INFINITY;
+    for (int b = threadIdx.x; b < n_blocks_total; b += kFastThreads) {
+        if (blockmap[b].x == task) {
+            smin = fmin(smin, partials[4LL * b + 0]);
+            smax = fmax(smax, partials[4LL * b + 1]);
+            cmin = fmin(cmin, partials[4LL * b + 2]);
+            cmax = fmax(cmax, partials[4LL * b + 3]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        smin = fmin(smin, __shfl_down(smin, off));
+        smax = fmax(smax, __shfl_down(smax, off));
+        cmin = fmin(cmin, __shfl_down(cmin, off));
+        cmax = fmax(cmax, __shfl_down(cmax, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        red[w][0] = smin;
+        red[w][1] = smax;
+        red[w][2] = cmin;
+        red[w][3] = cmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            red[0][0] = fmin(red[0][0], red[w][0]);
+            red[0][1] = fmax(red[0][1], red[w][1]);
+            red[0][2] = fmin(red[0][2], red[w][2]);
+            red[0][3] = fmax(red[0][3], red[w][3]);
+        }
+        for (int k = 0; k < 4; ++k) {
+            out[4LL * task + k] = red[0][k];
+        }
+    }
+}
+
+}  // namespace
+
+int launch_fast_round(const FastLaunch &L, hipStream_t stream)
+{
+    if (L.n_slots == 0 || L.n_blocks_total == 0) {
+        return ROCCO_HIP_OK;
+    }
+    const size_t lds_plain = (size_t)(kTileDoubles + 64) * sizeof(double);
+    const size_t lds_costs = (size_t)(2 * kTileDoubles + 64) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_aggregate_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_costs));
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_apply_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_costs));
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_aggregate_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plain));
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_apply_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plain));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)L.n_blocks_total), block(kFastThreads);
+    const unsigned scan_blocks = (unsigned)((L.n_chains + L.n_slots + 63) / 64);
+    const unsigned fill_blocks = (unsigned)((2 * L.n_slots + 63) / 64);
+
+    hipLaunchKernelGGL((fast_aggregate_kernel<false>), grid, block, lds_plain, stream, L);
+    if (L.any_costs) {
+        hipLaunchKernelGGL((fast_aggregate_kernel<true>), grid, block, lds_costs, stream, L);
+    }
+    hipLaunchKernelGGL(fast_blockscan_kernel, dim3(scan_blocks), dim3(64), 0, stream, L);
+    hipLaunchKernelGGL((fast_apply_kernel<false>), grid, block, lds_plain, stream, L);
+    if (L.any_costs) {
+        hipLaunchKernelGGL((fast_apply_kernel<true>), grid, block, lds_costs, stream, L);
+    }
+    hipLaunchKernelGGL(fast_fillscan_kernel, dim3(fill_blocks), dim3(64), 0, stream, L);
+    if (L.any_window) {
+        hipLaunchKernelGGL(fast_patch_kernel, grid, block, 0, stream, L);
+    }
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_stats(const StatsTask *tasks_dev, int n_tasks, const int2 *blockmap_dev, int n_blocks_total,
+                 double *partials_dev, double *out_dev, hipStream_t stream)
+{
+    if (n_tasks == 0 || n_blocks_total == 0) {
+        return ROCCO_HIP_OK;
+    }
+    hipLaunchKernelGGL(stats_partial_kernel, dim3((unsigned)n_blocks_total), dim3(kFastThreads), 0, stream,
+                       tasks_dev, blockmap_dev, partials_dev);
+    hipLaunchKernelGGL(stats_final_kernel, dim3((unsigned)n_tasks), dim3(kFastThreads), 0, stream, blockmap_dev,
+                       n_blocks_total, partials_dev, out_dev);
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+}  // namespace rocco

@@ -47,13 +47,13 @@ struct rocco_hip_solver {
     // tunables
     int force_exact = 0;
     int spec_depth = 2;
-    int m_cap = 1 << 20;
     // scratch
     rocco::DeviceBuffer dev_tasks;    // kernel task descriptors
     rocco::DeviceBuffer dev_params;   // per-launch lambda lists etc.
     rocco::DeviceBuffer dev_results;  // per-launch counters / values
     rocco::DeviceBuffer dev_bits;     // exact-path decision bits
     rocco::DeviceBuffer dev_misc;     // decode / reduction scratch
+    rocco::DeviceBuffer dev_solution; // solution scratch when the caller wants counts only
     rocco::PinnedBuffer host_stage;   // pinned staging for uploads
     rocco::PinnedBuffer host_back;    // pinned staging for readbacks
 };

@@ -69,6 +69,7 @@ struct State {
     // request in flight
     int tree_depth = 0;
     std::vector<double> tree;
+    std::vector<int> tree_slot;  // index into the request's penalty list, or -1 if decided analytically
 };
 
 // Advance through bracket / bisection steps whose outcome is known without device work.
@@ -255,7 +256,14 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 } else {
                     ProbeRequest r;
                     r.problem = b;
-                    r.lambdas = s.tree;
+                    s.tree_slot.assign(s.tree.size(), -1);
+                    long long unused = 0;
+                    for (size_t i = 0; i < s.tree.size(); ++i) {
+                        if (!analytic_count(p, s.tree[i], &unused)) {
+                            s.tree_slot[i] = (int)r.lambdas.size();
+                            r.lambdas.push_back(s.tree[i]);
+                        }
+                    }
                     probes.push_back(r);
                     probe_owner.push_back(b);
                 }
@@ -325,9 +333,17 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 continue;
             }
             // kBisect: walk the evaluated levels while the outcomes are certain
+            const ChainProblem &p = problems[probe_owner[q]];
             size_t i = 0;
             for (int level = 0; level < s.tree_depth; ++level) {
-                const Outcome o = classify(r.results[i], s.target);
+                Outcome o;
+                long long analytic = 0;
+                if (s.tree_slot[i] < 0) {
+                    analytic_count(p, s.tree[i], &analytic);
+                    o = (analytic > s.target) ? Outcome::kGreater : Outcome::kLessEqual;
+                } else {
+                    o = classify(r.results[(size_t)s.tree_slot[i]], s.target);
+                }
                 if (o == Outcome::kUncertain) {
                     s.phase = State::kZone;
                     s.out.zone_iters = s.iters_left;
@@ -336,10 +352,10 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 ++s.out.evaluations;
                 --s.iters_left;
                 if (o == Outcome::kGreater) {
-                    s.lower = r.lambdas[i];
+                    s.lower = s.tree[i];
                     i = 2 * i + 2;
                 } else {
-                    s.upper = r.lambdas[i];
+                    s.upper = s.tree[i];
                     i = 2 * i + 1;
                 }
             }

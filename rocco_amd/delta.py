@@ -1,0 +1,48 @@
+"""Python face of the delta-form evaluation entry points (rocco_hip_delta_probe_f64 /
+rocco_hip_delta_window_f64): count-only evaluation of the chain solve at several penalties in one
+pass, and the joint window evaluation used to certify the final solution.
+These replace the reference's one-call-per-penalty use of rocco/_chain_dp.c (rocco/dp.py:113-162)."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+from . import _native
+from . import dp as _dp
+
+
+def delta_probe_device(scores_t, switch_costs, lambdas: Sequence[float]) -> List[Dict[str, int]]:
+    n = int(scores_t.shape[0])
+    costs_t, gamma = _dp._costs_arg(switch_costs, n, scores_t.device)
+    lam = (ctypes.c_double * len(lambdas))(*[float(x) for x in lambdas])
+    stats = (_native.ProbeStats * max(1, len(lambdas)))()
+    solver = _native.solver_for(scores_t.device.index)
+    _native.check(_native.load().rocco_hip_delta_probe_f64(
+        solver.handle, scores_t.data_ptr(), costs_t.data_ptr() if costs_t is not None else None, gamma, n,
+        lam, len(lambdas), stats, _dp._stream_ptr(scores_t)), "rocco_hip_delta_probe_f64")
+    return [{"count": int(s.count), "uncertain": int(s.uncertain), "effect": int(s.effect),
+             "max_run": int(s.max_run)} for s in stats[:len(lambdas)]]
+
+
+def delta_window_device(scores_t, switch_costs, lambda_lo: float, lambda_hi: float):
+    import torch
+
+    n = int(scores_t.shape[0])
+    costs_t, gamma = _dp._costs_arg(switch_costs, n, scores_t.device)
+    sol_t = torch.empty(n, dtype=torch.uint8, device=scores_t.device)
+    st = _native.WindowStats()
+    solver = _native.solver_for(scores_t.device.index)
+    _native.check(_native.load().rocco_hip_delta_window_f64(
+        solver.handle, scores_t.data_ptr(), costs_t.data_ptr() if costs_t is not None else None, gamma, n,
+        float(lambda_lo), float(lambda_hi), sol_t.data_ptr(), ctypes.byref(st), _dp._stream_ptr(scores_t)),
+        "rocco_hip_delta_window_f64")
+    listed = min(int(st.n_diff), 16)
+    return sol_t, {
+        "count_lo": int(st.count_lo), "count_hi": int(st.count_hi), "n_diff": int(st.n_diff),
+        "diff_adjacent": bool(st.diff_adjacent), "overflow": bool(st.overflow), "max_run": int(st.max_run),
+        "diffs": [{"locus": int(st.diff_locus[k]), "margin_lo": float(st.diff_margin_lo[k]),
+                   "margin_hi": float(st.diff_margin_hi[k]), "run": int(st.diff_run[k]),
+                   "cls_lo": int(st.diff_cls_lo[k]), "cls_hi": int(st.diff_cls_hi[k])} for k in range(listed)],
+    }

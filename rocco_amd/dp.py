@@ -233,17 +233,12 @@ def solve_penalized_chain(scores, switch_costs, selection_penalty: float) -> Tup
     return sol_t.cpu().numpy().astype(np.uint8, copy=False), float(value), int(count)
 
 
-def _bracket_seeds(scores_t, costs_t, gamma: float) -> Tuple[float, float]:
-    """lower/upper of rocco/dp.py:110-111 with NumPy's exact min / max / pairwise-sum results."""
-    n = int(scores_t.shape[0])
-    smin = float(scores_t.min().item())
-    smax = float(scores_t.max().item())
+def _sum_costs(n: int, costs_t, gamma: float) -> float:
+    """np.sum(switch_costs) of rocco/dp.py:110-111, bit-for-bit."""
     if costs_t is None:
-        total = sum_constant_like_numpy(gamma, n - 1)
-    else:
-        # general vector: NumPy's own pairwise summation on the host copy (API-completeness path)
-        total = float(np.sum(costs_t.cpu().numpy()))
-    return float(smin - total - 1.0), float(smax + total + 1.0)
+        return sum_constant_like_numpy(gamma, n - 1)
+    # general vector: NumPy's own pairwise summation on the host copy (API-completeness path)
+    return float(np.sum(costs_t.cpu().numpy()))
 
 
 def calibrate_selection_penalty_device(scores_t, switch_costs, target_count: int, max_iter: int = 60):
@@ -267,10 +262,7 @@ def calibrate_batch_device(scores_list, switch_costs_list, target_counts, max_it
         n = int(s_t.shape[0])
         if n == 0:
             raise ValueError("`scores` cannot be empty")
-        if not torch.isfinite(s_t).all():
-            raise ValueError("`scores` contain non-finite values")
         costs_t, gamma = _costs_arg(costs, n, device)
-        lower0, upper0 = _bracket_seeds(s_t, costs_t, gamma)
         sol_t = torch.empty(n, dtype=torch.uint8, device=device)
         keep.append((s_t, costs_t))
         sols.append(sol_t)
@@ -279,8 +271,7 @@ def calibrate_batch_device(scores_list, switch_costs_list, target_counts, max_it
         tasks[i].gamma = gamma
         tasks[i].n = n
         tasks[i].target_count = int(target)
-        tasks[i].lower0 = lower0
-        tasks[i].upper0 = upper0
+        tasks[i].sum_costs = _sum_costs(n, costs_t, gamma)
         tasks[i].max_iter = int(max_iter)
         tasks[i].solution_dev = sol_t.data_ptr()
     solver = _native.solver_for(device.index)
@@ -291,7 +282,8 @@ def calibrate_batch_device(scores_list, switch_costs_list, target_counts, max_it
     for i in range(k):
         r = results[i]
         out.append((float(r.selection_penalty), sols[i], float(r.penalized_value), int(r.selected_count),
-                    {"evaluations": int(r.evaluations), "path": int(r.path), "passes": int(r.passes)}))
+                    {"evaluations": int(r.evaluations), "path": int(r.path), "passes": int(r.passes),
+                     "zone_iters": int(r.zone_iters), "n_diff": int(r.n_diff)}))
     return out
 
 

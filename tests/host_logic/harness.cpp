@@ -22,7 +22,6 @@ struct HostProblem {
     size_t n;
     int qexp;
     double cmax, sabs;
-    int m_cap;
     uint8_t *solution;
 };
 
@@ -46,11 +45,11 @@ public:
             for (size_t i = 0; i < r.lambdas.size(); ++i) {
                 oracle_delta_stats st;
                 const int rc = oracle_delta_chain_f64(p.scores, p.costs, p.gamma, p.n, r.lambdas[i], p.qexp,
-                                                      p.cmax, p.sabs, p.m_cap, nullptr, &st);
+                                                      p.cmax, p.sabs, nullptr, &st);
                 if (rc != 0) return rc;
                 r.results[i].count = st.count;
                 r.results[i].uncertain = st.uncertain;
-                r.results[i].effect = (st.max_run > p.m_cap) ? (long long)p.n + 1 : st.effect;
+                r.results[i].effect = st.overflow ? (long long)p.n + 1 : st.effect;
                 r.results[i].max_run = st.max_run;
             }
         }
@@ -64,7 +63,7 @@ public:
             oracle_window_stats st;
             oracle_window_diff diffs[16];
             const int rc = oracle_delta_window_f64(p.scores, p.costs, p.gamma, p.n, r.lambda_lo, r.lambda_hi,
-                                                   p.qexp, p.cmax, p.sabs, p.m_cap, p.solution, &st, diffs, 16);
+                                                   p.qexp, p.cmax, p.sabs, p.solution, &st, diffs, 16);
             if (rc != 0) return rc;
             r.result.count_lo = st.count_lo;
             r.result.count_hi = st.count_hi;
@@ -123,7 +122,7 @@ extern "C" {
 // out_i: [path, evaluations, passes, zone_iters, n_diff, probe_calls, window_calls, exact_calls, exact_lambdas]
 int hostlogic_calibrate(const double *scores, const double *costs, double gamma, size_t n,
                         long long target, double sum_costs, int max_iter, int spec_depth, int force_exact,
-                        int m_cap, uint8_t *solution, double *penalty_out, double *value_out,
+                        uint8_t *solution, double *penalty_out, double *value_out,
                         long long *count_out, long long *out_i)
 {
     double smin = scores[0], smax = scores[0];
@@ -141,7 +140,7 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     }
     OracleEvaluator ev;
     HostProblem h{scores, costs, gamma, n, grid_exponent(cmax, smin, smax), cmax,
-                  std::fmax(std::fabs(smin), std::fabs(smax)), m_cap, solution};
+                  std::fmax(std::fabs(smin), std::fabs(smax)), solution};
     ev.hp.push_back(h);
     ChainProblem p;
     p.n = n;
@@ -176,7 +175,7 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
 }
 
 int hostlogic_solve_fixed(const double *scores, const double *costs, double gamma, size_t n, double lambda,
-                          int m_cap, uint8_t *solution, double *value_out, long long *count_out,
+                          uint8_t *solution, double *value_out, long long *count_out,
                           long long *out_i)
 {
     double smin = scores[0], smax = scores[0];
@@ -196,7 +195,7 @@ int hostlogic_solve_fixed(const double *scores, const double *costs, double gamm
     // penalties outside [smin - 1, smax + 1] are legal here: widen the grid range accordingly
     const double lo = std::fmin(smin, lambda), hi = std::fmax(smax, lambda);
     HostProblem h{scores, costs, gamma, n, grid_exponent(cmax, lo, hi), cmax,
-                  std::fmax(std::fabs(smin), std::fabs(smax)), m_cap, solution};
+                  std::fmax(std::fabs(smin), std::fabs(smax)), solution};
     ev.hp.push_back(h);
     ChainProblem p;
     p.n = n;

@@ -18,11 +18,11 @@ def lib():
         _lib.hostlogic_calibrate.restype = ctypes.c_int
         _lib.hostlogic_calibrate.argtypes = [
             dp, dp, ctypes.c_double, ctypes.c_size_t, ctypes.c_longlong, ctypes.c_double, ctypes.c_int,
-            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8), dp, dp,
+            ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8), dp, dp,
             ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
         _lib.hostlogic_solve_fixed.restype = ctypes.c_int
         _lib.hostlogic_solve_fixed.argtypes = [
-            dp, dp, ctypes.c_double, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
+            dp, dp, ctypes.c_double, ctypes.c_size_t, ctypes.c_double,
             ctypes.POINTER(ctypes.c_uint8), dp, ctypes.POINTER(ctypes.c_longlong),
             ctypes.POINTER(ctypes.c_longlong)]
     return _lib
@@ -32,7 +32,7 @@ def _dp(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if a is not None else None
 
 
-def calibrate(scores, gamma_or_costs, target, max_iter=60, spec_depth=2, force_exact=False, m_cap=1048576):
+def calibrate(scores, gamma_or_costs, target, max_iter=60, spec_depth=2, force_exact=False):
     s = np.ascontiguousarray(scores, dtype=np.float64)
     n = s.shape[0]
     if np.isscalar(gamma_or_costs):
@@ -46,7 +46,7 @@ def calibrate(scores, gamma_or_costs, target, max_iter=60, spec_depth=2, force_e
     cnt = ctypes.c_longlong()
     info = (ctypes.c_longlong * 9)()
     rc = lib().hostlogic_calibrate(_dp(s), _dp(costs), gamma, n, int(target), total, int(max_iter),
-                                   int(spec_depth), int(force_exact), int(m_cap),
+                                   int(spec_depth), int(force_exact),
                                    sol.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(pen),
                                    ctypes.byref(val), ctypes.byref(cnt), info)
     assert rc == 0, rc
@@ -55,7 +55,7 @@ def calibrate(scores, gamma_or_costs, target, max_iter=60, spec_depth=2, force_e
     return pen.value, sol, val.value, cnt.value, dict(zip(keys, [int(x) for x in info]))
 
 
-def solve_fixed(scores, gamma_or_costs, lam, m_cap=1048576):
+def solve_fixed(scores, gamma_or_costs, lam):
     s = np.ascontiguousarray(scores, dtype=np.float64)
     n = s.shape[0]
     if np.isscalar(gamma_or_costs):
@@ -66,7 +66,7 @@ def solve_fixed(scores, gamma_or_costs, lam, m_cap=1048576):
     val = ctypes.c_double()
     cnt = ctypes.c_longlong()
     info = (ctypes.c_longlong * 9)()
-    rc = lib().hostlogic_solve_fixed(_dp(s), _dp(costs), gamma, n, float(lam), int(m_cap),
+    rc = lib().hostlogic_solve_fixed(_dp(s), _dp(costs), gamma, n, float(lam),
                                      sol.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(val),
                                      ctypes.byref(cnt), info)
     assert rc == 0, rc
