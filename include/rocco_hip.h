@@ -98,6 +98,7 @@ typedef struct {
     int passes;               /* device rounds this task took part in                            */
     int zone_iters;           /* bisection steps left at the first uncertain probe (-1: none)    */
     long long n_diff;         /* decisions left open by the final window (-1: no window)         */
+    int maps;                 /* binade maps built for this task                                 */
 } rocco_hip_budget_result;
 
 int rocco_hip_solve_budget_batch_f64(rocco_hip_solver *solver, size_t n_tasks,
@@ -118,10 +119,18 @@ typedef struct {
     long long max_run;   /* longest run without a provable clear clamp                          */
 } rocco_hip_probe_stats;
 
+/* `emap_dev`: per-chunk binade codes (ceil(n / 32) bytes, see rocco_hip_delta_build_map_f64) or NULL. */
 int rocco_hip_delta_probe_f64(rocco_hip_solver *solver, const double *scores_dev,
                               const double *switch_costs_dev, double gamma, size_t n,
-                              const double *lambdas, size_t n_lambdas,
+                              const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,
                               rocco_hip_probe_stats *stats_out, void *stream);
+
+/* Binade map at penalty lambda_ref: for every 32-locus chunk, the binade of the reference's running
+ * value (rocco/_chain_dp.c:118-129 operate on prev0 / prev1 of that magnitude) and whether it keeps
+ * a distance > margin from every power of two.  Writes ceil(n / 32) bytes to emap_dev. */
+int rocco_hip_delta_build_map_f64(rocco_hip_solver *solver, const double *scores_dev,
+                                  const double *switch_costs_dev, double gamma, size_t n,
+                                  double lambda_ref, double margin, uint8_t *emap_dev, void *stream);
 
 typedef struct {
     long long count_lo, count_hi; /* selected loci of fill(LO) / fill(HI)                 */
@@ -138,8 +147,8 @@ typedef struct {
 /* Writes fill(LO) (n bytes) to solution_dev. */
 int rocco_hip_delta_window_f64(rocco_hip_solver *solver, const double *scores_dev,
                                const double *switch_costs_dev, double gamma, size_t n,
-                               double lambda_lo, double lambda_hi, uint8_t *solution_dev,
-                               rocco_hip_window_stats *stats_out, void *stream);
+                               const uint8_t *emap_dev, double lambda_lo, double lambda_hi,
+                               uint8_t *solution_dev, rocco_hip_window_stats *stats_out, void *stream);
 
 /* ---- objective ------------------------------------------------------------------------------
  * Replaces rocco/dp.py:16-34 `objective_value`: -(s . z) + c . |diff z|  (fixed-order tree sum;

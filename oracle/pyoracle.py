@@ -100,18 +100,22 @@ def lib() -> ctypes.CDLL:
         _lib.oracle_objective_value_f64.restype = ctypes.c_double
         _lib.oracle_objective_value_f64.argtypes = [
             _c_u8_p, _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t]
-        _lib.oracle_noise_model.restype = None
-        _lib.oracle_noise_model.argtypes = [
-            _c_double_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_int, ctypes.c_double,
-            ctypes.c_double, ctypes.POINTER(Noise)]
+        _lib.oracle_global_exponent.restype = ctypes.c_int
+        _lib.oracle_global_exponent.argtypes = [
+            _c_double_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+            ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
+        _lib.oracle_binade_map.restype = ctypes.c_int
+        _lib.oracle_binade_map.argtypes = [
+            _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
+            ctypes.c_double, _c_u8_p]
         _lib.oracle_delta_chain_f64.restype = ctypes.c_int
         _lib.oracle_delta_chain_f64.argtypes = [
             _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
-            ctypes.c_double, ctypes.c_double, _c_u8_p, ctypes.POINTER(DeltaStats)]
+            ctypes.c_double, ctypes.c_double, _c_u8_p, _c_u8_p, ctypes.POINTER(DeltaStats)]
         _lib.oracle_delta_window_f64.restype = ctypes.c_int
         _lib.oracle_delta_window_f64.argtypes = [
             _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double,
-            ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, _c_u8_p,
+            ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, _c_u8_p, _c_u8_p,
             ctypes.POINTER(WindowStats), ctypes.POINTER(WindowDiff), ctypes.c_int]
         _lib.oracle_median_columns.restype = ctypes.c_int
         _lib.oracle_median_columns.argtypes = [
@@ -265,15 +269,20 @@ def _costs(gamma_or_costs):
     return c, 0.0, float(c.max()) if c.size else 0.0
 
 
-def noise_model(scores, selection_penalty: float, qexp: int, cmax: float):
+def binade_map(scores, gamma_or_costs, lambda_ref: float, margin: float, qexp: int = None) -> np.ndarray:
+    """Per-chunk binade codes at penalty lambda_ref (oracle_binade_map)."""
     scores_ = np.ascontiguousarray(scores, dtype=np.float64)
-    out = Noise()
-    lib().oracle_noise_model(_dptr(scores_), scores_.shape[0], float(selection_penalty), int(qexp),
-                             float(cmax), float(np.max(np.abs(scores_))), ctypes.byref(out))
-    return {"p16": out.p16, "npos": out.npos, "tau0": out.tau0, "tau_step": out.tau_step, "guard": out.guard}
+    n = scores_.shape[0]
+    costs_, gamma, cmax = _costs(gamma_or_costs)
+    if qexp is None:
+        qexp = grid_exponent(cmax, scores_.min(), scores_.max())
+    emap = np.zeros((n + 31) // 32, dtype=np.uint8)
+    _check(lib().oracle_binade_map(_dptr(scores_), _dptr(costs_), gamma, n, float(lambda_ref), int(qexp),
+                                   float(margin), _u8ptr(emap)))
+    return emap
 
 
-def delta_chain(scores, gamma_or_costs, selection_penalty: float, qexp: int = None,
+def delta_chain(scores, gamma_or_costs, selection_penalty: float, qexp: int = None, emap=None,
                 want_solution: bool = True):
     scores_ = np.ascontiguousarray(scores, dtype=np.float64)
     n = scores_.shape[0]
@@ -281,15 +290,16 @@ def delta_chain(scores, gamma_or_costs, selection_penalty: float, qexp: int = No
     if qexp is None:
         qexp = grid_exponent(cmax, scores_.min(), scores_.max())
     solution = np.zeros(n, dtype=np.uint8) if want_solution else None
+    emap_ = None if emap is None else np.ascontiguousarray(emap, dtype=np.uint8)
     stats = DeltaStats()
     _check(lib().oracle_delta_chain_f64(_dptr(scores_), _dptr(costs_), gamma, n, float(selection_penalty),
-                                        int(qexp), cmax, float(np.max(np.abs(scores_))),
+                                        int(qexp), cmax, float(np.max(np.abs(scores_))), _u8ptr(emap_),
                                         _u8ptr(solution), ctypes.byref(stats)))
     return solution, {"count": stats.count, "uncertain": stats.uncertain, "effect": stats.effect,
                       "max_run": stats.max_run, "overflow": bool(stats.overflow)}
 
 
-def delta_window(scores, gamma_or_costs, lambda_lo: float, lambda_hi: float, qexp: int = None,
+def delta_window(scores, gamma_or_costs, lambda_lo: float, lambda_hi: float, qexp: int = None, emap=None,
                  diff_capacity: int = 16):
     scores_ = np.ascontiguousarray(scores, dtype=np.float64)
     n = scores_.shape[0]
@@ -297,11 +307,12 @@ def delta_window(scores, gamma_or_costs, lambda_lo: float, lambda_hi: float, qex
     if qexp is None:
         qexp = grid_exponent(cmax, scores_.min(), scores_.max())
     solution = np.zeros(n, dtype=np.uint8)
+    emap_ = None if emap is None else np.ascontiguousarray(emap, dtype=np.uint8)
     stats = WindowStats()
     diffs = (WindowDiff * max(1, diff_capacity))()
     _check(lib().oracle_delta_window_f64(_dptr(scores_), _dptr(costs_), gamma, n, float(lambda_lo),
                                          float(lambda_hi), int(qexp), cmax,
-                                         float(np.max(np.abs(scores_))), _u8ptr(solution),
+                                         float(np.max(np.abs(scores_))), _u8ptr(emap_), _u8ptr(solution),
                                          ctypes.byref(stats), diffs, int(diff_capacity)))
     listed = min(int(stats.n_diff), diff_capacity)
     return solution, {"count_lo": stats.count_lo, "count_hi": stats.count_hi, "n_diff": stats.n_diff,

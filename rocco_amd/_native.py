@@ -46,6 +46,7 @@ class BudgetResult(ctypes.Structure):
         ("passes", ctypes.c_int),
         ("zone_iters", ctypes.c_int),
         ("n_diff", ctypes.c_longlong),
+        ("maps", ctypes.c_int),
     ]
 
 
@@ -92,10 +93,13 @@ PROTOTYPES = [
      [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(BudgetTask), ctypes.POINTER(BudgetResult),
       ctypes.c_void_p]),
     ("rocco_hip_delta_probe_f64", ctypes.c_int,
-     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p,
       c_double_p, ctypes.c_size_t, ctypes.POINTER(ProbeStats), ctypes.c_void_p]),
-    ("rocco_hip_delta_window_f64", ctypes.c_int,
+    ("rocco_hip_delta_build_map_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t,
+      ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_delta_window_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p,
       ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.POINTER(WindowStats), ctypes.c_void_p]),
     ("rocco_hip_objective_value_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,

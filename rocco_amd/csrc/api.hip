@@ -111,6 +111,7 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->dev_bits.release();
     solver->dev_misc.release();
     solver->dev_solution.release();
+    solver->dev_maps.release();
     solver->host_stage.release();
     solver->host_back.release();
     delete solver;
@@ -180,7 +181,7 @@ int rocco_hip_solve_budget_batch_f64(rocco_hip_solver *solver, size_t n_tasks,
 
 int rocco_hip_delta_probe_f64(rocco_hip_solver *solver, const double *scores_dev,
                               const double *switch_costs_dev, double gamma, size_t n,
-                              const double *lambdas, size_t n_lambdas,
+                              const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,
                               rocco_hip_probe_stats *stats_out, void *stream)
 {
     if (solver == nullptr || scores_dev == nullptr || n == 0 || n >= ((size_t)1 << 31) ||
@@ -188,22 +189,35 @@ int rocco_hip_delta_probe_f64(rocco_hip_solver *solver, const double *scores_dev
         return ROCCO_HIP_EINVAL;
     }
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
-    return delta_probe(solver, scores_dev, switch_costs_dev, gamma, n, lambdas, n_lambdas, stats_out,
-                       (hipStream_t)stream);
+    return delta_probe(solver, scores_dev, switch_costs_dev, gamma, n, emap_dev, lambdas, n_lambdas,
+                       stats_out, (hipStream_t)stream);
+}
+
+int rocco_hip_delta_build_map_f64(rocco_hip_solver *solver, const double *scores_dev,
+                                  const double *switch_costs_dev, double gamma, size_t n,
+                                  double lambda_ref, double margin, uint8_t *emap_dev, void *stream)
+{
+    if (solver == nullptr || scores_dev == nullptr || n == 0 || n >= ((size_t)1 << 31) || emap_dev == nullptr ||
+        !(margin >= 0.0)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return delta_build_map(solver, scores_dev, switch_costs_dev, gamma, n, lambda_ref, margin, emap_dev,
+                           (hipStream_t)stream);
 }
 
 int rocco_hip_delta_window_f64(rocco_hip_solver *solver, const double *scores_dev,
                                const double *switch_costs_dev, double gamma, size_t n,
-                               double lambda_lo, double lambda_hi, uint8_t *solution_dev,
-                               rocco_hip_window_stats *stats_out, void *stream)
+                               const uint8_t *emap_dev, double lambda_lo, double lambda_hi,
+                               uint8_t *solution_dev, rocco_hip_window_stats *stats_out, void *stream)
 {
     if (solver == nullptr || scores_dev == nullptr || n == 0 || n >= ((size_t)1 << 31) ||
         solution_dev == nullptr || stats_out == nullptr || !(lambda_lo <= lambda_hi)) {
         return ROCCO_HIP_EINVAL;
     }
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
-    return delta_window(solver, scores_dev, switch_costs_dev, gamma, n, lambda_lo, lambda_hi, solution_dev,
-                        stats_out, (hipStream_t)stream);
+    return delta_window(solver, scores_dev, switch_costs_dev, gamma, n, emap_dev, lambda_lo, lambda_hi,
+                        solution_dev, stats_out, (hipStream_t)stream);
 }
 
 int rocco_hip_objective_value_f64(rocco_hip_solver *solver, const uint8_t *solution_dev,

@@ -18,11 +18,15 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
 namespace rocco {
 
 int delta_probe(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
-                double gamma, size_t n, const double *lambdas, size_t n_lambdas,
+                double gamma, size_t n, const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,
                 rocco_hip_probe_stats *stats_out, hipStream_t stream);
 
+int delta_build_map(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
+                    double gamma, size_t n, double lambda_ref, double margin, uint8_t *emap_dev,
+                    hipStream_t stream);
+
 int delta_window(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
-                 double gamma, size_t n, double lambda_lo, double lambda_hi, uint8_t *solution_dev,
-                 rocco_hip_window_stats *stats_out, hipStream_t stream);
+                 double gamma, size_t n, const uint8_t *emap_dev, double lambda_lo, double lambda_hi,
+                 uint8_t *solution_dev, rocco_hip_window_stats *stats_out, hipStream_t stream);
 
 }  // namespace rocco

@@ -26,6 +26,7 @@ struct DevProblem {
     uint8_t *solution = nullptr;
     int qexp = 0;
     double cmax = 0.0, sabs = 0.0;
+    uint8_t *emap = nullptr;  // device binade map (owned by the solver's map buffer), null = none
 };
 
 int grid_exponent(double cmax, double lo, double hi)
@@ -72,6 +73,43 @@ public:
             tasks.push_back(t);
         }
         return run_round(tasks);
+    }
+
+    int build_map(std::vector<MapRequest> &reqs) override
+    {
+        // carve (once) a map region per problem out of the solver's map buffer
+        if (!maps_allocated_) {
+            size_t total = 0;
+            for (const DevProblem &p : probs) {
+                total += align_up((p.n + kChunk - 1) / kChunk, 256);
+            }
+            int rc;
+            if ((rc = solver_->dev_maps.reserve(total + 256)) != ROCCO_HIP_OK) return rc;
+            size_t off = 0;
+            map_ptrs_.resize(probs.size());
+            for (size_t b = 0; b < probs.size(); ++b) {
+                map_ptrs_[b] = (uint8_t *)solver_->dev_maps.ptr + off;
+                off += align_up((probs[b].n + kChunk - 1) / kChunk, 256);
+            }
+            maps_allocated_ = true;
+        }
+        std::vector<RoundTask> tasks;
+        for (MapRequest &r : reqs) {
+            RoundTask t;
+            t.problem = r.problem;
+            t.map = true;
+            t.margin = r.margin;
+            t.lambdas = {r.lambda_ref};
+            tasks.push_back(t);
+        }
+        const int rc = run_round(tasks);
+        if (rc != ROCCO_HIP_OK) {
+            return rc;
+        }
+        for (MapRequest &r : reqs) {
+            probs[r.problem].emap = map_ptrs_[r.problem];
+        }
+        return ROCCO_HIP_OK;
     }
 
     int exact(std::vector<ExactRequest> &reqs) override
@@ -216,6 +254,8 @@ private:
     struct RoundTask {
         size_t problem = 0;
         bool window = false;
+        bool map = false;
+        double margin = 0.0;
         std::vector<double> lambdas;
         ProbeRequest *probe = nullptr;
         WindowRequest *win = nullptr;
@@ -233,7 +273,7 @@ private:
         std::vector<FastSlot> slots;
         std::vector<int2> blockmap;
         long long chain_chunks = 0, chain_blocks = 0, slot_chunks = 0, slot_blocks = 0;
-        bool any_costs = false, any_window = false;
+        bool any_costs = false, any_plain = false, any_window = false, any_map = false;
         for (size_t t = 0; t < T; ++t) {
             const DevProblem &p = probs[rt[t].problem];
             FastTask &ft = tasks[t];
@@ -243,6 +283,10 @@ private:
             ft.switch_costs = p.costs;
             ft.gamma = p.gamma;
             ft.n = (long long)p.n;
+            ft.qexp = p.qexp;
+            ft.emap = p.emap;
+            ft.emap_out = rt[t].map ? map_ptrs_[rt[t].problem] : nullptr;
+            ft.map_margin = rt[t].margin;
             ft.magic = std::ldexp(1.5, 52 + p.qexp);
             ft.big = std::ldexp(1.0, 50 + p.qexp);
             ft.qstep = std::ldexp(1.0, p.qexp);
@@ -252,6 +296,8 @@ private:
             ft.solution = p.solution;
             ft.slot_begin = (int)slots.size();
             any_costs = any_costs || (p.costs != nullptr);
+            any_plain = any_plain || (p.costs == nullptr);
+            any_map = any_map || rt[t].map;
             if (rt[t].window) {
                 any_window = true;
                 FastSlot s;
@@ -278,7 +324,7 @@ private:
                 for (double lam : rt[t].lambdas) {
                     FastSlot s;
                     s.task = (int)t;
-                    s.mode = kModeProbe;
+                    s.mode = rt[t].map ? kModeMap : kModeProbe;
                     s.chain_a = s.chain_b = (int)chains.size();
                     s.chunk_off = slot_chunks;
                     s.block_off = slot_blocks;
@@ -331,7 +377,10 @@ private:
         const size_t o_blk_a = carve((size_t)chain_blocks * 8), o_blk_lo = carve((size_t)chain_blocks * 8),
                      o_blk_hi = carve((size_t)chain_blocks * 8), o_din = carve((size_t)chain_blocks * 8);
         const size_t o_lcc = carve((size_t)slot_chunks);
+        const size_t o_wc = carve((size_t)slot_chunks * 8), o_gc = carve(any_map ? (size_t)slot_chunks * 8 : 8);
         const size_t o_lcb = carve((size_t)slot_blocks * 4), o_lcin = carve((size_t)slot_blocks * 4);
+        const size_t o_wb = carve((size_t)slot_blocks * 8), o_winb = carve((size_t)slot_blocks * 8);
+        const size_t o_gb = carve((size_t)slot_blocks * 8), o_ginb = carve((size_t)slot_blocks * 8);
         const size_t o_fvlo = carve((size_t)slot_blocks), o_fvhi = carve((size_t)slot_blocks);
         const size_t o_plo = carve((size_t)slot_blocks * 4), o_phi = carve((size_t)slot_blocks * 4);
         const size_t o_blo = carve((size_t)slot_blocks * 4), o_bhi = carve((size_t)slot_blocks * 4);
@@ -350,7 +399,9 @@ private:
         L.n_slots = (int)S;
         L.n_blocks_total = (int)NB;
         L.any_costs = any_costs;
+        L.any_plain = any_plain;
         L.any_window = any_window;
+        L.any_map = any_map;
         L.buf.agg_a = (double *)(sc + o_agg_a);
         L.buf.agg_lo = (double *)(sc + o_agg_lo);
         L.buf.agg_hi = (double *)(sc + o_agg_hi);
@@ -360,6 +411,12 @@ private:
         L.buf.blk_hi = (double *)(sc + o_blk_hi);
         L.buf.din = (double *)(sc + o_din);
         L.buf.lc_chunk = (int8_t *)(sc + o_lcc);
+        L.buf.w_chunk = (double *)(sc + o_wc);
+        L.buf.gain_chunk = (double *)(sc + o_gc);
+        L.buf.w_block = (double *)(sc + o_wb);
+        L.buf.win_block = (double *)(sc + o_winb);
+        L.buf.gain_block = (double *)(sc + o_gb);
+        L.buf.gainin_block = (double *)(sc + o_ginb);
         L.buf.lc_block = (int *)(sc + o_lcb);
         L.buf.lcin_block = (int *)(sc + o_lcin);
         L.buf.bfv_lo = (uint8_t *)(sc + o_fvlo);
@@ -383,6 +440,9 @@ private:
         for (size_t t = 0; t < T; ++t) {
             const FastTask &ft = tasks[t];
             const DevProblem &p = probs[rt[t].problem];
+            if (rt[t].map) {
+                continue;
+            }
             if (rt[t].window) {
                 const FastSlotResult &r = hr[ft.slot_begin];
                 WindowResult &w = rt[t].win->result;
@@ -422,6 +482,8 @@ private:
 
     rocco_hip_solver *solver_;
     hipStream_t stream_;
+    bool maps_allocated_ = false;
+    std::vector<uint8_t *> map_ptrs_;
 };
 
 // Fill ChainProblem / DevProblem statistics from one stats pass.
@@ -495,8 +557,34 @@ int solve_fixed_penalty(rocco_hip_solver *solver, const double *scores_dev,
     return ROCCO_HIP_OK;
 }
 
+int delta_build_map(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
+                    double gamma, size_t n, double lambda_ref, double margin, uint8_t *emap_dev,
+                    hipStream_t stream)
+{
+    HipEvaluator ev(solver, stream);
+    DevProblem d;
+    d.scores = scores_dev;
+    d.costs = (n > 1) ? switch_costs_dev : nullptr;
+    d.gamma = gamma;
+    d.n = n;
+    ev.probs.push_back(d);
+    std::vector<ChainProblem> problems(1);
+    problems[0].n = n;
+    problems[0].gamma = gamma;
+    int rc;
+    if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    std::vector<MapRequest> reqs(1);
+    reqs[0].problem = 0;
+    reqs[0].lambda_ref = lambda_ref;
+    reqs[0].margin = margin;
+    if ((rc = ev.build_map(reqs)) != ROCCO_HIP_OK) return rc;
+    ROCCO_HIP_TRY(hipMemcpyAsync(emap_dev, ev.probs[0].emap, (n + kChunk - 1) / kChunk, hipMemcpyDeviceToDevice, stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+    return ROCCO_HIP_OK;
+}
+
 int delta_probe(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
-                double gamma, size_t n, const double *lambdas, size_t n_lambdas,
+                double gamma, size_t n, const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,
                 rocco_hip_probe_stats *stats_out, hipStream_t stream)
 {
     HipEvaluator ev(solver, stream);
@@ -511,6 +599,7 @@ int delta_probe(rocco_hip_solver *solver, const double *scores_dev, const double
     problems[0].gamma = gamma;
     int rc;
     if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    ev.probs[0].emap = const_cast<uint8_t *>(emap_dev);
     std::vector<ProbeRequest> reqs(1);
     reqs[0].problem = 0;
     reqs[0].lambdas.assign(lambdas, lambdas + n_lambdas);
@@ -525,8 +614,8 @@ int delta_probe(rocco_hip_solver *solver, const double *scores_dev, const double
 }
 
 int delta_window(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
-                 double gamma, size_t n, double lambda_lo, double lambda_hi, uint8_t *solution_dev,
-                 rocco_hip_window_stats *stats_out, hipStream_t stream)
+                 double gamma, size_t n, const uint8_t *emap_dev, double lambda_lo, double lambda_hi,
+                 uint8_t *solution_dev, rocco_hip_window_stats *stats_out, hipStream_t stream)
 {
     HipEvaluator ev(solver, stream);
     DevProblem d;
@@ -541,6 +630,7 @@ int delta_window(rocco_hip_solver *solver, const double *scores_dev, const doubl
     problems[0].gamma = gamma;
     int rc;
     if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    ev.probs[0].emap = const_cast<uint8_t *>(emap_dev);
     std::vector<WindowRequest> reqs(1);
     reqs[0].problem = 0;
     reqs[0].lambda_lo = lambda_lo;
@@ -606,6 +696,7 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
         results[t].passes = res[t].passes;
         results[t].zone_iters = res[t].zone_iters;
         results[t].n_diff = res[t].n_diff;
+        results[t].maps = res[t].maps;
     }
     return ROCCO_HIP_OK;
 }

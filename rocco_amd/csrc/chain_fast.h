@@ -1,37 +1,45 @@
 // rocco_amd/csrc/chain_fast.h -- device descriptors of the parallel delta-form ("fast path") kernels.
 //
 // SPEC: identical, bit for bit, to the sequential definition in oracle/delta_oracle.c (DESIGN.md
-// section 4): fixed-point grid q = 2^qexp, chunks of 32 loci, constant clear-clamp guard 2^-16,
-// integer noise bound (P16, npos), tolerance tau_j = tau0 + tau_step * m_j.
+// section 4): arithmetic grid q = 2^qexp, chunks of 32 loci carrying a binade code (clean chunks use
+// the reference's own rounding grid u = 2^(e-52), hazard chunks the grid q with a per-step
+// tolerance weight), constant clear-clamp guard 2^-16, tolerance tau_j = weight accumulated since
+// the last provable clear clamp.
 #pragma once
 
 #include "common.h"
 
 namespace rocco {
 
-constexpr int kChunk = 32;                          // loci per lane (== ORACLE_CHUNK)
-constexpr int kFastThreads = 256;                   // lanes per workgroup
+constexpr int kChunk = 32;                             // loci per lane (== ORACLE_CHUNK)
+constexpr int kFastThreads = 256;                      // lanes per workgroup
 constexpr int kFastBlockLoci = kChunk * kFastThreads;  // 8192 loci per workgroup
-constexpr double kGuard = 0x1p-16;                  // == ORACLE_GUARD
+constexpr double kGuard = 0x1p-16;                     // == ORACLE_GUARD
+constexpr int kMapBias = 64;                           // == ORACLE_MAP_BIAS
+constexpr int kMapNone = 0xFF;                         // == ORACLE_MAP_NONE
 constexpr int kMaxDiffs = 16;
 
-enum FastMode { kModeProbe = 0, kModeWindow = 1 };
+enum FastMode { kModeProbe = 0, kModeWindow = 1, kModeMap = 2 };
 
 struct FastTask {
     const double *scores;
     const double *switch_costs;  // n-1 or nullptr
     double gamma;
     long long n;
+    int qexp;
     double magic;  // 1.5 * 2^(52 + qexp)
     double big;    // 2^(50 + qexp): saturation bound of the shift component
     double qstep;  // 2^qexp
     double cmax, sabs;
     int slot_begin, slot_count;
     int n_blocks;
-    uint8_t *solution;  // n bytes (window slots write fill(LO) here)
+    uint8_t *solution;    // n bytes (window slots write fill(LO) here)
+    const uint8_t *emap;  // binade code per chunk, or nullptr (every chunk = hazard, global exponent)
+    uint8_t *emap_out;    // map slots write the new codes here
+    double map_margin;
 };
 
-// One delta chain = (task, penalty).  A probe slot owns one chain, a window slot two
+// One delta chain = (task, penalty).  A probe / map slot owns one chain, a window slot two
 // (chain_a = lambda_lo, the larger delta; chain_b = lambda_hi).
 struct FastChain {
     int task;
@@ -61,9 +69,10 @@ struct FastSlotResult {
     long long max_run;
     long long n_diff;
     long long p16, npos;
-    double tau0, tau_step;
+    int e_global;
     int overflow;
     int nonadjacent;
+    int pad;
     FastDiff diffs[kMaxDiffs];
 };
 
@@ -75,8 +84,12 @@ struct FastBuffers {
     double *blk_a, *blk_lo, *blk_hi, *din;
     // per (slot, chunk)
     int8_t *lc_chunk;
+    double *w_chunk;     // tolerance weight after the last clear clamp (or of the whole chunk)
+    double *gain_chunk;  // map slots: sum of max(0, delta - c) over the chunk's steps
     // per (slot, block)
     int *lc_block, *lcin_block;
+    double *w_block, *win_block;
+    double *gain_block, *gainin_block;
     uint8_t *bfv_lo, *bfv_hi;
     unsigned *bpend_lo, *bpend_hi, *bbase_lo, *bbase_hi;
     uint8_t *rin_lo;
@@ -90,8 +103,8 @@ struct FastLaunch {
     const FastSlot *slots;
     const int2 *blockmap;  // global workgroup -> (task, local block)
     int n_tasks, n_chains, n_slots, n_blocks_total;
-    bool any_costs;
-    bool any_window;
+    bool any_costs, any_plain;
+    bool any_window, any_map;
     FastBuffers buf;
 };
 

@@ -1,21 +1,26 @@
 // rocco_amd/csrc/chain_fast.hip -- parallel delta-form evaluation of the chain solve on gfx950.
 //
 // What it computes (sequential definition: oracle/delta_oracle.c; derivation: DESIGN.md section 4):
-// the reference's two-state Viterbi pass (rocco/_chain_dp.c:115-186) collapses, in exact arithmetic,
-// to   delta_j = clamp(delta_{j-1}, -c, +c) + (s_j - lambda)   plus a backward fill over per-locus
-// classes ONE / ZERO / COPY.  x -> clamp(x + a, lo, hi) is closed under composition, and with
-// a_j, c_j rounded to a fixed-point grid every add/min/max is exact, so the composition is exactly
-// associative: the scan below returns the same bits as the sequential recursion.
+// the reference's two-state Viterbi pass (rocco/_chain_dp.c:115-186) depends on its two running
+// values only through their difference, which obeys
+//     delta_j = clamp(delta_{j-1}, -c, +c) + a_j ,   classes ONE / ZERO / COPY,  backward fill.
+// x -> clamp(x + a, lo, hi) is closed under composition, and with every input on a fixed-point
+// grid each add/min/max is exact, so the composition is exactly associative: the scan below returns
+// the same bits as the sequential recursion.  In "clean" chunks the inputs are rounded the way the
+// reference's own arithmetic rounds them (grid u of the running value's binade, two-stage:
+// rn_u(s) + rn_u(-lambda)), which reproduces the reference's decisions exactly; elsewhere a
+// tolerance weight per step bounds the difference.
 //
-// One round = five launches, all streaming / scan work (no MFMA; BLAS-1 class, HBM-bound):
+// One round = a handful of launches, all streaming / scan work (no MFMA; BLAS-1 class, HBM-bound):
 //   K1 aggregate : each lane owns a 32-locus chunk staged through LDS (coalesced 16-B loads),
 //                  builds its chunk function for every penalty of the task, workgroup-reduces it
 //   K2 blockscan : per chain, the (short) sequence of workgroup functions -> incoming delta per
-//                  workgroup; per slot, noise model (tau0, tau_step) and incoming clear-clamp index
-//   K3 apply     : re-stage the tile, in-workgroup scan -> exact incoming delta per lane, run the
+//                  workgroup; per slot, incoming clear-clamp index / tolerance weight / gain
+//   K3 apply     : re-stage the tile, in-workgroup scans -> exact incoming state per lane, run the
 //                  recursion, classify, certify, per-chunk fill summaries, window: write fill(LO)
 //   K4 fillscan  : per slot, backward over workgroups: fill value entering from the right, counts
 //   K5 patch     : window slots only: trailing undetermined loci of a workgroup take that value
+//   K6 mapcodes  : map slots only: binade code per chunk from the running stay-off value
 // The scores are read twice per round (K1, K3): 16 B / locus for all penalties of the round.
 #include "chain_fast.h"
 
@@ -68,6 +73,71 @@ __device__ __forceinline__ Fn shfl_up_fn(const Fn &f, int off)
     return r;
 }
 
+// ---- per-chunk arithmetic mode (mirrors make_mode / step_inputs of oracle/delta_oracle.c) --------
+struct Mode {
+    bool clean;
+    bool mapped;  // false: no map code -> weights are counted in steps and scaled once e_global is known
+    double magic_u, half_u, w_tie, w_step, base, nlam;
+};
+
+__device__ __forceinline__ Mode make_mode(int code, bool force_hazard, int e_global, const FastTask &task,
+                                          double lambda)
+{
+    Mode m;
+    const bool none = (code == kMapNone);
+    const int e = none ? e_global : ((code & 0x7F) - kMapBias);
+    bool hazard = force_hazard || none || ((code & 0x80) != 0);
+    if (!hazard && e - 52 < task.qexp) {
+        hazard = true;
+    }
+    m.magic_u = ldexp(1.5, e);
+    m.half_u = ldexp(1.0, e - 53);
+    m.nlam = grid_round(-lambda, m.magic_u);
+    if (!hazard) {
+        if (fabs(-lambda - m.nlam) == m.half_u) {
+            hazard = true;
+        }
+        if (task.switch_costs == nullptr && fabs(task.gamma - grid_round(task.gamma, m.magic_u)) == m.half_u) {
+            hazard = true;
+        }
+    }
+    const double hb = ldexp(1.0, e + 2 - 53);
+    m.clean = !hazard;
+    m.mapped = !none;
+    m.w_step = 4.0 * hb + task.qstep;
+    m.w_tie = 2.0 * m.half_u;
+    m.base = hazard ? (9.0 * hb + 2.0 * task.qstep) : 0.0;
+    return m;
+}
+
+__device__ __forceinline__ double cost_on_grid(const Mode &m, double c_raw, double magic_q)
+{
+    return m.clean ? grid_round(c_raw, m.magic_u) : grid_round(c_raw, magic_q);
+}
+
+// a_j of one chain on the chunk's grid
+__device__ __forceinline__ double step_a(const Mode &m, double s, double lambda, double magic_q)
+{
+    if (m.clean) {
+        return grid_round(s, m.magic_u) + m.nlam;
+    }
+    return grid_round(s - lambda, magic_q);
+}
+
+// tolerance weight of step j (unit 1.0 for unmapped chunks; scaled later)
+template <bool HAS_COSTS>
+__device__ __forceinline__ double step_w(const Mode &m, double s, double c_raw_prev, bool first_locus)
+{
+    if (m.clean) {
+        double w = (fabs(s - grid_round(s, m.magic_u)) == m.half_u) ? m.w_tie : 0.0;
+        if (HAS_COSTS && !first_locus && fabs(c_raw_prev - grid_round(c_raw_prev, m.magic_u)) == m.half_u) {
+            w += m.w_tie;
+        }
+        return w;
+    }
+    return m.mapped ? m.w_step : 1.0;
+}
+
 // ---- tile staging -----------------------------------------------------------------------------
 // The workgroup's 8192 loci are loaded with coalesced 16-B accesses and laid out one 32-locus
 // chunk per LDS row (row stride 34 doubles), so that every lane then reads its own row with
@@ -103,14 +173,13 @@ __device__ __forceinline__ void stage_tile(const FastTask &task, int local_block
     __syncthreads();
 }
 
-// Per-lane view of its chunk on the grid: sv[i] raw scores, cv[i] = cost between loci j0+i and
-// j0+i+1, c_prev0 = cost between j0-1 and j0.
+// Per-lane view of its chunk (raw values): sv[i] scores, cv[i] = cost between loci j0+i and j0+i+1,
+// c_prev0 = cost between j0-1 and j0.
 template <bool HAS_COSTS>
 struct ChunkData {
     double sv[kChunk];
     double cv[HAS_COSTS ? kChunk : 1];
     double c_prev0;
-    double gq;
 };
 
 template <bool HAS_COSTS>
@@ -124,34 +193,41 @@ __device__ __forceinline__ void load_chunk(const FastTask &task, long long j0, c
         d.sv[i] = v.x;
         d.sv[i + 1] = v.y;
     }
-    d.gq = grid_round(task.gamma, task.magic);
     if (HAS_COSTS) {
 #pragma unroll
         for (int i = 0; i < kChunk; i += 2) {
             const double2 v = *reinterpret_cast<const double2 *>(lds_c + t * kLdsStride + i);
-            d.cv[i] = grid_round(v.x, task.magic);
-            d.cv[i + 1] = grid_round(v.y, task.magic);
+            d.cv[i] = v.x;
+            d.cv[i + 1] = v.y;
         }
         double cp = 0.0;
         if (j0 > 0 && j0 < task.n) {
             cp = (t > 0) ? lds_c[(t - 1) * kLdsStride + (kChunk - 1)] : task.switch_costs[j0 - 1];
         }
-        d.c_prev0 = grid_round(cp, task.magic);
+        d.c_prev0 = cp;
     } else {
-        d.c_prev0 = d.gq;
+        d.c_prev0 = task.gamma;
     }
 }
 
 template <bool HAS_COSTS>
-__device__ __forceinline__ double cost_at(const ChunkData<HAS_COSTS> &d, int i)
+__device__ __forceinline__ double raw_cost_at(const FastTask &task, const ChunkData<HAS_COSTS> &d, int i)
 {
     if (HAS_COSTS) {
         return d.cv[i];
     }
-    return d.gq;
+    return task.gamma;
 }
 
-// ---- K1: chunk functions, provable clear clamps, noise sums ------------------------------------
+__device__ __forceinline__ int chunk_code(const FastTask &task, const FastSlot &slot, long long chunk, bool valid)
+{
+    if (!valid || slot.mode == kModeMap || task.emap == nullptr) {
+        return kMapNone;
+    }
+    return (int)task.emap[chunk];
+}
+
+// ---- K1: chunk functions, provable clear clamps, tolerance weights, noise sums --------------------
 template <int NCH, bool HAS_COSTS>
 __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastSlot &slot, int slot_index,
                                                const FastChain *chains, const FastBuffers &buf,
@@ -170,6 +246,17 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
     if (NCH == 2) {
         lam[NCH - 1] = chains[slot.chain_b].lambda;
     }
+    const int code = chunk_code(task, slot, chunk, valid);
+    const bool need_noise = (code == kMapNone);
+    Mode mode[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        mode[k] = make_mode(code, false, 0, task, lam[k]);
+    }
+    if (NCH == 2 && mode[0].clean != mode[NCH - 1].clean) {
+        mode[0] = make_mode(code, true, 0, task, lam[0]);
+        mode[NCH - 1] = make_mode(code, true, 0, task, lam[NCH - 1]);
+    }
     Fn f[NCH];
     int pstar[NCH];
     bool known[NCH];
@@ -182,6 +269,7 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
         known[k] = false;
     }
     int lc = -1;
+    double wsum = 0.0;
     long long p16 = 0;
     long long npos = 0;
 
@@ -190,11 +278,12 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
         for (int i = 0; i < kChunk; ++i) {
             const long long j = j0 + i;
             if (j < n) {
-                const double c_prev = (i == 0) ? d.c_prev0 : cost_at(d, i - 1);
-                const double cj = cost_at(d, i);
+                const double c_raw_prev = (i == 0) ? d.c_prev0 : raw_cost_at(task, d, i - 1);
+                const double c_prev = cost_on_grid(mode[0], c_raw_prev, magic);
+                const double cj = cost_on_grid(mode[0], raw_cost_at(task, d, i), magic);
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    const double a = grid_round(d.sv[i] - lam[k], magic);
+                    const double a = step_a(mode[k], d.sv[i], lam[k], magic);
                     if (j == 0) {
                         f[k].a = 0.0;
                         f[k].lo = a;
@@ -212,11 +301,12 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
                         known[k] = true;
                         pstar[k] = i;
                     }
-                    if (k == 0 && a > 0.0) {
+                    if (k == 0 && need_noise && a > 0.0) {
                         p16 += (long long)(16.0 * a);
                         ++npos;
                     }
                 }
+                wsum += step_w<HAS_COSTS>(mode[0], d.sv[i], c_raw_prev, j == 0);
                 if (j + 1 < n) {
                     bool clear;
                     if (NCH == 1) {
@@ -227,6 +317,7 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
                     }
                     if (clear) {
                         lc = i;
+                        wsum = 0.0;
                     }
                 }
             }
@@ -243,6 +334,7 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
             buf.pstar[ch.chunk_off + chunk] = (uint8_t)pstar[k];
         }
         buf.lc_chunk[slot.chunk_off + chunk] = (int8_t)lc;
+        buf.w_chunk[slot.chunk_off + chunk] = wsum;
     }
 
     // workgroup-ordered composition of the chunk functions (per chain)
@@ -262,19 +354,33 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
             lds_red[(k * 4 + wave) * 3 + 2] = g.hi;
         }
     }
+    // ordered reduction of (has_clear, weight), max clear index, noise sums
     long long lcg = (lc >= 0) ? (j0 + lc) : -1;
+    int wflag = (lc >= 0) ? 1 : 0;
+    double wval = wsum;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const long long o = __shfl_down(lcg, off);
-        lcg = (o > lcg) ? o : lcg;
-        p16 += __shfl_down(p16, off);
-        npos += __shfl_down(npos, off);
+    for (int off = 1; off < 64; off <<= 1) {
+        const int pf = __shfl_down(wflag, off);
+        const double pv = __shfl_down(wval, off);
+        const long long pl = __shfl_down(lcg, off);
+        const long long pp = __shfl_down(p16, off);
+        const long long pn = __shfl_down(npos, off);
+        if (lane + off < 64) {
+            // own is the left operand, partner the right one
+            wval = pf ? pv : (wval + pv);
+            wflag = wflag | pf;
+            lcg = (pl > lcg) ? pl : lcg;
+            p16 += pp;
+            npos += pn;
+        }
     }
     long long *lds_ll = reinterpret_cast<long long *>(lds_red + 24);
     if (lane == 0) {
-        lds_ll[wave * 3 + 0] = lcg;
-        lds_ll[wave * 3 + 1] = p16;
-        lds_ll[wave * 3 + 2] = npos;
+        lds_ll[wave * 4 + 0] = lcg;
+        lds_ll[wave * 4 + 1] = p16;
+        lds_ll[wave * 4 + 2] = npos;
+        lds_ll[wave * 4 + 3] = (long long)wflag;
+        lds_red[40 + wave] = wval;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -297,12 +403,18 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
             buf.blk_hi[ch.block_off + local_block] = g.hi;
         }
         long long m = -1, sp = 0, sn = 0;
+        int bf = 0;
+        double bw = 0.0;
         for (int w = 0; w < 4; ++w) {
-            m = (lds_ll[w * 3] > m) ? lds_ll[w * 3] : m;
-            sp += lds_ll[w * 3 + 1];
-            sn += lds_ll[w * 3 + 2];
+            m = (lds_ll[w * 4] > m) ? lds_ll[w * 4] : m;
+            sp += lds_ll[w * 4 + 1];
+            sn += lds_ll[w * 4 + 2];
+            const int f2 = (int)lds_ll[w * 4 + 3];
+            bw = f2 ? lds_red[40 + w] : (bw + lds_red[40 + w]);
+            bf |= f2;
         }
         buf.lc_block[slot.block_off + local_block] = (int)m;
+        buf.w_block[slot.block_off + local_block] = bw;
         if (sp != 0) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&buf.results[slot_index].p16),
                       (unsigned long long)sp);
@@ -321,7 +433,7 @@ __global__ __launch_bounds__(kFastThreads) void fast_aggregate_kernel(FastLaunch
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *lds_s = smem;
     double *lds_c = HAS_COSTS ? (smem + kTileDoubles) : smem;
-    double *lds_red = smem + (HAS_COSTS ? 2 : 1) * kTileDoubles;  // 24 doubles + 12 long long
+    double *lds_red = smem + (HAS_COSTS ? 2 : 1) * kTileDoubles;
 
     const int2 bm = L.blockmap[blockIdx.x];
     const FastTask task = L.tasks[bm.x];
@@ -337,17 +449,17 @@ __global__ __launch_bounds__(kFastThreads) void fast_aggregate_kernel(FastLaunch
     for (int si = 0; si < task.slot_count; ++si) {
         const int slot_index = task.slot_begin + si;
         const FastSlot slot = L.slots[slot_index];
-        if (slot.mode == kModeProbe) {
-            aggregate_slot<1, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block,
+        if (slot.mode == kModeWindow) {
+            aggregate_slot<2, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block,
                                          lds_red);
         } else {
-            aggregate_slot<2, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block,
+            aggregate_slot<1, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block,
                                          lds_red);
         }
     }
 }
 
-// ---- K2: per chain incoming delta per workgroup; per slot noise model + incoming clear index ----
+// ---- K2: per chain incoming delta per workgroup; per slot incoming clear index / weight / gain ------
 __global__ __launch_bounds__(64) void fast_blockscan_kernel(FastLaunch L)
 {
     const int idx = blockIdx.x * 64 + threadIdx.x;
@@ -370,25 +482,31 @@ __global__ __launch_bounds__(64) void fast_blockscan_kernel(FastLaunch L)
         const FastTask &task = L.tasks[slot.task];
         const int nb = task.n_blocks;
         int run = -1;
+        double w = 0.0;
         for (int b = 0; b < nb; ++b) {
-            L.buf.lcin_block[slot.block_off + b] = run;
-            const int x = L.buf.lc_block[slot.block_off + b];
+            const long long at = slot.block_off + b;
+            L.buf.lcin_block[at] = run;
+            L.buf.win_block[at] = w;
+            const int x = L.buf.lc_block[at];
+            if (x >= 0) {
+                w = L.buf.w_block[at];
+            } else {
+                w += L.buf.w_block[at];
+            }
             run = (x > run) ? x : run;
         }
-        // noise model (oracle_noise_model): Pb bounds every intermediate of the reference's pass
+        // global exponent (oracle_global_exponent): Pb bounds every running value of the reference
         FastSlotResult &res = L.buf.results[si];
         const double lam = L.chains[slot.chain_a].lambda;
         const double pb = 2.0 * ((double)(res.p16 + res.npos) * 0.0625 + task.cmax + task.sabs + fabs(lam) + 1.0);
-        const double h = ldexp(1.0, ilogb(pb) - 53);
-        res.tau_step = 4.0 * h + task.qstep;
-        res.tau0 = 9.0 * h + 2.0 * task.qstep;
+        res.e_global = ilogb(pb);
     }
 }
 
 // ---- K3 helpers ---------------------------------------------------------------------------------
 // Within-chunk backward fill on bit masks: det = determined loci, val = class ONE among them.
-// Returns smeared masks: every locus below a determined one takes the nearest determined value
-// above it; loci above the highest determined one stay undetermined.
+// Every locus below a determined one takes the nearest determined value above it; loci above the
+// highest determined one stay undetermined.
 __device__ __forceinline__ void smear_fill(unsigned &det, unsigned &val)
 {
     val &= det;
@@ -408,9 +526,7 @@ __device__ __forceinline__ unsigned long long spread_bits_to_bytes(unsigned x8)
 }
 
 struct FillOut {
-    unsigned zbits;    // fill values of the chunk (pending loci as 0)
-    bool pending;      // the chunk's trailing undetermined loci wait for the value from the right
-    unsigned tailmask; // those loci
+    unsigned zbits;  // fill values of the chunk (pending loci as 0)
 };
 
 // Workgroup-level backward fill for one class variant.  D/V: determined / ONE masks of the lane's
@@ -427,8 +543,7 @@ __device__ __forceinline__ FillOut block_fill(unsigned D, unsigned V, unsigned v
     const int fv = (D != 0U) ? (int)((V >> (__ffs(D) - 1)) & 1U) : kFvNone;
     const unsigned long long has = __ballot(fv != kFvNone);
     const unsigned long long one = __ballot(fv == 1);
-    // nearest lane to the right (same wave) with a determined class
-    int r = kFvNone;
+    int r = kFvNone;  // value of the nearest determined class to the right of this chunk
     const unsigned long long right = (lane == 63) ? 0ULL : (has & (~0ULL << (lane + 1)));
     if (right != 0ULL) {
         const int u = __ffsll((long long)right) - 1;
@@ -456,11 +571,10 @@ __device__ __forceinline__ FillOut block_fill(unsigned D, unsigned V, unsigned v
     }
     __syncthreads();
     FillOut out;
-    out.tailmask = tailmask;
-    out.pending = (r == kFvNone) && (tailmask != 0U);
+    const bool pending = (r == kFvNone) && (tailmask != 0U);
     out.zbits = (val & det & validmask) | ((r == 1) ? tailmask : 0U);
     unsigned base = (unsigned)__popc(out.zbits);
-    unsigned pend = out.pending ? (unsigned)__popc(tailmask) : 0U;
+    unsigned pend = pending ? (unsigned)__popc(tailmask) : 0U;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         base += __shfl_down(base, off);
@@ -537,33 +651,53 @@ __device__ __forceinline__ double incoming_delta(const FastBuffers &buf, const F
     return apply_fn(total, buf.din[ch.block_off + local_block]);
 }
 
-// exclusive in-workgroup prefix max of the clear-clamp index (global locus index, -1 none)
-__device__ __forceinline__ long long incoming_clear(long long own, long long block_in, long long *lds_ll)
+// exclusive in-workgroup scans of the clear-clamp index (max) and of the tolerance weight
+// (segmented sum: a chunk with a clear clamp restarts the sum)
+__device__ __forceinline__ void incoming_clear(long long own_lc, double own_w, long long block_lc,
+                                               double block_w, long long *lds_ll, double *lds_w,
+                                               long long &lc_in, double &w_in)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    long long inc = own;
+    long long inc = own_lc;
+    int flag = (own_lc >= 0) ? 1 : 0;
+    double val = own_w;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const long long p = __shfl_up(inc, off);
+        const int pf = __shfl_up(flag, off);
+        const double pv = __shfl_up(val, off);
         if (lane >= off) {
             inc = (p > inc) ? p : inc;
+            if (!flag) {
+                val = pv + val;
+            }
+            flag |= pf;
         }
     }
     if (lane == 63) {
-        lds_ll[wave] = inc;
+        lds_ll[wave * 2] = inc;
+        lds_ll[wave * 2 + 1] = (long long)flag;
+        lds_w[wave] = val;
     }
     __syncthreads();
     long long ex = __shfl_up(inc, 1);
+    int exf = __shfl_up(flag, 1);
+    double exv = __shfl_up(val, 1);
     if (lane == 0) {
         ex = -1;
+        exf = 0;
+        exv = 0.0;
     }
-    long long pre = block_in;
+    long long pre = block_lc;
+    double prew = block_w;
     for (int w = 0; w < wave; ++w) {
-        pre = (lds_ll[w] > pre) ? lds_ll[w] : pre;
+        pre = (lds_ll[w * 2] > pre) ? lds_ll[w * 2] : pre;
+        prew = lds_ll[w * 2 + 1] ? lds_w[w] : (prew + lds_w[w]);
     }
     __syncthreads();
-    return (ex > pre) ? ex : pre;
+    lc_in = (ex > pre) ? ex : pre;
+    w_in = exf ? exv : (prew + exv);
 }
 
 // ---- K3: apply ------------------------------------------------------------------------------------
@@ -579,10 +713,9 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     const bool valid = j0 < n;
     const int lane = threadIdx.x & 63;
     FastSlotResult &res = buf.results[slot_index];
-    const double tau0 = res.tau0;
-    const double tau_step = res.tau_step;
     long long *lds_ll = reinterpret_cast<long long *>(lds_red + 24);
-    unsigned *lds_u = reinterpret_cast<unsigned *>(lds_red + 40);
+    double *lds_w = lds_red + 36;
+    unsigned *lds_u = reinterpret_cast<unsigned *>(lds_red + 44);
 
     double lam[NCH], delta[NCH];
     int pstar = 0;
@@ -596,14 +729,33 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
             pstar = (p > pstar) ? p : pstar;
         }
     }
+    const int code = chunk_code(task, slot, chunk, valid);
+    Mode mode[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        mode[k] = make_mode(code, false, res.e_global, task, lam[k]);
+    }
+    if (NCH == 2 && mode[0].clean != mode[NCH - 1].clean) {
+        mode[0] = make_mode(code, true, res.e_global, task, lam[0]);
+        mode[NCH - 1] = make_mode(code, true, res.e_global, task, lam[NCH - 1]);
+    }
+    // unmapped chunks counted their weights in steps
+    const double wscale = mode[0].mapped ? 1.0 : mode[0].w_step;
     const long long own_lc =
         (valid && buf.lc_chunk[slot.chunk_off + chunk] >= 0) ? (j0 + buf.lc_chunk[slot.chunk_off + chunk]) : -1;
-    long long lc = incoming_clear(own_lc, (long long)buf.lcin_block[slot.block_off + local_block], lds_ll);
+    const double own_w = valid ? buf.w_chunk[slot.chunk_off + chunk] : 0.0;
+    long long lc;
+    double wacc;
+    incoming_clear(own_lc, own_w, (long long)buf.lcin_block[slot.block_off + local_block],
+                   buf.win_block[slot.block_off + local_block], lds_ll, lds_w, lc, wacc);
+    // a task is either mapped everywhere or nowhere, so one scale applies to the incoming weight too
+    wacc *= wscale;
 
     unsigned D_lo = 0, V_lo = 0, D_hi = 0, V_hi = 0;
     long long uncertain = 0, effect = 0, max_run = 0;
     int overflow = 0, nonadjacent = 0;
     unsigned validmask = 0;
+    double gain = 0.0;
 
     if (valid) {
 #pragma unroll
@@ -611,16 +763,21 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
             const long long j = j0 + i;
             if (j < n) {
                 validmask |= 1U << i;
-                const double c_prev = (i == 0) ? d.c_prev0 : cost_at(d, i - 1);
-                const double cj = cost_at(d, i);
+                const double c_raw_prev = (i == 0) ? d.c_prev0 : raw_cost_at(task, d, i - 1);
+                const double c_prev = cost_on_grid(mode[0], c_raw_prev, magic);
+                const double cj = cost_on_grid(mode[0], raw_cost_at(task, d, i), magic);
+                if (slot.mode == kModeMap && j > 0) {
+                    gain += fmax(0.0, delta[0] - c_prev);
+                }
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    const double a = grid_round(d.sv[i] - lam[k], magic);
+                    const double a = step_a(mode[k], d.sv[i], lam[k], magic);
                     delta[k] = (j == 0) ? a : (clampc(delta[k], c_prev) + a);
                 }
+                wacc += step_w<HAS_COSTS>(mode[0], d.sv[i], c_raw_prev, j == 0) * wscale;
                 const long long m = j - 1 - lc;
                 max_run = (m > max_run) ? m : max_run;
-                const double tau = tau0 + tau_step * (double)m;
+                const double tau = wacc + mode[0].base;
                 const bool over = tau > kGuard;
                 overflow |= over ? 1 : 0;
                 const bool last = (j + 1 >= n);
@@ -634,6 +791,7 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
                         cls = (dl > cj) ? kClsOne : ((dl < -cj) ? kClsZero : kClsCopy);
                         if (i >= pstar && e > kGuard) {
                             lc = j;
+                            wacc = 0.0;
                         }
                     } else {
                         certain = !over && (fabs(dl) > tau);
@@ -650,14 +808,15 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
                     const double dhi = delta[NCH - 1];  // at lambda_hi (smaller)
                     int lo, hi;
                     if (!last) {
-                        lo = (dhi + cj < tau) ? kClsZero : ((dhi - cj > tau) ? kClsOne : kClsCopy);
-                        hi = (dlo - cj > -tau) ? kClsOne : ((dlo + cj < -tau) ? kClsZero : kClsCopy);
+                        lo = (dhi + cj <= tau) ? kClsZero : ((dhi - cj > tau) ? kClsOne : kClsCopy);
+                        hi = (dlo - cj >= -tau) ? kClsOne : ((dlo + cj < -tau) ? kClsZero : kClsCopy);
                         if (i >= pstar && ((dhi - cj > kGuard) || (-dlo - cj > kGuard))) {
                             lc = j;
+                            wacc = 0.0;
                         }
                     } else {
                         lo = (dhi > tau) ? kClsOne : kClsZero;
-                        hi = (dlo > -tau) ? kClsOne : kClsZero;
+                        hi = (dlo >= -tau) ? kClsOne : kClsZero;
                     }
                     if (lo != hi) {
                         const double bound = !last ? ((hi == kClsOne) ? cj : -cj) : 0.0;
@@ -703,6 +862,26 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
         if (nonadjacent) atomicOr(&res.nonadjacent, 1);
     }
 
+    // map slots: gain of this chunk and of the workgroup (fixed reduction order)
+    if (slot.mode == kModeMap) {
+        if (valid) {
+            buf.gain_chunk[slot.chunk_off + chunk] = gain;
+        }
+        double g = gain;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            g += __shfl_down(g, off);
+        }
+        if (lane == 0) {
+            lds_w[4 + (threadIdx.x >> 6)] = g;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            buf.gain_block[slot.block_off + local_block] = ((lds_w[4] + lds_w[5]) + lds_w[6]) + lds_w[7];
+        }
+        __syncthreads();
+    }
+
     // backward fill
     const long long bidx = slot.block_off + local_block;
     const FillOut f_lo = block_fill(D_lo, V_lo, validmask, buf.bfv_lo, buf.bpend_lo, buf.bbase_lo, bidx, lds_u);
@@ -714,10 +893,10 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
             const unsigned bits = f_lo.zbits;
             if (j0 + kChunk <= n && ((reinterpret_cast<uintptr_t>(z) & 15U) == 0)) {
                 uint4 w0, w1;
-                unsigned long long q0 = spread_bits_to_bytes(bits);
-                unsigned long long q1 = spread_bits_to_bytes(bits >> 8);
-                unsigned long long q2 = spread_bits_to_bytes(bits >> 16);
-                unsigned long long q3 = spread_bits_to_bytes(bits >> 24);
+                const unsigned long long q0 = spread_bits_to_bytes(bits);
+                const unsigned long long q1 = spread_bits_to_bytes(bits >> 8);
+                const unsigned long long q2 = spread_bits_to_bytes(bits >> 16);
+                const unsigned long long q3 = spread_bits_to_bytes(bits >> 24);
                 w0.x = (unsigned)q0;
                 w0.y = (unsigned)(q0 >> 32);
                 w0.z = (unsigned)q1;
@@ -743,7 +922,7 @@ __global__ __launch_bounds__(kFastThreads) void fast_apply_kernel(FastLaunch L)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *lds_s = smem;
     double *lds_c = HAS_COSTS ? (smem + kTileDoubles) : smem;
-    double *lds_red = smem + (HAS_COSTS ? 2 : 1) * kTileDoubles;  // 24 doubles + 16 long long + 16 unsigned
+    double *lds_red = smem + (HAS_COSTS ? 2 : 1) * kTileDoubles;
 
     const int2 bm = L.blockmap[blockIdx.x];
     const FastTask task = L.tasks[bm.x];
@@ -759,15 +938,15 @@ __global__ __launch_bounds__(kFastThreads) void fast_apply_kernel(FastLaunch L)
     for (int si = 0; si < task.slot_count; ++si) {
         const int slot_index = task.slot_begin + si;
         const FastSlot slot = L.slots[slot_index];
-        if (slot.mode == kModeProbe) {
-            apply_slot<1, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block, lds_red);
-        } else {
+        if (slot.mode == kModeWindow) {
             apply_slot<2, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block, lds_red);
+        } else {
+            apply_slot<1, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block, lds_red);
         }
     }
 }
 
-// ---- K4: backward over workgroups -------------------------------------------------------------------
+// ---- K4: backward over workgroups (fill) and forward (map gains) ---------------------------------
 __global__ __launch_bounds__(64) void fast_fillscan_kernel(FastLaunch L)
 {
     const int idx = blockIdx.x * 64 + threadIdx.x;
@@ -775,12 +954,20 @@ __global__ __launch_bounds__(64) void fast_fillscan_kernel(FastLaunch L)
         return;
     }
     const int si = idx >> 1;
-    const int variant = idx & 1;  // 0 = LO (probe: the exact-rule classes), 1 = HI (window only)
+    const int variant = idx & 1;  // 0 = LO (probe: the exact-rule classes), 1 = HI (window) / gains (map)
     const FastSlot slot = L.slots[si];
+    const FastTask &task = L.tasks[slot.task];
+    if (variant == 1 && slot.mode == kModeMap) {
+        double g = 0.0;
+        for (int b = 0; b < task.n_blocks; ++b) {
+            L.buf.gainin_block[slot.block_off + b] = g;
+            g += L.buf.gain_block[slot.block_off + b];
+        }
+        return;
+    }
     if (variant == 1 && slot.mode != kModeWindow) {
         return;
     }
-    const FastTask &task = L.tasks[slot.task];
     const uint8_t *bfv = variant ? L.buf.bfv_hi : L.buf.bfv_lo;
     const unsigned *bpend = variant ? L.buf.bpend_hi : L.buf.bpend_lo;
     const unsigned *bbase = variant ? L.buf.bbase_hi : L.buf.bbase_lo;
@@ -823,6 +1010,63 @@ __global__ __launch_bounds__(kFastThreads) void fast_patch_kernel(FastLaunch L)
         end = (end < task.n) ? end : task.n;
         for (long long j = end - pend + threadIdx.x; j < end; j += kFastThreads) {
             task.solution[j] = 1;
+        }
+    }
+}
+
+// ---- K6: binade codes from the running stay-off value (oracle_binade_code) ---------------------------
+__device__ __forceinline__ uint8_t binade_code(double p0_lo, double p0_hi, double margin)
+{
+    const double top = fmax(p0_hi, 1.0);
+    int e = ilogb(top);
+    if (e > 60) {
+        e = 60;
+    }
+    bool clean = false;
+    if (p0_lo > 0.0) {
+        const double lo_edge = ldexp(1.0, e), hi_edge = ldexp(1.0, e + 1);
+        clean = (p0_lo - lo_edge > margin) && (hi_edge - p0_hi > margin);
+    }
+    return (uint8_t)((clean ? 0 : 0x80) | (e + kMapBias));
+}
+
+__global__ __launch_bounds__(kFastThreads) void fast_mapcode_kernel(FastLaunch L)
+{
+    __shared__ double wsum[4];
+    const int2 bm = L.blockmap[blockIdx.x];
+    const FastTask task = L.tasks[bm.x];
+    const int local_block = bm.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int si = 0; si < task.slot_count; ++si) {
+        const FastSlot slot = L.slots[task.slot_begin + si];
+        if (slot.mode != kModeMap || task.emap_out == nullptr) {
+            continue;
+        }
+        const long long chunk = (long long)local_block * kFastThreads + threadIdx.x;
+        const bool valid = chunk * kChunk < task.n;
+        const double g = valid ? L.buf.gain_chunk[slot.chunk_off + chunk] : 0.0;
+        double inc = g;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double p = __shfl_up(inc, off);
+            if (lane >= off) {
+                inc += p;
+            }
+        }
+        if (lane == 63) {
+            wsum[wave] = inc;
+        }
+        __syncthreads();
+        double pre = L.buf.gainin_block[slot.block_off + local_block];
+        for (int w = 0; w < wave; ++w) {
+            pre += wsum[w];
+        }
+        __syncthreads();
+        const double p0_end = pre + inc;
+        const double p0_start = p0_end - g;
+        if (valid) {
+            task.emap_out[chunk] = binade_code(p0_start, p0_end, task.map_margin);
         }
     }
 }
@@ -945,18 +1189,25 @@ int launch_fast_round(const FastLaunch &L, hipStream_t stream)
     const unsigned scan_blocks = (unsigned)((L.n_chains + L.n_slots + 63) / 64);
     const unsigned fill_blocks = (unsigned)((2 * L.n_slots + 63) / 64);
 
-    hipLaunchKernelGGL((fast_aggregate_kernel<false>), grid, block, lds_plain, stream, L);
+    if (L.any_plain) {
+        hipLaunchKernelGGL((fast_aggregate_kernel<false>), grid, block, lds_plain, stream, L);
+    }
     if (L.any_costs) {
         hipLaunchKernelGGL((fast_aggregate_kernel<true>), grid, block, lds_costs, stream, L);
     }
     hipLaunchKernelGGL(fast_blockscan_kernel, dim3(scan_blocks), dim3(64), 0, stream, L);
-    hipLaunchKernelGGL((fast_apply_kernel<false>), grid, block, lds_plain, stream, L);
+    if (L.any_plain) {
+        hipLaunchKernelGGL((fast_apply_kernel<false>), grid, block, lds_plain, stream, L);
+    }
     if (L.any_costs) {
         hipLaunchKernelGGL((fast_apply_kernel<true>), grid, block, lds_costs, stream, L);
     }
     hipLaunchKernelGGL(fast_fillscan_kernel, dim3(fill_blocks), dim3(64), 0, stream, L);
     if (L.any_window) {
         hipLaunchKernelGGL(fast_patch_kernel, grid, block, 0, stream, L);
+    }
+    if (L.any_map) {
+        hipLaunchKernelGGL(fast_mapcode_kernel, grid, block, 0, stream, L);
     }
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;

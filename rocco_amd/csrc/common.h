@@ -54,6 +54,7 @@ struct rocco_hip_solver {
     rocco::DeviceBuffer dev_bits;     // exact-path decision bits
     rocco::DeviceBuffer dev_misc;     // decode / reduction scratch
     rocco::DeviceBuffer dev_solution; // solution scratch when the caller wants counts only
+    rocco::DeviceBuffer dev_maps;     // per-chunk binade maps of the problems being solved
     rocco::PinnedBuffer host_stage;   // pinned staging for uploads
     rocco::PinnedBuffer host_back;    // pinned staging for readbacks
 };

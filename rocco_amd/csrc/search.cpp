@@ -57,6 +57,7 @@ struct State {
         kLowerBracket,  // rocco/dp.py:113-125
         kUpperBracket,  // rocco/dp.py:127-138
         kBisect,        // rocco/dp.py:141-162
+        kNeedMap,       // an uncertain probe was met and the binade map is missing / too coarse
         kZone,          // an uncertain probe was met: joint window over the current bracket
         kFinalExact,    // exact solve at the final penalty (writes the solution)
         kDone
@@ -65,6 +66,10 @@ struct State {
     double lower = 0.0, upper = 0.0;
     int iters_left = 0;
     bool use_exact = false;
+    bool has_map = false;
+    double map_width = 0.0;      // bracket width the current map was built for
+    long long lower_count = 0;   // selected loci at `lower` (bounds the count anywhere in the bracket)
+    Phase after_map = kBisect;
     CalibrationResult out;
     // request in flight
     int tree_depth = 0;
@@ -183,13 +188,15 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
         s.use_exact = opt.force_exact || !fast_path_applicable(p);
         s.phase = (s.target == (long long)p.n) ? State::kAll : State::kLowerBracket;
         s.out.zone_iters = -1;
+        s.lower_count = (long long)p.n;
     }
 
     for (;;) {
         std::vector<ProbeRequest> probes;
         std::vector<WindowRequest> windows;
         std::vector<ExactRequest> exacts;
-        std::vector<size_t> probe_owner, window_owner, exact_owner;
+        std::vector<MapRequest> maps;
+        std::vector<size_t> probe_owner, window_owner, exact_owner, map_owner;
 
         for (size_t b = 0; b < B; ++b) {
             const ChainProblem &p = problems[b];
@@ -269,6 +276,19 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 }
                 break;
             }
+            case State::kNeedMap: {
+                MapRequest r;
+                r.problem = b;
+                r.lambda_ref = (s.lower + s.upper) / 2.0;
+                const double width = s.upper - s.lower;
+                // running values move by at most (count) * (penalty change) inside the bracket
+                r.margin = (p.cost_max + (p.score_max - p.score_min) + 2.0) +
+                           2.0 * width * (double)s.lower_count + 2.0;
+                s.map_width = width;
+                maps.push_back(r);
+                map_owner.push_back(b);
+                break;
+            }
             case State::kZone: {
                 WindowRequest r;
                 r.problem = b;
@@ -291,10 +311,22 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 break;
             }
         }
-        if (probes.empty() && windows.empty() && exacts.empty()) {
+        if (probes.empty() && windows.empty() && exacts.empty() && maps.empty()) {
             break;
         }
         int rc;
+        if (!maps.empty()) {
+            if ((rc = ev.build_map(maps)) != ROCCO_HIP_OK) {
+                return rc;
+            }
+            for (size_t q = 0; q < maps.size(); ++q) {
+                State &s = st[map_owner[q]];
+                ++s.out.passes;
+                ++s.out.maps;
+                s.has_map = true;
+                s.phase = s.after_map;
+            }
+        }
         if (!probes.empty() && (rc = ev.probe(probes)) != ROCCO_HIP_OK) {
             return rc;
         }
@@ -345,14 +377,24 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     o = classify(r.results[(size_t)s.tree_slot[i]], s.target);
                 }
                 if (o == Outcome::kUncertain) {
-                    s.phase = State::kZone;
-                    s.out.zone_iters = s.iters_left;
+                    const double width = s.upper - s.lower;
+                    if (!s.has_map || s.map_width > 4.0 * width) {
+                        s.phase = State::kNeedMap;  // sharpen the rounding model, then ask again
+                        s.after_map = State::kBisect;
+                    } else {
+                        s.phase = State::kZone;
+                        s.out.zone_iters = s.iters_left;
+                    }
                     break;
                 }
                 ++s.out.evaluations;
                 --s.iters_left;
                 if (o == Outcome::kGreater) {
                     s.lower = s.tree[i];
+                    if (s.tree_slot[i] >= 0) {
+                        s.lower_count = r.results[(size_t)s.tree_slot[i]].count +
+                                        r.results[(size_t)s.tree_slot[i]].effect;
+                    }
                     i = 2 * i + 2;
                 } else {
                     s.upper = s.tree[i];
@@ -374,6 +416,11 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     s.out.evaluations = 1;
                     s.out.path = ROCCO_HIP_PATH_CERTIFIED;
                     s.phase = State::kDone;
+                } else if (!s.has_map) {
+                    s.lower = s.upper = 0.0;  // map at the penalty being solved, zero width
+                    s.lower_count = 0;
+                    s.phase = State::kNeedMap;
+                    s.after_map = State::kAll;
                 } else {
                     s.use_exact = true;
                 }
@@ -483,40 +530,65 @@ int solve_fixed_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
 {
     const size_t B = problems.size();
     results.assign(B, CalibrationResult());
-    std::vector<WindowRequest> windows;
-    std::vector<size_t> owner;
-    std::vector<char> need_exact(B, 0);
+    std::vector<char> need_exact(B, 0), pending(B, 0);
     for (size_t b = 0; b < B; ++b) {
         results[b].selection_penalty = lambdas[b];
         results[b].evaluations = 1;
         results[b].zone_iters = -1;
         if (opt.force_exact || !fast_path_applicable(problems[b])) {
             need_exact[b] = 1;
-            continue;
+        } else {
+            pending[b] = 1;
         }
-        WindowRequest r;
-        r.problem = b;
-        r.lambda_lo = r.lambda_hi = lambdas[b];
-        windows.push_back(r);
-        owner.push_back(b);
     }
     int rc;
-    if (!windows.empty()) {
+    // attempt 0: global rounding bound; attempt 1: with a binade map at the penalty itself
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        std::vector<WindowRequest> windows;
+        std::vector<size_t> owner;
+        std::vector<MapRequest> maps;
+        for (size_t b = 0; b < B; ++b) {
+            if (!pending[b]) {
+                continue;
+            }
+            if (attempt == 1) {
+                MapRequest m;
+                m.problem = b;
+                m.lambda_ref = lambdas[b];
+                const ChainProblem &p = problems[b];
+                m.margin = p.cost_max + (std::max(p.score_max, lambdas[b]) - std::min(p.score_min, lambdas[b])) + 4.0;
+                maps.push_back(m);
+            }
+            WindowRequest r;
+            r.problem = b;
+            r.lambda_lo = r.lambda_hi = lambdas[b];
+            windows.push_back(r);
+            owner.push_back(b);
+        }
+        if (windows.empty()) {
+            break;
+        }
+        if (!maps.empty() && (rc = ev.build_map(maps)) != ROCCO_HIP_OK) {
+            return rc;
+        }
         if ((rc = ev.window(windows)) != ROCCO_HIP_OK) {
             return rc;
         }
         for (size_t q = 0; q < windows.size(); ++q) {
             const size_t b = owner[q];
             const WindowResult &w = windows[q].result;
-            results[b].passes = 1;
+            results[b].passes += 1 + attempt;
+            results[b].maps = attempt;
             results[b].n_diff = w.n_diff;
             if (w.n_diff == 0 && !w.overflow) {
                 results[b].selected_count = w.count_lo;
                 results[b].path = ROCCO_HIP_PATH_CERTIFIED;
+                pending[b] = 0;
                 if ((rc = ev.penalized_value(b, lambdas[b], w.count_lo, &results[b].penalized_value)) != ROCCO_HIP_OK) {
                     return rc;
                 }
-            } else {
+            } else if (attempt == 1) {
+                pending[b] = 0;
                 need_exact[b] = 1;
             }
         }

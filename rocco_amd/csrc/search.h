@@ -66,6 +66,15 @@ struct WindowRequest {
     WindowResult result;  // filled by the evaluator; the solution buffer of the problem = fill(LO)
 };
 
+// Build (or rebuild) the per-chunk binade map of a problem at penalty lambda_ref; `margin` is the
+// distance the reference's running value must keep from every power of two for a chunk to use
+// the reference's own rounding grid.
+struct MapRequest {
+    size_t problem = 0;
+    double lambda_ref = 0.0;
+    double margin = 0.0;
+};
+
 struct ExactRequest {
     size_t problem = 0;
     std::vector<double> lambdas;  // <= 64
@@ -80,6 +89,8 @@ public:
     virtual int probe(std::vector<ProbeRequest> &reqs) = 0;
     // joint window evaluation, writes fill(LO) into the problem's solution buffer
     virtual int window(std::vector<WindowRequest> &reqs) = 0;
+    // per-chunk binade map used by later probe / window calls on that problem
+    virtual int build_map(std::vector<MapRequest> &reqs) = 0;
     // exact emulation of the reference (always correct)
     virtual int exact(std::vector<ExactRequest> &reqs) = 0;
     // penalised value  sum (s - lambda) z - sum c |dz|  of the solution currently in the buffer
@@ -93,7 +104,8 @@ struct CalibrationResult {
     int evaluations = 0;   // chain evaluations the reference would have made
     int path = 0;          // ROCCO_HIP_PATH_*
     int passes = 0;        // device rounds this problem took part in
-    int zone_iters = 0;    // bisection steps left when the first uncertain probe was met (-1: none)
+    int zone_iters = 0;    // bisection steps left when the zone window was taken (-1: none)
+    int maps = 0;          // binade maps built
     long long n_diff = -1; // window differences (-1: no window evaluated)
 };
 

@@ -13,7 +13,22 @@ from . import _native
 from . import dp as _dp
 
 
-def delta_probe_device(scores_t, switch_costs, lambdas: Sequence[float]) -> List[Dict[str, int]]:
+def delta_build_map_device(scores_t, switch_costs, lambda_ref: float, margin: float):
+    """Per-chunk binade codes (uint8 CUDA tensor of ceil(n / 32) entries) at penalty lambda_ref."""
+    import torch
+
+    n = int(scores_t.shape[0])
+    costs_t, gamma = _dp._costs_arg(switch_costs, n, scores_t.device)
+    emap_t = torch.empty((n + 31) // 32, dtype=torch.uint8, device=scores_t.device)
+    solver = _native.solver_for(scores_t.device.index)
+    _native.check(_native.load().rocco_hip_delta_build_map_f64(
+        solver.handle, scores_t.data_ptr(), costs_t.data_ptr() if costs_t is not None else None, gamma, n,
+        float(lambda_ref), float(margin), emap_t.data_ptr(), _dp._stream_ptr(scores_t)),
+        "rocco_hip_delta_build_map_f64")
+    return emap_t
+
+
+def delta_probe_device(scores_t, switch_costs, lambdas: Sequence[float], emap_t=None) -> List[Dict[str, int]]:
     n = int(scores_t.shape[0])
     costs_t, gamma = _dp._costs_arg(switch_costs, n, scores_t.device)
     lam = (ctypes.c_double * len(lambdas))(*[float(x) for x in lambdas])
@@ -21,12 +36,13 @@ def delta_probe_device(scores_t, switch_costs, lambdas: Sequence[float]) -> List
     solver = _native.solver_for(scores_t.device.index)
     _native.check(_native.load().rocco_hip_delta_probe_f64(
         solver.handle, scores_t.data_ptr(), costs_t.data_ptr() if costs_t is not None else None, gamma, n,
-        lam, len(lambdas), stats, _dp._stream_ptr(scores_t)), "rocco_hip_delta_probe_f64")
+        emap_t.data_ptr() if emap_t is not None else None, lam, len(lambdas), stats,
+        _dp._stream_ptr(scores_t)), "rocco_hip_delta_probe_f64")
     return [{"count": int(s.count), "uncertain": int(s.uncertain), "effect": int(s.effect),
              "max_run": int(s.max_run)} for s in stats[:len(lambdas)]]
 
 
-def delta_window_device(scores_t, switch_costs, lambda_lo: float, lambda_hi: float):
+def delta_window_device(scores_t, switch_costs, lambda_lo: float, lambda_hi: float, emap_t=None):
     import torch
 
     n = int(scores_t.shape[0])
@@ -36,7 +52,8 @@ def delta_window_device(scores_t, switch_costs, lambda_lo: float, lambda_hi: flo
     solver = _native.solver_for(scores_t.device.index)
     _native.check(_native.load().rocco_hip_delta_window_f64(
         solver.handle, scores_t.data_ptr(), costs_t.data_ptr() if costs_t is not None else None, gamma, n,
-        float(lambda_lo), float(lambda_hi), sol_t.data_ptr(), ctypes.byref(st), _dp._stream_ptr(scores_t)),
+        emap_t.data_ptr() if emap_t is not None else None, float(lambda_lo), float(lambda_hi),
+        sol_t.data_ptr(), ctypes.byref(st), _dp._stream_ptr(scores_t)),
         "rocco_hip_delta_window_f64")
     listed = min(int(st.n_diff), 16)
     return sol_t, {

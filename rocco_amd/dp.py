@@ -283,7 +283,7 @@ def calibrate_batch_device(scores_list, switch_costs_list, target_counts, max_it
         r = results[i]
         out.append((float(r.selection_penalty), sols[i], float(r.penalized_value), int(r.selected_count),
                     {"evaluations": int(r.evaluations), "path": int(r.path), "passes": int(r.passes),
-                     "zone_iters": int(r.zone_iters), "n_diff": int(r.n_diff)}))
+                     "zone_iters": int(r.zone_iters), "n_diff": int(r.n_diff), "maps": int(r.maps)}))
     return out
 
 

@@ -23,6 +23,7 @@ struct HostProblem {
     int qexp;
     double cmax, sabs;
     uint8_t *solution;
+    std::vector<uint8_t> emap;  // empty = no map
 };
 
 int grid_exponent(double cmax, double smin, double smax)
@@ -34,7 +35,7 @@ int grid_exponent(double cmax, double smin, double smax)
 class OracleEvaluator : public Evaluator {
 public:
     std::vector<HostProblem> hp;
-    long long probe_calls = 0, window_calls = 0, exact_calls = 0, exact_lambdas = 0;
+    long long probe_calls = 0, window_calls = 0, exact_calls = 0, exact_lambdas = 0, map_calls = 0;
 
     int probe(std::vector<ProbeRequest> &reqs) override
     {
@@ -45,7 +46,7 @@ public:
             for (size_t i = 0; i < r.lambdas.size(); ++i) {
                 oracle_delta_stats st;
                 const int rc = oracle_delta_chain_f64(p.scores, p.costs, p.gamma, p.n, r.lambdas[i], p.qexp,
-                                                      p.cmax, p.sabs, nullptr, &st);
+                                                      p.cmax, p.sabs, p.emap.empty() ? nullptr : p.emap.data(), nullptr, &st);
                 if (rc != 0) return rc;
                 r.results[i].count = st.count;
                 r.results[i].uncertain = st.uncertain;
@@ -63,7 +64,8 @@ public:
             oracle_window_stats st;
             oracle_window_diff diffs[16];
             const int rc = oracle_delta_window_f64(p.scores, p.costs, p.gamma, p.n, r.lambda_lo, r.lambda_hi,
-                                                   p.qexp, p.cmax, p.sabs, p.solution, &st, diffs, 16);
+                                                   p.qexp, p.cmax, p.sabs, p.emap.empty() ? nullptr : p.emap.data(), p.solution, &st,
+                                                   diffs, 16);
             if (rc != 0) return rc;
             r.result.count_lo = st.count_lo;
             r.result.count_hi = st.count_hi;
@@ -82,6 +84,18 @@ public:
                 d.cls_hi = diffs[i].cls_hi;
                 r.result.diffs.push_back(d);
             }
+        }
+        return 0;
+    }
+    int build_map(std::vector<MapRequest> &reqs) override
+    {
+        ++map_calls;
+        for (MapRequest &r : reqs) {
+            HostProblem &p = hp[r.problem];
+            p.emap.assign((p.n + ORACLE_CHUNK - 1) / ORACLE_CHUNK, 0);
+            const int rc = oracle_binade_map(p.scores, p.costs, p.gamma, p.n, r.lambda_ref, p.qexp, r.margin,
+                                             p.emap.data());
+            if (rc != 0) return rc;
         }
         return 0;
     }
@@ -140,7 +154,7 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     }
     OracleEvaluator ev;
     HostProblem h{scores, costs, gamma, n, grid_exponent(cmax, smin, smax), cmax,
-                  std::fmax(std::fabs(smin), std::fabs(smax)), solution};
+                  std::fmax(std::fabs(smin), std::fabs(smax)), solution, {}};
     ev.hp.push_back(h);
     ChainProblem p;
     p.n = n;
@@ -171,6 +185,7 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     out_i[6] = ev.window_calls;
     out_i[7] = ev.exact_calls;
     out_i[8] = ev.exact_lambdas;
+    out_i[9] = res[0].maps;
     return 0;
 }
 
@@ -195,7 +210,7 @@ int hostlogic_solve_fixed(const double *scores, const double *costs, double gamm
     // penalties outside [smin - 1, smax + 1] are legal here: widen the grid range accordingly
     const double lo = std::fmin(smin, lambda), hi = std::fmax(smax, lambda);
     HostProblem h{scores, costs, gamma, n, grid_exponent(cmax, lo, hi), cmax,
-                  std::fmax(std::fabs(smin), std::fabs(smax)), solution};
+                  std::fmax(std::fabs(smin), std::fabs(smax)), solution, {}};
     ev.hp.push_back(h);
     ChainProblem p;
     p.n = n;

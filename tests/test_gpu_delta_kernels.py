@@ -82,3 +82,38 @@ def test_window_matches_sequential_definition(gpu, oracle, n):
             for a, b in zip(got["diffs"], want["diffs"]):
                 assert (a["margin_lo"], a["margin_hi"], a["run"], a["cls_lo"], a["cls_hi"]) == (
                     b["margin_lo"], b["margin_hi"], b["run"], b["cls_lo"], b["cls_hi"])
+
+
+@pytest.mark.parametrize("n", [1000, 8193, 50000, 300007])
+def test_map_mode_matches_sequential_definition(gpu, oracle, n):
+    """With a binade map, clean chunks use the reference's own rounding grid; the kernels must
+    still agree bit for bit with the sequential definition fed with the same map."""
+    import torch
+    from rocco_amd.delta import delta_build_map_device, delta_probe_device, delta_window_device
+
+    rng = np.random.default_rng(n)
+    s = _scores(n, n + 7, "gamma")
+    s[rng.integers(0, n, size=n // 50)] += 40.0  # make the running value cross several binades
+    s_t = torch.from_numpy(s).to(gpu)
+    lam_ref = 0.35
+    for margin in (14.0, 60.0):
+        emap_t = delta_build_map_device(s_t, 1.0, lam_ref, margin)
+        emap = emap_t.cpu().numpy()
+        want_map = oracle.binade_map(s, 1.0, lam_ref, margin)
+        # summation order differs between the device prefix sums and the sequential ones: codes may
+        # differ only where a chunk sits exactly on a margin boundary
+        assert np.mean(emap != want_map) < 1e-3
+        assert (emap & 0x80 == 0).any(), "expected some clean chunks"
+        lambdas = [lam_ref - 1e-3, lam_ref - 1e-7, lam_ref, lam_ref + 1e-9, lam_ref + 1e-3]
+        got = delta_probe_device(s_t, 1.0, lambdas, emap_t)
+        for lam, g in zip(lambdas, got):
+            _, want = oracle.delta_chain(s, 1.0, lam, emap=emap, want_solution=False)
+            eff = n + 1 if want["overflow"] else want["effect"]
+            assert (g["count"], g["uncertain"], g["effect"], g["max_run"]) == (
+                want["count"], want["uncertain"], eff, want["max_run"]), (n, margin, lam)
+        for half in (0.0, 1e-10, 1e-6):
+            sol_t, gw = delta_window_device(s_t, 1.0, lam_ref - half, lam_ref + half, emap_t)
+            want_sol, want = oracle.delta_window(s, 1.0, lam_ref - half, lam_ref + half, emap=emap)
+            assert np.array_equal(sol_t.cpu().numpy(), want_sol)
+            for key in ("count_lo", "count_hi", "n_diff", "diff_adjacent", "overflow", "max_run"):
+                assert gw[key] == want[key], (key, n, margin, half)
