@@ -252,6 +252,21 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 break;
             }
             case State::kBisect: {
+                if (!s.use_exact && s.has_map && s.map_width > 16.0 * (s.upper - s.lower)) {
+                    // the bracket shrank a lot since the map was built: its hazard margin can shrink too
+                    MapRequest r;
+                    r.problem = b;
+                    r.lambda_ref = (s.lower + s.upper) / 2.0;
+                    const double width = s.upper - s.lower;
+                    r.margin = (p.cost_max + (p.score_max - p.score_min) + 2.0) +
+                               2.0 * width * (double)s.lower_count + 2.0;
+                    s.map_width = width;
+                    s.after_map = State::kBisect;
+                    s.phase = State::kNeedMap;
+                    maps.push_back(r);
+                    map_owner.push_back(b);
+                    break;
+                }
                 s.tree_depth = std::min(s.use_exact ? opt.exact_depth : opt.spec_depth, s.iters_left);
                 build_tree(s.lower, s.upper, s.tree_depth, s.tree);
                 if (s.use_exact) {
@@ -378,7 +393,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 }
                 if (o == Outcome::kUncertain) {
                     const double width = s.upper - s.lower;
-                    if (!s.has_map || s.map_width > 4.0 * width) {
+                    if (!s.has_map || s.map_width > 2.0 * width) {
                         s.phase = State::kNeedMap;  // sharpen the rounding model, then ask again
                         s.after_map = State::kBisect;
                     } else {

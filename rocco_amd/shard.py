@@ -1,0 +1,65 @@
+"""Chromosome sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+The reference's only parallelism over chromosomes is a fork pool of at most 4 workers
+(rocco/rocco.py:792-806, 1176-1180) whose results come back as pickled tuples and temporary BED
+files.  Here chromosomes are independent units assigned to ranks by longest-processing-time-first
+on their locus counts; there is no collective on the data path.  The only exchange is the gather
+of the final interval lists to rank 0 (a few hundred KB for a whole genome): one all_gather of the
+per-rank interval counts and one all_gather of a padded int64 tensor -- RCCL over xGMI when the
+backend is "nccl", Gloo in the CPU tests.  Latency-bound, not link-bound: no ring is engineered.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+
+def lpt_partition(sizes: Sequence[int], n_ranks: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of units to ranks.  Returns, per rank, the indices
+    of its units in descending size order.  Deterministic (ties by index)."""
+    order = sorted(range(len(sizes)), key=lambda i: (-int(sizes[i]), i))
+    loads = [0] * n_ranks
+    owned: List[List[int]] = [[] for _ in range(n_ranks)]
+    for i in order:
+        r = min(range(n_ranks), key=lambda k: (loads[k], k))
+        owned[r].append(i)
+        loads[r] += int(sizes[i])
+    return owned
+
+
+def makespan(sizes: Sequence[int], owned: List[List[int]]) -> int:
+    return max((sum(int(sizes[i]) for i in part) for part in owned), default=0)
+
+
+def gather_intervals(local: Dict[int, np.ndarray], device=None, group=None) -> Dict[int, np.ndarray]:
+    """Gather per-unit interval arrays to every rank.
+
+    `local` maps unit index -> int64 array of shape [m, 2] (start, end).  Returns the union over all
+    ranks.  Uses two collectives on a flat int64 tensor of rows (unit, start, end)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dict(local)
+    world = dist.get_world_size(group)
+    rows = [np.concatenate([np.full((a.shape[0], 1), u, dtype=np.int64), a.astype(np.int64)], axis=1)
+            for u, a in sorted(local.items()) if a.shape[0] > 0]
+    flat = np.concatenate(rows, axis=0) if rows else np.zeros((0, 3), dtype=np.int64)
+    dev = device if device is not None else "cpu"
+    count = torch.tensor([flat.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    sizes = [int(c.item()) for c in counts]
+    width = max(max(sizes), 1)
+    mine = torch.zeros((width, 3), dtype=torch.int64, device=dev)
+    if flat.shape[0]:
+        mine[: flat.shape[0]] = torch.from_numpy(flat).to(dev)
+    parts = [torch.zeros((width, 3), dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    merged: Dict[int, List[np.ndarray]] = {}
+    for r, part in enumerate(parts):
+        arr = part[: sizes[r]].cpu().numpy()
+        for u in np.unique(arr[:, 0]) if arr.shape[0] else []:
+            merged.setdefault(int(u), []).append(arr[arr[:, 0] == u][:, 1:])
+    return {u: np.concatenate(v, axis=0) for u, v in merged.items()}

@@ -1,0 +1,132 @@
+"""The product's host-side search / certification logic (rocco_amd/csrc/search.cpp, the very file
+compiled into librocco_hip.so) driven on the CPU by an evaluator backed by the oracle
+(tests/host_logic/harness.cpp).  Whatever path it takes, its answer must be the reference's:
+solution and count bit-exact, penalty within 1e-9 (bit-exact when no decision was left open)."""
+import os
+
+import numpy as np
+import pytest
+
+import hostlogic as hl
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def test_golden_budget_cases(gold):
+    for name in gold["bud_names"]:
+        scores = gold[f"bud_{name}_scores"]
+        budget, gamma = gold[f"bud_{name}_params"]
+        target = int(np.floor(len(scores) * float(budget)))
+        pen, sol, val, cnt, info = hl.calibrate(scores, float(gamma), target)
+        pobj, count, frac, penalty = gold[f"bud_{name}_details"]
+        assert np.array_equal(sol, gold[f"bud_{name}_solution"]), (name, info)
+        assert cnt == int(count)
+        assert abs(pen - penalty) <= 1e-9
+        assert abs(val - pobj) <= 1e-9 * max(1.0, abs(pobj))
+        assert info["evaluations"] == 62
+
+
+def test_budget8_known_answer(gold):
+    pen, sol, val, cnt, info = hl.calibrate(gold["budget8_scores"], 1.0, 3)
+    assert sol.tolist() == [0, 0, 0, 0, 1, 1, 0, 0]
+    assert pen == 1.05 and cnt == 2
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_problems_match_oracle(oracle, seed):
+    from rocco_amd.synth import hash_matrix, survey_matrix
+
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([500, 5000, 40000]))
+    K = int(rng.choice([1, 3, 10]))
+    m = survey_matrix(n, K, 500 + seed) if seed % 2 == 0 else hash_matrix(K, n, seed=seed)
+    s = np.median(m, axis=0) if K > 1 else m[0]
+    budget = float(rng.choice([0.005, 0.02, 0.1]))
+    gamma = float(rng.choice([0.5, 1.0, 10.0]))
+    target = int(np.floor(n * budget))
+    ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, gamma), target)
+    for depth in (1, 3):
+        pen, sol, val, cnt, info = hl.calibrate(s, gamma, target, spec_depth=depth)
+        assert np.array_equal(sol, ref[1]), info
+        assert cnt == ref[3]
+        assert abs(pen - ref[0]) <= 1e-9
+    # forcing the exact evaluator gives the reference bit for bit
+    pen, sol, val, cnt, info = hl.calibrate(s, gamma, target, force_exact=True)
+    assert (pen, val, cnt) == (ref[0], ref[2], ref[3]) and np.array_equal(sol, ref[1])
+    assert info["path"] == 2
+
+
+def test_edge_cases_match_oracle(oracle):
+    rng = np.random.default_rng(0)
+    s = np.round(rng.gamma(1.0, 0.3, size=200), 5)
+    for target in (0, 1, 199, 200, 1000):
+        ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 1.0), target)
+        pen, sol, val, cnt, info = hl.calibrate(s, 1.0, target)
+        assert np.array_equal(sol, ref[1]) and cnt == ref[3], (target, info)
+        assert abs(pen - ref[0]) <= 1e-9
+    # degenerate switch cost: the fast path must refuse and the exact evaluator answer
+    ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 0.0), 10)
+    pen, sol, val, cnt, info = hl.calibrate(s, 0.0, 10)
+    assert info["path"] == 2 and (pen, cnt) == (ref[0], ref[3]) and np.array_equal(sol, ref[1])
+    # one locus
+    ref = oracle.calibrate_selection_penalty(np.array([0.7]), np.zeros(0), 0)
+    pen, sol, val, cnt, info = hl.calibrate(np.array([0.7]), 1.0, 0)
+    assert np.array_equal(sol, ref[1]) and cnt == ref[3]
+
+
+def test_integer_scores_many_ties(oracle):
+    """Integer data makes exact value ties the rule; whichever path is taken the answer is the
+    reference's (count tie-break of rocco/_chain_dp.c:133-179)."""
+    rng = np.random.default_rng(4)
+    for _ in range(6):
+        n = int(rng.integers(30, 3000))
+        s = rng.integers(0, 6, size=n).astype(np.float64)
+        target = int(n * 0.1)
+        ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 1.0), target)
+        pen, sol, val, cnt, info = hl.calibrate(s, 1.0, target)
+        assert np.array_equal(sol, ref[1]) and cnt == ref[3], info
+        assert abs(pen - ref[0]) <= 1e-9
+
+
+def test_fixed_penalty_matches_oracle(oracle):
+    rng = np.random.default_rng(9)
+    for _ in range(10):
+        n = int(rng.integers(1, 5000))
+        s = np.round(rng.gamma(1.0, 0.3, size=n), 5)
+        gamma = float(rng.choice([0.5, 1.0, 3.0]))
+        lam = float(rng.choice([-1.0, 0.0, 0.31, 2.0, 50.0]))
+        sol, val, cnt, info = hl.solve_fixed(s, gamma, lam)
+        o_sol, o_val, o_cnt = oracle.solve_penalized_chain(s, oracle.build_switch_costs(s, gamma), lam)
+        assert np.array_equal(sol, o_sol) and cnt == o_cnt, (n, gamma, lam, info)
+        assert abs(val - o_val) <= 1e-9 * max(1.0, abs(o_val))
+    # vector costs
+    n = 700
+    s = np.round(rng.gamma(1.0, 0.3, size=n), 5)
+    c = rng.uniform(0.2, 1.3, size=n - 1)
+    sol, val, cnt, info = hl.solve_fixed(s, c, 0.4)
+    o_sol, o_val, o_cnt = oracle.solve_penalized_chain(s, c, 0.4)
+    assert np.array_equal(sol, o_sol) and cnt == o_cnt
+
+
+def test_delta_definition_self_consistency(oracle):
+    """The sequential delta-form definition agrees with the exact DP wherever it claims certainty:
+    with no uncertain locus its fill equals the reference solution."""
+    rng = np.random.default_rng(21)
+    agree = 0
+    for _ in range(30):
+        n = int(rng.integers(10, 4000))
+        s = np.round(rng.gamma(1.0, 0.3, size=n), 5)
+        lam = float(rng.uniform(0.0, 1.0))
+        sol, st = oracle.delta_chain(s, 1.0, lam)
+        o_sol, _, o_cnt = oracle.solve_penalized_chain(s, oracle.build_switch_costs(s, 1.0), lam)
+        if st["uncertain"] == 0 and not st["overflow"]:
+            assert np.array_equal(sol, o_sol) and st["count"] == o_cnt
+            agree += 1
+        else:
+            assert abs(st["count"] - o_cnt) <= st["effect"]
+    assert agree >= 20
