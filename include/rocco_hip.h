@@ -33,6 +33,7 @@ extern "C" {
 #define ROCCO_HIP_PATH_CERTIFIED 1 /* parallel delta-form kernels, certified equal to the reference */
 #define ROCCO_HIP_PATH_EXACT 2     /* sequential exact emulation kernel (same IEEE op order)        */
 #define ROCCO_HIP_PATH_TRIVIAL 3   /* decided without a kernel launch (e.g. n == 1)                 */
+#define ROCCO_HIP_PATH_SPINE 4     /* parallel kernels + exact spine through the hazard chunks      */
 
 typedef struct rocco_hip_solver rocco_hip_solver;
 
@@ -149,6 +150,19 @@ int rocco_hip_delta_window_f64(rocco_hip_solver *solver, const double *scores_de
                                const double *switch_costs_dev, double gamma, size_t n,
                                const uint8_t *emap_dev, double lambda_lo, double lambda_hi,
                                uint8_t *solution_dev, rocco_hip_window_stats *stats_out, void *stream);
+
+/* Exact counts (and optionally one exact solution) for up to 64 penalties through the "spine":
+ * the parallel kernels record per-chunk state, then one wavefront per chromosome carries the
+ * reference's running values exactly -- stepping only through the chunks where the parallel
+ * recursion is not provably the reference's own.  `emap_dev` must be a map
+ * built by rocco_hip_delta_build_map_f64 at (or near) these penalties.  counts_out[i] is what
+ * rocco/_chain_dp.c returns as best_count for lambdas[i]; solution_dev (n bytes) receives the
+ * solution of lambdas[solution_index] when solution_index >= 0. */
+int rocco_hip_delta_spine_f64(rocco_hip_solver *solver, const double *scores_dev,
+                              const double *switch_costs_dev, double gamma, size_t n,
+                              const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,
+                              int solution_index, uint8_t *solution_dev, long long *counts_out,
+                              void *stream);
 
 /* ---- objective ------------------------------------------------------------------------------
  * Replaces rocco/dp.py:16-34 `objective_value`: -(s . z) + c . |diff z|  (fixed-order tree sum;

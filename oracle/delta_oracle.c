@@ -26,8 +26,11 @@
  *    (running value near a power of two, binade unknown, u < q, or rn_u(-lambda) / rn_u(gamma) is a
  *    tie) use a = rn_q(s - lambda), c = rn_q(c) and every step adds weight 4 hb + q, hb = 2^(e+2-53).
  *  - tolerance tau_j = (sum of step weights since the last provable clear clamp) + (9 hb + 2 q if
- *    the chunk is a hazard chunk).  A locus is certain iff ||delta_j| - c_j| > tau_j (for a clean
- *    run tau_j = 0: only exact grid ties are uncertain) and tau_j <= ORACLE_GUARD.
+ *    the chunk is a hazard chunk).  A locus is certain iff tau_j == 0 or ||delta_j| - c_j| > tau_j,
+ *    and tau_j <= ORACLE_GUARD.  With tau_j = 0 even exact ties are decided: the reference breaks
+ *    value ties by selected count (rocco/_chain_dp.c:133-134,147-148,167-168) and its state-1 path
+ *    always holds at least one more selected locus than its state-0 path, so delta == +c keeps the
+ *    state (COPY), delta == -c switches (ZERO) and a terminal tie ends in state 0.
  *  - provable clear clamp: inside a chunk two extreme chains start from the clamp bounds (+c, -c);
  *    a locus is "known" once they agree; a known locus with |delta| - c > ORACLE_GUARD is a provable
  *    clear clamp and resets the weight sum; m_j = j - 1 - (last provable clear clamp before j).
@@ -197,15 +200,15 @@ int oracle_delta_chain_f64(const double *scores, const double *switch_costs, dou
         if (j + 1 < n) {
             const double cj = cost_on_grid(&mode, vec ? switch_costs[j] : gamma, magic_q);
             const double e = fabs(delta) - cj;
-            certain = (tau <= ORACLE_GUARD) && (e > tau || e < -tau);
-            k = (delta > cj) ? CLS_ONE : ((delta < -cj) ? CLS_ZERO : CLS_COPY);
+            certain = (tau <= ORACLE_GUARD) && (tau == 0.0 || e > tau || e < -tau);
+            k = (delta > cj) ? CLS_ONE : ((delta <= -cj) ? CLS_ZERO : CLS_COPY);
             if (up == dn && e > ORACLE_GUARD) {
                 last_clear = (long long)j;
                 wacc = 0.0;
             }
         } else {
             const double e = fabs(delta);
-            certain = (tau <= ORACLE_GUARD) && (e > tau);
+            certain = (tau <= ORACLE_GUARD) && (tau == 0.0 || e > tau);
             k = (delta > 0.0) ? CLS_ONE : CLS_ZERO;
         }
         if (tau > ORACLE_GUARD) {
@@ -303,10 +306,10 @@ int oracle_delta_window_f64(const double *scores, const double *switch_costs, do
             } else {
                 lo = CLS_COPY;
             }
-            /* highest class */
-            if (d_lo - cj >= -tau) {
+            /* highest class (tau == 0: the exact tie rules, delta == c is COPY, delta == -c is ZERO) */
+            if ((tau > 0.0) ? (d_lo - cj >= -tau) : (d_lo - cj > 0.0)) {
                 hi = CLS_ONE;
-            } else if (d_lo + cj < -tau) {
+            } else if ((tau > 0.0) ? (d_lo + cj < -tau) : (d_lo + cj <= 0.0)) {
                 hi = CLS_ZERO;
             } else {
                 hi = CLS_COPY;
@@ -318,7 +321,7 @@ int oracle_delta_window_f64(const double *scores, const double *switch_costs, do
             }
         } else {
             lo = (d_hi > tau) ? CLS_ONE : CLS_ZERO;
-            hi = (d_lo >= -tau) ? CLS_ONE : CLS_ZERO;
+            hi = ((tau > 0.0) ? (d_lo >= -tau) : (d_lo > 0.0)) ? CLS_ONE : CLS_ZERO;
         }
         if (tau > ORACLE_GUARD) { /* tolerance model no longer valid */
             overflow = 1;

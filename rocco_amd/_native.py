@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librocco_hip.so")
 
 OK, ENOMEM, EINVAL, EHIP = 0, -1, -2, -3
-PATH_CERTIFIED, PATH_EXACT, PATH_TRIVIAL = 1, 2, 3
+PATH_CERTIFIED, PATH_EXACT, PATH_TRIVIAL, PATH_SPINE = 1, 2, 3, 4
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_ll_p = ctypes.POINTER(ctypes.c_longlong)
@@ -98,6 +98,9 @@ PROTOTYPES = [
     ("rocco_hip_delta_build_map_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t,
       ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_delta_spine_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p,
+      c_double_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, c_ll_p, ctypes.c_void_p]),
     ("rocco_hip_delta_window_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p,
       ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.POINTER(WindowStats), ctypes.c_void_p]),

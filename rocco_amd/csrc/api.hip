@@ -193,6 +193,22 @@ int rocco_hip_delta_probe_f64(rocco_hip_solver *solver, const double *scores_dev
                        stats_out, (hipStream_t)stream);
 }
 
+int rocco_hip_delta_spine_f64(rocco_hip_solver *solver, const double *scores_dev,
+                              const double *switch_costs_dev, double gamma, size_t n,
+                              const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,
+                              int solution_index, uint8_t *solution_dev, long long *counts_out,
+                              void *stream)
+{
+    if (solver == nullptr || scores_dev == nullptr || n == 0 || n >= ((size_t)1 << 31) || emap_dev == nullptr ||
+        lambdas == nullptr || counts_out == nullptr || n_lambdas == 0 || n_lambdas > 64 ||
+        solution_index >= (int)n_lambdas || (solution_index >= 0 && solution_dev == nullptr)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return delta_spine(solver, scores_dev, switch_costs_dev, gamma, n, emap_dev, lambdas, n_lambdas,
+                       solution_index, solution_dev, counts_out, (hipStream_t)stream);
+}
+
 int rocco_hip_delta_build_map_f64(rocco_hip_solver *solver, const double *scores_dev,
                                   const double *switch_costs_dev, double gamma, size_t n,
                                   double lambda_ref, double margin, uint8_t *emap_dev, void *stream)

@@ -21,6 +21,10 @@ int delta_probe(rocco_hip_solver *solver, const double *scores_dev, const double
                 double gamma, size_t n, const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,
                 rocco_hip_probe_stats *stats_out, hipStream_t stream);
 
+int delta_spine(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
+                double gamma, size_t n, const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,
+                int solution_index, uint8_t *solution_dev, long long *counts_out, hipStream_t stream);
+
 int delta_build_map(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
                     double gamma, size_t n, double lambda_ref, double margin, uint8_t *emap_dev,
                     hipStream_t stream);

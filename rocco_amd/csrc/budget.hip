@@ -112,6 +112,24 @@ public:
         return ROCCO_HIP_OK;
     }
 
+    int spine(std::vector<SpineRequest> &reqs) override
+    {
+        std::vector<RoundTask> tasks;
+        for (SpineRequest &r : reqs) {
+            if (r.lambdas.empty() || r.lambdas.size() > 64 || probs[r.problem].emap == nullptr) {
+                return ROCCO_HIP_EINVAL;
+            }
+            RoundTask t;
+            t.problem = r.problem;
+            t.record = true;
+            t.solution_index = r.solution_index;
+            t.lambdas = r.lambdas;
+            t.spine = &r;
+            tasks.push_back(t);
+        }
+        return run_round(tasks);
+    }
+
     int exact(std::vector<ExactRequest> &reqs) override
     {
         const size_t R = reqs.size();
@@ -255,10 +273,13 @@ private:
         size_t problem = 0;
         bool window = false;
         bool map = false;
+        bool record = false;
+        int solution_index = -1;
         double margin = 0.0;
         std::vector<double> lambdas;
         ProbeRequest *probe = nullptr;
         WindowRequest *win = nullptr;
+        SpineRequest *spine = nullptr;
     };
 
     int run_round(std::vector<RoundTask> &rt)
@@ -272,7 +293,9 @@ private:
         std::vector<FastChain> chains;
         std::vector<FastSlot> slots;
         std::vector<int2> blockmap;
-        long long chain_chunks = 0, chain_blocks = 0, slot_chunks = 0, slot_blocks = 0;
+        long long chain_chunks = 0, chain_blocks = 0, slot_chunks = 0, slot_blocks = 0, rec_entries = 0;
+        bool any_record = false;
+        std::vector<int> solution_slot(T, -1);
         bool any_costs = false, any_plain = false, any_window = false, any_map = false;
         for (size_t t = 0; t < T; ++t) {
             const DevProblem &p = probs[rt[t].problem];
@@ -324,7 +347,7 @@ private:
                 for (double lam : rt[t].lambdas) {
                     FastSlot s;
                     s.task = (int)t;
-                    s.mode = rt[t].map ? kModeMap : kModeProbe;
+                    s.mode = rt[t].map ? kModeMap : (rt[t].record ? kModeRecord : kModeProbe);
                     s.chain_a = s.chain_b = (int)chains.size();
                     s.chunk_off = slot_chunks;
                     s.block_off = slot_blocks;
@@ -342,6 +365,15 @@ private:
                 }
             }
             ft.slot_count = (int)slots.size() - ft.slot_begin;
+            ft.rec_off = 0;
+            if (rt[t].record) {
+                any_record = true;
+                ft.rec_off = rec_entries;
+                rec_entries += nchunks * ft.slot_count;
+                if (rt[t].solution_index >= 0) {
+                    solution_slot[t] = ft.slot_begin + rt[t].solution_index;
+                }
+            }
             for (int k = 0; k < nblocks; ++k) {
                 blockmap.push_back(make_int2((int)t, k));
             }
@@ -385,6 +417,10 @@ private:
         const size_t o_plo = carve((size_t)slot_blocks * 4), o_phi = carve((size_t)slot_blocks * 4);
         const size_t o_blo = carve((size_t)slot_blocks * 4), o_bhi = carve((size_t)slot_blocks * 4);
         const size_t o_rin = carve((size_t)slot_blocks);
+        const size_t o_rdin = carve((size_t)rec_entries * 8 + 8), o_rgain = carve((size_t)rec_entries * 8 + 8);
+        const size_t o_rd = carve((size_t)rec_entries * 4 + 8), o_rv = carve((size_t)rec_entries * 4 + 8);
+        const size_t o_rf = carve((size_t)rec_entries + 8);
+        const size_t o_ss = carve(T * sizeof(int));
         const size_t o_res = carve(S * sizeof(FastSlotResult));
         if ((rc = solver_->dev_params.reserve(off)) != ROCCO_HIP_OK) return rc;
         char *sc = (char *)solver_->dev_params.ptr;
@@ -426,10 +462,24 @@ private:
         L.buf.bbase_lo = (unsigned *)(sc + o_blo);
         L.buf.bbase_hi = (unsigned *)(sc + o_bhi);
         L.buf.rin_lo = (uint8_t *)(sc + o_rin);
+        L.buf.rec_din = (double *)(sc + o_rdin);
+        L.buf.rec_gain = (double *)(sc + o_rgain);
+        L.buf.rec_d = (unsigned *)(sc + o_rd);
+        L.buf.rec_v = (unsigned *)(sc + o_rv);
+        L.buf.rec_flags = (uint8_t *)(sc + o_rf);
         L.buf.results = (FastSlotResult *)(sc + o_res);
         ROCCO_HIP_TRY(hipMemsetAsync(L.buf.results, 0, S * sizeof(FastSlotResult), stream_));
         if ((rc = launch_fast_round(L, stream_)) != ROCCO_HIP_OK) {
             return rc;
+        }
+        if (any_record) {
+            if ((rc = solver_->host_back.reserve(T * sizeof(int) + S * sizeof(FastSlotResult))) != ROCCO_HIP_OK) return rc;
+            int *h_ss = (int *)((char *)solver_->host_back.ptr + S * sizeof(FastSlotResult));
+            std::memcpy(h_ss, solution_slot.data(), T * sizeof(int));
+            ROCCO_HIP_TRY(hipMemcpyAsync(sc + o_ss, h_ss, T * sizeof(int), hipMemcpyHostToDevice, stream_));
+            if ((rc = launch_spine(L, (const int *)(sc + o_ss), stream_)) != ROCCO_HIP_OK) {
+                return rc;
+            }
         }
         if ((rc = solver_->host_back.reserve(S * sizeof(FastSlotResult))) != ROCCO_HIP_OK) return rc;
         ROCCO_HIP_TRY(hipMemcpyAsync(solver_->host_back.ptr, L.buf.results, S * sizeof(FastSlotResult),
@@ -441,6 +491,15 @@ private:
             const FastTask &ft = tasks[t];
             const DevProblem &p = probs[rt[t].problem];
             if (rt[t].map) {
+                continue;
+            }
+            if (rt[t].record) {
+                rt[t].spine->counts.resize(rt[t].lambdas.size());
+                rt[t].spine->stepped.resize(rt[t].lambdas.size());
+                for (int k = 0; k < ft.slot_count; ++k) {
+                    rt[t].spine->counts[k] = hr[ft.slot_begin + k].count_lo;
+                    rt[t].spine->stepped[k] = hr[ft.slot_begin + k].uncertain;
+                }
                 continue;
             }
             if (rt[t].window) {
@@ -580,6 +639,38 @@ int delta_build_map(rocco_hip_solver *solver, const double *scores_dev, const do
     if ((rc = ev.build_map(reqs)) != ROCCO_HIP_OK) return rc;
     ROCCO_HIP_TRY(hipMemcpyAsync(emap_dev, ev.probs[0].emap, (n + kChunk - 1) / kChunk, hipMemcpyDeviceToDevice, stream));
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+    return ROCCO_HIP_OK;
+}
+
+int delta_spine(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
+                double gamma, size_t n, const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,
+                int solution_index, uint8_t *solution_dev, long long *counts_out, hipStream_t stream)
+{
+    HipEvaluator ev(solver, stream);
+    DevProblem d;
+    d.scores = scores_dev;
+    d.costs = (n > 1) ? switch_costs_dev : nullptr;
+    d.gamma = gamma;
+    d.n = n;
+    d.solution = solution_dev;
+    ev.probs.push_back(d);
+    std::vector<ChainProblem> problems(1);
+    problems[0].n = n;
+    problems[0].gamma = gamma;
+    int rc;
+    if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    ev.probs[0].emap = const_cast<uint8_t *>(emap_dev);
+    std::vector<SpineRequest> reqs(1);
+    reqs[0].problem = 0;
+    reqs[0].lambdas.assign(lambdas, lambdas + n_lambdas);
+    reqs[0].solution_index = solution_index;
+    if ((rc = ev.spine(reqs)) != ROCCO_HIP_OK) return rc;
+    for (size_t i = 0; i < n_lambdas; ++i) {
+        counts_out[i] = reqs[0].counts[i];
+    }
+    if (getenv("ROCCO_HIP_DEBUG") != nullptr) {
+        fprintf(stderr, "[rocco_hip] spine: n=%zu chunks=%zu stepped[0]=%lld\n", n, (n + 31) / 32, reqs[0].stepped[0]);
+    }
     return ROCCO_HIP_OK;
 }
 

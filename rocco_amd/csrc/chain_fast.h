@@ -19,7 +19,7 @@ constexpr int kMapBias = 64;                           // == ORACLE_MAP_BIAS
 constexpr int kMapNone = 0xFF;                         // == ORACLE_MAP_NONE
 constexpr int kMaxDiffs = 16;
 
-enum FastMode { kModeProbe = 0, kModeWindow = 1, kModeMap = 2 };
+enum FastMode { kModeProbe = 0, kModeWindow = 1, kModeMap = 2, kModeRecord = 3 };
 
 struct FastTask {
     const double *scores;
@@ -33,6 +33,7 @@ struct FastTask {
     double cmax, sabs;
     int slot_begin, slot_count;
     int n_blocks;
+    long long rec_off;  // record slots: offset of this task in the [chunk][slot] record arrays
     uint8_t *solution;    // n bytes (window slots write fill(LO) here)
     const uint8_t *emap;  // binade code per chunk, or nullptr (every chunk = hazard, global exponent)
     uint8_t *emap_out;    // map slots write the new codes here
@@ -93,6 +94,10 @@ struct FastBuffers {
     uint8_t *bfv_lo, *bfv_hi;
     unsigned *bpend_lo, *bpend_hi, *bbase_lo, *bbase_hi;
     uint8_t *rin_lo;
+    // record slots (exact spine): per (chunk, slot of the task), slot fastest
+    double *rec_din, *rec_gain;
+    unsigned *rec_d, *rec_v;
+    uint8_t *rec_flags;  // bit 0: the parallel recursion is exact in this chunk (clean, no rounding tie)
     // per slot
     FastSlotResult *results;
 };
@@ -109,6 +114,10 @@ struct FastLaunch {
 };
 
 int launch_fast_round(const FastLaunch &L, hipStream_t stream);
+
+// Exact spine over the record arrays of a round (chain_spine.hip): afterwards rec_d / rec_v hold the
+// reference's exact classes for every slot; then counts (and one solution per task) are rebuilt.
+int launch_spine(const FastLaunch &L, const int *solution_slot_dev, hipStream_t stream);
 
 // min / max of scores (and of switch costs) per task: out[4 * t + {0,1,2,3}] = smin, smax, cmin, cmax
 struct StatsTask {

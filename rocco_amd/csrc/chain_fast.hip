@@ -718,12 +718,16 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     unsigned *lds_u = reinterpret_cast<unsigned *>(lds_red + 44);
 
     double lam[NCH], delta[NCH];
+    double delta_in0 = 0.0;
     int pstar = 0;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const FastChain &ch = chains[k == 0 ? slot.chain_a : slot.chain_b];
         lam[k] = ch.lambda;
         delta[k] = incoming_delta(buf, ch, chunk, valid, local_block, big, lds_red);
+        if (k == 0) {
+            delta_in0 = delta[0];
+        }
         if (valid) {
             const int p = (int)buf.pstar[ch.chunk_off + chunk];
             pstar = (p > pstar) ? p : pstar;
@@ -756,6 +760,7 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     int overflow = 0, nonadjacent = 0;
     unsigned validmask = 0;
     double gain = 0.0;
+    double wsum_chunk = 0.0;
 
     if (valid) {
 #pragma unroll
@@ -766,7 +771,7 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
                 const double c_raw_prev = (i == 0) ? d.c_prev0 : raw_cost_at(task, d, i - 1);
                 const double c_prev = cost_on_grid(mode[0], c_raw_prev, magic);
                 const double cj = cost_on_grid(mode[0], raw_cost_at(task, d, i), magic);
-                if (slot.mode == kModeMap && j > 0) {
+                if ((slot.mode == kModeMap || slot.mode == kModeRecord) && j > 0) {
                     gain += fmax(0.0, delta[0] - c_prev);
                 }
 #pragma unroll
@@ -774,7 +779,9 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
                     const double a = step_a(mode[k], d.sv[i], lam[k], magic);
                     delta[k] = (j == 0) ? a : (clampc(delta[k], c_prev) + a);
                 }
-                wacc += step_w<HAS_COSTS>(mode[0], d.sv[i], c_raw_prev, j == 0) * wscale;
+                const double w_here = step_w<HAS_COSTS>(mode[0], d.sv[i], c_raw_prev, j == 0) * wscale;
+                wacc += w_here;
+                wsum_chunk += w_here;
                 const long long m = j - 1 - lc;
                 max_run = (m > max_run) ? m : max_run;
                 const double tau = wacc + mode[0].base;
@@ -787,14 +794,14 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
                     bool certain;
                     if (!last) {
                         const double e = fabs(dl) - cj;
-                        certain = !over && (e > tau || e < -tau);
-                        cls = (dl > cj) ? kClsOne : ((dl < -cj) ? kClsZero : kClsCopy);
+                        certain = !over && (tau == 0.0 || e > tau || e < -tau);
+                        cls = (dl > cj) ? kClsOne : ((dl <= -cj) ? kClsZero : kClsCopy);
                         if (i >= pstar && e > kGuard) {
                             lc = j;
                             wacc = 0.0;
                         }
                     } else {
-                        certain = !over && (fabs(dl) > tau);
+                        certain = !over && (tau == 0.0 || fabs(dl) > tau);
                         cls = (dl > 0.0) ? kClsOne : kClsZero;
                     }
                     if (!certain) {
@@ -809,14 +816,16 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
                     int lo, hi;
                     if (!last) {
                         lo = (dhi + cj <= tau) ? kClsZero : ((dhi - cj > tau) ? kClsOne : kClsCopy);
-                        hi = (dlo - cj >= -tau) ? kClsOne : ((dlo + cj < -tau) ? kClsZero : kClsCopy);
+                        const bool hi_one = (tau > 0.0) ? (dlo - cj >= -tau) : (dlo - cj > 0.0);
+                        const bool hi_zero = (tau > 0.0) ? (dlo + cj < -tau) : (dlo + cj <= 0.0);
+                        hi = hi_one ? kClsOne : (hi_zero ? kClsZero : kClsCopy);
                         if (i >= pstar && ((dhi - cj > kGuard) || (-dlo - cj > kGuard))) {
                             lc = j;
                             wacc = 0.0;
                         }
                     } else {
                         lo = (dhi > tau) ? kClsOne : kClsZero;
-                        hi = (dlo >= -tau) ? kClsOne : kClsZero;
+                        hi = ((tau > 0.0) ? (dlo >= -tau) : (dlo > 0.0)) ? kClsOne : kClsZero;
                     }
                     if (lo != hi) {
                         const double bound = !last ? ((hi == kClsOne) ? cj : -cj) : 0.0;
@@ -860,6 +869,16 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
         if (max_run > 0) atomicMax(reinterpret_cast<long long *>(&res.max_run), max_run);
         if (overflow) atomicOr(&res.overflow, 1);
         if (nonadjacent) atomicOr(&res.nonadjacent, 1);
+    }
+
+    // record slots: what the exact spine needs per chunk, laid out [chunk][slot of the task]
+    if (slot.mode == kModeRecord && valid) {
+        const long long at = task.rec_off + chunk * task.slot_count + (slot_index - task.slot_begin);
+        buf.rec_din[at] = delta_in0;
+        buf.rec_gain[at] = gain;
+        buf.rec_d[at] = D_lo;
+        buf.rec_v[at] = V_lo;
+        buf.rec_flags[at] = (uint8_t)((mode[0].clean && wsum_chunk == 0.0) ? 1 : 0);
     }
 
     // map slots: gain of this chunk and of the workgroup (fixed reduction order)
@@ -1164,6 +1183,265 @@ __global__ __launch_bounds__(kFastThreads) void stats_final_kernel(const int2 *b
     }
 }
 
+// broadcast lane `src` (a compile-time constant once the caller's loop is unrolled) of a double
+__device__ __forceinline__ double read_lane_f64(double x, int src)
+{
+    const long long bits = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xFFFFFFFFLL), src);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// ---- exact spine ----------------------------------------------------------------------------------
+// One wavefront per chromosome, lane = record slot (penalty).  The reference's running values
+// (prev0 = P0, prev1 = P1, rocco/_chain_dp.c:117-165) are carried EXACTLY: over chunks where the
+// parallel recursion is exact (clean, no rounding tie) and the lane is synchronised with it, P0 just
+// receives the chunk's exact gain; every other chunk is stepped with the reference's own
+// operations on absolute values, and stepping continues until P1 - P0 equals the parallel
+// recursion's incoming delta of an exact chunk again.  Stepped chunks get their class words
+// rewritten with the reference's actual decisions (ties: the state-1 path always holds more
+// selected loci, so "leave" needs a strict win and "enter" wins ties).
+__global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
+{
+    const FastTask task = L.tasks[blockIdx.x];
+    if (task.slot_count == 0 || L.slots[task.slot_begin].mode != kModeRecord) {
+        return;
+    }
+    const int lane = threadIdx.x;
+    const int S = task.slot_count;
+    const bool active = lane < S;
+    const double lam = active ? L.chains[L.slots[task.slot_begin + lane].chain_a].lambda : 0.0;
+    const long long n = task.n;
+    const long long nchunks = (n + kChunk - 1) / kChunk;
+    const double *__restrict__ sc = task.scores;
+    const double *__restrict__ cs = task.switch_costs;
+    const bool has_costs = (cs != nullptr);
+    const FastBuffers &buf = L.buf;
+
+    double P0 = 0.0, P1 = 0.0;
+    bool stepping = true;  // chunk 0 is always stepped (the map never marks it clean)
+    unsigned D = 0, V = 0;  // class word under construction for the chunk being stepped
+    long long stepped = 0;
+
+    constexpr int kGroup = 32;  // chunks skipped per iteration while every lane is synchronised
+    for (long long k = 0; k < nchunks; ++k) {
+        if ((k % kGroup) == 0 && !__any(active && stepping)) {
+            // fast path: a whole group of chunks is exact for every lane -> add their gains at once
+            // (all loads independent; the sums are exact, so their order does not matter)
+            unsigned okbits = 1U;
+            double gsum = 0.0;
+            if (active) {
+                // branch-free so that all 64 loads of the group are in flight together
+                unsigned fl[kGroup];
+                double gv[kGroup];
+#pragma unroll
+                for (int c = 0; c < kGroup; ++c) {
+                    const long long kk = (k + c < nchunks) ? (k + c) : (nchunks - 1);
+                    const long long a2 = task.rec_off + kk * S + lane;
+                    fl[c] = buf.rec_flags[a2];
+                    gv[c] = buf.rec_gain[a2];
+                }
+#pragma unroll
+                for (int c = 0; c < kGroup; ++c) {
+                    const bool in = (k + c < nchunks);
+                    okbits &= in ? fl[c] : 1U;
+                    gsum += in ? gv[c] : 0.0;
+                }
+            }
+            const bool ok = (okbits & 1U) != 0U;
+            if (__all(ok)) {
+                P0 += gsum;
+                k += kGroup - 1;
+                continue;
+            }
+        }
+        const long long at = task.rec_off + k * S + lane;
+        const bool exact_here = active ? ((buf.rec_flags[at] & 1U) != 0U) : true;
+        const bool need = active && (stepping || !exact_here);
+        if (active && !need) {
+            P0 += buf.rec_gain[at];
+        }
+        if (!__any(need)) {
+            continue;
+        }
+        const long long j0 = k * kChunk;
+        const long long j_end = j0 + kChunk;  // first locus of the next chunk
+        const bool fresh = need && !stepping;  // was synchronised: enter with the parallel delta
+        // issue every load this chunk needs up front (independent addresses: one memory latency)
+        const long long jl = j0 + (lane & 31);
+        const double sv = (jl < n) ? sc[jl] : 0.0;
+        const double cvr = has_costs ? ((jl < n - 1) ? cs[jl] : 0.0) : task.gamma;
+        const double c_prev0 = has_costs ? ((j0 > 0) ? cs[j0 - 1] : 0.0) : task.gamma;
+        const double din_here = need ? buf.rec_din[at] : 0.0;
+        const bool has_next = j_end < n;
+        const double s_next = has_next ? sc[j_end] : 0.0;
+        const double c_last = has_costs ? (has_next ? cs[j_end - 1] : 0.0) : task.gamma;
+        const long long at_next = at + S;
+        const bool next_exact = (need && has_next) ? ((buf.rec_flags[at_next] & 1U) != 0U) : false;
+        const double din_next = (need && has_next) ? buf.rec_din[at_next] : 0.0;
+        unsigned prev_d = 0, prev_v = 0;
+        if (need && k > 0) {
+            prev_d = buf.rec_d[at - S];
+            prev_v = buf.rec_v[at - S];
+        }
+        if (fresh) {
+            P1 = P0 + din_here;
+            stepping = true;
+            D = 0;
+            V = 0;
+        }
+        if (need) {
+            ++stepped;
+        }
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            const long long j = j0 + i;
+            const double s_j = read_lane_f64(sv, i);
+            const double c_prev = (i == 0) ? c_prev0 : read_lane_f64(cvr, i - 1);
+            if (need && j < n) {
+                if (j == 0) {
+                    P0 = 0.0;
+                    P1 = s_j - lam;  // rocco/_chain_dp.c:109-112
+                } else {
+                    const double leave = P1 - c_prev;
+                    const double keep = P1 + s_j - lam;
+                    const double enter = P0 - c_prev + s_j - lam;
+                    const bool tl = leave > P0;
+                    const bool te = enter >= keep;
+                    const unsigned dbit = (tl || te) ? 1U : 0U;  // class of locus j-1: ONE / ZERO / COPY
+                    const unsigned vbit = tl ? 1U : 0U;
+                    if (i == 0) {
+                        // last locus of the previous chunk
+                        const long long prev = at - S;
+                        buf.rec_d[prev] = (prev_d & 0x7FFFFFFFU) | (dbit << 31);
+                        buf.rec_v[prev] = (prev_v & 0x7FFFFFFFU) | (vbit << 31);
+                    } else {
+                        D |= dbit << (i - 1);
+                        V |= vbit << (i - 1);
+                    }
+                    P0 = tl ? leave : P0;
+                    P1 = te ? enter : keep;
+                }
+            }
+        }
+        // end of chunk k for the stepping lanes
+        if (!has_next) {
+            if (need) {
+                const int il = (int)(n - 1 - j0);
+                const unsigned one = (P1 > P0) ? 1U : 0U;  // rocco/_chain_dp.c:167-179, tie -> state 0
+                D |= 1U << il;
+                V |= one << il;
+                buf.rec_d[at] = D;
+                buf.rec_v[at] = V;
+            }
+        } else {
+            const bool resync = need && next_exact && ((P1 - P0) == din_next);
+            if (need) {
+                if (resync) {
+                    // decision of the next step classifies this chunk's last locus; state untouched
+                    const double leave = P1 - c_last;
+                    const double keep = P1 + s_next - lam;
+                    const double enter = P0 - c_last + s_next - lam;
+                    const bool tl = leave > P0;
+                    const bool te = enter >= keep;
+                    D |= ((tl || te) ? 1U : 0U) << 31;
+                    V |= (tl ? 1U : 0U) << 31;
+                    stepping = false;
+                }
+                // bit 31 of a chunk that keeps stepping is filled in by the next chunk's first step
+                buf.rec_d[at] = D;
+                buf.rec_v[at] = V;
+                D = 0;
+                V = 0;
+            }
+        }
+    }
+    if (active) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&buf.results[task.slot_begin + lane].uncertain),
+                  (unsigned long long)stepped);  // diagnostic: chunks stepped exactly
+    }
+}
+
+// Rebuild fill summaries (and one solution per task) from the record class words.
+__global__ __launch_bounds__(kFastThreads) void fill_from_classes_kernel(FastLaunch L, const int *solution_slot)
+{
+    __shared__ unsigned lds_u[16];
+    const int2 bm = L.blockmap[blockIdx.x];
+    const FastTask task = L.tasks[bm.x];
+    const int local_block = bm.y;
+    const long long chunk = (long long)local_block * kFastThreads + threadIdx.x;
+    const long long j0 = chunk * kChunk;
+    const bool valid = j0 < task.n;
+    const int S = task.slot_count;
+    const int sol_slot = solution_slot[bm.x];
+    unsigned validmask = 0;
+    if (valid) {
+        const long long left = task.n - j0;
+        validmask = (left >= kChunk) ? 0xFFFFFFFFU : ((1U << left) - 1U);
+    }
+    for (int si = 0; si < S; ++si) {
+        const FastSlot slot = L.slots[task.slot_begin + si];
+        if (slot.mode != kModeRecord) {
+            continue;
+        }
+        unsigned D = 0, V = 0;
+        if (valid) {
+            const long long at = task.rec_off + chunk * S + si;
+            D = L.buf.rec_d[at] & validmask;
+            V = L.buf.rec_v[at] & validmask;
+        }
+        const long long bidx = slot.block_off + local_block;
+        const FillOut f = block_fill(D, V, validmask, L.buf.bfv_lo, L.buf.bpend_lo, L.buf.bbase_lo, bidx, lds_u);
+        if (task.slot_begin + si == sol_slot && valid) {
+            uint8_t *z = task.solution + j0;
+            const unsigned bits = f.zbits;
+            if (j0 + kChunk <= task.n && ((reinterpret_cast<uintptr_t>(z) & 15U) == 0)) {
+                uint4 w0, w1;
+                const unsigned long long q0 = spread_bits_to_bytes(bits);
+                const unsigned long long q1 = spread_bits_to_bytes(bits >> 8);
+                const unsigned long long q2 = spread_bits_to_bytes(bits >> 16);
+                const unsigned long long q3 = spread_bits_to_bytes(bits >> 24);
+                w0.x = (unsigned)q0;
+                w0.y = (unsigned)(q0 >> 32);
+                w0.z = (unsigned)q1;
+                w0.w = (unsigned)(q1 >> 32);
+                w1.x = (unsigned)q2;
+                w1.y = (unsigned)(q2 >> 32);
+                w1.z = (unsigned)q3;
+                w1.w = (unsigned)(q3 >> 32);
+                reinterpret_cast<uint4 *>(z)[0] = w0;
+                reinterpret_cast<uint4 *>(z)[1] = w1;
+            } else {
+                for (int i = 0; i < kChunk && j0 + i < task.n; ++i) {
+                    z[i] = (uint8_t)((bits >> i) & 1U);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kFastThreads) void spine_patch_kernel(FastLaunch L, const int *solution_slot)
+{
+    const int2 bm = L.blockmap[blockIdx.x];
+    const FastTask task = L.tasks[bm.x];
+    const int local_block = bm.y;
+    const int sol_slot = solution_slot[bm.x];
+    if (sol_slot < 0) {
+        return;
+    }
+    const FastSlot slot = L.slots[sol_slot];
+    const long long at = slot.block_off + local_block;
+    const unsigned pend = L.buf.bpend_lo[at];
+    if (pend == 0U || L.buf.rin_lo[at] == 0) {
+        return;
+    }
+    long long end = (long long)(local_block + 1) * kFastBlockLoci;
+    end = (end < task.n) ? end : task.n;
+    for (long long j = end - pend + threadIdx.x; j < end; j += kFastThreads) {
+        task.solution[j] = 1;
+    }
+}
+
 }  // namespace
 
 int launch_fast_round(const FastLaunch &L, hipStream_t stream)
@@ -1209,6 +1487,21 @@ int launch_fast_round(const FastLaunch &L, hipStream_t stream)
     if (L.any_map) {
         hipLaunchKernelGGL(fast_mapcode_kernel, grid, block, 0, stream, L);
     }
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_spine(const FastLaunch &L, const int *solution_slot_dev, hipStream_t stream)
+{
+    if (L.n_tasks == 0 || L.n_blocks_total == 0) {
+        return ROCCO_HIP_OK;
+    }
+    const dim3 grid((unsigned)L.n_blocks_total), block(kFastThreads);
+    const unsigned fill_blocks = (unsigned)((2 * L.n_slots + 63) / 64);
+    hipLaunchKernelGGL(spine_kernel, dim3((unsigned)L.n_tasks), dim3(64), 0, stream, L);
+    hipLaunchKernelGGL(fill_from_classes_kernel, grid, block, 0, stream, L, solution_slot_dev);
+    hipLaunchKernelGGL(fast_fillscan_kernel, dim3(fill_blocks), dim3(64), 0, stream, L);
+    hipLaunchKernelGGL(spine_patch_kernel, grid, block, 0, stream, L, solution_slot_dev);
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }

@@ -60,14 +60,18 @@ struct State {
         kNeedMap,       // an uncertain probe was met and the binade map is missing / too coarse
         kZone,          // an uncertain probe was met: joint window over the current bracket
         kFinalExact,    // exact solve at the final penalty (writes the solution)
+        kFinalSpine,    // spine solve at the final penalty (writes the solution)
         kDone
     } phase = kLowerBracket;
     long long target = 0;
     double lower = 0.0, upper = 0.0;
     int iters_left = 0;
     bool use_exact = false;
+    bool use_spine = false;  // decisions left open by the window: finish through the exact spine
     bool has_map = false;
-    double map_width = 0.0;      // bracket width the current map was built for
+    double map_lo = 0.0, map_hi = 0.0;  // penalties the current binade map is valid for
+    bool point_pending = false;         // the map is a point map at the next midpoint: probe it alone
+    double req_ref = 0.0, req_lo = 0.0, req_hi = 0.0, req_margin = 0.0;  // map being requested
     long long lower_count = 0;   // selected loci at `lower` (bounds the count anywhere in the bracket)
     Phase after_map = kBisect;
     CalibrationResult out;
@@ -138,6 +142,27 @@ void replay_with_critical(State &s, double critical)
     }
 }
 
+// Decide which binade map to build for the current bracket: one valid for the whole bracket when
+// the running values cannot move much inside it, otherwise a point map at the next midpoint.
+void plan_map(const ChainProblem &p, State &s, bool force_bracket)
+{
+    const double width = s.upper - s.lower;
+    const double reach = p.cost_max + (p.score_max - p.score_min) + 2.0;
+    const double drift = 2.0 * width * (double)s.lower_count;
+    if (force_bracket || drift <= 4.0 * reach) {
+        s.req_ref = (s.lower + s.upper) / 2.0;
+        s.req_lo = s.lower;
+        s.req_hi = s.upper;
+        s.req_margin = reach + drift + 2.0;
+        s.point_pending = false;
+    } else {
+        s.req_ref = s.req_lo = s.req_hi = (s.lower + s.upper) / 2.0;
+        s.req_margin = reach + 2.0;
+        s.point_pending = true;
+    }
+    s.phase = State::kNeedMap;
+}
+
 }  // namespace
 
 bool analytic_count(const ChainProblem &p, double lambda, long long *count_out)
@@ -196,7 +221,8 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
         std::vector<WindowRequest> windows;
         std::vector<ExactRequest> exacts;
         std::vector<MapRequest> maps;
-        std::vector<size_t> probe_owner, window_owner, exact_owner, map_owner;
+        std::vector<SpineRequest> spines;
+        std::vector<size_t> probe_owner, window_owner, exact_owner, map_owner, spine_owner;
 
         for (size_t b = 0; b < B; ++b) {
             const ChainProblem &p = problems[b];
@@ -209,6 +235,8 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 // every step was decided with certainty: the final penalty is `upper`
                 if (s.use_exact) {
                     s.phase = State::kFinalExact;
+                } else if (s.use_spine) {
+                    s.phase = State::kFinalSpine;
                 } else {
                     s.phase = State::kZone;  // degenerate zone [upper, upper]: certify + materialise
                     s.lower = s.upper;
@@ -252,22 +280,39 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 break;
             }
             case State::kBisect: {
-                if (!s.use_exact && s.has_map && s.map_width > 16.0 * (s.upper - s.lower)) {
-                    // the bracket shrank a lot since the map was built: its hazard margin can shrink too
-                    MapRequest r;
+                if (!s.use_exact && s.use_spine) {
+                    s.tree_depth = std::min(opt.exact_depth, s.iters_left);
+                    build_tree(s.lower, s.upper, s.tree_depth, s.tree);
+                    SpineRequest r;
                     r.problem = b;
-                    r.lambda_ref = (s.lower + s.upper) / 2.0;
-                    const double width = s.upper - s.lower;
-                    r.margin = (p.cost_max + (p.score_max - p.score_min) + 2.0) +
-                               2.0 * width * (double)s.lower_count + 2.0;
-                    s.map_width = width;
-                    s.after_map = State::kBisect;
-                    s.phase = State::kNeedMap;
-                    maps.push_back(r);
-                    map_owner.push_back(b);
+                    r.lambdas = s.tree;
+                    spines.push_back(r);
+                    spine_owner.push_back(b);
                     break;
                 }
+                if (!s.use_exact && s.has_map) {
+                    const double width = s.upper - s.lower;
+                    const double mid = (s.lower + s.upper) / 2.0;
+                    const bool inside = (s.map_lo <= s.lower && s.upper <= s.map_hi);
+                    const bool point_ok = s.point_pending && s.map_lo == mid && s.map_hi == mid;
+                    if ((!inside && !point_ok) || (inside && (s.map_hi - s.map_lo) > 16.0 * width)) {
+                        // the map does not cover this bracket, or the bracket shrank a lot since it was
+                        // built (its hazard margin can shrink too)
+                        plan_map(p, s, false);
+                        s.after_map = State::kBisect;
+                        MapRequest r;
+                        r.problem = b;
+                        r.lambda_ref = s.req_ref;
+                        r.margin = s.req_margin;
+                        maps.push_back(r);
+                        map_owner.push_back(b);
+                        break;
+                    }
+                }
                 s.tree_depth = std::min(s.use_exact ? opt.exact_depth : opt.spec_depth, s.iters_left);
+                if (!s.use_exact && s.has_map && s.point_pending) {
+                    s.tree_depth = std::min(1, s.iters_left);
+                }
                 build_tree(s.lower, s.upper, s.tree_depth, s.tree);
                 if (s.use_exact) {
                     ExactRequest r;
@@ -294,12 +339,8 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
             case State::kNeedMap: {
                 MapRequest r;
                 r.problem = b;
-                r.lambda_ref = (s.lower + s.upper) / 2.0;
-                const double width = s.upper - s.lower;
-                // running values move by at most (count) * (penalty change) inside the bracket
-                r.margin = (p.cost_max + (p.score_max - p.score_min) + 2.0) +
-                           2.0 * width * (double)s.lower_count + 2.0;
-                s.map_width = width;
+                r.lambda_ref = s.req_ref;
+                r.margin = s.req_margin;
                 maps.push_back(r);
                 map_owner.push_back(b);
                 break;
@@ -311,6 +352,15 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 r.lambda_hi = s.upper;
                 windows.push_back(r);
                 window_owner.push_back(b);
+                break;
+            }
+            case State::kFinalSpine: {
+                SpineRequest r;
+                r.problem = b;
+                r.lambdas = {s.upper};
+                r.solution_index = 0;
+                spines.push_back(r);
+                spine_owner.push_back(b);
                 break;
             }
             case State::kFinalExact: {
@@ -326,7 +376,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 break;
             }
         }
-        if (probes.empty() && windows.empty() && exacts.empty() && maps.empty()) {
+        if (probes.empty() && windows.empty() && exacts.empty() && maps.empty() && spines.empty()) {
             break;
         }
         int rc;
@@ -339,6 +389,8 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 ++s.out.passes;
                 ++s.out.maps;
                 s.has_map = true;
+                s.map_lo = s.req_lo;
+                s.map_hi = s.req_hi;
                 s.phase = s.after_map;
             }
         }
@@ -350,6 +402,38 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
         }
         if (!exacts.empty() && (rc = ev.exact(exacts)) != ROCCO_HIP_OK) {
             return rc;
+        }
+        if (!spines.empty() && (rc = ev.spine(spines)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+
+        // ---- consume spine results (exact counts) ----
+        for (size_t q = 0; q < spines.size(); ++q) {
+            State &s = st[spine_owner[q]];
+            const SpineRequest &r = spines[q];
+            ++s.out.passes;
+            if (s.phase == State::kFinalSpine) {
+                s.out.selection_penalty = s.upper;
+                s.out.selected_count = r.counts[0];
+                s.out.path = ROCCO_HIP_PATH_SPINE;
+                s.phase = State::kDone;
+                continue;
+            }
+            size_t i = 0;
+            for (int level = 0; level < s.tree_depth; ++level) {
+                ++s.out.evaluations;
+                --s.iters_left;
+                if (r.counts[i] > s.target) {
+                    s.lower = r.lambdas[i];
+                    i = 2 * i + 2;
+                } else {
+                    s.upper = r.lambdas[i];
+                    i = 2 * i + 1;
+                }
+            }
+            if (s.iters_left <= 0) {
+                s.phase = State::kFinalSpine;
+            }
         }
 
         // ---- consume probe results ----
@@ -392,16 +476,31 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     o = classify(r.results[(size_t)s.tree_slot[i]], s.target);
                 }
                 if (o == Outcome::kUncertain) {
-                    const double width = s.upper - s.lower;
-                    if (!s.has_map || s.map_width > 2.0 * width) {
-                        s.phase = State::kNeedMap;  // sharpen the rounding model, then ask again
+                    // the uncertain node is the midpoint of the current bracket
+                    const double mid = s.tree[i];
+                    const bool is_point_here = s.has_map && s.map_lo == mid && s.map_hi == mid;
+                    const bool covers = s.has_map && s.map_lo <= s.lower && s.upper <= s.map_hi;
+                    if (!s.has_map) {
+                        plan_map(p, s, false);  // sharpen the rounding model, then ask again
                         s.after_map = State::kBisect;
+                    } else if (!is_point_here) {
+                        // retry this midpoint alone with a map built exactly at it
+                        s.req_ref = s.req_lo = s.req_hi = mid;
+                        s.req_margin = p.cost_max + (p.score_max - p.score_min) + 4.0;
+                        s.point_pending = true;
+                        s.phase = State::kNeedMap;
+                        s.after_map = State::kBisect;
+                    } else if (!covers) {
+                        plan_map(p, s, true);  // the window needs a map valid across the bracket
+                        s.after_map = State::kZone;
+                        s.out.zone_iters = s.iters_left;
                     } else {
                         s.phase = State::kZone;
                         s.out.zone_iters = s.iters_left;
                     }
                     break;
                 }
+                s.point_pending = false;
                 ++s.out.evaluations;
                 --s.iters_left;
                 if (o == Outcome::kGreater) {
@@ -421,6 +520,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
         // ---- consume window results ----
         for (size_t q = 0; q < windows.size(); ++q) {
             State &s = st[window_owner[q]];
+            const ChainProblem &p = problems[window_owner[q]];
             const WindowResult &w = windows[q].result;
             ++s.out.passes;
             s.out.n_diff = w.n_diff;
@@ -432,10 +532,15 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     s.out.path = ROCCO_HIP_PATH_CERTIFIED;
                     s.phase = State::kDone;
                 } else if (!s.has_map) {
-                    s.lower = s.upper = 0.0;  // map at the penalty being solved, zero width
-                    s.lower_count = 0;
+                    s.req_ref = s.req_lo = s.req_hi = 0.0;  // map at the penalty being solved
+                    s.req_margin = p.cost_max + (p.score_max - p.score_min) + 4.0;
                     s.phase = State::kNeedMap;
                     s.after_map = State::kAll;
+                } else if (opt.use_spine) {
+                    s.use_spine = true;
+                    s.upper = 0.0;
+                    s.out.evaluations = 1;
+                    s.phase = State::kFinalSpine;
                 } else {
                     s.use_exact = true;
                 }
@@ -465,8 +570,11 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 s.out.selection_penalty = s.upper;
                 s.out.path = ROCCO_HIP_PATH_CERTIFIED;
                 s.phase = State::kDone;
+            } else if (opt.use_spine && s.has_map && s.map_lo <= s.lower && s.upper <= s.map_hi) {
+                // not separable by the window: finish the reference's own steps through the exact spine
+                s.use_spine = true;
+                s.phase = (s.iters_left > 0) ? State::kBisect : State::kFinalSpine;
             } else {
-                // not separable by the window: finish the reference's own steps exactly
                 s.use_exact = true;
                 s.phase = (s.iters_left > 0) ? State::kBisect : State::kFinalExact;
             }
@@ -527,7 +635,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
     results.resize(B);
     for (size_t b = 0; b < B; ++b) {
         State &s = st[b];
-        if (s.out.path == ROCCO_HIP_PATH_CERTIFIED) {
+        if (s.out.path == ROCCO_HIP_PATH_CERTIFIED || s.out.path == ROCCO_HIP_PATH_SPINE) {
             const int rc = ev.penalized_value(b, s.out.selection_penalty, s.out.selected_count,
                                               &s.out.penalized_value);
             if (rc != ROCCO_HIP_OK) {
@@ -545,7 +653,7 @@ int solve_fixed_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
 {
     const size_t B = problems.size();
     results.assign(B, CalibrationResult());
-    std::vector<char> need_exact(B, 0), pending(B, 0);
+    std::vector<char> need_exact(B, 0), need_spine(B, 0), pending(B, 0);
     for (size_t b = 0; b < B; ++b) {
         results[b].selection_penalty = lambdas[b];
         results[b].evaluations = 1;
@@ -604,7 +712,37 @@ int solve_fixed_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 }
             } else if (attempt == 1) {
                 pending[b] = 0;
-                need_exact[b] = 1;
+                if (opt.use_spine) {
+                    need_spine[b] = 1;
+                } else {
+                    need_exact[b] = 1;
+                }
+            }
+        }
+    }
+    std::vector<SpineRequest> spines;
+    std::vector<size_t> spine_owner;
+    for (size_t b = 0; b < B; ++b) {
+        if (need_spine[b]) {
+            SpineRequest r;
+            r.problem = b;
+            r.lambdas = {lambdas[b]};
+            r.solution_index = 0;
+            spines.push_back(r);
+            spine_owner.push_back(b);
+        }
+    }
+    if (!spines.empty()) {
+        if ((rc = ev.spine(spines)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        for (size_t q = 0; q < spines.size(); ++q) {
+            const size_t b = spine_owner[q];
+            results[b].selected_count = spines[q].counts[0];
+            results[b].path = ROCCO_HIP_PATH_SPINE;
+            ++results[b].passes;
+            if ((rc = ev.penalized_value(b, lambdas[b], results[b].selected_count, &results[b].penalized_value)) != ROCCO_HIP_OK) {
+                return rc;
             }
         }
     }

@@ -82,6 +82,17 @@ struct ExactRequest {
     std::vector<ExactResult> results;
 };
 
+// Exact evaluation of a handful of penalties through the "spine" (chain_fast.hip): the reference's
+// own counts, and optionally the reference's solution for one of them.  Needs a binade map that is
+// valid for these penalties.
+struct SpineRequest {
+    size_t problem = 0;
+    std::vector<double> lambdas;   // <= 64
+    int solution_index = -1;       // write the solution of lambdas[solution_index]
+    std::vector<long long> counts; // filled by the evaluator
+    std::vector<long long> stepped; // diagnostic: chunks the spine had to step exactly
+};
+
 class Evaluator {
 public:
     virtual ~Evaluator() = default;
@@ -91,6 +102,8 @@ public:
     virtual int window(std::vector<WindowRequest> &reqs) = 0;
     // per-chunk binade map used by later probe / window calls on that problem
     virtual int build_map(std::vector<MapRequest> &reqs) = 0;
+    // exact counts / solution through the spine (requires a map built by build_map)
+    virtual int spine(std::vector<SpineRequest> &reqs) = 0;
     // exact emulation of the reference (always correct)
     virtual int exact(std::vector<ExactRequest> &reqs) = 0;
     // penalised value  sum (s - lambda) z - sum c |dz|  of the solution currently in the buffer
@@ -113,6 +126,7 @@ struct SearchOptions {
     int spec_depth = 2;     // levels of the bisection tree evaluated per probe round
     int exact_depth = 6;    // same for the exact kernel (63 lanes)
     bool force_exact = false;
+    bool use_spine = true;  // finish undecided endgames through the exact spine (else the exact kernel)
 };
 
 // Calibrate every problem of the batch; solutions are left in the evaluator's solution buffers.

@@ -63,3 +63,21 @@ def delta_window_device(scores_t, switch_costs, lambda_lo: float, lambda_hi: flo
                    "margin_hi": float(st.diff_margin_hi[k]), "run": int(st.diff_run[k]),
                    "cls_lo": int(st.diff_cls_lo[k]), "cls_hi": int(st.diff_cls_hi[k])} for k in range(listed)],
     }
+
+
+def delta_spine_device(scores_t, switch_costs, lambdas: Sequence[float], emap_t, solution_index: int = -1):
+    """Exact counts (and optionally one exact solution) through the spine."""
+    import torch
+
+    n = int(scores_t.shape[0])
+    costs_t, gamma = _dp._costs_arg(switch_costs, n, scores_t.device)
+    lam = (ctypes.c_double * len(lambdas))(*[float(x) for x in lambdas])
+    counts = (ctypes.c_longlong * len(lambdas))()
+    sol_t = torch.empty(n, dtype=torch.uint8, device=scores_t.device) if solution_index >= 0 else None
+    solver = _native.solver_for(scores_t.device.index)
+    _native.check(_native.load().rocco_hip_delta_spine_f64(
+        solver.handle, scores_t.data_ptr(), costs_t.data_ptr() if costs_t is not None else None, gamma, n,
+        emap_t.data_ptr(), lam, len(lambdas), int(solution_index),
+        sol_t.data_ptr() if sol_t is not None else None, counts, _dp._stream_ptr(scores_t)),
+        "rocco_hip_delta_spine_f64")
+    return [int(c) for c in counts], sol_t

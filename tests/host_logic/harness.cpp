@@ -35,7 +35,7 @@ int grid_exponent(double cmax, double smin, double smax)
 class OracleEvaluator : public Evaluator {
 public:
     std::vector<HostProblem> hp;
-    long long probe_calls = 0, window_calls = 0, exact_calls = 0, exact_lambdas = 0, map_calls = 0;
+    long long probe_calls = 0, window_calls = 0, exact_calls = 0, exact_lambdas = 0, map_calls = 0, spine_calls = 0;
 
     int probe(std::vector<ProbeRequest> &reqs) override
     {
@@ -96,6 +96,25 @@ public:
             const int rc = oracle_binade_map(p.scores, p.costs, p.gamma, p.n, r.lambda_ref, p.qexp, r.margin,
                                              p.emap.data());
             if (rc != 0) return rc;
+        }
+        return 0;
+    }
+    int spine(std::vector<SpineRequest> &reqs) override
+    {
+        ++spine_calls;
+        for (SpineRequest &r : reqs) {
+            const HostProblem &p = hp[r.problem];
+            if (p.emap.empty()) return -2;  // the product only asks for the spine with a map in place
+            r.counts.resize(r.lambdas.size());
+            for (size_t i = 0; i < r.lambdas.size(); ++i) {
+                double v = 0.0;
+                long long c = 0;
+                const int rc = oracle_solve_penalized_chain_f64(
+                    p.scores, p.costs, p.gamma, p.n, r.lambdas[i],
+                    ((int)i == r.solution_index) ? p.solution : nullptr, &v, &c);
+                if (rc != 0) return rc;
+                r.counts[i] = c;
+            }
         }
         return 0;
     }
@@ -186,6 +205,7 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     out_i[7] = ev.exact_calls;
     out_i[8] = ev.exact_lambdas;
     out_i[9] = res[0].maps;
+    out_i[10] = ev.spine_calls;
     return 0;
 }
 

@@ -117,3 +117,28 @@ def test_map_mode_matches_sequential_definition(gpu, oracle, n):
             assert np.array_equal(sol_t.cpu().numpy(), want_sol)
             for key in ("count_lo", "count_hi", "n_diff", "diff_adjacent", "overflow", "max_run"):
                 assert gw[key] == want[key], (key, n, margin, half)
+
+
+@pytest.mark.parametrize("n,kind", [(5000, "gamma"), (40000, "gamma"), (300007, "gamma"), (120000, "flat")])
+def test_spine_reproduces_the_reference_exactly(gpu, oracle, n, kind):
+    """The spine's counts and solution are the exact DP's (oracle = reference, bit-pinned), for
+    penalties the tolerance model alone cannot always decide (hazard chunks, long runs)."""
+    import torch
+    from rocco_amd.delta import delta_build_map_device, delta_spine_device
+
+    rng = np.random.default_rng(n)
+    s = _scores(n, n + 13, kind)
+    s[rng.integers(0, n, size=n // 40)] += 25.0  # several binade crossings of the running value
+    s_t = torch.from_numpy(s).to(gpu)
+    for gamma in (1.0, 0.37):
+        costs = oracle.build_switch_costs(s, gamma)
+        lam_ref = float(np.quantile(s, 0.9))
+        reach = gamma + (s.max() - s.min()) + 4.0
+        emap_t = delta_build_map_device(s_t, gamma, lam_ref, reach)
+        lambdas = [lam_ref + d for d in (-1e-9, -1e-12, 0.0, 3e-13, 1e-10)]
+        counts, sol_t = delta_spine_device(s_t, gamma, lambdas, emap_t, solution_index=2)
+        for lam, c in zip(lambdas, counts):
+            o_sol, o_val, o_cnt = oracle.solve_penalized_chain(s, costs, lam)
+            assert c == o_cnt, (n, kind, gamma, lam)
+        o_sol, _, _ = oracle.solve_penalized_chain(s, costs, lambdas[2])
+        assert np.array_equal(sol_t.cpu().numpy(), o_sol)
