@@ -462,19 +462,48 @@ __global__ __launch_bounds__(kFastThreads) void fast_aggregate_kernel(FastLaunch
 // ---- K2: per chain incoming delta per workgroup; per slot incoming clear index / weight / gain ------
 __global__ __launch_bounds__(64) void fast_blockscan_kernel(FastLaunch L)
 {
-    const int idx = blockIdx.x * 64 + threadIdx.x;
+    // one wavefront per chain / slot; the (short) per-workgroup sequences are scanned 64 at a time
+    const int idx = blockIdx.x;
+    const int lane = threadIdx.x;
     if (idx < L.n_chains) {
         const FastChain ch = L.chains[idx];
         const FastTask &task = L.tasks[ch.task];
         const int nb = task.n_blocks;
-        double v = 0.0;  // delta at the last locus of the previous workgroup (unused for block 0)
-        for (int b = 0; b < nb; ++b) {
-            L.buf.din[ch.block_off + b] = v;
+        const double big = task.big;
+        double v = 0.0;  // delta at the last locus before the tile (unused for block 0)
+        for (int base = 0; base < nb; base += 64) {
+            const int b = base + lane;
             Fn f;
-            f.a = L.buf.blk_a[ch.block_off + b];
-            f.lo = L.buf.blk_lo[ch.block_off + b];
-            f.hi = L.buf.blk_hi[ch.block_off + b];
-            v = apply_fn(f, v);
+            f.a = 0.0;
+            f.lo = -big;
+            f.hi = big;
+            if (b < nb) {
+                f.a = L.buf.blk_a[ch.block_off + b];
+                f.lo = L.buf.blk_lo[ch.block_off + b];
+                f.hi = L.buf.blk_hi[ch.block_off + b];
+            }
+            Fn inc = f;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const Fn p = shfl_up_fn(inc, off);
+                if (lane >= off) {
+                    inc = compose(p, inc, big);
+                }
+            }
+            Fn ex = shfl_up_fn(inc, 1);
+            if (lane == 0) {
+                ex.a = 0.0;
+                ex.lo = -big;
+                ex.hi = big;
+            }
+            if (b < nb) {
+                L.buf.din[ch.block_off + b] = apply_fn(ex, v);
+            }
+            Fn tot;
+            tot.a = __shfl(inc.a, 63);
+            tot.lo = __shfl(inc.lo, 63);
+            tot.hi = __shfl(inc.hi, 63);
+            v = apply_fn(tot, v);
         }
     } else if (idx < L.n_chains + L.n_slots) {
         const int si = idx - L.n_chains;
@@ -483,23 +512,57 @@ __global__ __launch_bounds__(64) void fast_blockscan_kernel(FastLaunch L)
         const int nb = task.n_blocks;
         int run = -1;
         double w = 0.0;
-        for (int b = 0; b < nb; ++b) {
+        for (int base = 0; base < nb; base += 64) {
+            const int b = base + lane;
             const long long at = slot.block_off + b;
-            L.buf.lcin_block[at] = run;
-            L.buf.win_block[at] = w;
-            const int x = L.buf.lc_block[at];
-            if (x >= 0) {
-                w = L.buf.w_block[at];
-            } else {
-                w += L.buf.w_block[at];
+            int x = -1;
+            double wv = 0.0;
+            if (b < nb) {
+                x = L.buf.lc_block[at];
+                wv = L.buf.w_block[at];
             }
-            run = (x > run) ? x : run;
+            int inc = x;
+            int flag = (x >= 0) ? 1 : 0;
+            double val = wv;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int p = __shfl_up(inc, off);
+                const int pf = __shfl_up(flag, off);
+                const double pv = __shfl_up(val, off);
+                if (lane >= off) {
+                    inc = (p > inc) ? p : inc;
+                    if (!flag) {
+                        val = pv + val;
+                    }
+                    flag |= pf;
+                }
+            }
+            int ex = __shfl_up(inc, 1);
+            int exf = __shfl_up(flag, 1);
+            double exv = __shfl_up(val, 1);
+            if (lane == 0) {
+                ex = -1;
+                exf = 0;
+                exv = 0.0;
+            }
+            if (b < nb) {
+                L.buf.lcin_block[at] = (ex > run) ? ex : run;
+                L.buf.win_block[at] = exf ? exv : (w + exv);
+            }
+            const int tinc = __shfl(inc, 63);
+            const int tflag = __shfl(flag, 63);
+            const double tval = __shfl(val, 63);
+            run = (tinc > run) ? tinc : run;
+            w = tflag ? tval : (w + tval);
         }
-        // global exponent (oracle_global_exponent): Pb bounds every running value of the reference
-        FastSlotResult &res = L.buf.results[si];
-        const double lam = L.chains[slot.chain_a].lambda;
-        const double pb = 2.0 * ((double)(res.p16 + res.npos) * 0.0625 + task.cmax + task.sabs + fabs(lam) + 1.0);
-        res.e_global = ilogb(pb);
+        if (lane == 0) {
+            // global exponent (oracle_global_exponent): Pb bounds every running value of the reference
+            FastSlotResult &res = L.buf.results[si];
+            const double lam = L.chains[slot.chain_a].lambda;
+            const double pb =
+                2.0 * ((double)(res.p16 + res.npos) * 0.0625 + task.cmax + task.sabs + fabs(lam) + 1.0);
+            res.e_global = ilogb(pb);
+        }
     }
 }
 
@@ -968,7 +1031,9 @@ __global__ __launch_bounds__(kFastThreads) void fast_apply_kernel(FastLaunch L)
 // ---- K4: backward over workgroups (fill) and forward (map gains) ---------------------------------
 __global__ __launch_bounds__(64) void fast_fillscan_kernel(FastLaunch L)
 {
-    const int idx = blockIdx.x * 64 + threadIdx.x;
+    // one wavefront per (slot, variant)
+    const int idx = blockIdx.x;
+    const int lane = threadIdx.x;
     if (idx >= 2 * L.n_slots) {
         return;
     }
@@ -976,11 +1041,24 @@ __global__ __launch_bounds__(64) void fast_fillscan_kernel(FastLaunch L)
     const int variant = idx & 1;  // 0 = LO (probe: the exact-rule classes), 1 = HI (window) / gains (map)
     const FastSlot slot = L.slots[si];
     const FastTask &task = L.tasks[slot.task];
+    const int nb = task.n_blocks;
     if (variant == 1 && slot.mode == kModeMap) {
-        double g = 0.0;
-        for (int b = 0; b < task.n_blocks; ++b) {
-            L.buf.gainin_block[slot.block_off + b] = g;
-            g += L.buf.gain_block[slot.block_off + b];
+        double carry = 0.0;
+        for (int base = 0; base < nb; base += 64) {
+            const int b = base + lane;
+            const double g = (b < nb) ? L.buf.gain_block[slot.block_off + b] : 0.0;
+            double inc = g;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double p = __shfl_up(inc, off);
+                if (lane >= off) {
+                    inc += p;
+                }
+            }
+            if (b < nb) {
+                L.buf.gainin_block[slot.block_off + b] = carry + (inc - g);
+            }
+            carry += __shfl(inc, 63);
         }
         return;
     }
@@ -991,21 +1069,44 @@ __global__ __launch_bounds__(64) void fast_fillscan_kernel(FastLaunch L)
     const unsigned *bpend = variant ? L.buf.bpend_hi : L.buf.bpend_lo;
     const unsigned *bbase = variant ? L.buf.bbase_hi : L.buf.bbase_lo;
     long long count = 0;
-    int r = 0;  // the last workgroup never has pending loci (the terminal locus is determined)
-    for (int b = task.n_blocks - 1; b >= 0; --b) {
+    int carry_r = 0;  // the last workgroup never has pending loci (the terminal locus is determined)
+    for (int base = ((nb - 1) / 64) * 64; base >= 0; base -= 64) {
+        const int b = base + lane;
         const long long at = slot.block_off + b;
-        if (variant == 0) {
-            L.buf.rin_lo[at] = (uint8_t)r;
+        int fv = kFvNone;
+        long long pend = 0, bs = 0;
+        if (b < nb) {
+            fv = (int)bfv[at];
+            pend = (long long)bpend[at];
+            bs = (long long)bbase[at];
         }
-        count += (long long)bbase[at] + (r ? (long long)bpend[at] : 0LL);
-        if (bfv[at] != kFvNone) {
-            r = (int)bfv[at];
+        const unsigned long long has = __ballot(fv != kFvNone);
+        const unsigned long long one = __ballot(fv == 1);
+        int r = carry_r;
+        const unsigned long long right = (lane == 63) ? 0ULL : (has & (~0ULL << (lane + 1)));
+        if (right != 0ULL) {
+            r = (int)((one >> (__ffsll((long long)right) - 1)) & 1ULL);
+        }
+        if (b < nb) {
+            if (variant == 0) {
+                L.buf.rin_lo[at] = (uint8_t)r;
+            }
+            count += bs + (r ? pend : 0LL);
+        }
+        if (has != 0ULL) {
+            carry_r = (int)((one >> (__ffsll((long long)has) - 1)) & 1ULL);
         }
     }
-    if (variant == 0) {
-        L.buf.results[si].count_lo = count;
-    } else {
-        L.buf.results[si].count_hi = count;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        count += __shfl_down(count, off);
+    }
+    if (lane == 0) {
+        if (variant == 0) {
+            L.buf.results[si].count_lo = count;
+        } else {
+            L.buf.results[si].count_hi = count;
+        }
     }
 }
 
@@ -1464,8 +1565,8 @@ int launch_fast_round(const FastLaunch &L, hipStream_t stream)
         attr_set = true;
     }
     const dim3 grid((unsigned)L.n_blocks_total), block(kFastThreads);
-    const unsigned scan_blocks = (unsigned)((L.n_chains + L.n_slots + 63) / 64);
-    const unsigned fill_blocks = (unsigned)((2 * L.n_slots + 63) / 64);
+    const unsigned scan_blocks = (unsigned)(L.n_chains + L.n_slots);
+    const unsigned fill_blocks = (unsigned)(2 * L.n_slots);
 
     if (L.any_plain) {
         hipLaunchKernelGGL((fast_aggregate_kernel<false>), grid, block, lds_plain, stream, L);
@@ -1497,7 +1598,7 @@ int launch_spine(const FastLaunch &L, const int *solution_slot_dev, hipStream_t 
         return ROCCO_HIP_OK;
     }
     const dim3 grid((unsigned)L.n_blocks_total), block(kFastThreads);
-    const unsigned fill_blocks = (unsigned)((2 * L.n_slots + 63) / 64);
+    const unsigned fill_blocks = (unsigned)(2 * L.n_slots);
     hipLaunchKernelGGL(spine_kernel, dim3((unsigned)L.n_tasks), dim3(64), 0, stream, L);
     hipLaunchKernelGGL(fill_from_classes_kernel, grid, block, 0, stream, L, solution_slot_dev);
     hipLaunchKernelGGL(fast_fillscan_kernel, dim3(fill_blocks), dim3(64), 0, stream, L);
