@@ -43,30 +43,47 @@ __device__ __forceinline__ void select_middle(double (&v)[N])
     }
 }
 
-template <typename T, int KP>
-__global__ __launch_bounds__(256) void median_kernel(const T *__restrict__ m, int K, long long n,
+__device__ __forceinline__ bool is_nan_bits(double x)
+{
+    // this file is compiled with -fno-honor-nans (so that the network is bare v_min_f64 / v_max_f64);
+    // NaN tests therefore go through the bit pattern
+    return (__double_as_longlong(x) & 0x7FFFFFFFFFFFFFFFLL) > 0x7FF0000000000000LL;
+}
+
+// EXACT: K == KP is known at compile time (no padding, unpredicated loads).
+template <typename T, int KP, bool EXACT>
+__global__ __launch_bounds__(256) void median_kernel(const T *__restrict__ m, int K_runtime, long long n,
                                                      long long stride, double *__restrict__ out)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) {
         return;
     }
+    const int K = EXACT ? KP : K_runtime;
     const int pad = KP - K;
     const int n_lo = pad / 2;  // -inf entries; the remaining pad entries are +inf
     double v[KP];
-    bool has_nan = false;
+    double sum = 0.0;  // NaN in the column <=> NaN sum (or +inf and -inf together: checked below)
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
-        double x;
-        if (k < K) {
-            x = (double)m[(long long)k * stride + j];
-            has_nan |= (x != x);
-            x = (x != x) ? std::numeric_limits<double>::infinity() : x;
+        if (EXACT || k < K) {
+            v[k] = (double)m[(long long)k * stride + j];
+            sum += v[k];
         } else {
-            x = (k - K < n_lo) ? -std::numeric_limits<double>::infinity()
-                               : std::numeric_limits<double>::infinity();
+            v[k] = (k - K < n_lo) ? -std::numeric_limits<double>::infinity()
+                                  : std::numeric_limits<double>::infinity();
         }
-        v[k] = x;
+    }
+    bool has_nan = false;
+    if (is_nan_bits(sum)) {  // rare: find out whether a real NaN is present, park NaNs at +inf
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            if (EXACT || k < K) {
+                const bool bad = is_nan_bits(v[k]);
+                has_nan |= bad;
+                v[k] = bad ? std::numeric_limits<double>::infinity() : v[k];
+            }
+        }
     }
     select_middle<KP>(v);
     double r;
@@ -75,7 +92,7 @@ __global__ __launch_bounds__(256) void median_kernel(const T *__restrict__ m, in
     } else {
         r = (v[KP / 2 - 1] + v[KP / 2]) / 2.0;
     }
-    out[j] = has_nan ? std::numeric_limits<double>::quiet_NaN() : r;
+    out[j] = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : r;
 }
 
 // K == 1: copy (rocco.py:254-255; power == 1.0 is the identity)
@@ -104,7 +121,7 @@ __global__ __launch_bounds__(256) void median_rank_kernel(const T *__restrict__ 
     bool has_nan = false;
     for (int a = 0; a < K; ++a) {
         const double x = (double)m[(long long)a * stride + j];
-        if (x != x) {
+        if (is_nan_bits(x)) {
             has_nan = true;
             continue;
         }
@@ -122,7 +139,7 @@ __global__ __launch_bounds__(256) void median_rank_kernel(const T *__restrict__ 
             hi = x;
         }
     }
-    out[j] = has_nan ? std::numeric_limits<double>::quiet_NaN() : ((K & 1) ? lo : (lo + hi) / 2.0);
+    out[j] = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : ((K & 1) ? lo : (lo + hi) / 2.0);
 }
 
 template <typename T, int KP>
@@ -130,8 +147,13 @@ void launch_kp(const T *m, int K, long long n, long long stride, double *out, hi
 {
     const int threads = 256;
     const long long blocks = (n + threads - 1) / threads;
-    hipLaunchKernelGGL((median_kernel<T, KP>), dim3((unsigned)blocks), dim3(threads), 0, stream, m, K,
-                       n, stride, out);
+    if (K == KP) {
+        hipLaunchKernelGGL((median_kernel<T, KP, true>), dim3((unsigned)blocks), dim3(threads), 0, stream, m,
+                           K, n, stride, out);
+    } else {
+        hipLaunchKernelGGL((median_kernel<T, KP, false>), dim3((unsigned)blocks), dim3(threads), 0, stream, m,
+                           K, n, stride, out);
+    }
 }
 
 template <typename T>
