@@ -112,6 +112,7 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->dev_misc.release();
     solver->dev_solution.release();
     solver->dev_maps.release();
+    solver->dev_frozen.release();
     solver->host_stage.release();
     solver->host_back.release();
     delete solver;
@@ -130,6 +131,8 @@ int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long va
             return ROCCO_HIP_EINVAL;
         }
         solver->spec_depth = (int)value;
+    } else if (k == "active_set") {
+        solver->active_set = value ? 1 : 0;
     } else {
         set_last_error("rocco_hip_solver_set: unknown key " + k);
         return ROCCO_HIP_EINVAL;

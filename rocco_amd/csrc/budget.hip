@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "chain_fast.h"
 #include "search.h"
@@ -27,7 +29,31 @@ struct DevProblem {
     int qexp = 0;
     double cmax = 0.0, sabs = 0.0;
     uint8_t *emap = nullptr;  // device binade map (owned by the solver's map buffer), null = none
+    // frozen blocks (active-set rounds): device summaries + host copy of the flags
+    FrozenArrays frz = {};
+    bool frz_valid = false;
+    double frz_lo = 0.0, frz_hi = 0.0;  // the (latest) surveyed bracket
+    std::vector<uint8_t> frz_flags;
+    std::vector<int> active_blocks;
 };
+
+// true when -lambda lies exactly half-way between two points of a grid u = 2^(e-52) that a clean
+// chunk can use (u >= q = 2^qexp)
+bool lambda_ties_some_grid(double lambda, int qexp)
+{
+    if (lambda == 0.0) {
+        return false;
+    }
+    for (int e = qexp + 52; e <= 62; ++e) {
+        const double magic_u = std::ldexp(1.5, e);
+        volatile double t = -lambda + magic_u;
+        const double r = t - magic_u;
+        if (std::fabs(-lambda - r) == std::ldexp(1.0, e - 53)) {
+            return true;
+        }
+    }
+    return false;
+}
 
 int grid_exponent(double cmax, double lo, double hi)
 {
@@ -68,6 +94,61 @@ public:
             RoundTask t;
             t.problem = r.problem;
             t.window = true;
+            t.lambdas = {r.lambda_lo, r.lambda_hi};
+            t.win = &r;
+            tasks.push_back(t);
+        }
+        return run_round(tasks);
+    }
+
+    int survey(std::vector<WindowRequest> &reqs) override
+    {
+        if (solver_->active_set == 0) {
+            return ROCCO_HIP_OK;
+        }
+        int rc;
+        if (!frozen_allocated_) {
+            size_t total_blocks = 0;
+            for (const DevProblem &p : probs) {
+                total_blocks += align_up((p.n + kFastBlockLoci - 1) / kFastBlockLoci, 32);
+            }
+            const size_t per_block = 8 * 8 + 4 * 4 + 3;  // doubles, ints/unsigneds, bytes
+            if ((rc = solver_->dev_frozen.reserve(total_blocks * per_block + 4096)) != ROCCO_HIP_OK) return rc;
+            char *base = (char *)solver_->dev_frozen.ptr;
+            double *dbl = (double *)base;
+            int *i32 = (int *)(base + total_blocks * 64);
+            uint8_t *u8 = (uint8_t *)(base + total_blocks * 80);
+            size_t off = 0;
+            for (DevProblem &p : probs) {
+                const size_t nb = align_up((p.n + kFastBlockLoci - 1) / kFastBlockLoci, 32);
+                p.frz.B = dbl + off;
+                p.frz.gain_lo = dbl + total_blocks + off;
+                p.frz.gain_hi = dbl + 2 * total_blocks + off;
+                p.frz.lam_lo = dbl + 3 * total_blocks + off;
+                p.frz.lam_hi = dbl + 4 * total_blocks + off;
+                p.frz.gx_lo = dbl + 5 * total_blocks + off;
+                p.frz.mg = dbl + 6 * total_blocks + off;
+                p.frz.cprev = dbl + 7 * total_blocks + off;
+                p.frz.m = i32 + off;
+                p.frz.lc = i32 + total_blocks + off;
+                p.frz.pend = (unsigned *)(i32 + 2 * total_blocks + off);
+                p.frz.base = (unsigned *)(i32 + 3 * total_blocks + off);
+                p.frz.flag = u8 + off;
+                p.frz.e = (int8_t *)(u8 + total_blocks + off);
+                p.frz.fv = u8 + 2 * total_blocks + off;
+                off += nb;
+            }
+            frozen_allocated_ = true;
+        }
+        std::vector<RoundTask> tasks;
+        for (WindowRequest &r : reqs) {
+            if (probs[r.problem].emap == nullptr) {
+                continue;
+            }
+            RoundTask t;
+            t.problem = r.problem;
+            t.window = true;
+            t.survey = true;
             t.lambdas = {r.lambda_lo, r.lambda_hi};
             t.win = &r;
             tasks.push_back(t);
@@ -267,6 +348,7 @@ public:
     }
 
     int rounds = 0;
+    long long blocks_launched = 0;
 
 private:
     struct RoundTask {
@@ -274,6 +356,8 @@ private:
         bool window = false;
         bool map = false;
         bool record = false;
+        bool survey = false;
+        bool use_frozen = false;
         int solution_index = -1;
         double margin = 0.0;
         std::vector<double> lambdas;
@@ -292,7 +376,10 @@ private:
         std::vector<FastTask> tasks(T);
         std::vector<FastChain> chains;
         std::vector<FastSlot> slots;
-        std::vector<int2> blockmap;
+        std::vector<int2> blockmap, blockmap_all;
+        std::vector<std::vector<int>> launched(T);
+        std::vector<long long> skip_off(T, -1);
+        std::vector<uint8_t> skip_bytes;
         long long chain_chunks = 0, chain_blocks = 0, slot_chunks = 0, slot_blocks = 0, rec_entries = 0;
         bool any_record = false;
         std::vector<int> solution_slot(T, -1);
@@ -317,6 +404,54 @@ private:
             ft.sabs = p.sabs;
             ft.n_blocks = nblocks;
             ft.solution = p.solution;
+            ft.frz = FrozenArrays{};
+            ft.frz_out = FrozenArrays{};
+            // rounds inside the surveyed bracket skip the frozen blocks (the final zone windows and
+            // the spine always run over everything: they materialise the solution)
+            bool use_frozen = p.frz_valid && !no_frozen_ && solver_->active_set != 0;
+            if (use_frozen) {
+                for (double lam : rt[t].lambdas) {
+                    if (!(lam >= p.frz_lo && lam <= p.frz_hi) || lambda_ties_some_grid(lam, p.qexp)) {
+                        use_frozen = false;
+                    }
+                }
+            }
+            rt[t].use_frozen = use_frozen;
+            launched[t].clear();
+            if (use_frozen) {
+                ft.frz = p.frz;
+                if (rt[t].record) {
+                    // the spine may still be stepping when it leaves an active block: also evaluate
+                    // the block after each active one (it resynchronises there)
+                    skip_off[t] = (long long)skip_bytes.size();
+                    std::vector<uint8_t> skip(p.frz_flags);
+                    for (int k : p.active_blocks) {
+                        if (k + 1 < nblocks) {
+                            skip[k + 1] = 0;
+                        }
+                    }
+                    for (int k = 0; k < nblocks; ++k) {
+                        if (!skip[k]) {
+                            launched[t].push_back(k);
+                        }
+                    }
+                    skip.resize(align_up((size_t)nblocks, 64), 0);
+                    skip_bytes.insert(skip_bytes.end(), skip.begin(), skip.end());
+                } else {
+                    launched[t] = p.active_blocks;
+                }
+            } else {
+                for (int k = 0; k < nblocks; ++k) {
+                    launched[t].push_back(k);
+                }
+            }
+            if (rt[t].survey) {
+                ft.frz_out = p.frz;
+            }
+            if (rt[t].record && std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                std::fprintf(stderr, "[spine] problem %zu: %zu lambdas, %zu / %d blocks evaluated (frozen %d)\n",
+                             rt[t].problem, rt[t].lambdas.size(), launched[t].size(), nblocks, (int)use_frozen);
+            }
             ft.slot_begin = (int)slots.size();
             any_costs = any_costs || (p.costs != nullptr);
             any_plain = any_plain || (p.costs == nullptr);
@@ -374,27 +509,42 @@ private:
                     solution_slot[t] = ft.slot_begin + rt[t].solution_index;
                 }
             }
-            for (int k = 0; k < nblocks; ++k) {
+            for (int k : launched[t]) {
                 blockmap.push_back(make_int2((int)t, k));
             }
+            for (int k = 0; k < nblocks; ++k) {
+                blockmap_all.push_back(make_int2((int)t, k));
+            }
         }
-        const size_t C = chains.size(), S = slots.size(), NB = blockmap.size();
+        const size_t C = chains.size(), S = slots.size(), NB = blockmap.size(), NBA = blockmap_all.size();
+        blocks_launched += (long long)NB;
 
         // ---- descriptor upload ----
         const size_t b_tasks = align_up(T * sizeof(FastTask), 256);
         const size_t b_chains = align_up(C * sizeof(FastChain), 256);
         const size_t b_slots = align_up(S * sizeof(FastSlot), 256);
         const size_t b_map = align_up(NB * sizeof(int2), 256);
-        const size_t desc_bytes = b_tasks + b_chains + b_slots + b_map;
+        const size_t b_mapall = align_up(NBA * sizeof(int2), 256);
+        const size_t b_skip = align_up(skip_bytes.size() + 1, 256);
+        const size_t desc_bytes = b_tasks + b_chains + b_slots + b_map + b_mapall + b_skip;
         int rc;
         if ((rc = solver_->dev_tasks.reserve(desc_bytes)) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_stage.reserve(desc_bytes)) != ROCCO_HIP_OK) return rc;
         char *h = (char *)solver_->host_stage.ptr;
+        char *dd = (char *)solver_->dev_tasks.ptr;
+        for (size_t t = 0; t < T; ++t) {
+            if (skip_off[t] >= 0) {  // record rounds: "not evaluated this round" instead of "frozen"
+                tasks[t].frz.flag = (uint8_t *)(dd + b_tasks + b_chains + b_slots + b_map + b_mapall + skip_off[t]);
+            }
+        }
         std::memcpy(h, tasks.data(), T * sizeof(FastTask));
         std::memcpy(h + b_tasks, chains.data(), C * sizeof(FastChain));
         std::memcpy(h + b_tasks + b_chains, slots.data(), S * sizeof(FastSlot));
         std::memcpy(h + b_tasks + b_chains + b_slots, blockmap.data(), NB * sizeof(int2));
-        char *dd = (char *)solver_->dev_tasks.ptr;
+        std::memcpy(h + b_tasks + b_chains + b_slots + b_map, blockmap_all.data(), NBA * sizeof(int2));
+        if (!skip_bytes.empty()) {
+            std::memcpy(h + b_tasks + b_chains + b_slots + b_map + b_mapall, skip_bytes.data(), skip_bytes.size());
+        }
         ROCCO_HIP_TRY(hipMemcpyAsync(dd, h, desc_bytes, hipMemcpyHostToDevice, stream_));
 
         // ---- scratch carve ----
@@ -433,7 +583,9 @@ private:
         L.n_tasks = (int)T;
         L.n_chains = (int)C;
         L.n_slots = (int)S;
+        L.blockmap_all = (const int2 *)(dd + b_tasks + b_chains + b_slots + b_map);
         L.n_blocks_total = (int)NB;
+        L.n_blocks_all = (int)NBA;
         L.any_costs = any_costs;
         L.any_plain = any_plain;
         L.any_window = any_window;
@@ -481,11 +633,84 @@ private:
                 return rc;
             }
         }
-        if ((rc = solver_->host_back.reserve(S * sizeof(FastSlotResult))) != ROCCO_HIP_OK) return rc;
+        size_t flag_bytes = 0;
+        for (size_t t = 0; t < T; ++t) {
+            if (rt[t].survey) {
+                flag_bytes += align_up((size_t)tasks[t].n_blocks, 64);
+            }
+        }
+        if ((rc = solver_->host_back.reserve(S * sizeof(FastSlotResult) + flag_bytes + 64)) != ROCCO_HIP_OK) return rc;
         ROCCO_HIP_TRY(hipMemcpyAsync(solver_->host_back.ptr, L.buf.results, S * sizeof(FastSlotResult),
                                      hipMemcpyDeviceToHost, stream_));
+        {
+            char *hf = (char *)solver_->host_back.ptr + S * sizeof(FastSlotResult);
+            for (size_t t = 0; t < T; ++t) {
+                if (rt[t].survey) {
+                    ROCCO_HIP_TRY(hipMemcpyAsync(hf, probs[rt[t].problem].frz.flag, (size_t)tasks[t].n_blocks,
+                                                 hipMemcpyDeviceToHost, stream_));
+                    hf += align_up((size_t)tasks[t].n_blocks, 64);
+                }
+            }
+        }
         ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
         const FastSlotResult *hr = (const FastSlotResult *)solver_->host_back.ptr;
+        for (size_t t = 0; t < T; ++t) {
+            if (!(rt[t].record && rt[t].use_frozen)) {
+                continue;
+            }
+            for (int k = 0; k < tasks[t].slot_count; ++k) {
+                if (hr[tasks[t].slot_begin + k].overflow) {
+                    // a lane was still stepping when it reached a block that was not evaluated
+                    if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                        std::fprintf(stderr, "[spine] problem %zu: repeated in full\n", rt[t].problem);
+                    }
+                    no_frozen_ = true;
+                    const int rc2 = run_round(rt);
+                    no_frozen_ = false;
+                    return rc2;
+                }
+            }
+        }
+        {
+            const char *hf = (const char *)solver_->host_back.ptr + S * sizeof(FastSlotResult);
+            for (size_t t = 0; t < T; ++t) {
+                if (!rt[t].survey) {
+                    continue;
+                }
+                DevProblem &p = probs[rt[t].problem];
+                const int nb = tasks[t].n_blocks;
+                if (!rt[t].use_frozen) {
+                    p.frz_flags.assign(nb, 0);
+                }
+                // a block surveyed this round carries its new verdict; skipped (frozen) blocks stay frozen
+                std::vector<int> active;
+                const std::vector<int> *surveyed = rt[t].use_frozen ? &launched[t] : nullptr;
+                if (surveyed == nullptr) {
+                    for (int k = 0; k < nb; ++k) {
+                        p.frz_flags[k] = (uint8_t)hf[k];
+                    }
+                } else {
+                    for (int k : *surveyed) {
+                        p.frz_flags[k] = (uint8_t)hf[k];
+                    }
+                }
+                for (int k = 0; k < nb; ++k) {
+                    if (!p.frz_flags[k]) {
+                        active.push_back(k);
+                    }
+                }
+                p.active_blocks.swap(active);
+                if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                    std::fprintf(stderr, "[survey] problem %zu: bracket [%.17g, %.17g] width %.3g active %zu / %d blocks\n",
+                                 rt[t].problem, rt[t].lambdas[0], rt[t].lambdas[1],
+                                 rt[t].lambdas[1] - rt[t].lambdas[0], p.active_blocks.size(), nb);
+                }
+                p.frz_valid = true;
+                p.frz_lo = rt[t].lambdas[0];
+                p.frz_hi = rt[t].lambdas[1];
+                hf += align_up((size_t)nb, 64);
+            }
+        }
 
         for (size_t t = 0; t < T; ++t) {
             const FastTask &ft = tasks[t];
@@ -542,6 +767,8 @@ private:
     rocco_hip_solver *solver_;
     hipStream_t stream_;
     bool maps_allocated_ = false;
+    bool frozen_allocated_ = false;
+    bool no_frozen_ = false;
     std::vector<uint8_t *> map_ptrs_;
 };
 

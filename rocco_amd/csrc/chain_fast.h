@@ -21,6 +21,24 @@ constexpr int kMaxDiffs = 16;
 
 enum FastMode { kModeProbe = 0, kModeWindow = 1, kModeMap = 2, kModeRecord = 3 };
 
+// Per-workgroup summaries of "frozen" blocks (valid for every penalty of a surveyed bracket): all
+// chunks clean with one binade exponent and no rounding tie, identical classes at both ends of the
+// bracket, constant block function.  Then, exactly,  delta_out(lambda) = B + m * rn_u(-lambda).
+struct FrozenArrays {
+    uint8_t *flag;       // 1 = frozen
+    double *B;           // delta at the block's last locus minus m * rn_u(-lambda)
+    int *m;              // steps since the last clamp before the block's last locus
+    int8_t *e;           // binade exponent of the block's chunks
+    double *gain_lo, *gain_hi;  // gain of the block at the bracket ends (maps: interpolated)
+    // exact spine: gain without the block's first step = gx_lo + mg * (rn_u(-lambda) - rn_u(-lam_lo)),
+    // and the first step's cost on the block's grid
+    double *gx_lo, *mg, *cprev;
+    int *lc;             // last jointly clear clamp (global locus index, -1 none)
+    uint8_t *fv;         // fill summary of the (identical) classes
+    unsigned *pend, *base;
+    double *lam_lo, *lam_hi;  // bracket ends the gains were taken at
+};
+
 struct FastTask {
     const double *scores;
     const double *switch_costs;  // n-1 or nullptr
@@ -38,6 +56,8 @@ struct FastTask {
     const uint8_t *emap;  // binade code per chunk, or nullptr (every chunk = hazard, global exponent)
     uint8_t *emap_out;    // map slots write the new codes here
     double map_margin;
+    FrozenArrays frz;      // frz.flag == nullptr: no frozen blocks in use this round
+    FrozenArrays frz_out;  // frz_out.flag != nullptr: the window slot of this task is a survey
 };
 
 // One delta chain = (task, penalty).  A probe / map slot owns one chain, a window slot two
@@ -106,8 +126,9 @@ struct FastLaunch {
     const FastTask *tasks;
     const FastChain *chains;
     const FastSlot *slots;
-    const int2 *blockmap;  // global workgroup -> (task, local block)
-    int n_tasks, n_chains, n_slots, n_blocks_total;
+    const int2 *blockmap;      // global workgroup -> (task, local block): the blocks evaluated this round
+    const int2 *blockmap_all;  // every block of every task (tail patches)
+    int n_tasks, n_chains, n_slots, n_blocks_total, n_blocks_all;
     bool any_costs, any_plain;
     bool any_window, any_map;
     FastBuffers buf;

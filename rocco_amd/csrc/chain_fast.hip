@@ -478,9 +478,18 @@ __global__ __launch_bounds__(64) void fast_blockscan_kernel(FastLaunch L)
             f.lo = -big;
             f.hi = big;
             if (b < nb) {
-                f.a = L.buf.blk_a[ch.block_off + b];
-                f.lo = L.buf.blk_lo[ch.block_off + b];
-                f.hi = L.buf.blk_hi[ch.block_off + b];
+                if (task.frz.flag != nullptr && task.frz.flag[b]) {
+                    // frozen block: constant function with the closed-form value at this penalty
+                    const double nlam = grid_round(-ch.lambda, ldexp(1.5, (int)task.frz.e[b]));
+                    const double v_const = task.frz.B[b] + (double)task.frz.m[b] * nlam;
+                    f.a = 0.0;
+                    f.lo = v_const;
+                    f.hi = v_const;
+                } else {
+                    f.a = L.buf.blk_a[ch.block_off + b];
+                    f.lo = L.buf.blk_lo[ch.block_off + b];
+                    f.hi = L.buf.blk_hi[ch.block_off + b];
+                }
             }
             Fn inc = f;
 #pragma unroll
@@ -518,8 +527,13 @@ __global__ __launch_bounds__(64) void fast_blockscan_kernel(FastLaunch L)
             int x = -1;
             double wv = 0.0;
             if (b < nb) {
-                x = L.buf.lc_block[at];
-                wv = L.buf.w_block[at];
+                if (task.frz.flag != nullptr && task.frz.flag[b]) {
+                    x = task.frz.lc[b];
+                    wv = 0.0;
+                } else {
+                    x = L.buf.lc_block[at];
+                    wv = L.buf.w_block[at];
+                }
             }
             int inc = x;
             int flag = (x >= 0) ? 1 : 0;
@@ -780,7 +794,7 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     double *lds_w = lds_red + 36;
     unsigned *lds_u = reinterpret_cast<unsigned *>(lds_red + 44);
 
-    double lam[NCH], delta[NCH];
+    double lam[NCH], delta[NCH], delta_in[NCH];
     double delta_in0 = 0.0;
     int pstar = 0;
 #pragma unroll
@@ -788,6 +802,7 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
         const FastChain &ch = chains[k == 0 ? slot.chain_a : slot.chain_b];
         lam[k] = ch.lambda;
         delta[k] = incoming_delta(buf, ch, chunk, valid, local_block, big, lds_red);
+        delta_in[k] = delta[k];
         if (k == 0) {
             delta_in0 = delta[0];
         }
@@ -822,8 +837,9 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     long long uncertain = 0, effect = 0, max_run = 0;
     int overflow = 0, nonadjacent = 0;
     unsigned validmask = 0;
-    double gain = 0.0;
+    double gain = 0.0, gain_b = 0.0;
     double wsum_chunk = 0.0;
+    const bool survey = (NCH == 2) && (task.frz_out.flag != nullptr);
 
     if (valid) {
 #pragma unroll
@@ -834,8 +850,11 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
                 const double c_raw_prev = (i == 0) ? d.c_prev0 : raw_cost_at(task, d, i - 1);
                 const double c_prev = cost_on_grid(mode[0], c_raw_prev, magic);
                 const double cj = cost_on_grid(mode[0], raw_cost_at(task, d, i), magic);
-                if ((slot.mode == kModeMap || slot.mode == kModeRecord) && j > 0) {
+                if ((slot.mode == kModeMap || slot.mode == kModeRecord || survey) && j > 0) {
                     gain += fmax(0.0, delta[0] - c_prev);
+                    if (survey) {
+                        gain_b += fmax(0.0, delta[NCH - 1] - c_prev);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
@@ -995,6 +1014,100 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
                 }
             }
         }
+        // survey: can this workgroup's block be frozen for every penalty of [lambda_lo, lambda_hi]?
+        if (survey) {
+            const int wave = threadIdx.x >> 6;
+            const long long bstart = (long long)local_block * kFastBlockLoci;
+            long long bend = bstart + kFastBlockLoci;
+            bend = ((bend < n) ? bend : n) - 1;  // the block's last locus
+            if (threadIdx.x == 0) {
+                lds_u[0] = (unsigned)code;  // lane 0's chunk is always valid
+            }
+            __syncthreads();
+            const unsigned code0 = lds_u[0];
+            int ok = 1;
+            long long lastpos = -1;
+            if (valid) {
+                ok = (mode[0].clean && mode[NCH - 1].clean && mode[0].mapped && wsum_chunk == 0.0 && D_lo == D_hi &&
+                      V_lo == V_hi && (unsigned)code == code0)
+                         ? 1
+                         : 0;
+                unsigned dm = D_lo;
+                if (bend - j0 < kChunk) {  // the chunk holding the block's last locus
+                    dm &= ~(1U << (int)(bend - j0));
+                    lds_red[52] = delta[0];
+                    lds_red[53] = delta[NCH - 1];
+                }
+                if (dm != 0U) {
+                    lastpos = j0 + 31 - __clz(dm);
+                }
+            }
+            double g0 = gain, g1 = gain_b;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                g0 += __shfl_down(g0, off);
+                g1 += __shfl_down(g1, off);
+                const long long o = __shfl_down(lastpos, off);
+                lastpos = (o > lastpos) ? o : lastpos;
+            }
+            if (lane == 0) {
+                lds_red[54 + wave] = g0;
+                lds_red[58 + wave] = g1;
+                lds_ll[wave] = lastpos;
+            }
+            const int all_ok = __syncthreads_and(ok);
+            if (threadIdx.x == 0) {
+                long long lp = lds_ll[0];
+                for (int w = 1; w < 4; ++w) {
+                    lp = (lds_ll[w] > lp) ? lds_ll[w] : lp;
+                }
+                const FastChain &ca = chains[slot.chain_a];
+                const FastChain &cb = chains[slot.chain_b];
+                const double dlo = lds_red[52], dhi = lds_red[53];
+                const double fa_lo = buf.blk_lo[ca.block_off + local_block];
+                const double fa_hi = buf.blk_hi[ca.block_off + local_block];
+                const double fb_lo = buf.blk_lo[cb.block_off + local_block];
+                const double fb_hi = buf.blk_hi[cb.block_off + local_block];
+                const int m = (int)(bend - lp);
+                bool frozen = all_ok && lp >= bstart && fa_lo == fa_hi && fb_lo == fb_hi && fa_lo == dlo &&
+                              fb_lo == dhi;
+                // the closed form must reproduce both ends exactly
+                const double B = dlo - (double)m * mode[0].nlam;
+                frozen = frozen && (B + (double)m * mode[NCH - 1].nlam == dhi);
+                // gain without the first step (whose incoming delta belongs to the previous block): it
+                // is linear in rn_u(-lambda) with an integer slope while the classes stay put
+                const double g_lo = ((lds_red[54] + lds_red[55]) + lds_red[56]) + lds_red[57];
+                const double g_hi = ((lds_red[58] + lds_red[59]) + lds_red[60]) + lds_red[61];
+                const double cg = cost_on_grid(mode[0], d.c_prev0, magic);
+                const double gx_lo = g_lo - ((j0 > 0) ? fmax(0.0, delta_in[0] - cg) : 0.0);
+                const double gx_hi = g_hi - ((j0 > 0) ? fmax(0.0, delta_in[NCH - 1] - cg) : 0.0);
+                const double dn = mode[0].nlam - mode[NCH - 1].nlam;
+                double mg = 0.0;
+                if (dn != 0.0) {
+                    mg = (gx_lo - gx_hi) / dn;
+                    frozen = frozen && (mg == floor(mg)) && (mg * dn == gx_lo - gx_hi) && mg >= 0.0 && mg < 0x1p40;
+                } else {
+                    frozen = frozen && (gx_lo == gx_hi);
+                }
+                const FrozenArrays &fo = task.frz_out;
+                fo.gx_lo[local_block] = gx_lo;
+                fo.mg[local_block] = mg;
+                fo.cprev[local_block] = cg;
+                fo.flag[local_block] = frozen ? 1 : 0;
+                fo.B[local_block] = B;
+                fo.m[local_block] = m;
+                fo.e[local_block] = (int8_t)((int)(code0 & 0x7FU) - kMapBias);
+                fo.gain_lo[local_block] = g_lo;
+                fo.gain_hi[local_block] = g_hi;
+                fo.lam_lo[local_block] = lam[0];
+                fo.lam_hi[local_block] = lam[NCH - 1];
+                fo.lc[local_block] = buf.lc_block[bidx];
+                fo.fv[local_block] = buf.bfv_lo[bidx];
+                fo.pend[local_block] = buf.bpend_lo[bidx];
+                fo.base[local_block] = buf.bbase_lo[bidx];
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1046,7 +1159,18 @@ __global__ __launch_bounds__(64) void fast_fillscan_kernel(FastLaunch L)
         double carry = 0.0;
         for (int base = 0; base < nb; base += 64) {
             const int b = base + lane;
-            const double g = (b < nb) ? L.buf.gain_block[slot.block_off + b] : 0.0;
+            double g = 0.0;
+            if (b < nb) {
+                if (task.frz.flag != nullptr && task.frz.flag[b]) {
+                    // maps only need the stay-off value to within their margin: interpolate
+                    const double lam = L.chains[slot.chain_a].lambda;
+                    const double span = task.frz.lam_hi[b] - task.frz.lam_lo[b];
+                    const double t = (span > 0.0) ? (lam - task.frz.lam_lo[b]) / span : 0.0;
+                    g = task.frz.gain_lo[b] + t * (task.frz.gain_hi[b] - task.frz.gain_lo[b]);
+                } else {
+                    g = L.buf.gain_block[slot.block_off + b];
+                }
+            }
             double inc = g;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -1076,9 +1200,15 @@ __global__ __launch_bounds__(64) void fast_fillscan_kernel(FastLaunch L)
         int fv = kFvNone;
         long long pend = 0, bs = 0;
         if (b < nb) {
-            fv = (int)bfv[at];
-            pend = (long long)bpend[at];
-            bs = (long long)bbase[at];
+            if (task.frz.flag != nullptr && task.frz.flag[b]) {
+                fv = (int)task.frz.fv[b];
+                pend = (long long)task.frz.pend[b];
+                bs = (long long)task.frz.base[b];
+            } else {
+                fv = (int)bfv[at];
+                pend = (long long)bpend[at];
+                bs = (long long)bbase[at];
+            }
         }
         const unsigned long long has = __ballot(fv != kFvNone);
         const unsigned long long one = __ballot(fv == 1);
@@ -1113,23 +1243,25 @@ __global__ __launch_bounds__(64) void fast_fillscan_kernel(FastLaunch L)
 // ---- K5: patch pending tails of fill(LO) ------------------------------------------------------------
 __global__ __launch_bounds__(kFastThreads) void fast_patch_kernel(FastLaunch L)
 {
-    const int2 bm = L.blockmap[blockIdx.x];
+    const int2 bm = L.blockmap_all[blockIdx.x];
     const FastTask task = L.tasks[bm.x];
     const int local_block = bm.y;
+    const bool skipped = task.frz.flag != nullptr && task.frz.flag[local_block];
     for (int si = 0; si < task.slot_count; ++si) {
         const FastSlot slot = L.slots[task.slot_begin + si];
         if (slot.mode != kModeWindow) {
             continue;
         }
         const long long at = slot.block_off + local_block;
-        const unsigned pend = L.buf.bpend_lo[at];
-        if (pend == 0U || L.buf.rin_lo[at] == 0) {
+        const unsigned pend = skipped ? task.frz.pend[local_block] : L.buf.bpend_lo[at];
+        if (pend == 0U) {
             continue;
         }
+        const uint8_t value = L.buf.rin_lo[at];
         long long end = (long long)(local_block + 1) * kFastBlockLoci;
         end = (end < task.n) ? end : task.n;
         for (long long j = end - pend + threadIdx.x; j < end; j += kFastThreads) {
-            task.solution[j] = 1;
+            task.solution[j] = value;
         }
     }
 }
@@ -1324,8 +1456,29 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
     unsigned D = 0, V = 0;  // class word under construction for the chunk being stepped
     long long stepped = 0;
 
+    const long long lane_block_off =
+        active ? L.chains[L.slots[task.slot_begin + lane].chain_a].block_off : 0;
     constexpr int kGroup = 32;  // chunks skipped per iteration while every lane is synchronised
     for (long long k = 0; k < nchunks; ++k) {
+        if ((k % kFastThreads) == 0 && task.frz.flag != nullptr && task.frz.flag[k / kFastThreads]) {
+            // a block that was not evaluated this round: its classes are settled and its gain has a
+            // closed form.  (The host evaluates the block after every active block, so a stepping
+            // lane has resynchronised before it gets here; otherwise the round is repeated in full.)
+            const long long b = k / kFastThreads;
+            if (active) {
+                if (stepping) {
+                    atomicOr(&buf.results[task.slot_begin + lane].overflow, 1);
+                    stepping = false;
+                }
+                const double magic_u = ldexp(1.5, (int)task.frz.e[b]);
+                const double nl = grid_round(-lam, magic_u);
+                const double nl_lo = grid_round(-task.frz.lam_lo[b], magic_u);
+                const double first = fmax(0.0, buf.din[lane_block_off + b] - task.frz.cprev[b]);
+                P0 += first + (task.frz.gx_lo[b] + task.frz.mg[b] * (nl - nl_lo));
+            }
+            k += kFastThreads - 1;
+            continue;
+        }
         if ((k % kGroup) == 0 && !__any(active && stepping)) {
             // fast path: a whole group of chunks is exact for every lane -> add their gains at once
             // (all loads independent; the sums are exact, so their order does not matter)
@@ -1523,7 +1676,7 @@ __global__ __launch_bounds__(kFastThreads) void fill_from_classes_kernel(FastLau
 
 __global__ __launch_bounds__(kFastThreads) void spine_patch_kernel(FastLaunch L, const int *solution_slot)
 {
-    const int2 bm = L.blockmap[blockIdx.x];
+    const int2 bm = L.blockmap_all[blockIdx.x];
     const FastTask task = L.tasks[bm.x];
     const int local_block = bm.y;
     const int sol_slot = solution_slot[bm.x];
@@ -1532,14 +1685,16 @@ __global__ __launch_bounds__(kFastThreads) void spine_patch_kernel(FastLaunch L,
     }
     const FastSlot slot = L.slots[sol_slot];
     const long long at = slot.block_off + local_block;
-    const unsigned pend = L.buf.bpend_lo[at];
-    if (pend == 0U || L.buf.rin_lo[at] == 0) {
+    const bool skipped = task.frz.flag != nullptr && task.frz.flag[local_block];
+    const unsigned pend = skipped ? task.frz.pend[local_block] : L.buf.bpend_lo[at];
+    if (pend == 0U) {
         return;
     }
+    const uint8_t value = L.buf.rin_lo[at];
     long long end = (long long)(local_block + 1) * kFastBlockLoci;
     end = (end < task.n) ? end : task.n;
     for (long long j = end - pend + threadIdx.x; j < end; j += kFastThreads) {
-        task.solution[j] = 1;
+        task.solution[j] = value;
     }
 }
 
@@ -1583,7 +1738,7 @@ int launch_fast_round(const FastLaunch &L, hipStream_t stream)
     }
     hipLaunchKernelGGL(fast_fillscan_kernel, dim3(fill_blocks), dim3(64), 0, stream, L);
     if (L.any_window) {
-        hipLaunchKernelGGL(fast_patch_kernel, grid, block, 0, stream, L);
+        hipLaunchKernelGGL(fast_patch_kernel, dim3((unsigned)L.n_blocks_all), block, 0, stream, L);
     }
     if (L.any_map) {
         hipLaunchKernelGGL(fast_mapcode_kernel, grid, block, 0, stream, L);
@@ -1602,7 +1757,7 @@ int launch_spine(const FastLaunch &L, const int *solution_slot_dev, hipStream_t 
     hipLaunchKernelGGL(spine_kernel, dim3((unsigned)L.n_tasks), dim3(64), 0, stream, L);
     hipLaunchKernelGGL(fill_from_classes_kernel, grid, block, 0, stream, L, solution_slot_dev);
     hipLaunchKernelGGL(fast_fillscan_kernel, dim3(fill_blocks), dim3(64), 0, stream, L);
-    hipLaunchKernelGGL(spine_patch_kernel, grid, block, 0, stream, L, solution_slot_dev);
+    hipLaunchKernelGGL(spine_patch_kernel, dim3((unsigned)L.n_blocks_all), block, 0, stream, L, solution_slot_dev);
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }

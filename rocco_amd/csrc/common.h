@@ -47,6 +47,7 @@ struct rocco_hip_solver {
     // tunables
     int force_exact = 0;
     int spec_depth = 2;
+    int active_set = 1;  // skip blocks that a survey proved settled for the whole bracket
     // scratch
     rocco::DeviceBuffer dev_tasks;    // kernel task descriptors
     rocco::DeviceBuffer dev_params;   // per-launch lambda lists etc.
@@ -55,6 +56,7 @@ struct rocco_hip_solver {
     rocco::DeviceBuffer dev_misc;     // decode / reduction scratch
     rocco::DeviceBuffer dev_solution; // solution scratch when the caller wants counts only
     rocco::DeviceBuffer dev_maps;     // per-chunk binade maps of the problems being solved
+    rocco::DeviceBuffer dev_frozen;   // per-block frozen summaries of the problems being solved
     rocco::PinnedBuffer host_stage;   // pinned staging for uploads
     rocco::PinnedBuffer host_back;    // pinned staging for readbacks
 };

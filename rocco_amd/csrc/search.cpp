@@ -384,6 +384,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
             if ((rc = ev.build_map(maps)) != ROCCO_HIP_OK) {
                 return rc;
             }
+            std::vector<WindowRequest> surveys;
             for (size_t q = 0; q < maps.size(); ++q) {
                 State &s = st[map_owner[q]];
                 ++s.out.passes;
@@ -392,6 +393,17 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 s.map_lo = s.req_lo;
                 s.map_hi = s.req_hi;
                 s.phase = s.after_map;
+                if (s.map_lo < s.map_hi && s.phase == State::kBisect) {
+                    // a map for the whole bracket: let the evaluator find what is already settled
+                    WindowRequest w;
+                    w.problem = map_owner[q];
+                    w.lambda_lo = s.lower;
+                    w.lambda_hi = s.upper;
+                    surveys.push_back(w);
+                }
+            }
+            if (!surveys.empty() && (rc = ev.survey(surveys)) != ROCCO_HIP_OK) {
+                return rc;
             }
         }
         if (!probes.empty() && (rc = ev.probe(probes)) != ROCCO_HIP_OK) {

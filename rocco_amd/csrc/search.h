@@ -102,6 +102,14 @@ public:
     virtual int window(std::vector<WindowRequest> &reqs) = 0;
     // per-chunk binade map used by later probe / window calls on that problem
     virtual int build_map(std::vector<MapRequest> &reqs) = 0;
+    // Optional: after a map valid for the whole bracket was built, learn which parts of each
+    // problem cannot change any more inside [lambda_lo, lambda_hi] so that later rounds can skip
+    // them.  Never changes results; the default does nothing.
+    virtual int survey(std::vector<WindowRequest> &reqs)
+    {
+        (void)reqs;
+        return 0;
+    }
     // exact counts / solution through the spine (requires a map built by build_map)
     virtual int spine(std::vector<SpineRequest> &reqs) = 0;
     // exact emulation of the reference (always correct)
