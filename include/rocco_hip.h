@@ -117,7 +117,7 @@ typedef struct {
     long long count;     /* selected loci under the exact-rule classes                          */
     long long uncertain; /* loci whose class is not certified                                   */
     long long effect;    /* bound on |count(reference) - count| (n + 1 if the model overflowed) */
-    long long max_run;   /* longest run without a provable clear clamp                          */
+    long long max_run;   /* longest run without a clear clamp behind a locus with tolerance      */
 } rocco_hip_probe_stats;
 
 /* `emap_dev`: per-chunk binade codes (ceil(n / 32) bytes, see rocco_hip_delta_build_map_f64) or NULL. */

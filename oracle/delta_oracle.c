@@ -191,10 +191,10 @@ int oracle_delta_chain_f64(const double *scores, const double *switch_costs, dou
         }
         wacc += w;
         const long long m = (long long)j - 1 - last_clear;
-        if (m > max_run) {
+        const double tau = wacc + mode.base;
+        if (tau > 0.0 && m > max_run) { /* diagnostic: longest run behind a locus that carries tolerance */
             max_run = m;
         }
-        const double tau = wacc + mode.base;
         int certain;
         uint8_t k;
         if (j + 1 < n) {
@@ -289,10 +289,10 @@ int oracle_delta_window_f64(const double *scores, const double *switch_costs, do
         }
         wacc += wmax;
         const long long m = (long long)j - 1 - last_clear;
-        if (m > max_run) {
+        const double tau = wacc + mode[0].base;
+        if (tau > 0.0 && m > max_run) {
             max_run = m;
         }
-        const double tau = wacc + mode[0].base;
         const double d_lo = d[0], d_hi = d[1];
         double cj = 0.0;
         uint8_t lo, hi;

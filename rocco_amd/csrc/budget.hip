@@ -448,9 +448,11 @@ private:
             if (rt[t].survey) {
                 ft.frz_out = p.frz;
             }
-            if (rt[t].record && std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
-                std::fprintf(stderr, "[spine] problem %zu: %zu lambdas, %zu / %d blocks evaluated (frozen %d)\n",
-                             rt[t].problem, rt[t].lambdas.size(), launched[t].size(), nblocks, (int)use_frozen);
+            if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                const char *kind = rt[t].record ? "spine" : (rt[t].survey ? "survey" : (rt[t].window ? "window" : (rt[t].map ? "map" : "probe")));
+                std::fprintf(stderr, "[round %d] %s problem %zu: %zu lambdas (first %.17g, margin %.3g), %zu / %d blocks%s\n",
+                             rounds, kind, rt[t].problem, rt[t].lambdas.size(), rt[t].lambdas[0], rt[t].margin,
+                             launched[t].size(), nblocks, p.emap ? "" : " [no map]");
             }
             ft.slot_begin = (int)slots.size();
             any_costs = any_costs || (p.costs != nullptr);

@@ -173,12 +173,12 @@ __device__ __forceinline__ void stage_tile(const FastTask &task, int local_block
     __syncthreads();
 }
 
-// Per-lane view of its chunk (raw values): sv[i] scores, cv[i] = cost between loci j0+i and j0+i+1,
-// c_prev0 = cost between j0-1 and j0.
+// Per-lane view of its chunk (raw values, read from the workgroup's LDS tile): sv[i] scores,
+// cost(i) = cost between loci j0+i and j0+i+1, c_prev0 = cost between j0-1 and j0.
 template <bool HAS_COSTS>
 struct ChunkData {
-    double sv[kChunk];
-    double cv[HAS_COSTS ? kChunk : 1];
+    const double *sv;
+    const double *cv;
     double c_prev0;
 };
 
@@ -187,19 +187,9 @@ __device__ __forceinline__ void load_chunk(const FastTask &task, long long j0, c
                                            const double *lds_c, ChunkData<HAS_COSTS> &d)
 {
     const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < kChunk; i += 2) {
-        const double2 v = *reinterpret_cast<const double2 *>(lds_s + t * kLdsStride + i);
-        d.sv[i] = v.x;
-        d.sv[i + 1] = v.y;
-    }
+    d.sv = lds_s + t * kLdsStride;
+    d.cv = lds_c + t * kLdsStride;
     if (HAS_COSTS) {
-#pragma unroll
-        for (int i = 0; i < kChunk; i += 2) {
-            const double2 v = *reinterpret_cast<const double2 *>(lds_c + t * kLdsStride + i);
-            d.cv[i] = v.x;
-            d.cv[i + 1] = v.y;
-        }
         double cp = 0.0;
         if (j0 > 0 && j0 < task.n) {
             cp = (t > 0) ? lds_c[(t - 1) * kLdsStride + (kChunk - 1)] : task.switch_costs[j0 - 1];
@@ -225,6 +215,104 @@ __device__ __forceinline__ int chunk_code(const FastTask &task, const FastSlot &
         return kMapNone;
     }
     return (int)task.emap[chunk];
+}
+
+// ---- lean paths ---------------------------------------------------------------------------------
+// Nearly every wavefront of a mapped round holds only interior chunks (not the first, not the one
+// with the last locus) that are clean and free of tolerance weight, and map rounds certify nothing at
+// all.  For those the per-step work collapses to the recursion itself; the general loops below
+// (same results, every corner case) run for the remaining wavefronts.
+
+// K1, one chain: chunk function + first coalescence index + last provable clear clamp; `tie` reports
+// a rounding tie (clean grids only), in which case the caller repeats the chunk on the general path.
+template <bool CLEAN, bool HAS_COSTS>
+__device__ __forceinline__ void lean_aggregate_steps(const double *__restrict__ sv, const double *__restrict__ cv,
+                                                     double c_prev0_raw, double gamma, double mg, double half_u,
+                                                     double nl, double big, Fn &f, int &pstar, int &lc, bool &tie)
+{
+    const double c_const = (gamma + mg) - mg;
+    double c_prev = HAS_COSTS ? ((c_prev0_raw + mg) - mg) : c_const;
+    bool tied = HAS_COSTS && CLEAN && (fabs(c_prev0_raw - c_prev) == half_u);
+    bool known = false;
+    int ps = kChunk, last_clear = -1;
+    // x -> clamp(x, -big, big) is the identity on every reachable value: the first step needs no case
+    double fa = 0.0, lo = -big, hi = big;
+#pragma unroll 1
+    for (int i0 = 0; i0 < kChunk; i0 += 8) {
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+        const int i = i0 + ii;
+        const double sj = sv[i];
+        double a;
+        if (CLEAN) {
+            const double rs = (sj + mg) - mg;
+            tied = tied || (fabs(sj - rs) == half_u);
+            a = rs + nl;
+        } else {
+            a = ((sj - nl) + mg) - mg;  // nl = lambda on the hazard grid
+        }
+        double cj = c_const;
+        if (HAS_COSTS) {
+            const double craw = cv[i];
+            cj = (craw + mg) - mg;
+            tied = tied || (CLEAN && fabs(craw - cj) == half_u);
+        }
+        fa = fmin(fmax(fa + a, -big), big);
+        lo = fmin(fmax(lo, -c_prev), c_prev) + a;
+        hi = fmin(fmax(hi, -c_prev), c_prev) + a;
+        if (!known && lo == hi) {
+            known = true;
+            ps = i;
+        }
+        if (known && (fabs(hi) - cj > kGuard)) {
+            last_clear = i;
+        }
+        c_prev = cj;
+    }
+    }
+    f.a = fa;
+    f.lo = lo;
+    f.hi = hi;
+    pstar = ps;
+    lc = last_clear;
+    tie = tied;
+}
+
+// K3, one chain: the recursion from the true incoming delta, classes, optional gain.
+template <bool CLEAN, bool HAS_COSTS, bool GAIN, bool CLASSES>
+__device__ __forceinline__ void lean_apply_steps(const double *__restrict__ sv, const double *__restrict__ cv,
+                                                 double c_prev0_raw, double gamma, double mg, double nl, double &delta,
+                                                 double &gain, unsigned &D, unsigned &V)
+{
+    const double c_const = (gamma + mg) - mg;
+    double c_prev = HAS_COSTS ? ((c_prev0_raw + mg) - mg) : c_const;
+    double dl = delta, g = 0.0;
+    unsigned dm = 0, vm = 0;
+#pragma unroll 1
+    for (int i0 = 0; i0 < kChunk; i0 += 8) {
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+        const int i = i0 + ii;
+        const double sj = sv[i];
+        const double a = CLEAN ? (((sj + mg) - mg) + nl) : (((sj - nl) + mg) - mg);
+        const double cj = HAS_COSTS ? ((cv[i] + mg) - mg) : c_const;
+        if (GAIN) {
+            g += fmax(0.0, dl - c_prev);
+        }
+        dl = fmin(fmax(dl, -c_prev), c_prev) + a;
+        if (CLASSES) {
+            const bool one = dl > cj;
+            const bool zero = dl <= -cj;
+            dm |= ((one || zero) ? 1U : 0U) << i;
+            vm |= (one ? 1U : 0U) << i;
+        }
+        c_prev = cj;
+    }
+    }
+    delta = dl;
+    gain = g;
+    D = dm;
+    V = vm;
 }
 
 // ---- K1: chunk functions, provable clear clamps, tolerance weights, noise sums --------------------
@@ -273,8 +361,39 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
     long long p16 = 0;
     long long npos = 0;
 
-    if (valid) {
-#pragma unroll
+    // lean path: the whole wavefront holds interior chunks that are clean (or belong to a map round)
+    bool done = false;
+    bool anyw = false;
+    if (NCH == 1) {
+        const bool interior = valid && j0 > 0 && (j0 + kChunk < n);
+        const bool map_round = (slot.mode == kModeMap);
+        const bool lane_lean = interior && (map_round || (mode[0].clean && mode[0].mapped));
+        if (__all(lane_lean)) {
+            bool tie = false;
+            if (map_round) {
+                lean_aggregate_steps<false, HAS_COSTS>(d.sv, d.cv, d.c_prev0, task.gamma, magic, 0.0, lam[0], big,
+                                                       f[0], pstar[0], lc, tie);
+                lc = -1;  // a map round certifies nothing
+            } else {
+                lean_aggregate_steps<true, HAS_COSTS>(d.sv, d.cv, d.c_prev0, task.gamma, mode[0].magic_u,
+                                                      mode[0].half_u, mode[0].nlam, big, f[0], pstar[0], lc, tie);
+            }
+            known[0] = pstar[0] < kChunk;
+            if (!__any(tie)) {
+                done = true;
+            } else {
+                f[0].a = 0.0;
+                f[0].lo = -big;
+                f[0].hi = big;
+                pstar[0] = kChunk;
+                known[0] = false;
+                lc = -1;
+            }
+        }
+    }
+
+    if (valid && !done) {
+#pragma unroll 1
         for (int i = 0; i < kChunk; ++i) {
             const long long j = j0 + i;
             if (j < n) {
@@ -306,7 +425,9 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
                         ++npos;
                     }
                 }
-                wsum += step_w<HAS_COSTS>(mode[0], d.sv[i], c_raw_prev, j == 0);
+                const double w_step_here = step_w<HAS_COSTS>(mode[0], d.sv[i], c_raw_prev, j == 0);
+                anyw = anyw || (w_step_here != 0.0);
+                wsum += w_step_here;
                 if (j + 1 < n) {
                     bool clear;
                     if (NCH == 1) {
@@ -331,7 +452,7 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
             buf.agg_a[ch.chunk_off + chunk] = f[k].a;
             buf.agg_lo[ch.chunk_off + chunk] = f[k].lo;
             buf.agg_hi[ch.chunk_off + chunk] = f[k].hi;
-            buf.pstar[ch.chunk_off + chunk] = (uint8_t)pstar[k];
+            buf.pstar[ch.chunk_off + chunk] = (uint8_t)(pstar[k] | ((k == 0 && anyw) ? 0x80 : 0));
         }
         buf.lc_chunk[slot.chunk_off + chunk] = (int8_t)lc;
         buf.w_chunk[slot.chunk_off + chunk] = wsum;
@@ -797,6 +918,7 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     double lam[NCH], delta[NCH], delta_in[NCH];
     double delta_in0 = 0.0;
     int pstar = 0;
+    bool anyw = false;  // K1: some step of this chunk carries tolerance weight
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const FastChain &ch = chains[k == 0 ? slot.chain_a : slot.chain_b];
@@ -807,8 +929,10 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
             delta_in0 = delta[0];
         }
         if (valid) {
-            const int p = (int)buf.pstar[ch.chunk_off + chunk];
+            const int praw = (int)buf.pstar[ch.chunk_off + chunk];
+            const int p = praw & 0x7F;
             pstar = (p > pstar) ? p : pstar;
+            anyw = anyw || (k == 0 && (praw & 0x80) != 0);
         }
     }
     const int code = chunk_code(task, slot, chunk, valid);
@@ -841,8 +965,32 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     double wsum_chunk = 0.0;
     const bool survey = (NCH == 2) && (task.frz_out.flag != nullptr);
 
-    if (valid) {
-#pragma unroll
+    // lean path: every chunk of the wavefront is interior and either belongs to a map round (nothing
+    // is certified) or is clean with no tolerance anywhere (tau == 0: every class is certain)
+    bool done = false;
+    if (NCH == 1) {
+        const bool interior = valid && j0 > 0 && (j0 + kChunk < n);
+        const bool map_round = (slot.mode == kModeMap);
+        const bool lane_lean =
+            interior && (map_round || (mode[0].clean && mode[0].mapped && !anyw && wacc == 0.0));
+        if (__all(lane_lean)) {
+            done = true;
+            validmask = 0xFFFFFFFFU;
+            if (map_round) {
+                lean_apply_steps<false, HAS_COSTS, true, false>(d.sv, d.cv, d.c_prev0, task.gamma, magic, lam[0],
+                                                                delta[0], gain, D_lo, V_lo);
+            } else if (slot.mode == kModeRecord) {
+                lean_apply_steps<true, HAS_COSTS, true, true>(d.sv, d.cv, d.c_prev0, task.gamma, mode[0].magic_u,
+                                                              mode[0].nlam, delta[0], gain, D_lo, V_lo);
+            } else {
+                lean_apply_steps<true, HAS_COSTS, false, true>(d.sv, d.cv, d.c_prev0, task.gamma, mode[0].magic_u,
+                                                               mode[0].nlam, delta[0], gain, D_lo, V_lo);
+            }
+        }
+    }
+
+    if (valid && !done) {
+#pragma unroll 1
         for (int i = 0; i < kChunk; ++i) {
             const long long j = j0 + i;
             if (j < n) {
@@ -865,8 +1013,10 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
                 wacc += w_here;
                 wsum_chunk += w_here;
                 const long long m = j - 1 - lc;
-                max_run = (m > max_run) ? m : max_run;
                 const double tau = wacc + mode[0].base;
+                if (tau > 0.0) {  // diagnostic: longest run behind a locus that carries tolerance
+                    max_run = (m > max_run) ? m : max_run;
+                }
                 const bool over = tau > kGuard;
                 overflow |= over ? 1 : 0;
                 const bool last = (j + 1 >= n);
@@ -935,7 +1085,8 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
         }
     }
 
-    // certification statistics
+    // certification statistics (a lean wavefront has none)
+    if (!done) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         uncertain += __shfl_down(uncertain, off);
@@ -951,6 +1102,7 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
         if (max_run > 0) atomicMax(reinterpret_cast<long long *>(&res.max_run), max_run);
         if (overflow) atomicOr(&res.overflow, 1);
         if (nonadjacent) atomicOr(&res.nonadjacent, 1);
+    }
     }
 
     // record slots: what the exact spine needs per chunk, laid out [chunk][slot of the task]
