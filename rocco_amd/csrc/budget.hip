@@ -156,6 +156,15 @@ public:
         return run_round(tasks);
     }
 
+    double work_fraction(size_t problem) const override
+    {
+        const DevProblem &p = probs[problem];
+        if (!p.frz_valid || solver_->active_set == 0 || p.frz_flags.empty()) {
+            return 1.0;
+        }
+        return (double)p.active_blocks.size() / (double)p.frz_flags.size();
+    }
+
     int build_map(std::vector<MapRequest> &reqs) override
     {
         // carve (once) a map region per problem out of the solver's map buffer
@@ -1005,6 +1014,9 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     SearchOptions opt;
     opt.force_exact = solver->force_exact != 0;
     opt.spec_depth = solver->spec_depth;
+    if (const char *e = std::getenv("ROCCO_HIP_BIG_ROUND")) opt.big_round_loci = std::atof(e);
+    if (const char *e = std::getenv("ROCCO_HIP_SMALL_ROUND")) opt.small_round_loci = std::atof(e);
+    if (const char *e = std::getenv("ROCCO_HIP_SURVEY_GATE")) opt.survey_gate = std::atof(e);
     std::vector<CalibrationResult> res;
     if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
     for (size_t t = 0; t < n_tasks; ++t) {

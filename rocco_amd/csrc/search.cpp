@@ -73,6 +73,7 @@ struct State {
     bool point_pending = false;         // the map is a point map at the next midpoint: probe it alone
     double req_ref = 0.0, req_lo = 0.0, req_hi = 0.0, req_margin = 0.0;  // map being requested
     long long lower_count = 0;   // selected loci at `lower` (bounds the count anywhere in the bracket)
+    long long upper_count = -1;  // selected loci at `upper` (-1: not evaluated yet)
     Phase after_map = kBisect;
     CalibrationResult out;
     // request in flight
@@ -223,6 +224,18 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
         std::vector<MapRequest> maps;
         std::vector<SpineRequest> spines;
         std::vector<size_t> probe_owner, window_owner, exact_owner, map_owner, spine_owner;
+        std::vector<WindowRequest> surveys;
+
+        // speculation depth of this iteration's probe rounds, from the loci they will cover
+        double round_loci = 0.0;
+        for (size_t b = 0; b < B; ++b) {
+            if (st[b].phase != State::kDone && !st[b].use_exact) {
+                round_loci += (double)problems[b].n * ev.work_fraction(b);
+            }
+        }
+        const int spec_depth = (round_loci > opt.big_round_loci)
+                                   ? 1
+                                   : ((round_loci < opt.small_round_loci) ? opt.spec_depth + 1 : opt.spec_depth);
 
         for (size_t b = 0; b < B; ++b) {
             const ChainProblem &p = problems[b];
@@ -309,7 +322,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                         break;
                     }
                 }
-                s.tree_depth = std::min(s.use_exact ? opt.exact_depth : opt.spec_depth, s.iters_left);
+                s.tree_depth = std::min(s.use_exact ? opt.exact_depth : spec_depth, s.iters_left);
                 if (!s.use_exact && s.has_map && s.point_pending) {
                     s.tree_depth = std::min(1, s.iters_left);
                 }
@@ -384,7 +397,6 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
             if ((rc = ev.build_map(maps)) != ROCCO_HIP_OK) {
                 return rc;
             }
-            std::vector<WindowRequest> surveys;
             for (size_t q = 0; q < maps.size(); ++q) {
                 State &s = st[map_owner[q]];
                 ++s.out.passes;
@@ -393,18 +405,24 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 s.map_lo = s.req_lo;
                 s.map_hi = s.req_hi;
                 s.phase = s.after_map;
-                if (s.map_lo < s.map_hi && s.phase == State::kBisect) {
-                    // a map for the whole bracket: let the evaluator find what is already settled
-                    WindowRequest w;
-                    w.problem = map_owner[q];
-                    w.lambda_lo = s.lower;
-                    w.lambda_hi = s.upper;
-                    surveys.push_back(w);
+                if (s.map_lo < s.map_hi && s.phase == State::kBisect && s.upper_count >= 0) {
+                    // a map for the whole bracket: when few loci can still change inside it, let the
+                    // evaluator find the settled parts so that later rounds skip them
+                    const ChainProblem &p = problems[map_owner[q]];
+                    const long long diffs = s.lower_count - s.upper_count;
+                    const long long blocks = (long long)(p.n / 8192) + 1;
+                    if ((double)diffs <= opt.survey_gate * (double)blocks) {
+                        WindowRequest w;
+                        w.problem = map_owner[q];
+                        w.lambda_lo = s.lower;
+                        w.lambda_hi = s.upper;
+                        surveys.push_back(w);
+                    }
                 }
             }
-            if (!surveys.empty() && (rc = ev.survey(surveys)) != ROCCO_HIP_OK) {
-                return rc;
-            }
+        }
+        if (!surveys.empty() && (rc = ev.survey(surveys)) != ROCCO_HIP_OK) {
+            return rc;
         }
         if (!probes.empty() && (rc = ev.probe(probes)) != ROCCO_HIP_OK) {
             return rc;
@@ -524,6 +542,10 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     i = 2 * i + 2;
                 } else {
                     s.upper = s.tree[i];
+                    if (s.tree_slot[i] >= 0) {
+                        s.upper_count = std::max(0LL, r.results[(size_t)s.tree_slot[i]].count -
+                                                          r.results[(size_t)s.tree_slot[i]].effect);
+                    }
                     i = 2 * i + 1;
                 }
             }

@@ -110,6 +110,12 @@ public:
         (void)reqs;
         return 0;
     }
+    // Fraction of a problem's loci that rounds inside the surveyed bracket still evaluate.
+    virtual double work_fraction(size_t problem) const
+    {
+        (void)problem;
+        return 1.0;
+    }
     // exact counts / solution through the spine (requires a map built by build_map)
     virtual int spine(std::vector<SpineRequest> &reqs) = 0;
     // exact emulation of the reference (always correct)
@@ -131,7 +137,12 @@ struct CalibrationResult {
 };
 
 struct SearchOptions {
-    int spec_depth = 2;     // levels of the bisection tree evaluated per probe round
+    int spec_depth = 2;     // levels of the bisection tree evaluated per probe round (medium rounds)
+    // rounds are throughput-bound when they cover many loci (speculating wastes evaluations) and
+    // latency-bound when they cover few (speculating deeper saves launches)
+    double big_round_loci = 1.0e18;     // above: one level per round
+    double small_round_loci = 1.0e6;   // below: spec_depth + 1 levels per round
+    double survey_gate = 0.5;          // survey a bracket when (loci that can still change) <= gate * workgroups
     int exact_depth = 6;    // same for the exact kernel (63 lanes)
     bool force_exact = false;
     bool use_spine = true;  // finish undecided endgames through the exact spine (else the exact kernel)
