@@ -223,59 +223,126 @@ __device__ __forceinline__ int chunk_code(const FastTask &task, const FastSlot &
 // all.  For those the per-step work collapses to the recursion itself; the general loops below
 // (same results, every corner case) run for the remaining wavefronts.
 
-// K1, one chain: chunk function + first coalescence index + last provable clear clamp; `tie` reports
-// a rounding tie (clean grids only), in which case the caller repeats the chunk on the general path.
-template <bool CLEAN, bool HAS_COSTS>
-__device__ __forceinline__ void lean_aggregate_steps(const double *__restrict__ sv, const double *__restrict__ cv,
-                                                     double c_prev0_raw, double gamma, double mg, double half_u,
-                                                     double nl, double big, Fn &f, int &pstar, int &lc, bool &tie)
+// K1, one chain, any interior chunk.  Per-lane parameters select the arithmetic: a = rn_mg(s - sub) + add
+// is rn_u(s) + rn_u(-lambda) for a clean chunk (sub = 0) and rn_q(s - lambda) for a hazard chunk
+// (add = 0); half_u < 0 switches the rounding-tie test off (hazard grids have none); w_const is the
+// tolerance weight of every step (0 for clean chunks).  `tie` reports a rounding tie, in which case the
+// caller repeats the wavefront on the general path.
+template <bool HAS_COSTS, bool NOISE>
+__device__ __forceinline__ void mid_aggregate_steps(const double *__restrict__ sv, const double *__restrict__ cv,
+                                                    double c_prev0_raw, double gamma, double mg, double sub,
+                                                    double add, double half_u, double w_const, double big, Fn &f,
+                                                    int &pstar, int &lc, double &wsum_out, bool &tie,
+                                                    long long &p16, long long &npos)
 {
     const double c_const = (gamma + mg) - mg;
     double c_prev = HAS_COSTS ? ((c_prev0_raw + mg) - mg) : c_const;
-    bool tied = HAS_COSTS && CLEAN && (fabs(c_prev0_raw - c_prev) == half_u);
+    bool tied = HAS_COSTS && (fabs(c_prev0_raw - c_prev) == half_u);
     bool known = false;
     int ps = kChunk, last_clear = -1;
+    double wsum = 0.0;
     // x -> clamp(x, -big, big) is the identity on every reachable value: the first step needs no case
     double fa = 0.0, lo = -big, hi = big;
 #pragma unroll 1
     for (int i0 = 0; i0 < kChunk; i0 += 8) {
 #pragma unroll
-    for (int ii = 0; ii < 8; ++ii) {
-        const int i = i0 + ii;
-        const double sj = sv[i];
-        double a;
-        if (CLEAN) {
-            const double rs = (sj + mg) - mg;
-            tied = tied || (fabs(sj - rs) == half_u);
-            a = rs + nl;
-        } else {
-            a = ((sj - nl) + mg) - mg;  // nl = lambda on the hazard grid
+        for (int ii = 0; ii < 8; ++ii) {
+            const int i = i0 + ii;
+            const double x = sv[i] - sub;
+            const double rs = (x + mg) - mg;
+            tied = tied || (fabs(x - rs) == half_u);
+            const double a = rs + add;
+            double cj = c_const;
+            if (HAS_COSTS) {
+                const double craw = cv[i];
+                cj = (craw + mg) - mg;
+                tied = tied || (fabs(craw - cj) == half_u);
+            }
+            fa = fmin(fmax(fa + a, -big), big);
+            lo = fmin(fmax(lo, -c_prev), c_prev) + a;
+            hi = fmin(fmax(hi, -c_prev), c_prev) + a;
+            if (!known && lo == hi) {
+                known = true;
+                ps = i;
+            }
+            if (NOISE && a > 0.0) {
+                p16 += (long long)(16.0 * a);
+                ++npos;
+            }
+            wsum += w_const;
+            if (known && (fabs(hi) - cj > kGuard)) {
+                last_clear = i;
+                wsum = 0.0;
+            }
+            c_prev = cj;
         }
-        double cj = c_const;
-        if (HAS_COSTS) {
-            const double craw = cv[i];
-            cj = (craw + mg) - mg;
-            tied = tied || (CLEAN && fabs(craw - cj) == half_u);
-        }
-        fa = fmin(fmax(fa + a, -big), big);
-        lo = fmin(fmax(lo, -c_prev), c_prev) + a;
-        hi = fmin(fmax(hi, -c_prev), c_prev) + a;
-        if (!known && lo == hi) {
-            known = true;
-            ps = i;
-        }
-        if (known && (fabs(hi) - cj > kGuard)) {
-            last_clear = i;
-        }
-        c_prev = cj;
-    }
     }
     f.a = fa;
     f.lo = lo;
     f.hi = hi;
     pstar = ps;
     lc = last_clear;
+    wsum_out = wsum;
     tie = tied;
+}
+
+// K3, one chain, any interior chunk whose weights are the same at every step (hazard chunks, and
+// clean chunks without rounding ties): the general loop without its case distinctions.
+template <bool HAS_COSTS, bool GAIN>
+__device__ __forceinline__ void mid_apply_steps(const double *__restrict__ sv, const double *__restrict__ cv,
+                                                double c_prev0_raw, double gamma, double mg, double sub, double add,
+                                                double w_const, double base, int pstar, int mrun, double wacc,
+                                                double &delta, double &gain, unsigned &D, unsigned &V,
+                                                long long &uncertain_out, long long &effect_out,
+                                                long long &max_run_out, int &overflow_out)
+{
+    const double c_const = (gamma + mg) - mg;
+    double c_prev = HAS_COSTS ? ((c_prev0_raw + mg) - mg) : c_const;
+    double dl = delta, g = 0.0;
+    unsigned dm = 0, vm = 0;
+    int uncertain = 0, max_run = 0;
+    long long effect = 0;
+    bool overflow = false;
+#pragma unroll 1
+    for (int i0 = 0; i0 < kChunk; i0 += 8) {
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const int i = i0 + ii;
+            const double x = sv[i] - sub;
+            const double a = ((x + mg) - mg) + add;
+            const double cj = HAS_COSTS ? ((cv[i] + mg) - mg) : c_const;
+            if (GAIN) {
+                g += fmax(0.0, dl - c_prev);
+            }
+            dl = fmin(fmax(dl, -c_prev), c_prev) + a;
+            wacc += w_const;
+            const double tau = wacc + base;
+            const bool toler = tau > 0.0;
+            max_run = (toler && mrun > max_run) ? mrun : max_run;
+            const bool over = tau > kGuard;
+            overflow = overflow || over;
+            const double e = fabs(dl) - cj;
+            const bool unc = over || (toler && !(fabs(e) > tau));
+            uncertain += unc ? 1 : 0;
+            effect += unc ? (long long)(mrun + 1) : 0LL;
+            const bool one = dl > cj;
+            const bool zero = dl <= -cj;
+            dm |= ((one || zero) ? 1U : 0U) << i;
+            vm |= (one ? 1U : 0U) << i;
+            const bool clear = (i >= pstar) && (e > kGuard);
+            mrun = clear ? 0 : (mrun + 1);
+            wacc = clear ? 0.0 : wacc;
+            c_prev = cj;
+        }
+    }
+    delta = dl;
+    gain = g;
+    D = dm;
+    V = vm;
+    uncertain_out = uncertain;
+    effect_out = effect;
+    max_run_out = max_run;
+    overflow_out = overflow ? 1 : 0;
 }
 
 // K3, one chain: the recursion from the true incoming delta, classes, optional gain.
@@ -335,7 +402,7 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
         lam[NCH - 1] = chains[slot.chain_b].lambda;
     }
     const int code = chunk_code(task, slot, chunk, valid);
-    const bool need_noise = (code == kMapNone);
+    const bool need_noise = (code == kMapNone) && slot.mode != kModeMap;  // map rounds certify nothing
     Mode mode[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
@@ -361,32 +428,42 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
     long long p16 = 0;
     long long npos = 0;
 
-    // lean path: the whole wavefront holds interior chunks that are clean (or belong to a map round)
+    // streamlined path: the whole wavefront holds interior chunks (not the first of the chromosome,
+    // not the one with its last locus); a rounding tie sends the wavefront to the general loop
     bool done = false;
     bool anyw = false;
     if (NCH == 1) {
         const bool interior = valid && j0 > 0 && (j0 + kChunk < n);
-        const bool map_round = (slot.mode == kModeMap);
-        const bool lane_lean = interior && (map_round || (mode[0].clean && mode[0].mapped));
-        if (__all(lane_lean)) {
+        const bool noise_all = __all(need_noise);
+        if (__all(interior) && (noise_all || !__any(need_noise))) {
+            const bool clean = mode[0].clean;
+            const double mg = clean ? mode[0].magic_u : magic;
+            const double sub = clean ? 0.0 : lam[0];
+            const double add = clean ? mode[0].nlam : 0.0;
+            const double half_u = clean ? mode[0].half_u : -1.0;
+            const double w_const = clean ? 0.0 : (mode[0].mapped ? mode[0].w_step : 1.0);
             bool tie = false;
-            if (map_round) {
-                lean_aggregate_steps<false, HAS_COSTS>(d.sv, d.cv, d.c_prev0, task.gamma, magic, 0.0, lam[0], big,
-                                                       f[0], pstar[0], lc, tie);
-                lc = -1;  // a map round certifies nothing
+            long long p16_l = 0, npos_l = 0;
+            double wsum_l = 0.0;
+            if (noise_all) {
+                mid_aggregate_steps<HAS_COSTS, true>(d.sv, d.cv, d.c_prev0, task.gamma, mg, sub, add, half_u, w_const,
+                                                     big, f[0], pstar[0], lc, wsum_l, tie, p16_l, npos_l);
             } else {
-                lean_aggregate_steps<true, HAS_COSTS>(d.sv, d.cv, d.c_prev0, task.gamma, mode[0].magic_u,
-                                                      mode[0].half_u, mode[0].nlam, big, f[0], pstar[0], lc, tie);
+                mid_aggregate_steps<HAS_COSTS, false>(d.sv, d.cv, d.c_prev0, task.gamma, mg, sub, add, half_u,
+                                                      w_const, big, f[0], pstar[0], lc, wsum_l, tie, p16_l, npos_l);
             }
-            known[0] = pstar[0] < kChunk;
             if (!__any(tie)) {
                 done = true;
+                known[0] = pstar[0] < kChunk;
+                wsum = wsum_l;
+                p16 = p16_l;
+                npos = npos_l;
+                anyw = (w_const != 0.0);
             } else {
                 f[0].a = 0.0;
                 f[0].lo = -big;
                 f[0].hi = big;
                 pstar[0] = kChunk;
-                known[0] = false;
                 lc = -1;
             }
         }
@@ -989,6 +1066,31 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
         }
     }
 
+    bool stats_pending = !done;
+    if (NCH == 1 && !done && n < (1LL << 31)) {
+        const bool interior = valid && j0 > 0 && (j0 + kChunk < n);
+        if (__all(interior && (!mode[0].clean || !anyw))) {
+            done = true;
+            validmask = 0xFFFFFFFFU;
+            const bool clean = mode[0].clean;
+            const double mg = clean ? mode[0].magic_u : magic;
+            const double sub = clean ? 0.0 : lam[0];
+            const double add = clean ? mode[0].nlam : 0.0;
+            const double w_const = clean ? 0.0 : ((mode[0].mapped ? mode[0].w_step : 1.0) * wscale);
+            const int mrun0 = (int)(j0 - 1 - lc);
+            if (slot.mode == kModeMap || slot.mode == kModeRecord) {
+                mid_apply_steps<HAS_COSTS, true>(d.sv, d.cv, d.c_prev0, task.gamma, mg, sub, add, w_const,
+                                                 mode[0].base, pstar, mrun0, wacc, delta[0], gain, D_lo, V_lo,
+                                                 uncertain, effect, max_run, overflow);
+            } else {
+                mid_apply_steps<HAS_COSTS, false>(d.sv, d.cv, d.c_prev0, task.gamma, mg, sub, add, w_const,
+                                                  mode[0].base, pstar, mrun0, wacc, delta[0], gain, D_lo, V_lo,
+                                                  uncertain, effect, max_run, overflow);
+            }
+            wsum_chunk = w_const;
+        }
+    }
+
     if (valid && !done) {
 #pragma unroll 1
         for (int i = 0; i < kChunk; ++i) {
@@ -1086,7 +1188,7 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     }
 
     // certification statistics (a lean wavefront has none)
-    if (!done) {
+    if (stats_pending) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         uncertain += __shfl_down(uncertain, off);
