@@ -213,6 +213,8 @@ public:
             t.problem = r.problem;
             t.record = true;
             t.solution_index = r.solution_index;
+            t.select_depth = r.select_depth;
+            t.select_target = r.select_target;
             t.lambdas = r.lambdas;
             t.spine = &r;
             tasks.push_back(t);
@@ -368,6 +370,8 @@ private:
         bool survey = false;
         bool use_frozen = false;
         int solution_index = -1;
+        int select_depth = 0;
+        long long select_target = 0;
         double margin = 0.0;
         std::vector<double> lambdas;
         ProbeRequest *probe = nullptr;
@@ -390,7 +394,8 @@ private:
         std::vector<long long> skip_off(T, -1);
         std::vector<uint8_t> skip_bytes;
         long long chain_chunks = 0, chain_blocks = 0, slot_chunks = 0, slot_blocks = 0, rec_entries = 0;
-        bool any_record = false;
+        long long rec_groups = 0;
+        bool any_record = false, any_select = false;
         std::vector<int> solution_slot(T, -1);
         bool any_costs = false, any_plain = false, any_window = false, any_map = false;
         for (size_t t = 0; t < T; ++t) {
@@ -512,10 +517,16 @@ private:
             }
             ft.slot_count = (int)slots.size() - ft.slot_begin;
             ft.rec_off = 0;
+            ft.rec_goff = 0;
+            ft.sel_depth = rt[t].record ? rt[t].select_depth : 0;
+            ft.sel_target = rt[t].select_target;
+            any_select = any_select || (ft.sel_depth > 0);
             if (rt[t].record) {
                 any_record = true;
                 ft.rec_off = rec_entries;
                 rec_entries += nchunks * ft.slot_count;
+                ft.rec_goff = rec_groups;
+                rec_groups += ((nchunks + 31) / 32) * ft.slot_count;
                 if (rt[t].solution_index >= 0) {
                     solution_slot[t] = ft.slot_begin + rt[t].solution_index;
                 }
@@ -581,6 +592,7 @@ private:
         const size_t o_rdin = carve((size_t)rec_entries * 8 + 8), o_rgain = carve((size_t)rec_entries * 8 + 8);
         const size_t o_rd = carve((size_t)rec_entries * 4 + 8), o_rv = carve((size_t)rec_entries * 4 + 8);
         const size_t o_rf = carve((size_t)rec_entries + 8);
+        const size_t o_rgs = carve((size_t)rec_groups * 8 + 8), o_rgo = carve((size_t)rec_groups + 8);
         const size_t o_ss = carve(T * sizeof(int));
         const size_t o_res = carve(S * sizeof(FastSlotResult));
         if ((rc = solver_->dev_params.reserve(off)) != ROCCO_HIP_OK) return rc;
@@ -597,6 +609,18 @@ private:
         L.blockmap_all = (const int2 *)(dd + b_tasks + b_chains + b_slots + b_map);
         L.n_blocks_total = (int)NB;
         L.n_blocks_all = (int)NBA;
+        {
+            // few blocks with many penalties each (spine rounds): spread the slots over workgroups
+            int max_slots = 1;
+            for (size_t t = 0; t < T; ++t) {
+                max_slots = std::max(max_slots, tasks[t].slot_count);
+            }
+            int groups = 1;
+            while (groups < max_slots && (size_t)(2 * groups) * NB <= 2048) {
+                groups *= 2;
+            }
+            L.slot_groups = std::min(groups, max_slots);
+        }
         L.any_costs = any_costs;
         L.any_plain = any_plain;
         L.any_window = any_window;
@@ -630,6 +654,8 @@ private:
         L.buf.rec_d = (unsigned *)(sc + o_rd);
         L.buf.rec_v = (unsigned *)(sc + o_rv);
         L.buf.rec_flags = (uint8_t *)(sc + o_rf);
+        L.buf.rec_gsum = (double *)(sc + o_rgs);
+        L.buf.rec_gok = (uint8_t *)(sc + o_rgo);
         L.buf.results = (FastSlotResult *)(sc + o_res);
         ROCCO_HIP_TRY(hipMemsetAsync(L.buf.results, 0, S * sizeof(FastSlotResult), stream_));
         if ((rc = launch_fast_round(L, stream_)) != ROCCO_HIP_OK) {
@@ -640,7 +666,7 @@ private:
             int *h_ss = (int *)((char *)solver_->host_back.ptr + S * sizeof(FastSlotResult));
             std::memcpy(h_ss, solution_slot.data(), T * sizeof(int));
             ROCCO_HIP_TRY(hipMemcpyAsync(sc + o_ss, h_ss, T * sizeof(int), hipMemcpyHostToDevice, stream_));
-            if ((rc = launch_spine(L, (const int *)(sc + o_ss), stream_)) != ROCCO_HIP_OK) {
+            if ((rc = launch_spine(L, (int *)(sc + o_ss), any_select, stream_)) != ROCCO_HIP_OK) {
                 return rc;
             }
         }
@@ -735,6 +761,11 @@ private:
                 for (int k = 0; k < ft.slot_count; ++k) {
                     rt[t].spine->counts[k] = hr[ft.slot_begin + k].count_lo;
                     rt[t].spine->stepped[k] = hr[ft.slot_begin + k].uncertain;
+                }
+                rt[t].spine->selected = (ft.sel_depth > 0) ? hr[ft.slot_begin].e_global : -1;
+                if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                    std::fprintf(stderr, "[spine] problem %zu: lane 0 stepped %lld chunks of %lld\n", rt[t].problem,
+                                 (long long)hr[ft.slot_begin].uncertain, (long long)((p.n + kChunk - 1) / kChunk));
                 }
                 continue;
             }

@@ -51,7 +51,10 @@ struct FastTask {
     double cmax, sabs;
     int slot_begin, slot_count;
     int n_blocks;
-    long long rec_off;  // record slots: offset of this task in the [chunk][slot] record arrays
+    long long rec_off;   // record slots: offset of this task in the [chunk][slot] record arrays
+    long long rec_goff;  // ... and in the [group of 32 chunks][slot] summary arrays
+    int sel_depth;          // record slots: > 0 = slots are a bisection tree (heap order) + the current upper end;
+    long long sel_target;   //   the spine launch walks it against this target and materialises the answer
     uint8_t *solution;    // n bytes (window slots write fill(LO) here)
     const uint8_t *emap;  // binade code per chunk, or nullptr (every chunk = hazard, global exponent)
     uint8_t *emap_out;    // map slots write the new codes here
@@ -118,6 +121,8 @@ struct FastBuffers {
     double *rec_din, *rec_gain;
     unsigned *rec_d, *rec_v;
     uint8_t *rec_flags;  // bit 0: the parallel recursion is exact in this chunk (clean, no rounding tie)
+    double *rec_gsum;    // per (group of 32 chunks, slot): sum of the chunks' gains
+    uint8_t *rec_gok;    // ... and whether every chunk of the group is exact
     // per slot
     FastSlotResult *results;
 };
@@ -129,6 +134,7 @@ struct FastLaunch {
     const int2 *blockmap;      // global workgroup -> (task, local block): the blocks evaluated this round
     const int2 *blockmap_all;  // every block of every task (tail patches)
     int n_tasks, n_chains, n_slots, n_blocks_total, n_blocks_all;
+    int slot_groups;  // K1 / K3 / class fill: workgroups per block, each taking every slot_groups-th slot
     bool any_costs, any_plain;
     bool any_window, any_map;
     FastBuffers buf;
@@ -138,7 +144,7 @@ int launch_fast_round(const FastLaunch &L, hipStream_t stream);
 
 // Exact spine over the record arrays of a round (chain_spine.hip): afterwards rec_d / rec_v hold the
 // reference's exact classes for every slot; then counts (and one solution per task) are rebuilt.
-int launch_spine(const FastLaunch &L, const int *solution_slot_dev, hipStream_t stream);
+int launch_spine(const FastLaunch &L, int *solution_slot_dev, bool any_select, hipStream_t stream);
 
 // min / max of scores (and of switch costs) per task: out[4 * t + {0,1,2,3}] = smin, smax, cmin, cmax
 struct StatsTask {

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(kFastThreads) void fast_aggregate_kernel(FastLaunch
     double *lds_c = HAS_COSTS ? (smem + kTileDoubles) : smem;
     double *lds_red = smem + (HAS_COSTS ? 2 : 1) * kTileDoubles;
 
-    const int2 bm = L.blockmap[blockIdx.x];
+    const int2 bm = L.blockmap[blockIdx.x / L.slot_groups];
     const FastTask task = L.tasks[bm.x];
     if (HAS_COSTS != (task.switch_costs != nullptr)) {
         return;
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(kFastThreads) void fast_aggregate_kernel(FastLaunch
     const long long j0 = chunk * kChunk;
     ChunkData<HAS_COSTS> d;
     load_chunk<HAS_COSTS>(task, j0, lds_s, lds_c, d);
-    for (int si = 0; si < task.slot_count; ++si) {
+    for (int si = (int)(blockIdx.x % L.slot_groups); si < task.slot_count; si += L.slot_groups) {
         const int slot_index = task.slot_begin + si;
         const FastSlot slot = L.slots[slot_index];
         if (slot.mode == kModeWindow) {
@@ -1208,13 +1208,29 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     }
 
     // record slots: what the exact spine needs per chunk, laid out [chunk][slot of the task]
-    if (slot.mode == kModeRecord && valid) {
-        const long long at = task.rec_off + chunk * task.slot_count + (slot_index - task.slot_begin);
-        buf.rec_din[at] = delta_in0;
-        buf.rec_gain[at] = gain;
-        buf.rec_d[at] = D_lo;
-        buf.rec_v[at] = V_lo;
-        buf.rec_flags[at] = (uint8_t)((mode[0].clean && wsum_chunk == 0.0) ? 1 : 0);
+    if (slot.mode == kModeRecord) {
+        const bool exact_chunk = !valid || (mode[0].clean && wsum_chunk == 0.0);
+        if (valid) {
+            const long long at = task.rec_off + chunk * task.slot_count + (slot_index - task.slot_begin);
+            buf.rec_din[at] = delta_in0;
+            buf.rec_gain[at] = gain;
+            buf.rec_d[at] = D_lo;
+            buf.rec_v[at] = V_lo;
+            buf.rec_flags[at] = (uint8_t)(exact_chunk ? 1 : 0);
+        }
+        // summary of each group of 32 chunks (half a wavefront): the spine adds whole groups at once
+        double gs = valid ? gain : 0.0;
+        int ok = exact_chunk ? 1 : 0;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            gs += __shfl_down(gs, off, 32);
+            ok &= __shfl_down(ok, off, 32);
+        }
+        if ((lane & 31) == 0 && valid) {
+            const long long gat = task.rec_goff + (chunk / 32) * task.slot_count + (slot_index - task.slot_begin);
+            buf.rec_gsum[gat] = gs;
+            buf.rec_gok[gat] = (uint8_t)ok;
+        }
     }
 
     // map slots: gain of this chunk and of the workgroup (fixed reduction order)
@@ -1373,7 +1389,7 @@ __global__ __launch_bounds__(kFastThreads) void fast_apply_kernel(FastLaunch L)
     double *lds_c = HAS_COSTS ? (smem + kTileDoubles) : smem;
     double *lds_red = smem + (HAS_COSTS ? 2 : 1) * kTileDoubles;
 
-    const int2 bm = L.blockmap[blockIdx.x];
+    const int2 bm = L.blockmap[blockIdx.x / L.slot_groups];
     const FastTask task = L.tasks[bm.x];
     if (HAS_COSTS != (task.switch_costs != nullptr)) {
         return;
@@ -1384,7 +1400,7 @@ __global__ __launch_bounds__(kFastThreads) void fast_apply_kernel(FastLaunch L)
     const long long j0 = chunk * kChunk;
     ChunkData<HAS_COSTS> d;
     load_chunk<HAS_COSTS>(task, j0, lds_s, lds_c, d);
-    for (int si = 0; si < task.slot_count; ++si) {
+    for (int si = (int)(blockIdx.x % L.slot_groups); si < task.slot_count; si += L.slot_groups) {
         const int slot_index = task.slot_begin + si;
         const FastSlot slot = L.slots[slot_index];
         if (slot.mode == kModeWindow) {
@@ -1700,114 +1716,192 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
     const double lam = active ? L.chains[L.slots[task.slot_begin + lane].chain_a].lambda : 0.0;
     const long long n = task.n;
     const long long nchunks = (n + kChunk - 1) / kChunk;
+    const int nb = task.n_blocks;
     const double *__restrict__ sc = task.scores;
     const double *__restrict__ cs = task.switch_costs;
     const bool has_costs = (cs != nullptr);
     const FastBuffers &buf = L.buf;
+    const long long lane_block_off =
+        active ? L.chains[L.slots[task.slot_begin + lane].chain_a].block_off : 0;
+
+    // One memory round trip per group of 32 chunks: the lanes fetch the group's record entries
+    // (their own column) and, together, its scores / costs into LDS; everything after that is served
+    // from LDS.  (The record arrays were written by other compute units: every global load here is a
+    // trip to memory, so dependent loads are what this kernel must avoid.)
+    constexpr int kGroup = 32;
+    constexpr int kGroupLoci = kGroup * kChunk;
+    __shared__ double sh_s[kGroupLoci + 1];       // scores of the group and the first one after it
+    __shared__ double sh_c[kGroupLoci + 1];       // sh_c[x]: cost between loci g0 + x - 1 and g0 + x
+    __shared__ double sh_din[kGroup + 1][64];
+    __shared__ double sh_gain[kGroup][64];
+    __shared__ uint8_t sh_fl[kGroup + 1][64];
 
     double P0 = 0.0, P1 = 0.0;
     bool stepping = true;  // chunk 0 is always stepped (the map never marks it clean)
     unsigned D = 0, V = 0;  // class word under construction for the chunk being stepped
+    long long pend_at = -1;  // class word of the previous chunk, waiting for its bit 31
+    unsigned pend_d = 0, pend_v = 0;
     long long stepped = 0;
 
-    const long long lane_block_off =
-        active ? L.chains[L.slots[task.slot_begin + lane].chain_a].block_off : 0;
-    constexpr int kGroup = 32;  // chunks skipped per iteration while every lane is synchronised
-    for (long long k = 0; k < nchunks; ++k) {
-        if ((k % kFastThreads) == 0 && task.frz.flag != nullptr && task.frz.flag[k / kFastThreads]) {
-            // a block that was not evaluated this round: its classes are settled and its gain has a
+    __shared__ double sh_gs[8][64];
+    __shared__ uint8_t sh_ok[8][64];
+    const long long ngroups = (nchunks + kGroup - 1) / kGroup;
+    constexpr int kGroupsPerBlock = kFastThreads / kGroup;  // 8
+
+    for (long long b = 0; b < nb; ++b) {
+        if (task.frz.flag != nullptr) {
+            // Blocks that were not evaluated this round: their classes are settled and their gain has a
             // closed form.  (The host evaluates the block after every active block, so a stepping
             // lane has resynchronised before it gets here; otherwise the round is repeated in full.)
-            const long long b = k / kFastThreads;
-            if (active) {
-                if (stepping) {
-                    atomicOr(&buf.results[task.slot_begin + lane].overflow, 1);
-                    stepping = false;
-                }
-                const double magic_u = ldexp(1.5, (int)task.frz.e[b]);
-                const double nl = grid_round(-lam, magic_u);
-                const double nl_lo = grid_round(-task.frz.lam_lo[b], magic_u);
-                const double first = fmax(0.0, buf.din[lane_block_off + b] - task.frz.cprev[b]);
-                P0 += first + (task.frz.gx_lo[b] + task.frz.mg[b] * (nl - nl_lo));
-            }
-            k += kFastThreads - 1;
-            continue;
-        }
-        if ((k % kGroup) == 0 && !__any(active && stepping)) {
-            // fast path: a whole group of chunks is exact for every lane -> add their gains at once
-            // (all loads independent; the sums are exact, so their order does not matter)
-            unsigned okbits = 1U;
-            double gsum = 0.0;
-            if (active) {
-                // branch-free so that all 64 loads of the group are in flight together
-                unsigned fl[kGroup];
-                double gv[kGroup];
+            // The lanes look at the next 64 block flags together: one memory latency per run.
+            const bool mine = (b + lane < nb) && (task.frz.flag[b + lane] != 0);
+            const unsigned long long run_mask = __ballot(mine);
+            const int run = (~run_mask == 0ULL) ? 64 : (__ffsll((long long)~run_mask) - 1);
+            if (run > 0) {
+                if (active) {
+                    if (stepping) {
+                        atomicOr(&buf.results[task.slot_begin + lane].overflow, 1);
+                        stepping = false;
+                    }
+                    // all loads of the run are independent; the sums are exact in any order
+                    for (int r0 = 0; r0 < run; r0 += 4) {
+                        double add[4];
 #pragma unroll
-                for (int c = 0; c < kGroup; ++c) {
-                    const long long kk = (k + c < nchunks) ? (k + c) : (nchunks - 1);
-                    const long long a2 = task.rec_off + kk * S + lane;
-                    fl[c] = buf.rec_flags[a2];
-                    gv[c] = buf.rec_gain[a2];
-                }
+                        for (int q = 0; q < 4; ++q) {
+                            const long long bb = b + ((r0 + q < run) ? (r0 + q) : (run - 1));
+                            const double magic_u = ldexp(1.5, (int)task.frz.e[bb]);
+                            const double nl = grid_round(-lam, magic_u);
+                            const double nl_lo = grid_round(-task.frz.lam_lo[bb], magic_u);
+                            const double first = fmax(0.0, buf.din[lane_block_off + bb] - task.frz.cprev[bb]);
+                            add[q] = first + (task.frz.gx_lo[bb] + task.frz.mg[bb] * (nl - nl_lo));
+                        }
 #pragma unroll
-                for (int c = 0; c < kGroup; ++c) {
-                    const bool in = (k + c < nchunks);
-                    okbits &= in ? fl[c] : 1U;
-                    gsum += in ? gv[c] : 0.0;
+                        for (int q = 0; q < 4; ++q) {
+                            P0 += (r0 + q < run) ? add[q] : 0.0;
+                        }
+                    }
                 }
-            }
-            const bool ok = (okbits & 1U) != 0U;
-            if (__all(ok)) {
-                P0 += gsum;
-                k += kGroup - 1;
+                b += run - 1;
                 continue;
             }
         }
-        const long long at = task.rec_off + k * S + lane;
-        const bool exact_here = active ? ((buf.rec_flags[at] & 1U) != 0U) : true;
-        const bool need = active && (stepping || !exact_here);
-        if (active && !need) {
-            P0 += buf.rec_gain[at];
+        // the block's eight group summaries: one memory latency
+        {
+            double gs[kGroupsPerBlock];
+            unsigned ok[kGroupsPerBlock];
+#pragma unroll
+            for (int q = 0; q < kGroupsPerBlock; ++q) {
+                const long long g = b * kGroupsPerBlock + q;
+                const bool in = active && (g < ngroups);
+                const long long gat = task.rec_goff + (in ? g : 0) * S + (active ? lane : 0);
+                gs[q] = in ? buf.rec_gsum[gat] : 0.0;
+                ok[q] = in ? buf.rec_gok[gat] : 1U;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kGroupsPerBlock; ++q) {
+                sh_gs[q][lane] = gs[q];
+                sh_ok[q][lane] = (uint8_t)ok[q];
+            }
+            __syncthreads();
         }
-        if (!__any(need)) {
+#pragma unroll 1
+        for (int q = 0; q < kGroupsPerBlock; ++q) {
+        const long long k = (b * kGroupsPerBlock + q) * kGroup;  // first chunk of the group
+        if (k >= nchunks) {
+            break;
+        }
+        if (!__any(active && stepping) && __all(sh_ok[q][lane] != 0)) {
+            P0 += sh_gs[q][lane];  // every chunk exact for every lane: the group's gain in one add
             continue;
         }
-        const long long j0 = k * kChunk;
-        const long long j_end = j0 + kChunk;  // first locus of the next chunk
-        const bool fresh = need && !stepping;  // was synchronised: enter with the parallel delta
-        // issue every load this chunk needs up front (independent addresses: one memory latency)
-        const long long jl = j0 + (lane & 31);
-        const double sv = (jl < n) ? sc[jl] : 0.0;
-        const double cvr = has_costs ? ((jl < n - 1) ? cs[jl] : 0.0) : task.gamma;
-        const double c_prev0 = has_costs ? ((j0 > 0) ? cs[j0 - 1] : 0.0) : task.gamma;
-        const double din_here = need ? buf.rec_din[at] : 0.0;
-        const bool has_next = j_end < n;
-        const double s_next = has_next ? sc[j_end] : 0.0;
-        const double c_last = has_costs ? (has_next ? cs[j_end - 1] : 0.0) : task.gamma;
-        const long long at_next = at + S;
-        const bool next_exact = (need && has_next) ? ((buf.rec_flags[at_next] & 1U) != 0U) : false;
-        const double din_next = (need && has_next) ? buf.rec_din[at_next] : 0.0;
-        unsigned prev_d = 0, prev_v = 0;
-        if (need && k > 0) {
-            prev_d = buf.rec_d[at - S];
-            prev_v = buf.rec_v[at - S];
-        }
-        if (fresh) {
-            P1 = P0 + din_here;
-            stepping = true;
-            D = 0;
-            V = 0;
-        }
-        if (need) {
-            ++stepped;
-        }
+        // ---- fetch the group's details: one memory latency ----
+        const long long g0 = k * kChunk;  // first locus of the group
+        {
+            unsigned fl[kGroup + 1];
+            double dv[kGroup + 1];
+            double gv[kGroup];
 #pragma unroll
-        for (int i = 0; i < kChunk; ++i) {
-            const long long j = j0 + i;
-            const double s_j = read_lane_f64(sv, i);
-            const double c_prev = (i == 0) ? c_prev0 : read_lane_f64(cvr, i - 1);
-            if (need && j < n) {
-                if (j == 0) {
+            for (int c = 0; c <= kGroup; ++c) {
+                const bool in = active && (k + c < nchunks);
+                const long long a2 = task.rec_off + (in ? (k + c) : 0) * S + (active ? lane : 0);
+                fl[c] = in ? buf.rec_flags[a2] : 1U;
+                dv[c] = in ? buf.rec_din[a2] : 0.0;
+                if (c < kGroup) {
+                    gv[c] = in ? buf.rec_gain[a2] : 0.0;
+                }
+            }
+            double sv[kGroupLoci / 64], cv[kGroupLoci / 64];
+#pragma unroll
+            for (int qq = 0; qq < kGroupLoci / 64; ++qq) {
+                const long long j = g0 + qq * 64 + lane;
+                sv[qq] = (j < n) ? sc[j] : 0.0;
+                cv[qq] = has_costs ? ((j > 0 && j < n) ? cs[j - 1] : 0.0) : task.gamma;
+            }
+            const long long jx = g0 + kGroupLoci;
+            const double s_x = (jx < n) ? sc[jx] : 0.0;
+            const double c_x = has_costs ? ((jx < n) ? cs[jx - 1] : 0.0) : task.gamma;
+            __syncthreads();  // the previous group's readers are done
+#pragma unroll
+            for (int c = 0; c <= kGroup; ++c) {
+                sh_fl[c][lane] = (uint8_t)(fl[c] & 1U);
+                sh_din[c][lane] = dv[c];
+                if (c < kGroup) {
+                    sh_gain[c][lane] = gv[c];
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < kGroupLoci / 64; ++qq) {
+                sh_s[qq * 64 + lane] = sv[qq];
+                sh_c[qq * 64 + lane] = cv[qq];
+            }
+            if (lane == 0) {
+                sh_s[kGroupLoci] = s_x;
+                sh_c[kGroupLoci] = c_x;
+            }
+            __syncthreads();
+        }
+        // ---- chunk by chunk, from LDS ----
+        const int c_end = (int)((nchunks - k < kGroup) ? (nchunks - k) : kGroup);
+#pragma unroll 1
+        for (int c = 0; c < c_end; ++c) {
+            const long long kk = k + c;
+            const long long at = task.rec_off + kk * S + lane;
+            const bool exact_here = active ? (sh_fl[c][lane] != 0) : true;
+            const bool need = active && (stepping || !exact_here);
+            if (active && !need) {
+                P0 += sh_gain[c][lane];
+            }
+            if (!__any(need)) {
+                continue;
+            }
+            const long long j0 = kk * kChunk;
+            const long long j_end = j0 + kChunk;  // first locus of the next chunk
+            const bool fresh = need && !stepping;  // was synchronised: enter with the parallel delta
+            const bool has_next = j_end < n;
+            const bool next_exact = need && has_next && (sh_fl[c + 1][lane] != 0);
+            const double din_next = sh_din[c + 1][lane];
+            if (fresh) {
+                P1 = P0 + sh_din[c][lane];
+                stepping = true;
+                D = 0;
+                V = 0;
+            }
+            if (need) {
+                ++stepped;
+            }
+            const int steps = (int)((n - j0 < kChunk) ? (n - j0) : kChunk);
+            double srow[kChunk], crow[kChunk];  // the chunk's rows, read ahead of the dependent chain
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) {
+                srow[i] = sh_s[c * kChunk + i];
+                crow[i] = sh_c[c * kChunk + i];
+            }
+            // step 0 classifies the last locus of the previous chunk (or starts the chromosome)
+            if (need) {
+                const double s_j = srow[0];
+                const double c_prev = crow[0];
+                if (j0 == 0) {
                     P0 = 0.0;
                     P1 = s_j - lam;  // rocco/_chain_dp.c:109-112
                 } else {
@@ -1818,35 +1912,71 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
                     const bool te = enter >= keep;
                     const unsigned dbit = (tl || te) ? 1U : 0U;  // class of locus j-1: ONE / ZERO / COPY
                     const unsigned vbit = tl ? 1U : 0U;
-                    if (i == 0) {
-                        // last locus of the previous chunk
-                        const long long prev = at - S;
-                        buf.rec_d[prev] = (prev_d & 0x7FFFFFFFU) | (dbit << 31);
-                        buf.rec_v[prev] = (prev_v & 0x7FFFFFFFU) | (vbit << 31);
+                    const long long prev = at - S;
+                    if (pend_at == prev) {
+                        buf.rec_d[prev] = pend_d | (dbit << 31);
+                        buf.rec_v[prev] = pend_v | (vbit << 31);
+                        pend_at = -1;
                     } else {
-                        D |= dbit << (i - 1);
-                        V |= vbit << (i - 1);
+                        // the previous chunk was not stepped by this lane: patch its word in place
+                        if (dbit) {
+                            atomicOr(&buf.rec_d[prev], 0x80000000U);
+                        } else {
+                            atomicAnd(&buf.rec_d[prev], 0x7FFFFFFFU);
+                        }
+                        if (vbit) {
+                            atomicOr(&buf.rec_v[prev], 0x80000000U);
+                        } else {
+                            atomicAnd(&buf.rec_v[prev], 0x7FFFFFFFU);
+                        }
                     }
                     P0 = tl ? leave : P0;
                     P1 = te ? enter : keep;
                 }
             }
-        }
-        // end of chunk k for the stepping lanes
-        if (!has_next) {
-            if (need) {
-                const int il = (int)(n - 1 - j0);
-                const unsigned one = (P1 > P0) ? 1U : 0U;  // rocco/_chain_dp.c:167-179, tie -> state 0
-                D |= 1U << il;
-                V |= one << il;
-                buf.rec_d[at] = D;
-                buf.rec_v[at] = V;
+            // steps 1..: every lane runs them on copies (no per-step masking); only the lanes that
+            // needed the chunk keep the result
+            double p0 = P0, p1 = P1;
+            unsigned dd = D, vv = V;
+#pragma unroll
+            for (int i = 1; i < kChunk; ++i) {
+                if (i >= steps) {
+                    break;
+                }
+                const double s_j = srow[i];
+                const double c_prev = crow[i];
+                const double leave = p1 - c_prev;
+                const double keep = p1 + s_j - lam;
+                const double enter = p0 - c_prev + s_j - lam;
+                const bool tl = leave > p0;
+                const bool te = enter >= keep;
+                dd |= ((tl || te) ? 1U : 0U) << (i - 1);
+                vv |= (tl ? 1U : 0U) << (i - 1);
+                p0 = tl ? leave : p0;
+                p1 = te ? enter : keep;
             }
-        } else {
-            const bool resync = need && next_exact && ((P1 - P0) == din_next);
             if (need) {
+                P0 = p0;
+                P1 = p1;
+                D = dd;
+                V = vv;
+            }
+            // end of chunk kk for the stepping lanes
+            if (!has_next) {
+                if (need) {
+                    const int il = (int)(n - 1 - j0);
+                    const unsigned one = (P1 > P0) ? 1U : 0U;  // rocco/_chain_dp.c:167-179, tie -> state 0
+                    D |= 1U << il;
+                    V |= one << il;
+                    buf.rec_d[at] = D;
+                    buf.rec_v[at] = V;
+                }
+            } else if (need) {
+                const bool resync = next_exact && ((P1 - P0) == din_next);
                 if (resync) {
                     // decision of the next step classifies this chunk's last locus; state untouched
+                    const double s_next = sh_s[(c + 1) * kChunk];
+                    const double c_last = sh_c[(c + 1) * kChunk];
                     const double leave = P1 - c_last;
                     const double keep = P1 + s_next - lam;
                     const double enter = P0 - c_last + s_next - lam;
@@ -1855,14 +1985,19 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
                     D |= ((tl || te) ? 1U : 0U) << 31;
                     V |= (tl ? 1U : 0U) << 31;
                     stepping = false;
+                    buf.rec_d[at] = D;
+                    buf.rec_v[at] = V;
+                } else {
+                    // bit 31 is filled in by the next chunk's first step
+                    pend_at = at;
+                    pend_d = D;
+                    pend_v = V;
                 }
-                // bit 31 of a chunk that keeps stepping is filled in by the next chunk's first step
-                buf.rec_d[at] = D;
-                buf.rec_v[at] = V;
                 D = 0;
                 V = 0;
             }
         }
+        }  // groups of the block
     }
     if (active) {
         atomicAdd(reinterpret_cast<unsigned long long *>(&buf.results[task.slot_begin + lane].uncertain),
@@ -1874,7 +2009,7 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
 __global__ __launch_bounds__(kFastThreads) void fill_from_classes_kernel(FastLaunch L, const int *solution_slot)
 {
     __shared__ unsigned lds_u[16];
-    const int2 bm = L.blockmap[blockIdx.x];
+    const int2 bm = L.blockmap[blockIdx.x / L.slot_groups];
     const FastTask task = L.tasks[bm.x];
     const int local_block = bm.y;
     const long long chunk = (long long)local_block * kFastThreads + threadIdx.x;
@@ -1887,7 +2022,7 @@ __global__ __launch_bounds__(kFastThreads) void fill_from_classes_kernel(FastLau
         const long long left = task.n - j0;
         validmask = (left >= kChunk) ? 0xFFFFFFFFU : ((1U << left) - 1U);
     }
-    for (int si = 0; si < S; ++si) {
+    for (int si = (int)(blockIdx.x % L.slot_groups); si < S; si += L.slot_groups) {
         const FastSlot slot = L.slots[task.slot_begin + si];
         if (slot.mode != kModeRecord) {
             continue;
@@ -1974,21 +2109,22 @@ int launch_fast_round(const FastLaunch &L, hipStream_t stream)
         attr_set = true;
     }
     const dim3 grid((unsigned)L.n_blocks_total), block(kFastThreads);
+    const dim3 grid_split((unsigned)(L.n_blocks_total * L.slot_groups));  // K1 / K3: slots spread over workgroups
     const unsigned scan_blocks = (unsigned)(L.n_chains + L.n_slots);
     const unsigned fill_blocks = (unsigned)(2 * L.n_slots);
 
     if (L.any_plain) {
-        hipLaunchKernelGGL((fast_aggregate_kernel<false>), grid, block, lds_plain, stream, L);
+        hipLaunchKernelGGL((fast_aggregate_kernel<false>), grid_split, block, lds_plain, stream, L);
     }
     if (L.any_costs) {
-        hipLaunchKernelGGL((fast_aggregate_kernel<true>), grid, block, lds_costs, stream, L);
+        hipLaunchKernelGGL((fast_aggregate_kernel<true>), grid_split, block, lds_costs, stream, L);
     }
     hipLaunchKernelGGL(fast_blockscan_kernel, dim3(scan_blocks), dim3(64), 0, stream, L);
     if (L.any_plain) {
-        hipLaunchKernelGGL((fast_apply_kernel<false>), grid, block, lds_plain, stream, L);
+        hipLaunchKernelGGL((fast_apply_kernel<false>), grid_split, block, lds_plain, stream, L);
     }
     if (L.any_costs) {
-        hipLaunchKernelGGL((fast_apply_kernel<true>), grid, block, lds_costs, stream, L);
+        hipLaunchKernelGGL((fast_apply_kernel<true>), grid_split, block, lds_costs, stream, L);
     }
     hipLaunchKernelGGL(fast_fillscan_kernel, dim3(fill_blocks), dim3(64), 0, stream, L);
     if (L.any_window) {
@@ -2001,7 +2137,33 @@ int launch_fast_round(const FastLaunch &L, hipStream_t stream)
     return ROCCO_HIP_OK;
 }
 
-int launch_spine(const FastLaunch &L, const int *solution_slot_dev, hipStream_t stream)
+// Last tree of a bisection: walk it with the exact counts (rocco/dp.py:139-151: count > target moves the
+// lower end, otherwise the upper end) and name the slot whose penalty is the final upper end.
+__global__ void spine_select_kernel(FastLaunch L, int *solution_slot)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L.n_tasks) {
+        return;
+    }
+    const FastTask &task = L.tasks[t];
+    if (task.sel_depth <= 0 || task.slot_count == 0 || L.slots[task.slot_begin].mode != kModeRecord) {
+        return;
+    }
+    int i = 0;
+    int answer = task.slot_count - 1;  // the current upper end
+    for (int level = 0; level < task.sel_depth; ++level) {
+        if (L.buf.results[task.slot_begin + i].count_lo > task.sel_target) {
+            i = 2 * i + 2;
+        } else {
+            answer = i;
+            i = 2 * i + 1;
+        }
+    }
+    solution_slot[t] = task.slot_begin + answer;
+    L.buf.results[task.slot_begin].e_global = answer;  // reported to the host
+}
+
+int launch_spine(const FastLaunch &L, int *solution_slot_dev, bool any_select, hipStream_t stream)
 {
     if (L.n_tasks == 0 || L.n_blocks_total == 0) {
         return ROCCO_HIP_OK;
@@ -2009,8 +2171,16 @@ int launch_spine(const FastLaunch &L, const int *solution_slot_dev, hipStream_t 
     const dim3 grid((unsigned)L.n_blocks_total), block(kFastThreads);
     const unsigned fill_blocks = (unsigned)(2 * L.n_slots);
     hipLaunchKernelGGL(spine_kernel, dim3((unsigned)L.n_tasks), dim3(64), 0, stream, L);
-    hipLaunchKernelGGL(fill_from_classes_kernel, grid, block, 0, stream, L, solution_slot_dev);
+    hipLaunchKernelGGL(fill_from_classes_kernel, dim3((unsigned)(L.n_blocks_total * L.slot_groups)), block, 0, stream,
+                       L, solution_slot_dev);
     hipLaunchKernelGGL(fast_fillscan_kernel, dim3(fill_blocks), dim3(64), 0, stream, L);
+    if (any_select) {
+        // the counts are known now: pick the answer on the device and materialise it
+        hipLaunchKernelGGL(spine_select_kernel, dim3((unsigned)((L.n_tasks + 63) / 64)), dim3(64), 0, stream, L,
+                           solution_slot_dev);
+        hipLaunchKernelGGL(fill_from_classes_kernel, dim3((unsigned)(L.n_blocks_total * L.slot_groups)), block, 0,
+                           stream, L, solution_slot_dev);
+    }
     hipLaunchKernelGGL(spine_patch_kernel, dim3((unsigned)L.n_blocks_all), block, 0, stream, L, solution_slot_dev);
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;

@@ -299,6 +299,12 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     SpineRequest r;
                     r.problem = b;
                     r.lambdas = s.tree;
+                    if (s.tree_depth == s.iters_left && s.tree.size() < 64) {
+                        // the last tree: let the evaluator also pick and materialise the answer
+                        r.lambdas.push_back(s.upper);
+                        r.select_depth = s.tree_depth;
+                        r.select_target = s.target;
+                    }
                     spines.push_back(r);
                     spine_owner.push_back(b);
                     break;
@@ -450,6 +456,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 continue;
             }
             size_t i = 0;
+            size_t answer = r.lambdas.size() - 1;  // index of the final penalty when this was the last tree
             for (int level = 0; level < s.tree_depth; ++level) {
                 ++s.out.evaluations;
                 --s.iters_left;
@@ -458,11 +465,20 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     i = 2 * i + 2;
                 } else {
                     s.upper = r.lambdas[i];
+                    answer = i;
                     i = 2 * i + 1;
                 }
             }
             if (s.iters_left <= 0) {
-                s.phase = State::kFinalSpine;
+                if (r.select_depth > 0 && r.selected == (int)answer) {
+                    // the evaluator walked the same path and wrote that solution already
+                    s.out.selection_penalty = s.upper;
+                    s.out.selected_count = r.counts[answer];
+                    s.out.path = ROCCO_HIP_PATH_SPINE;
+                    s.phase = State::kDone;
+                } else {
+                    s.phase = State::kFinalSpine;
+                }
             }
         }
 

@@ -89,6 +89,13 @@ struct SpineRequest {
     size_t problem = 0;
     std::vector<double> lambdas;   // <= 64
     int solution_index = -1;       // write the solution of lambdas[solution_index]
+    // Last tree of a bisection: lambdas = the tree in heap order followed by the current upper end.
+    // An evaluator that supports it walks the tree itself (count > select_target: right child, else
+    // this node becomes the answer and the walk goes left), writes that penalty's solution and
+    // reports its index in `selected`; otherwise it leaves selected = -1.
+    int select_depth = 0;
+    long long select_target = 0;
+    int selected = -1;
     std::vector<long long> counts; // filled by the evaluator
     std::vector<long long> stepped; // diagnostic: chunks the spine had to step exactly
 };
