@@ -12,7 +12,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librocco_hip.so")
+LIB_PATH = os.environ.get("ROCCO_HIP_LIBRARY") or os.path.join(_HERE, "librocco_hip.so")  # override: A/B builds
 
 OK, ENOMEM, EINVAL, EHIP = 0, -1, -2, -3
 PATH_CERTIFIED, PATH_EXACT, PATH_TRIVIAL, PATH_SPINE = 1, 2, 3, 4

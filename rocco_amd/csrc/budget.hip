@@ -766,6 +766,9 @@ private:
                 if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
                     std::fprintf(stderr, "[spine] problem %zu: lane 0 stepped %lld chunks of %lld\n", rt[t].problem,
                                  (long long)hr[ft.slot_begin].uncertain, (long long)((p.n + kChunk - 1) / kChunk));
+                    std::fprintf(stderr, "[spine] prof (100 MHz ticks): fetch %lld loop %lld (steps %lld) slow groups %lld\n",
+                                 hr[ft.slot_begin].p16, hr[ft.slot_begin].npos, hr[ft.slot_begin].max_run,
+                                 hr[ft.slot_begin].n_diff);
                 }
                 continue;
             }

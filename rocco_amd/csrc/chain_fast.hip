@@ -1739,6 +1739,14 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
     double P0 = 0.0, P1 = 0.0;
     bool stepping = true;  // chunk 0 is always stepped (the map never marks it clean)
     unsigned D = 0, V = 0;  // class word under construction for the chunk being stepped
+#ifdef SPINE_PROF
+    long long t_fetch = 0, t_loop = 0, t_step = 0, n_slow = 0;
+#define SPINE_T0() const long long t0_ = wall_clock64()
+#define SPINE_T1(acc) acc += wall_clock64() - t0_
+#else
+#define SPINE_T0()
+#define SPINE_T1(acc)
+#endif
     long long pend_at = -1;  // class word of the previous chunk, waiting for its bit 31
     unsigned pend_d = 0, pend_v = 0;
     long long stepped = 0;
@@ -1817,6 +1825,10 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
         }
         // ---- fetch the group's details: one memory latency ----
         const long long g0 = k * kChunk;  // first locus of the group
+#ifdef SPINE_PROF
+        ++n_slow;
+        const long long tf0 = wall_clock64();
+#endif
         {
             unsigned fl[kGroup + 1];
             double dv[kGroup + 1];
@@ -1861,6 +1873,10 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
             }
             __syncthreads();
         }
+#ifdef SPINE_PROF
+        t_fetch += wall_clock64() - tf0;
+        const long long tl0 = wall_clock64();
+#endif
         // ---- chunk by chunk, from LDS ----
         const int c_end = (int)((nchunks - k < kGroup) ? (nchunks - k) : kGroup);
 #pragma unroll 1
@@ -1891,6 +1907,9 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
                 ++stepped;
             }
             const int steps = (int)((n - j0 < kChunk) ? (n - j0) : kChunk);
+#ifdef SPINE_PROF
+            const long long ts0 = wall_clock64();
+#endif
             double srow[kChunk], crow[kChunk];  // the chunk's rows, read ahead of the dependent chain
 #pragma unroll
             for (int i = 0; i < kChunk; ++i) {
@@ -1938,22 +1957,37 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
             // needed the chunk keep the result
             double p0 = P0, p1 = P1;
             unsigned dd = D, vv = V;
+            if (steps == kChunk) {
 #pragma unroll
-            for (int i = 1; i < kChunk; ++i) {
-                if (i >= steps) {
-                    break;
+                for (int i = 1; i < kChunk; ++i) {  // fully unrolled: the rows stay in registers
+                    const double s_j = srow[i];
+                    const double c_prev = crow[i];
+                    const double leave = p1 - c_prev;
+                    const double keep = p1 + s_j - lam;
+                    const double enter = p0 - c_prev + s_j - lam;
+                    const bool tl = leave > p0;
+                    const bool te = enter >= keep;
+                    dd |= ((tl || te) ? 1U : 0U) << (i - 1);
+                    vv |= (tl ? 1U : 0U) << (i - 1);
+                    p0 = tl ? leave : p0;
+                    p1 = te ? enter : keep;
                 }
-                const double s_j = srow[i];
-                const double c_prev = crow[i];
-                const double leave = p1 - c_prev;
-                const double keep = p1 + s_j - lam;
-                const double enter = p0 - c_prev + s_j - lam;
-                const bool tl = leave > p0;
-                const bool te = enter >= keep;
-                dd |= ((tl || te) ? 1U : 0U) << (i - 1);
-                vv |= (tl ? 1U : 0U) << (i - 1);
-                p0 = tl ? leave : p0;
-                p1 = te ? enter : keep;
+            } else {
+                // the chromosome's last, partial chunk: straight from LDS
+#pragma unroll 1
+                for (int i = 1; i < steps; ++i) {
+                    const double s_j = sh_s[c * kChunk + i];
+                    const double c_prev = sh_c[c * kChunk + i];
+                    const double leave = p1 - c_prev;
+                    const double keep = p1 + s_j - lam;
+                    const double enter = p0 - c_prev + s_j - lam;
+                    const bool tl = leave > p0;
+                    const bool te = enter >= keep;
+                    dd |= ((tl || te) ? 1U : 0U) << (i - 1);
+                    vv |= (tl ? 1U : 0U) << (i - 1);
+                    p0 = tl ? leave : p0;
+                    p1 = te ? enter : keep;
+                }
             }
             if (need) {
                 P0 = p0;
@@ -1961,6 +1995,9 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
                 D = dd;
                 V = vv;
             }
+#ifdef SPINE_PROF
+            t_step += wall_clock64() - ts0;
+#endif
             // end of chunk kk for the stepping lanes
             if (!has_next) {
                 if (need) {
@@ -1997,8 +2034,20 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
                 V = 0;
             }
         }
+#ifdef SPINE_PROF
+        t_loop += wall_clock64() - tl0;
+#endif
         }  // groups of the block
     }
+#ifdef SPINE_PROF
+    if (lane == 0) {
+        FastSlotResult &r0 = buf.results[task.slot_begin];
+        r0.p16 = t_fetch;
+        r0.npos = t_loop;
+        r0.max_run = t_step;
+        r0.n_diff = n_slow;
+    }
+#endif
     if (active) {
         atomicAdd(reinterpret_cast<unsigned long long *>(&buf.results[task.slot_begin + lane].uncertain),
                   (unsigned long long)stepped);  // diagnostic: chunks stepped exactly
