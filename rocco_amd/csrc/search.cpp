@@ -72,6 +72,8 @@ struct State {
     double map_lo = 0.0, map_hi = 0.0;  // penalties the current binade map is valid for
     bool point_pending = false;         // the map is a point map at the next midpoint: probe it alone
     double req_ref = 0.0, req_lo = 0.0, req_hi = 0.0, req_margin = 0.0;  // map being requested
+    double map_margin = 0.0;                                              // margin of the map in use
+    double survey_width = -1.0;                                           // bracket width at the last survey
     long long lower_count = 0;   // selected loci at `lower` (bounds the count anywhere in the bracket)
     long long upper_count = -1;  // selected loci at `upper` (-1: not evaluated yet)
     Phase after_map = kBisect;
@@ -233,9 +235,12 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 round_loci += (double)problems[b].n * ev.work_fraction(b);
             }
         }
-        const int spec_depth = (round_loci > opt.big_round_loci)
-                                   ? 1
-                                   : ((round_loci < opt.small_round_loci) ? opt.spec_depth + 1 : opt.spec_depth);
+        const int spec_depth =
+            (round_loci > opt.big_round_loci)
+                ? 1
+                : ((round_loci < opt.tiny_round_loci)
+                       ? opt.spec_depth + 3
+                       : ((round_loci < opt.small_round_loci) ? opt.spec_depth + 1 : opt.spec_depth));
 
         for (size_t b = 0; b < B; ++b) {
             const ChainProblem &p = problems[b];
@@ -314,7 +319,13 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     const double mid = (s.lower + s.upper) / 2.0;
                     const bool inside = (s.map_lo <= s.lower && s.upper <= s.map_hi);
                     const bool point_ok = s.point_pending && s.map_lo == mid && s.map_hi == mid;
-                    if ((!inside && !point_ok) || (inside && (s.map_hi - s.map_lo) > 16.0 * width)) {
+                    // a map built for a much wider bracket carries a larger hazard margin than needed:
+                    // rebuild it once that margin would shrink materially
+                    const double reach = p.cost_max + (p.score_max - p.score_min) + 2.0;
+                    const double margin_now = reach + 2.0 * width * (double)s.lower_count + 2.0;
+                    const bool stale = inside && (s.map_hi - s.map_lo) > 16.0 * width &&
+                                       margin_now < opt.map_rebuild_ratio * s.map_margin;
+                    if ((!inside && !point_ok) || stale) {
                         // the map does not cover this bracket, or the bracket shrank a lot since it was
                         // built (its hazard margin can shrink too)
                         plan_map(p, s, false);
@@ -326,6 +337,21 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                         maps.push_back(r);
                         map_owner.push_back(b);
                         break;
+                    }
+                }
+                if (!s.use_exact && s.has_map && !s.point_pending && s.map_lo < s.map_hi && s.upper_count >= 0 &&
+                    (s.survey_width < 0.0 || s.survey_width > 16.0 * (s.upper - s.lower))) {
+                    // the map covers the whole bracket: when few loci can still change inside it, let the
+                    // evaluator find the settled parts so that later rounds skip them
+                    const long long diffs = s.lower_count - s.upper_count;
+                    const long long blocks = (long long)(p.n / 8192) + 1;
+                    if ((double)diffs <= opt.survey_gate * (double)blocks) {
+                        WindowRequest w;
+                        w.problem = b;
+                        w.lambda_lo = s.lower;
+                        w.lambda_hi = s.upper;
+                        surveys.push_back(w);
+                        s.survey_width = s.upper - s.lower;
                     }
                 }
                 s.tree_depth = std::min(s.use_exact ? opt.exact_depth : spec_depth, s.iters_left);
@@ -410,21 +436,8 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 s.has_map = true;
                 s.map_lo = s.req_lo;
                 s.map_hi = s.req_hi;
+                s.map_margin = s.req_margin;
                 s.phase = s.after_map;
-                if (s.map_lo < s.map_hi && s.phase == State::kBisect && s.upper_count >= 0) {
-                    // a map for the whole bracket: when few loci can still change inside it, let the
-                    // evaluator find the settled parts so that later rounds skip them
-                    const ChainProblem &p = problems[map_owner[q]];
-                    const long long diffs = s.lower_count - s.upper_count;
-                    const long long blocks = (long long)(p.n / 8192) + 1;
-                    if ((double)diffs <= opt.survey_gate * (double)blocks) {
-                        WindowRequest w;
-                        w.problem = map_owner[q];
-                        w.lambda_lo = s.lower;
-                        w.lambda_hi = s.upper;
-                        surveys.push_back(w);
-                    }
-                }
             }
         }
         if (!surveys.empty() && (rc = ev.survey(surveys)) != ROCCO_HIP_OK) {

@@ -149,6 +149,8 @@ struct SearchOptions {
     // latency-bound when they cover few (speculating deeper saves launches)
     double big_round_loci = 1.0e18;     // above: one level per round
     double small_round_loci = 1.0e6;   // below: spec_depth + 1 levels per round
+    double tiny_round_loci = 0.3e6;     // below: spec_depth + 3 levels per round
+    double map_rebuild_ratio = 0.8;    // rebuild a bracket map when its margin would shrink below this ratio
     double survey_gate = 0.5;          // survey a bracket when (loci that can still change) <= gate * workgroups
     int exact_depth = 6;    // same for the exact kernel (63 lanes)
     bool force_exact = false;
