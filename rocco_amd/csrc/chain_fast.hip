@@ -151,6 +151,26 @@ __device__ __forceinline__ void stage_tile(const FastTask &task, int local_block
     const double *__restrict__ cs = task.switch_costs;
     const long long n = task.n;
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(s) & 15U) == 0);
+    if (!HAS_COSTS && aligned16 && base + kFastBlockLoci <= n) {
+        // whole tile in range (workgroup-uniform): unconditional 16-byte loads, all in flight together.
+        // (Loads inside per-element conditionals are waited for one by one.)
+        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(s + base) + threadIdx.x;
+        const double2 v0 = src[0 * kFastThreads], v1 = src[1 * kFastThreads], v2 = src[2 * kFastThreads],
+                      v3 = src[3 * kFastThreads], v4 = src[4 * kFastThreads], v5 = src[5 * kFastThreads],
+                      v6 = src[6 * kFastThreads], v7 = src[7 * kFastThreads], v8 = src[8 * kFastThreads],
+                      v9 = src[9 * kFastThreads], v10 = src[10 * kFastThreads], v11 = src[11 * kFastThreads],
+                      v12 = src[12 * kFastThreads], v13 = src[13 * kFastThreads], v14 = src[14 * kFastThreads],
+                      v15 = src[15 * kFastThreads];
+        static_assert(kChunk / 2 == 16, "tile staging is written out for 16 loads per lane");
+        auto put = [&](int r, const double2 &v) {
+            const int e = 2 * (r * kFastThreads + (int)threadIdx.x);
+            *reinterpret_cast<double2 *>(lds_s + (e >> 5) * kLdsStride + (e & 31)) = v;
+        };
+        put(0, v0); put(1, v1); put(2, v2); put(3, v3); put(4, v4); put(5, v5); put(6, v6); put(7, v7);
+        put(8, v8); put(9, v9); put(10, v10); put(11, v11); put(12, v12); put(13, v13); put(14, v14); put(15, v15);
+        __syncthreads();
+        return;
+    }
 #pragma unroll 4
     for (int r = 0; r < kChunk / 2; ++r) {
         const int e = 2 * (r * kFastThreads + (int)threadIdx.x);  // even element index in the tile
@@ -626,7 +646,7 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
 }
 
 template <bool HAS_COSTS>
-__global__ __launch_bounds__(kFastThreads) void fast_aggregate_kernel(FastLaunch L)
+__global__ __launch_bounds__(kFastThreads, 2) void fast_aggregate_kernel(FastLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *lds_s = smem;
@@ -1382,7 +1402,7 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
 }
 
 template <bool HAS_COSTS>
-__global__ __launch_bounds__(kFastThreads) void fast_apply_kernel(FastLaunch L)
+__global__ __launch_bounds__(kFastThreads, 2) void fast_apply_kernel(FastLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *lds_s = smem;
