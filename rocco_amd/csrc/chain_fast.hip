@@ -559,11 +559,19 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         Fn g = f[k];
+        const double last_lo = __shfl(f[k].lo, 63), last_hi = __shfl(f[k].hi, 63);
+        if (last_lo == last_hi) {
+            // the wavefront's last chunk function is constant: so is the composition, with that value
+            g.a = 0.0;
+            g.lo = last_lo;
+            g.hi = last_hi;
+        } else {
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const Fn p = shfl_down_fn(g, off);
-            if (lane + off < 64) {
-                g = compose(g, p, big);
+            for (int off = 1; off < 64; off <<= 1) {
+                const Fn p = shfl_down_fn(g, off);
+                if (lane + off < 64) {
+                    g = compose(g, p, big);
+                }
             }
         }
         if (lane == 0) {
@@ -576,20 +584,33 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
     long long lcg = (lc >= 0) ? (j0 + lc) : -1;
     int wflag = (lc >= 0) ? 1 : 0;
     double wval = wsum;
+    if (!__any(wsum != 0.0 || p16 != 0 || npos != 0)) {
+        // no weights and no noise sums in this wavefront: only the clear-clamp index is reduced
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int pf = __shfl_down(wflag, off);
-        const double pv = __shfl_down(wval, off);
-        const long long pl = __shfl_down(lcg, off);
-        const long long pp = __shfl_down(p16, off);
-        const long long pn = __shfl_down(npos, off);
-        if (lane + off < 64) {
-            // own is the left operand, partner the right one
-            wval = pf ? pv : (wval + pv);
-            wflag = wflag | pf;
-            lcg = (pl > lcg) ? pl : lcg;
-            p16 += pp;
-            npos += pn;
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long pl = __shfl_down(lcg, off);
+            const int pf = __shfl_down(wflag, off);
+            if (lane + off < 64) {
+                lcg = (pl > lcg) ? pl : lcg;
+                wflag = wflag | pf;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int pf = __shfl_down(wflag, off);
+            const double pv = __shfl_down(wval, off);
+            const long long pl = __shfl_down(lcg, off);
+            const long long pp = __shfl_down(p16, off);
+            const long long pn = __shfl_down(npos, off);
+            if (lane + off < 64) {
+                // own is the left operand, partner the right one
+                wval = pf ? pv : (wval + pv);
+                wflag = wflag | pf;
+                lcg = (pl > lcg) ? pl : lcg;
+                p16 += pp;
+                npos += pn;
+            }
         }
     }
     long long *lds_ll = reinterpret_cast<long long *>(lds_red + 24);
@@ -911,11 +932,15 @@ __device__ __forceinline__ double incoming_delta(const FastBuffers &buf, const F
         f.hi = buf.agg_hi[ch.chunk_off + chunk];
     }
     Fn inc = f;
+    // anything composed with a constant function is that constant: when every chunk function of the
+    // wavefront has coalesced (the usual case) the inclusive scan is the functions themselves
+    if (!__all(f.lo == f.hi)) {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const Fn p = shfl_up_fn(inc, off);
-        if (lane >= off) {
-            inc = compose(p, inc, big);
+        for (int off = 1; off < 64; off <<= 1) {
+            const Fn p = shfl_up_fn(inc, off);
+            if (lane >= off) {
+                inc = compose(p, inc, big);
+            }
         }
     }
     if (lane == 63) {
@@ -948,12 +973,19 @@ __device__ __forceinline__ double incoming_delta(const FastBuffers &buf, const F
 
 // exclusive in-workgroup scans of the clear-clamp index (max) and of the tolerance weight
 // (segmented sum: a chunk with a clear clamp restarts the sum)
-__device__ __forceinline__ void incoming_clear(long long own_lc, double own_w, long long block_lc,
-                                               double block_w, long long *lds_ll, double *lds_w,
-                                               long long &lc_in, double &w_in)
+__device__ __forceinline__ void incoming_clear(long long own_lc, double own_w, bool own_any_weight,
+                                               long long block_lc, double block_w, long long *lds_ll,
+                                               double *lds_w, long long &lc_in, double &w_in)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    if (__syncthreads_and((!own_any_weight && block_w == 0.0) ? 1 : 0)) {
+        // no tolerance weight in or before this workgroup's chunks: tau is zero everywhere in it, and
+        // the clear-clamp index (only used where tau > 0) does not matter
+        lc_in = block_lc;
+        w_in = 0.0;
+        return;
+    }
     long long inc = own_lc;
     int flag = (own_lc >= 0) ? 1 : 0;
     double val = own_w;
@@ -1049,7 +1081,8 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     const double own_w = valid ? buf.w_chunk[slot.chunk_off + chunk] : 0.0;
     long long lc;
     double wacc;
-    incoming_clear(own_lc, own_w, (long long)buf.lcin_block[slot.block_off + local_block],
+    incoming_clear(own_lc, own_w, valid && anyw,
+                   (long long)buf.lcin_block[slot.block_off + local_block],
                    buf.win_block[slot.block_off + local_block], lds_ll, lds_w, lc, wacc);
     // a task is either mapped everywhere or nowhere, so one scale applies to the incoming weight too
     wacc *= wscale;
