@@ -81,10 +81,16 @@ def main():
 
     def one_step():
         res = pipeline.solve_rank(works)
-        local = {}
-        for idx, r in zip(mine, res):
-            local[idx] = torch.stack([r["begin"], r["end"]], dim=1).cpu().numpy() if r["begin"].numel() else \
-                np.zeros((0, 2), dtype=np.int64)
+        # intervals of every owned chromosome to the host in ONE transfer
+        counts = [int(r["begin"].numel()) for r in res]
+        if sum(counts):
+            flat = torch.cat([torch.stack([r["begin"], r["end"]], dim=1) for r in res if r["begin"].numel()]).cpu().numpy()
+        else:
+            flat = np.zeros((0, 2), dtype=np.int64)
+        local, at = {}, 0
+        for idx, c in zip(mine, counts):
+            local[idx] = flat[at:at + c]
+            at += c
         merged = shard.gather_intervals(local, device=device) if world > 1 else local
         return res, merged
 
@@ -129,10 +135,21 @@ def main():
         esize = big.matrix_t.element_size()
         alg_bytes = (esize * K + 8) * big.n  # 8K read + 8 written per locus
         achieved = alg_bytes / (dur_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 on gfx950 +
+        # WRITE_SIZE, separate runs; profiles/README.md) -- only when they were taken on this very launch
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_median.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+            if int(pmc.get("K", -1)) == K and int(pmc.get("n", -1)) == big.n and esize == 8:
+                traffic = int(round(pmc["traffic_bytes_per_launch"]))
+                traffic_src = "profiles/r01_pmc_median.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         roofline = {"bound": "hbm", "kernel": f"median_kernel<K={K}> on {big.name} (n={big.n})",
                     "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "avg_kernel_ms": round(dur_ms, 4),
-                    "algorithmic_bytes_per_launch": int(alg_bytes), "traffic": None}
+                    "algorithmic_bytes_per_launch": int(alg_bytes), "traffic": traffic,
+                    "traffic_source": traffic_src}
         for r in res:
             paths[r["name"]] = {"path": r["path"], "passes": r["info"]["passes"], "maps": r["info"].get("maps", 0),
                                 "zone_iters": r["info"].get("zone_iters", -1)}

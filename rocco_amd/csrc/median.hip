@@ -55,7 +55,16 @@ template <typename T, int KP, bool EXACT>
 __global__ __launch_bounds__(256) void median_kernel(const T *__restrict__ m, int K_runtime, long long n,
                                                      long long stride, double *__restrict__ out)
 {
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Rows are not aligned to
+    // cache lines (n is arbitrary), so neighbouring workgroups share the line that straddles their
+    // boundary in every row: give each XCD one contiguous range of loci so that the shared lines meet
+    // in one L2 instead of being fetched from memory twice.
+    const unsigned nblk = gridDim.x;
+    const unsigned per = nblk / 8U, rem = nblk % 8U;
+    const unsigned xcd = blockIdx.x % 8U, slot = blockIdx.x / 8U;
+    // XCD x owns per + (x < rem) workgroups, laid out one range after the other
+    const unsigned logical = xcd * per + (xcd < rem ? xcd : rem) + slot;
+    const long long j = (long long)logical * blockDim.x + threadIdx.x;
     if (j >= n) {
         return;
     }
