@@ -69,9 +69,25 @@ public:
 
     std::vector<DevProblem> probs;
 
-    int probe(std::vector<ProbeRequest> &reqs) override
+    struct RoundTask {
+        size_t problem = 0;
+        bool window = false;
+        bool map = false;
+        bool record = false;
+        bool survey = false;
+        bool use_frozen = false;
+        int solution_index = -1;
+        int select_depth = 0;
+        long long select_target = 0;
+        double margin = 0.0;
+        std::vector<double> lambdas;
+        ProbeRequest *probe = nullptr;
+        WindowRequest *win = nullptr;
+        SpineRequest *spine = nullptr;
+    };
+
+    void add_probe_tasks(std::vector<ProbeRequest> &reqs, std::vector<RoundTask> &tasks)
     {
-        std::vector<RoundTask> tasks;
         for (ProbeRequest &r : reqs) {
             r.results.assign(r.lambdas.size(), ProbeResult());
             if (r.lambdas.empty()) {
@@ -84,12 +100,17 @@ public:
             t.probe = &r;
             tasks.push_back(t);
         }
+    }
+
+    int probe(std::vector<ProbeRequest> &reqs) override
+    {
+        std::vector<RoundTask> tasks;
+        add_probe_tasks(reqs, tasks);
         return run_round(tasks);
     }
 
-    int window(std::vector<WindowRequest> &reqs) override
+    void add_window_tasks(std::vector<WindowRequest> &reqs, std::vector<RoundTask> &tasks)
     {
-        std::vector<RoundTask> tasks;
         for (WindowRequest &r : reqs) {
             RoundTask t;
             t.problem = r.problem;
@@ -98,12 +119,18 @@ public:
             t.win = &r;
             tasks.push_back(t);
         }
+    }
+
+    int window(std::vector<WindowRequest> &reqs) override
+    {
+        std::vector<RoundTask> tasks;
+        add_window_tasks(reqs, tasks);
         return run_round(tasks);
     }
 
-    int survey(std::vector<WindowRequest> &reqs) override
+    int add_survey_tasks(std::vector<WindowRequest> &reqs, std::vector<RoundTask> &tasks)
     {
-        if (solver_->active_set == 0) {
+        if (solver_->active_set == 0 || reqs.empty()) {
             return ROCCO_HIP_OK;
         }
         int rc;
@@ -140,7 +167,6 @@ public:
             }
             frozen_allocated_ = true;
         }
-        std::vector<RoundTask> tasks;
         for (WindowRequest &r : reqs) {
             if (probs[r.problem].emap == nullptr) {
                 continue;
@@ -152,6 +178,16 @@ public:
             t.lambdas = {r.lambda_lo, r.lambda_hi};
             t.win = &r;
             tasks.push_back(t);
+        }
+        return ROCCO_HIP_OK;
+    }
+
+    int survey(std::vector<WindowRequest> &reqs) override
+    {
+        std::vector<RoundTask> tasks;
+        const int rc = add_survey_tasks(reqs, tasks);
+        if (rc != ROCCO_HIP_OK) {
+            return rc;
         }
         return run_round(tasks);
     }
@@ -165,8 +201,11 @@ public:
         return (double)p.active_blocks.size() / (double)p.frz_flags.size();
     }
 
-    int build_map(std::vector<MapRequest> &reqs) override
+    int add_map_tasks(std::vector<MapRequest> &reqs, std::vector<RoundTask> &tasks)
     {
+        if (reqs.empty()) {
+            return ROCCO_HIP_OK;
+        }
         // carve (once) a map region per problem out of the solver's map buffer
         if (!maps_allocated_) {
             size_t total = 0;
@@ -183,7 +222,6 @@ public:
             }
             maps_allocated_ = true;
         }
-        std::vector<RoundTask> tasks;
         for (MapRequest &r : reqs) {
             RoundTask t;
             t.problem = r.problem;
@@ -192,19 +230,33 @@ public:
             t.lambdas = {r.lambda_ref};
             tasks.push_back(t);
         }
-        const int rc = run_round(tasks);
-        if (rc != ROCCO_HIP_OK) {
-            return rc;
-        }
-        for (MapRequest &r : reqs) {
-            probs[r.problem].emap = map_ptrs_[r.problem];
-        }
         return ROCCO_HIP_OK;
     }
 
-    int spine(std::vector<SpineRequest> &reqs) override
+    void adopt_maps(std::vector<MapRequest> &reqs)
+    {
+        for (MapRequest &r : reqs) {
+            probs[r.problem].emap = map_ptrs_[r.problem];
+        }
+    }
+
+    int build_map(std::vector<MapRequest> &reqs) override
     {
         std::vector<RoundTask> tasks;
+        int rc = add_map_tasks(reqs, tasks);
+        if (rc != ROCCO_HIP_OK) {
+            return rc;
+        }
+        rc = run_round(tasks);
+        if (rc != ROCCO_HIP_OK) {
+            return rc;
+        }
+        adopt_maps(reqs);
+        return ROCCO_HIP_OK;
+    }
+
+    int add_spine_tasks(std::vector<SpineRequest> &reqs, std::vector<RoundTask> &tasks)
+    {
         for (SpineRequest &r : reqs) {
             if (r.lambdas.empty() || r.lambdas.size() > 64 || probs[r.problem].emap == nullptr) {
                 return ROCCO_HIP_EINVAL;
@@ -219,7 +271,33 @@ public:
             t.spine = &r;
             tasks.push_back(t);
         }
+        return ROCCO_HIP_OK;
+    }
+
+    int spine(std::vector<SpineRequest> &reqs) override
+    {
+        std::vector<RoundTask> tasks;
+        const int rc = add_spine_tasks(reqs, tasks);
+        if (rc != ROCCO_HIP_OK) {
+            return rc;
+        }
         return run_round(tasks);
+    }
+
+    // every request of one search iteration in a single device pass
+    int round(std::vector<MapRequest> &maps, std::vector<WindowRequest> &surveys, std::vector<ProbeRequest> &probes,
+              std::vector<WindowRequest> &windows, std::vector<SpineRequest> &spines) override
+    {
+        std::vector<RoundTask> tasks;
+        int rc;
+        if ((rc = add_map_tasks(maps, tasks)) != ROCCO_HIP_OK) return rc;
+        if ((rc = add_survey_tasks(surveys, tasks)) != ROCCO_HIP_OK) return rc;
+        add_probe_tasks(probes, tasks);
+        add_window_tasks(windows, tasks);
+        if ((rc = add_spine_tasks(spines, tasks)) != ROCCO_HIP_OK) return rc;
+        if ((rc = run_round(tasks)) != ROCCO_HIP_OK) return rc;
+        adopt_maps(maps);
+        return ROCCO_HIP_OK;
     }
 
     int exact(std::vector<ExactRequest> &reqs) override
@@ -362,22 +440,6 @@ public:
     long long blocks_launched = 0;
 
 private:
-    struct RoundTask {
-        size_t problem = 0;
-        bool window = false;
-        bool map = false;
-        bool record = false;
-        bool survey = false;
-        bool use_frozen = false;
-        int solution_index = -1;
-        int select_depth = 0;
-        long long select_target = 0;
-        double margin = 0.0;
-        std::vector<double> lambdas;
-        ProbeRequest *probe = nullptr;
-        WindowRequest *win = nullptr;
-        SpineRequest *spine = nullptr;
-    };
 
     int run_round(std::vector<RoundTask> &rt)
     {
@@ -434,26 +496,26 @@ private:
             launched[t].clear();
             if (use_frozen) {
                 ft.frz = p.frz;
+                // the flags are read from a copy uploaded with the descriptors: a survey of the same
+                // problem may be rewriting the live ones in this very round
+                skip_off[t] = (long long)skip_bytes.size();
+                std::vector<uint8_t> skip(p.frz_flags);
                 if (rt[t].record) {
                     // the spine may still be stepping when it leaves an active block: also evaluate
                     // the block after each active one (it resynchronises there)
-                    skip_off[t] = (long long)skip_bytes.size();
-                    std::vector<uint8_t> skip(p.frz_flags);
                     for (int k : p.active_blocks) {
                         if (k + 1 < nblocks) {
                             skip[k + 1] = 0;
                         }
                     }
-                    for (int k = 0; k < nblocks; ++k) {
-                        if (!skip[k]) {
-                            launched[t].push_back(k);
-                        }
-                    }
-                    skip.resize(align_up((size_t)nblocks, 64), 0);
-                    skip_bytes.insert(skip_bytes.end(), skip.begin(), skip.end());
-                } else {
-                    launched[t] = p.active_blocks;
                 }
+                for (int k = 0; k < nblocks; ++k) {
+                    if (!skip[k]) {
+                        launched[t].push_back(k);
+                    }
+                }
+                skip.resize(align_up((size_t)nblocks, 64), 0);
+                skip_bytes.insert(skip_bytes.end(), skip.begin(), skip.end());
             } else {
                 for (int k = 0; k < nblocks; ++k) {
                     launched[t].push_back(k);

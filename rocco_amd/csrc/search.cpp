@@ -425,34 +425,20 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
             break;
         }
         int rc;
-        if (!maps.empty()) {
-            if ((rc = ev.build_map(maps)) != ROCCO_HIP_OK) {
-                return rc;
-            }
-            for (size_t q = 0; q < maps.size(); ++q) {
-                State &s = st[map_owner[q]];
-                ++s.out.passes;
-                ++s.out.maps;
-                s.has_map = true;
-                s.map_lo = s.req_lo;
-                s.map_hi = s.req_hi;
-                s.map_margin = s.req_margin;
-                s.phase = s.after_map;
-            }
-        }
-        if (!surveys.empty() && (rc = ev.survey(surveys)) != ROCCO_HIP_OK) {
+        if ((rc = ev.round(maps, surveys, probes, windows, spines)) != ROCCO_HIP_OK) {
             return rc;
         }
-        if (!probes.empty() && (rc = ev.probe(probes)) != ROCCO_HIP_OK) {
-            return rc;
-        }
-        if (!windows.empty() && (rc = ev.window(windows)) != ROCCO_HIP_OK) {
-            return rc;
+        for (size_t q = 0; q < maps.size(); ++q) {
+            State &s = st[map_owner[q]];
+            ++s.out.passes;
+            ++s.out.maps;
+            s.has_map = true;
+            s.map_lo = s.req_lo;
+            s.map_hi = s.req_hi;
+            s.map_margin = s.req_margin;
+            s.phase = s.after_map;
         }
         if (!exacts.empty() && (rc = ev.exact(exacts)) != ROCCO_HIP_OK) {
-            return rc;
-        }
-        if (!spines.empty() && (rc = ev.spine(spines)) != ROCCO_HIP_OK) {
             return rc;
         }
 

@@ -117,6 +117,21 @@ public:
         (void)reqs;
         return 0;
     }
+    // One search iteration's device work.  Requests of different kinds never depend on each other
+    // inside an iteration (a problem asks for a map OR a probe OR a window OR a spine; a survey may
+    // accompany a probe and only prunes later rounds), so an evaluator may run them all in one pass.
+    virtual int round(std::vector<MapRequest> &maps, std::vector<WindowRequest> &surveys,
+                      std::vector<ProbeRequest> &probes, std::vector<WindowRequest> &windows,
+                      std::vector<SpineRequest> &spines)
+    {
+        int rc;
+        if (!maps.empty() && (rc = build_map(maps)) != 0) return rc;
+        if (!surveys.empty() && (rc = survey(surveys)) != 0) return rc;
+        if (!probes.empty() && (rc = probe(probes)) != 0) return rc;
+        if (!windows.empty() && (rc = window(windows)) != 0) return rc;
+        if (!spines.empty() && (rc = spine(spines)) != 0) return rc;
+        return 0;
+    }
     // Fraction of a problem's loci that rounds inside the surveyed bracket still evaluate.
     virtual double work_fraction(size_t problem) const
     {
