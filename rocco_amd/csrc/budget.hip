@@ -75,6 +75,7 @@ public:
         bool map = false;
         bool record = false;
         bool survey = false;
+        bool bound = false;
         bool use_frozen = false;
         int solution_index = -1;
         int select_depth = 0;
@@ -96,6 +97,7 @@ public:
             RoundTask t;
             t.problem = r.problem;
             t.window = false;
+            t.bound = r.bound;
             t.lambdas = r.lambdas;
             t.probe = &r;
             tasks.push_back(t);
@@ -484,7 +486,7 @@ private:
             ft.frz_out = FrozenArrays{};
             // rounds inside the surveyed bracket skip the frozen blocks (the final zone windows and
             // the spine always run over everything: they materialise the solution)
-            bool use_frozen = p.frz_valid && !no_frozen_ && solver_->active_set != 0;
+            bool use_frozen = p.frz_valid && !no_frozen_ && solver_->active_set != 0 && !rt[t].bound;
             if (use_frozen) {
                 for (double lam : rt[t].lambdas) {
                     if (!(lam >= p.frz_lo && lam <= p.frz_hi) || lambda_ties_some_grid(lam, p.qexp)) {
@@ -560,7 +562,8 @@ private:
                 for (double lam : rt[t].lambdas) {
                     FastSlot s;
                     s.task = (int)t;
-                    s.mode = rt[t].map ? kModeMap : (rt[t].record ? kModeRecord : kModeProbe);
+                    s.mode = rt[t].map ? kModeMap
+                                       : (rt[t].record ? kModeRecord : (rt[t].bound ? kModeBound : kModeProbe));
                     s.chain_a = s.chain_b = (int)chains.size();
                     s.chunk_off = slot_chunks;
                     s.block_off = slot_blocks;
@@ -862,8 +865,8 @@ private:
                     const FastSlotResult &r = hr[ft.slot_begin + k];
                     ProbeResult &o = rt[t].probe->results[k];
                     o.count = r.count_lo;
-                    o.uncertain = r.uncertain;
-                    o.effect = r.overflow ? (long long)p.n + 1 : r.effect;
+                    o.uncertain = rt[t].bound ? 0 : r.uncertain;
+                    o.effect = rt[t].bound ? 0 : (r.overflow ? (long long)p.n + 1 : r.effect);
                     o.max_run = r.max_run;
                 }
             }
@@ -1115,6 +1118,7 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_SURVEY_GATE")) opt.survey_gate = std::atof(e);
     if (const char *e = std::getenv("ROCCO_HIP_TINY_ROUND")) opt.tiny_round_loci = std::atof(e);
     if (const char *e = std::getenv("ROCCO_HIP_MAP_REBUILD")) opt.map_rebuild_ratio = std::atof(e);
+    if (const char *e = std::getenv("ROCCO_HIP_BOUNDS")) opt.use_bounds = std::atoi(e) != 0;
     std::vector<CalibrationResult> res;
     if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
     for (size_t t = 0; t < n_tasks; ++t) {

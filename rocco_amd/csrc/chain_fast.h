@@ -19,7 +19,9 @@ constexpr int kMapBias = 64;                           // == ORACLE_MAP_BIAS
 constexpr int kMapNone = 0xFF;                         // == ORACLE_MAP_NONE
 constexpr int kMaxDiffs = 16;
 
-enum FastMode { kModeProbe = 0, kModeWindow = 1, kModeMap = 2, kModeRecord = 3 };
+// kModeBound: exact arithmetic on the grid q with no rounding model at all (like a map round, but it
+// counts): evaluated at lambda -/+ epsilon it brackets the reference's count at lambda
+enum FastMode { kModeProbe = 0, kModeWindow = 1, kModeMap = 2, kModeRecord = 3, kModeBound = 4 };
 
 // Per-workgroup summaries of "frozen" blocks (valid for every penalty of a surveyed bracket): all
 // chunks clean with one binade exponent and no rounding tie, identical classes at both ends of the

@@ -231,7 +231,7 @@ __device__ __forceinline__ double raw_cost_at(const FastTask &task, const ChunkD
 
 __device__ __forceinline__ int chunk_code(const FastTask &task, const FastSlot &slot, long long chunk, bool valid)
 {
-    if (!valid || slot.mode == kModeMap || task.emap == nullptr) {
+    if (!valid || slot.mode == kModeMap || slot.mode == kModeBound || task.emap == nullptr) {
         return kMapNone;
     }
     return (int)task.emap[chunk];
@@ -422,7 +422,8 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
         lam[NCH - 1] = chains[slot.chain_b].lambda;
     }
     const int code = chunk_code(task, slot, chunk, valid);
-    const bool need_noise = (code == kMapNone) && slot.mode != kModeMap;  // map rounds certify nothing
+    // map and bound rounds certify nothing
+    const bool need_noise = (code == kMapNone) && slot.mode != kModeMap && slot.mode != kModeBound;
     Mode mode[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
@@ -1081,7 +1082,7 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     const double own_w = valid ? buf.w_chunk[slot.chunk_off + chunk] : 0.0;
     long long lc;
     double wacc;
-    incoming_clear(own_lc, own_w, valid && anyw,
+    incoming_clear(own_lc, own_w, valid && anyw && slot.mode != kModeBound,
                    (long long)buf.lcin_block[slot.block_off + local_block],
                    buf.win_block[slot.block_off + local_block], lds_ll, lds_w, lc, wacc);
     // a task is either mapped everywhere or nowhere, so one scale applies to the incoming weight too
@@ -1101,12 +1102,16 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     if (NCH == 1) {
         const bool interior = valid && j0 > 0 && (j0 + kChunk < n);
         const bool map_round = (slot.mode == kModeMap);
+        const bool bound_round = (slot.mode == kModeBound);
         const bool lane_lean =
-            interior && (map_round || (mode[0].clean && mode[0].mapped && !anyw && wacc == 0.0));
+            interior && (map_round || bound_round || (mode[0].clean && mode[0].mapped && !anyw && wacc == 0.0));
         if (__all(lane_lean)) {
             done = true;
             validmask = 0xFFFFFFFFU;
-            if (map_round) {
+            if (bound_round) {
+                lean_apply_steps<false, HAS_COSTS, false, true>(d.sv, d.cv, d.c_prev0, task.gamma, magic, lam[0],
+                                                                delta[0], gain, D_lo, V_lo);
+            } else if (map_round) {
                 lean_apply_steps<false, HAS_COSTS, true, false>(d.sv, d.cv, d.c_prev0, task.gamma, magic, lam[0],
                                                                 delta[0], gain, D_lo, V_lo);
             } else if (slot.mode == kModeRecord) {

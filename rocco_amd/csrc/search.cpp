@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "../../include/rocco_hip.h"
 
@@ -74,6 +76,12 @@ struct State {
     double req_ref = 0.0, req_lo = 0.0, req_hi = 0.0, req_margin = 0.0;  // map being requested
     double map_margin = 0.0;                                              // margin of the map in use
     double survey_width = -1.0;                                           // bracket width at the last survey
+    // bound probes (exact arithmetic at lambda -/+ eps brackets the reference's count at lambda)
+    bool bound_ok = false;
+    bool bound_round = false;     // the probe request of this iteration is a bound request
+    double eps = 0.0;
+    int retry_sign = 0;           // the root was inconclusive with the other sign
+    std::vector<int> tree_sign;
     long long lower_count = 0;   // selected loci at `lower` (bounds the count anywhere in the bracket)
     long long upper_count = -1;  // selected loci at `upper` (-1: not evaluated yet)
     Phase after_map = kBisect;
@@ -168,6 +176,32 @@ void plan_map(const ChainProblem &p, State &s, bool force_bracket)
 
 }  // namespace
 
+// Shift that makes exact arithmetic on the grid q bracket the reference: every
+// step of the reference's recursion, seen through delta = prev1 - prev0, differs from the exact step by
+// at most w = 4 hb + q and its comparisons have slack 9 hb + 2 q, hb = 2^(e+2-53) with 2^(e+1) above every
+// running value (same constants as the hazard mode of oracle/delta_oracle.c; here e comes from an
+// a-priori bound valid for every penalty that is not decided analytically).  With eps >= w + slack, a
+// multiple of q:  count_q(lambda + eps) <= count_reference(lambda) <= count_q(lambda - eps).
+static bool bound_epsilon(const ChainProblem &p, double *eps_out)
+{
+    const double range = (p.score_max - p.score_min) + 2.0;  // penalties evaluated lie in [s_min - 1, s_max + 1]
+    const double sabs = std::max(std::fabs(p.score_min), std::fabs(p.score_max));
+    const double pb = 2.0 * ((double)p.n * (range + 0.0625) + std::max(p.cost_max, 0.0) + 2.0 * sabs + 4.0);
+    if (!(pb > 0.0) || !std::isfinite(pb) || !(p.cost_min >= 0.0)) {
+        return false;
+    }
+    const int e = std::ilogb(pb);
+    const double r = std::max(p.cost_max, 0.0) + (p.score_max - p.score_min) + 2.0;
+    const int qexp = (int)std::ceil(std::log2(8.0 * r)) - 52;
+    const double hb = std::ldexp(1.0, e + 2 - 53);
+    const double q = std::ldexp(1.0, qexp);
+    if (!(hb >= q)) {
+        return false;
+    }
+    *eps_out = 16.0 * hb + 4.0 * q;
+    return true;
+}
+
 bool analytic_count(const ChainProblem &p, double lambda, long long *count_out)
 {
     // every partial sum of the reference stays far below 2^50 so that a margin of 1 in every
@@ -217,6 +251,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
         s.phase = (s.target == (long long)p.n) ? State::kAll : State::kLowerBracket;
         s.out.zone_iters = -1;
         s.lower_count = (long long)p.n;
+        s.bound_ok = opt.use_bounds && !s.use_exact && bound_epsilon(p, &s.eps);
     }
 
     for (;;) {
@@ -312,6 +347,39 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     }
                     spines.push_back(r);
                     spine_owner.push_back(b);
+                    break;
+                }
+                s.bound_round = false;
+                if (!s.use_exact && s.bound_ok) {
+                    // decide the next levels from exact-arithmetic counts at node -/+ eps: one sign per
+                    // node, chosen by where the count is expected to fall (a wrong guess costs a retry)
+                    s.tree_depth = std::min(spec_depth, s.iters_left);
+                    build_tree(s.lower, s.upper, s.tree_depth, s.tree);
+                    ProbeRequest r;
+                    r.problem = b;
+                    r.bound = true;
+                    s.tree_slot.assign(s.tree.size(), -1);
+                    s.tree_sign.assign(s.tree.size(), 0);
+                    const double c_lo = (double)s.lower_count;
+                    const double c_hi = (double)std::max(0LL, s.upper_count);
+                    long long unused = 0;
+                    for (size_t i = 0; i < s.tree.size(); ++i) {
+                        if (analytic_count(p, s.tree[i], &unused)) {
+                            continue;
+                        }
+                        const double t = (s.tree[i] - s.lower) / (s.upper - s.lower);
+                        const double expected = c_lo + (c_hi - c_lo) * t;
+                        int sign = (expected > (double)s.target) ? +1 : -1;
+                        if (i == 0 && s.retry_sign != 0) {
+                            sign = s.retry_sign;
+                        }
+                        s.tree_sign[i] = sign;
+                        s.tree_slot[i] = (int)r.lambdas.size();
+                        r.lambdas.push_back(s.tree[i] + (double)sign * s.eps);
+                    }
+                    s.bound_round = true;
+                    probes.push_back(r);
+                    probe_owner.push_back(b);
                     break;
                 }
                 if (!s.use_exact && s.has_map) {
@@ -508,8 +576,57 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 }
                 continue;
             }
-            // kBisect: walk the evaluated levels while the outcomes are certain
             const ChainProblem &p = problems[probe_owner[q]];
+            if (s.bound_round) {
+                // node + eps counted above the target: the reference's count is above it too;
+                // node - eps counted at or below it: so is the reference's.  Anything else says nothing.
+                size_t i = 0;
+                for (int level = 0; level < s.tree_depth; ++level) {
+                    Outcome o = Outcome::kUncertain;
+                    long long c = 0;
+                    if (s.tree_slot[i] < 0) {
+                        analytic_count(p, s.tree[i], &c);
+                        o = (c > s.target) ? Outcome::kGreater : Outcome::kLessEqual;
+                    } else {
+                        c = r.results[(size_t)s.tree_slot[i]].count;
+                        if (s.tree_sign[i] > 0 && c > s.target) {
+                            o = Outcome::kGreater;
+                        } else if (s.tree_sign[i] < 0 && c <= s.target) {
+                            o = Outcome::kLessEqual;
+                        }
+                    }
+                    if (std::getenv("ROCCO_SEARCH_DEBUG") != nullptr) {
+                        std::fprintf(stderr, "[bound] level-in-round %d node %.17g sign %d eval-count %lld target %lld -> %s (eps %.3g)\n",
+                                     level, s.tree[i], s.tree_slot[i] < 0 ? 0 : s.tree_sign[i], c, s.target,
+                                     o == Outcome::kGreater ? "greater" : (o == Outcome::kLessEqual ? "lessequal" : "unknown"), s.eps);
+                    }
+                    if (o == Outcome::kUncertain) {
+                        if (level == 0 && s.retry_sign != 0) {
+                            // both signs tried: the target lies inside the bracketing counts -> from here
+                            // on the rounding model proper decides (binade maps, windows, spine)
+                            s.bound_ok = false;
+                            s.retry_sign = 0;
+                        } else {
+                            s.retry_sign = -s.tree_sign[i];
+                        }
+                        break;
+                    }
+                    s.retry_sign = 0;
+                    ++s.out.evaluations;
+                    --s.iters_left;
+                    if (o == Outcome::kGreater) {
+                        s.lower = s.tree[i];
+                        s.lower_count = c;
+                        i = 2 * i + 2;
+                    } else {
+                        s.upper = s.tree[i];
+                        s.upper_count = c;
+                        i = 2 * i + 1;
+                    }
+                }
+                continue;
+            }
+            // kBisect: walk the evaluated levels while the outcomes are certain
             size_t i = 0;
             for (int level = 0; level < s.tree_depth; ++level) {
                 Outcome o;
@@ -601,8 +718,12 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 // every remaining probe selects count_lo <= target loci: upper = mid each step
                 replay_with_critical(s, -INFINITY);
                 certified = true;
-            } else if (!w.overflow && w.n_diff == 1 && w.diff_adjacent && w.count_lo <= s.target &&
+            } else if (!(opt.use_spine && opt.exact_penalty && s.has_map && s.map_lo <= s.lower &&
+                         s.upper <= s.map_hi) &&
+                       !w.overflow && w.n_diff == 1 && w.diff_adjacent && w.count_lo <= s.target &&
                        w.count_hi > s.target && !w.diffs.empty()) {
+                // (only when the exact spine cannot take over: it returns the reference's penalty bit
+                // for bit, this rule to within the interpolation of the crossing)
                 // exactly one decision separates the two candidates; the reference keeps the one
                 // within budget.  The reported penalty follows the crossing of that decision.
                 const WindowDiff &d = w.diffs[0];

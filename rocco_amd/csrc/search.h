@@ -56,6 +56,10 @@ struct ExactResult {
 // One batch round of device work.  Indices refer to the problems of the batch.
 struct ProbeRequest {
     size_t problem = 0;
+    // bound = true: evaluate every lambda in exact arithmetic on the problem's grid q with no rounding
+    // model (results carry only `count`); the caller shifts lambda by -/+ epsilon to bracket the
+    // reference's count
+    bool bound = false;
     std::vector<double> lambdas;
     std::vector<ProbeResult> results;  // filled by the evaluator
 };
@@ -166,6 +170,8 @@ struct SearchOptions {
     double small_round_loci = 1.0e6;   // below: spec_depth + 1 levels per round
     double tiny_round_loci = 0.3e6;     // below: spec_depth + 3 levels per round
     double map_rebuild_ratio = 0.8;    // rebuild a bracket map when its margin would shrink below this ratio
+    bool exact_penalty = true;         // settle a lone open decision through the spine (penalty bit-exact)
+    bool use_bounds = true;            // decide early bisection steps with shifted exact-arithmetic counts
     double survey_gate = 0.5;          // survey a bracket when (loci that can still change) <= gate * workgroups
     int exact_depth = 6;    // same for the exact kernel (63 lanes)
     bool force_exact = false;

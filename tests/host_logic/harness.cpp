@@ -5,6 +5,7 @@
 // certification / replay logic can be checked against the reference without a GPU.
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/rocco_hip.h"
@@ -45,12 +46,14 @@ public:
             r.results.resize(r.lambdas.size());
             for (size_t i = 0; i < r.lambdas.size(); ++i) {
                 oracle_delta_stats st;
+                // bound requests: plain grid-q arithmetic (= the map-less evaluation), count only
                 const int rc = oracle_delta_chain_f64(p.scores, p.costs, p.gamma, p.n, r.lambdas[i], p.qexp,
-                                                      p.cmax, p.sabs, p.emap.empty() ? nullptr : p.emap.data(), nullptr, &st);
+                                                      p.cmax, p.sabs,
+                                                      (r.bound || p.emap.empty()) ? nullptr : p.emap.data(), nullptr, &st);
                 if (rc != 0) return rc;
                 r.results[i].count = st.count;
-                r.results[i].uncertain = st.uncertain;
-                r.results[i].effect = st.overflow ? (long long)p.n + 1 : st.effect;
+                r.results[i].uncertain = r.bound ? 0 : st.uncertain;
+                r.results[i].effect = r.bound ? 0 : (st.overflow ? (long long)p.n + 1 : st.effect);
                 r.results[i].max_run = st.max_run;
             }
         }
@@ -189,6 +192,7 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     SearchOptions opt;
     opt.spec_depth = spec_depth;
     opt.force_exact = force_exact != 0;
+    if (const char *e = std::getenv("ROCCO_HIP_BOUNDS")) opt.use_bounds = std::atoi(e) != 0;
     std::vector<CalibrationResult> res;
     const int rc = calibrate_batch(ev, {p}, opt, res);
     if (rc != 0) return rc;
