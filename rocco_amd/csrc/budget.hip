@@ -396,7 +396,7 @@ public:
     int compute_stats(std::vector<double> &out)
     {
         const size_t B = probs.size();
-        out.assign(4 * B, 0.0);
+        out.assign(5 * B, 0.0);
         if (B == 0) {
             return ROCCO_HIP_OK;
         }
@@ -410,8 +410,8 @@ public:
         const size_t nbt = blockmap.size();
         const size_t bytes_tasks = align_up(B * sizeof(StatsTask), 256);
         const size_t bytes_map = align_up(nbt * sizeof(int2), 256);
-        const size_t bytes_part = align_up(nbt * 4 * sizeof(double), 256);
-        const size_t bytes_out = align_up(B * 4 * sizeof(double), 256);
+        const size_t bytes_part = align_up(nbt * 5 * sizeof(double), 256);
+        const size_t bytes_out = align_up(B * 5 * sizeof(double), 256);
         int rc;
         if ((rc = solver_->dev_misc.reserve(bytes_tasks + bytes_map + bytes_part + bytes_out)) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_stage.reserve(bytes_tasks + bytes_map)) != ROCCO_HIP_OK) return rc;
@@ -432,9 +432,9 @@ public:
                                d_out, stream_)) != ROCCO_HIP_OK) {
             return rc;
         }
-        ROCCO_HIP_TRY(hipMemcpyAsync(solver_->host_back.ptr, d_out, B * 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        ROCCO_HIP_TRY(hipMemcpyAsync(solver_->host_back.ptr, d_out, B * 5 * sizeof(double), hipMemcpyDeviceToHost, stream_));
         ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
-        std::memcpy(out.data(), solver_->host_back.ptr, B * 4 * sizeof(double));
+        std::memcpy(out.data(), solver_->host_back.ptr, B * 5 * sizeof(double));
         return ROCCO_HIP_OK;
     }
 
@@ -893,11 +893,12 @@ int prepare(HipEvaluator &ev, std::vector<ChainProblem> &problems, const std::ve
     for (size_t b = 0; b < problems.size(); ++b) {
         ChainProblem &p = problems[b];
         DevProblem &d = ev.probs[b];
-        p.score_min = stats[4 * b + 0];
-        p.score_max = stats[4 * b + 1];
+        p.score_min = stats[5 * b + 0];
+        p.score_max = stats[5 * b + 1];
+        p.score_abs_sum = stats[5 * b + 4];
         if (d.costs != nullptr && d.n > 1) {
-            p.cost_min = stats[4 * b + 2];
-            p.cost_max = stats[4 * b + 3];
+            p.cost_min = stats[5 * b + 2];
+            p.cost_max = stats[5 * b + 3];
             p.has_cost_vector = true;
         } else {
             p.cost_min = p.cost_max = d.gamma;
@@ -1119,6 +1120,7 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_TINY_ROUND")) opt.tiny_round_loci = std::atof(e);
     if (const char *e = std::getenv("ROCCO_HIP_MAP_REBUILD")) opt.map_rebuild_ratio = std::atof(e);
     if (const char *e = std::getenv("ROCCO_HIP_BOUNDS")) opt.use_bounds = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ROCCO_HIP_BOTH_MARGIN")) opt.bound_both_margin = std::atof(e);
     std::vector<CalibrationResult> res;
     if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
     for (size_t t = 0; t < n_tasks; ++t) {

@@ -148,7 +148,8 @@ int launch_fast_round(const FastLaunch &L, hipStream_t stream);
 // reference's exact classes for every slot; then counts (and one solution per task) are rebuilt.
 int launch_spine(const FastLaunch &L, int *solution_slot_dev, bool any_select, hipStream_t stream);
 
-// min / max of scores (and of switch costs) per task: out[4 * t + {0,1,2,3}] = smin, smax, cmin, cmax
+// min / max of scores (and of switch costs) and sum |score| per task:
+// out[5 * t + {0,1,2,3,4}] = smin, smax, cmin, cmax, sum_abs
 struct StatsTask {
     const double *scores;
     const double *switch_costs;

@@ -1651,41 +1651,26 @@ __global__ __launch_bounds__(kFastThreads) void fast_mapcode_kernel(FastLaunch L
     }
 }
 
-// ---- stats: min / max of scores and costs --------------------------------------------------------
-__global__ __launch_bounds__(kFastThreads) void stats_partial_kernel(const StatsTask *tasks, const int2 *blockmap,
-                                                                   double *partials)
+// ---- stats: min / max of scores and costs, sum of |score| ------------------------------------------
+// out[5 * t + {0,1,2,3,4}] = smin, smax, cmin, cmax, sum |s| (the last one only bounds running values:
+// any summation order will do)
+constexpr int kStat = 5;
+
+__device__ __forceinline__ void stats_reduce(double (&v)[kStat], double (*red)[kStat])
 {
-    __shared__ double red[4][4];
-    const int2 bm = blockmap[blockIdx.x];
-    const StatsTask t = tasks[bm.x];
-    const long long base = (long long)bm.y * kFastBlockLoci;
-    double smin = INFINITY, smax = -INFINITY, cmin = INFINITY, cmax = -INFINITY;
-    for (int r = 0; r < kChunk; ++r) {
-        const long long j = base + r * kFastThreads + threadIdx.x;
-        if (j < t.n) {
-            const double v = t.scores[j];
-            smin = fmin(smin, v);
-            smax = fmax(smax, v);
-            if (t.switch_costs != nullptr && j < t.n - 1) {
-                const double c = t.switch_costs[j];
-                cmin = fmin(cmin, c);
-                cmax = fmax(cmax, c);
-            }
-        }
-    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        smin = fmin(smin, __shfl_down(smin, off));
-        smax = fmax(smax, __shfl_down(smax, off));
-        cmin = fmin(cmin, __shfl_down(cmin, off));
-        cmax = fmax(cmax, __shfl_down(cmax, off));
+        v[0] = fmin(v[0], __shfl_down(v[0], off));
+        v[1] = fmax(v[1], __shfl_down(v[1], off));
+        v[2] = fmin(v[2], __shfl_down(v[2], off));
+        v[3] = fmax(v[3], __shfl_down(v[3], off));
+        v[4] += __shfl_down(v[4], off);
     }
     if ((threadIdx.x & 63) == 0) {
         const int w = threadIdx.x >> 6;
-        red[w][0] = smin;
-        red[w][1] = smax;
-        red[w][2] = cmin;
-        red[w][3] = cmax;
+        for (int k = 0; k < kStat; ++k) {
+            red[w][k] = v[k];
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1694,9 +1679,37 @@ __global__ __launch_bounds__(kFastThreads) void stats_partial_kernel(const Stats
             red[0][1] = fmax(red[0][1], red[w][1]);
             red[0][2] = fmin(red[0][2], red[w][2]);
             red[0][3] = fmax(red[0][3], red[w][3]);
+            red[0][4] += red[w][4];
         }
-        for (int k = 0; k < 4; ++k) {
-            partials[4LL * blockIdx.x + k] = red[0][k];
+    }
+}
+
+__global__ __launch_bounds__(kFastThreads) void stats_partial_kernel(const StatsTask *tasks, const int2 *blockmap,
+                                                                   double *partials)
+{
+    __shared__ double red[4][kStat];
+    const int2 bm = blockmap[blockIdx.x];
+    const StatsTask t = tasks[bm.x];
+    const long long base = (long long)bm.y * kFastBlockLoci;
+    double v[kStat] = {INFINITY, -INFINITY, INFINITY, -INFINITY, 0.0};
+    for (int r = 0; r < kChunk; ++r) {
+        const long long j = base + r * kFastThreads + threadIdx.x;
+        if (j < t.n) {
+            const double x = t.scores[j];
+            v[0] = fmin(v[0], x);
+            v[1] = fmax(v[1], x);
+            v[4] += fabs(x);
+            if (t.switch_costs != nullptr && j < t.n - 1) {
+                const double c = t.switch_costs[j];
+                v[2] = fmin(v[2], c);
+                v[3] = fmax(v[3], c);
+            }
+        }
+    }
+    stats_reduce(v, red);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < kStat; ++k) {
+            partials[(long long)kStat * blockIdx.x + k] = red[0][k];
         }
     }
 }
@@ -1705,41 +1718,22 @@ __global__ __launch_bounds__(kFastThreads) void stats_final_kernel(const int2 *b
                                                                  const double *partials, double *out)
 {
     // one workgroup per task: reduce the partials of that task's workgroups
-    __shared__ double red[4][4];
+    __shared__ double red[4][kStat];
     const int task = blockIdx.x;
-    double smin = INFINITY, smax = -INFINITY, cmin = INFINITY, cmax = -INFINITY;
+    double v[kStat] = {INFINITY, -INFINITY, INFINITY, -INFINITY, 0.0};
     for (int b = threadIdx.x; b < n_blocks_total; b += kFastThreads) {
         if (blockmap[b].x == task) {
-            smin = fmin(smin, partials[4LL * b + 0]);
-            smax = fmax(smax, partials[4LL * b + 1]);
-            cmin = fmin(cmin, partials[4LL * b + 2]);
-            cmax = fmax(cmax, partials[4LL * b + 3]);
+            v[0] = fmin(v[0], partials[(long long)kStat * b + 0]);
+            v[1] = fmax(v[1], partials[(long long)kStat * b + 1]);
+            v[2] = fmin(v[2], partials[(long long)kStat * b + 2]);
+            v[3] = fmax(v[3], partials[(long long)kStat * b + 3]);
+            v[4] += partials[(long long)kStat * b + 4];
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        smin = fmin(smin, __shfl_down(smin, off));
-        smax = fmax(smax, __shfl_down(smax, off));
-        cmin = fmin(cmin, __shfl_down(cmin, off));
-        cmax = fmax(cmax, __shfl_down(cmax, off));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        const int w = threadIdx.x >> 6;
-        red[w][0] = smin;
-        red[w][1] = smax;
-        red[w][2] = cmin;
-        red[w][3] = cmax;
-    }
-    __syncthreads();
+    stats_reduce(v, red);
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) {
-            red[0][0] = fmin(red[0][0], red[w][0]);
-            red[0][1] = fmax(red[0][1], red[w][1]);
-            red[0][2] = fmin(red[0][2], red[w][2]);
-            red[0][3] = fmax(red[0][3], red[w][3]);
-        }
-        for (int k = 0; k < 4; ++k) {
-            out[4LL * task + k] = red[0][k];
+        for (int k = 0; k < kStat; ++k) {
+            out[(long long)kStat * task + k] = red[0][k];
         }
     }
 }

@@ -82,6 +82,7 @@ struct State {
     double eps = 0.0;
     int retry_sign = 0;           // the root was inconclusive with the other sign
     std::vector<int> tree_sign;
+    std::vector<int> tree_slot2;  // slot of the evaluation with the opposite sign (-1: not evaluated)
     long long lower_count = 0;   // selected loci at `lower` (bounds the count anywhere in the bracket)
     long long upper_count = -1;  // selected loci at `upper` (-1: not evaluated yet)
     Phase after_map = kBisect;
@@ -179,14 +180,16 @@ void plan_map(const ChainProblem &p, State &s, bool force_bracket)
 // Shift that makes exact arithmetic on the grid q bracket the reference: every
 // step of the reference's recursion, seen through delta = prev1 - prev0, differs from the exact step by
 // at most w = 4 hb + q and its comparisons have slack 9 hb + 2 q, hb = 2^(e+2-53) with 2^(e+1) above every
-// running value (same constants as the hazard mode of oracle/delta_oracle.c; here e comes from an
-// a-priori bound valid for every penalty that is not decided analytically).  With eps >= w + slack, a
+// running value (same constants and the same bound on the running values as the hazard mode of
+// oracle/delta_oracle.c, with sum |s| in place of the sum of the positive parts).  With eps >= w + slack, a
 // multiple of q:  count_q(lambda + eps) <= count_reference(lambda) <= count_q(lambda - eps).
-static bool bound_epsilon(const ChainProblem &p, double *eps_out)
+static bool bound_epsilon(const ChainProblem &p, double lambda, double *eps_out)
 {
-    const double range = (p.score_max - p.score_min) + 2.0;  // penalties evaluated lie in [s_min - 1, s_max + 1]
+    // sum_j max(0, s_j - lambda) <= sum |s_j| + n * max(0, -lambda)
     const double sabs = std::max(std::fabs(p.score_min), std::fabs(p.score_max));
-    const double pb = 2.0 * ((double)p.n * (range + 0.0625) + std::max(p.cost_max, 0.0) + 2.0 * sabs + 4.0);
+    const double sum_abs = (p.score_abs_sum >= 0.0) ? (p.score_abs_sum * (1.0 + 1e-9) + 1.0) : ((double)p.n * sabs);
+    const double pos = sum_abs + (double)p.n * std::max(0.0, -lambda);
+    const double pb = 2.0 * (pos + (double)p.n * 0.0625 + std::max(p.cost_max, 0.0) + sabs + std::fabs(lambda) + 1.0);
     if (!(pb > 0.0) || !std::isfinite(pb) || !(p.cost_min >= 0.0)) {
         return false;
     }
@@ -251,7 +254,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
         s.phase = (s.target == (long long)p.n) ? State::kAll : State::kLowerBracket;
         s.out.zone_iters = -1;
         s.lower_count = (long long)p.n;
-        s.bound_ok = opt.use_bounds && !s.use_exact && bound_epsilon(p, &s.eps);
+        s.bound_ok = opt.use_bounds && !s.use_exact && bound_epsilon(p, p.score_min - 1.0, &s.eps);
     }
 
     for (;;) {
@@ -350,6 +353,12 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     break;
                 }
                 s.bound_round = false;
+                if (!s.use_exact && s.bound_ok && s.upper_count >= 0 &&
+                    (double)(s.lower_count - s.upper_count) <= opt.survey_gate * (double)((long long)(p.n / 8192) + 1)) {
+                    // few loci can still change inside the bracket: from here on the rounding model
+                    // with its frozen blocks (rounds that skip the settled parts) is cheaper
+                    s.bound_ok = false;
+                }
                 if (!s.use_exact && s.bound_ok) {
                     // decide the next levels from exact-arithmetic counts at node -/+ eps: one sign per
                     // node, chosen by where the count is expected to fall (a wrong guess costs a retry)
@@ -360,22 +369,37 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     r.bound = true;
                     s.tree_slot.assign(s.tree.size(), -1);
                     s.tree_sign.assign(s.tree.size(), 0);
-                    const double c_lo = (double)s.lower_count;
-                    const double c_hi = (double)std::max(0LL, s.upper_count);
+                    // expected count at a node: log-linear between the bracket ends (the count falls
+                    // steeply and convexly with the penalty); close calls are evaluated with both signs
+                    const bool ends_known = s.upper_count >= 0 && s.lower_count < (long long)p.n;
+                    const double c_lo = std::log((double)std::max(1LL, s.lower_count));
+                    const double c_hi = std::log((double)std::max(1LL, s.upper_count));
+                    s.tree_slot2.assign(s.tree.size(), -1);
                     long long unused = 0;
                     for (size_t i = 0; i < s.tree.size(); ++i) {
                         if (analytic_count(p, s.tree[i], &unused)) {
                             continue;
                         }
+                        double eps = s.eps;
+                        bound_epsilon(p, s.tree[i], &eps);
+                        // where the (log-linear) count is expected to cross the target, as a fraction of
+                        // the bracket; a node well to one side of it is evaluated with one sign only
                         const double t = (s.tree[i] - s.lower) / (s.upper - s.lower);
-                        const double expected = c_lo + (c_hi - c_lo) * t;
-                        int sign = (expected > (double)s.target) ? +1 : -1;
+                        const double tgt = std::log((double)std::max(1LL, s.target));
+                        const double t_cross = (c_lo > c_hi) ? (c_lo - tgt) / (c_lo - c_hi) : 0.5;
+                        int sign = (t < t_cross) ? +1 : -1;
+                        bool both = !ends_known || std::fabs(t - t_cross) < opt.bound_both_margin;
                         if (i == 0 && s.retry_sign != 0) {
                             sign = s.retry_sign;
+                            both = false;
                         }
                         s.tree_sign[i] = sign;
                         s.tree_slot[i] = (int)r.lambdas.size();
-                        r.lambdas.push_back(s.tree[i] + (double)sign * s.eps);
+                        r.lambdas.push_back(s.tree[i] + (double)sign * eps);
+                        if (both) {
+                            s.tree_slot2[i] = (int)r.lambdas.size();
+                            r.lambdas.push_back(s.tree[i] - (double)sign * eps);
+                        }
                     }
                     s.bound_round = true;
                     probes.push_back(r);
@@ -584,6 +608,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 for (int level = 0; level < s.tree_depth; ++level) {
                     Outcome o = Outcome::kUncertain;
                     long long c = 0;
+                    bool both_failed = false;
                     if (s.tree_slot[i] < 0) {
                         analytic_count(p, s.tree[i], &c);
                         o = (c > s.target) ? Outcome::kGreater : Outcome::kLessEqual;
@@ -593,6 +618,17 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                             o = Outcome::kGreater;
                         } else if (s.tree_sign[i] < 0 && c <= s.target) {
                             o = Outcome::kLessEqual;
+                        } else if (s.tree_slot2[i] >= 0) {
+                            const long long c2 = r.results[(size_t)s.tree_slot2[i]].count;  // the opposite sign
+                            if (s.tree_sign[i] < 0 && c2 > s.target) {
+                                o = Outcome::kGreater;
+                                c = c2;
+                            } else if (s.tree_sign[i] > 0 && c2 <= s.target) {
+                                o = Outcome::kLessEqual;
+                                c = c2;
+                            } else {
+                                both_failed = true;
+                            }
                         }
                     }
                     if (std::getenv("ROCCO_SEARCH_DEBUG") != nullptr) {
@@ -601,7 +637,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                                      o == Outcome::kGreater ? "greater" : (o == Outcome::kLessEqual ? "lessequal" : "unknown"), s.eps);
                     }
                     if (o == Outcome::kUncertain) {
-                        if (level == 0 && s.retry_sign != 0) {
+                        if (both_failed || (level == 0 && s.retry_sign != 0)) {
                             // both signs tried: the target lies inside the bracketing counts -> from here
                             // on the rounding model proper decides (binade maps, windows, spine)
                             s.bound_ok = false;

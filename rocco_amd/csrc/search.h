@@ -20,6 +20,7 @@ struct ChainProblem {
     double cost_min = 0.0;  // min / max switch cost (== gamma for the scalar case)
     double cost_max = 0.0;
     double score_min = 0.0, score_max = 0.0;
+    double score_abs_sum = -1.0;  // sum of |score| (any summation order), < 0: unknown
     long long target_count = 0;
     double sum_costs = 0.0;  // np.sum(switch_costs) as NumPy computes it (rocco/dp.py:110-111)
     int max_iter = 60;
@@ -171,6 +172,7 @@ struct SearchOptions {
     double tiny_round_loci = 0.3e6;     // below: spec_depth + 3 levels per round
     double map_rebuild_ratio = 0.8;    // rebuild a bracket map when its margin would shrink below this ratio
     bool exact_penalty = true;         // settle a lone open decision through the spine (penalty bit-exact)
+    double bound_both_margin = 0.15;   // bound probes: both signs when the node is this close (bracket fraction) to the expected crossing
     bool use_bounds = true;            // decide early bisection steps with shifted exact-arithmetic counts
     double survey_gate = 0.5;          // survey a bracket when (loci that can still change) <= gate * workgroups
     int exact_depth = 6;    // same for the exact kernel (63 lanes)

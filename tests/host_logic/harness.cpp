@@ -186,6 +186,13 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     p.cost_max = cmax;
     p.score_min = smin;
     p.score_max = smax;
+    {
+        double sabs_sum = 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            sabs_sum += std::fabs(scores[i]);
+        }
+        p.score_abs_sum = sabs_sum;
+    }
     p.target_count = target;
     p.sum_costs = sum_costs;
     p.max_iter = max_iter;
