@@ -1120,7 +1120,7 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_TINY_ROUND")) opt.tiny_round_loci = std::atof(e);
     if (const char *e = std::getenv("ROCCO_HIP_MAP_REBUILD")) opt.map_rebuild_ratio = std::atof(e);
     if (const char *e = std::getenv("ROCCO_HIP_BOUNDS")) opt.use_bounds = std::atoi(e) != 0;
-    if (const char *e = std::getenv("ROCCO_HIP_BOTH_MARGIN")) opt.bound_both_margin = std::atof(e);
+    if (const char *e = std::getenv("ROCCO_HIP_SEARCH_GATE")) opt.search_gate = std::atof(e);
     std::vector<CalibrationResult> res;
     if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
     for (size_t t = 0; t < n_tasks; ++t) {

@@ -76,13 +76,19 @@ struct State {
     double req_ref = 0.0, req_lo = 0.0, req_hi = 0.0, req_margin = 0.0;  // map being requested
     double map_margin = 0.0;                                              // margin of the map in use
     double survey_width = -1.0;                                           // bracket width at the last survey
-    // bound probes (exact arithmetic at lambda -/+ eps brackets the reference's count at lambda)
-    bool bound_ok = false;
-    bool bound_round = false;     // the probe request of this iteration is a bound request
+    // Threshold search (exact arithmetic on the grid q).  count_q is monotone in the
+    // penalty and brackets the reference:  count_q(x) > target  =>  the reference selects more than the
+    // target at every penalty <= x - eps;  count_q(x) <= target  =>  at most the target at every penalty
+    // >= x + eps.  G / L are the best such certified thresholds; every bracket or bisection step of the
+    // reference whose penalty lies outside (G, L) is then decided on the host for free.
+    bool searching = false;
+    bool bound_round = false;  // the probe request in flight belongs to the threshold search
     double eps = 0.0;
-    int retry_sign = 0;           // the root was inconclusive with the other sign
-    std::vector<int> tree_sign;
-    std::vector<int> tree_slot2;  // slot of the evaluation with the opposite sign (-1: not evaluated)
+    double G = 0.0, L = 0.0;
+    long long cG = 0, cL = 0;   // counts behind the thresholds (cG > target >= cL)
+    bool G_real = false, L_real = false;  // thresholds come from an evaluation (not from the analytic range)
+    int search_rounds = 0;
+    std::vector<std::pair<double, long long>> evals;  // every (x, count_q(x)) evaluated so far
     long long lower_count = 0;   // selected loci at `lower` (bounds the count anywhere in the bracket)
     long long upper_count = -1;  // selected loci at `upper` (-1: not evaluated yet)
     Phase after_map = kBisect;
@@ -93,13 +99,48 @@ struct State {
     std::vector<int> tree_slot;  // index into the request's penalty list, or -1 if decided analytically
 };
 
+// Outcome of the reference at `lambda` known without device work: analytic, or outside the certified
+// thresholds of the search.  `c` is only compared with the target.
+bool known_count(const ChainProblem &p, const State &s, double lambda, long long *c)
+{
+    if (analytic_count(p, lambda, c)) {
+        return true;
+    }
+    if (s.G_real && lambda <= s.G) {
+        *c = s.cG;
+        return true;
+    }
+    if (s.L_real && lambda >= s.L) {
+        *c = s.cL;
+        return true;
+    }
+    return false;
+}
+
+// Counts bounding the reference's count at the ends of the current bracket, from the evaluations of
+// the search (count_q is non-increasing and brackets the reference's count within eps).
+void bracket_counts_from_evals(const ChainProblem &p, State &s)
+{
+    long long up = (long long)p.n, lo = -1;
+    for (const auto &e : s.evals) {
+        if (e.first <= s.lower - s.eps && e.second < up) {
+            up = e.second;  // count(lower) <= count_q(lower - eps) <= count_q(x) for x <= lower - eps
+        }
+        if (e.first >= s.upper + s.eps && e.second > lo) {
+            lo = e.second;  // count(upper) >= count_q(upper + eps) >= count_q(x) for x >= upper + eps
+        }
+    }
+    s.lower_count = up;
+    s.upper_count = (lo < 0) ? 0 : lo;
+}
+
 // Advance through bracket / bisection steps whose outcome is known without device work.
 void advance_analytic(const ChainProblem &p, State &s)
 {
     long long c = 0;
     for (;;) {
         if (s.phase == State::kLowerBracket) {
-            if (!analytic_count(p, s.lower, &c)) {
+            if (!known_count(p, s, s.lower, &c)) {
                 return;
             }
             ++s.out.evaluations;
@@ -109,7 +150,7 @@ void advance_analytic(const ChainProblem &p, State &s)
                 s.phase = State::kUpperBracket;
             }
         } else if (s.phase == State::kUpperBracket) {
-            if (!analytic_count(p, s.upper, &c)) {
+            if (!known_count(p, s, s.upper, &c)) {
                 return;
             }
             ++s.out.evaluations;
@@ -123,7 +164,7 @@ void advance_analytic(const ChainProblem &p, State &s)
                 return;
             }
             const double mid = (s.lower + s.upper) / 2.0;
-            if (!analytic_count(p, mid, &c)) {
+            if (!known_count(p, s, mid, &c)) {
                 return;
             }
             ++s.out.evaluations;
@@ -254,7 +295,14 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
         s.phase = (s.target == (long long)p.n) ? State::kAll : State::kLowerBracket;
         s.out.zone_iters = -1;
         s.lower_count = (long long)p.n;
-        s.bound_ok = opt.use_bounds && !s.use_exact && bound_epsilon(p, p.score_min - 1.0, &s.eps);
+        if (opt.use_bounds && !s.use_exact && s.phase != State::kAll && bound_epsilon(p, p.score_min - 1.0, &s.eps)) {
+            // penalties outside [s_min - 1, s_max + 1] are decided analytically: the search starts there
+            s.searching = true;
+            s.G = p.score_min - 1.0;
+            s.L = p.score_max + 1.0;
+            s.cG = (long long)p.n;
+            s.cL = 0;
+        }
     }
 
     for (;;) {
@@ -285,6 +333,36 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
             State &s = st[b];
             if (s.phase == State::kDone) {
                 continue;
+            }
+            s.bound_round = false;
+            if (s.searching) {
+                // threshold search: a few exact-arithmetic counts inside (G, L); every one of them moves
+                // G or L (quartiles, plus the log-linear estimate of the crossing once both ends are real)
+                const double width = s.L - s.G;
+                std::vector<double> fr = {0.25, 0.5, 0.75};
+                if (s.G_real && s.L_real && s.cG > s.cL && s.cL > 0) {
+                    const double lg = std::log((double)s.cG), ll = std::log((double)s.cL);
+                    const double lt = std::log((double)std::max(1LL, s.target));
+                    fr.push_back(std::min(0.98, std::max(0.02, (lg - lt) / (lg - ll))));
+                }
+                ProbeRequest r;
+                r.problem = b;
+                r.bound = true;
+                for (double f : fr) {
+                    const double x = s.G + f * width;
+                    if (x - s.eps > s.G && x + s.eps < s.L) {
+                        r.lambdas.push_back(x);
+                    }
+                }
+                if (!r.lambdas.empty()) {
+                    s.bound_round = true;
+                    probes.push_back(r);
+                    probe_owner.push_back(b);
+                    continue;
+                }
+                s.searching = false;  // (G, L) is as narrow as eps allows
+                advance_analytic(p, s);
+                bracket_counts_from_evals(p, s);
             }
             advance_analytic(p, s);
             if (s.phase == State::kBisect && s.iters_left <= 0) {
@@ -352,58 +430,16 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     spine_owner.push_back(b);
                     break;
                 }
-                s.bound_round = false;
-                if (!s.use_exact && s.bound_ok && s.upper_count >= 0 &&
-                    (double)(s.lower_count - s.upper_count) <= opt.survey_gate * (double)((long long)(p.n / 8192) + 1)) {
-                    // few loci can still change inside the bracket: from here on the rounding model
-                    // with its frozen blocks (rounds that skip the settled parts) is cheaper
-                    s.bound_ok = false;
-                }
-                if (!s.use_exact && s.bound_ok) {
-                    // decide the next levels from exact-arithmetic counts at node -/+ eps: one sign per
-                    // node, chosen by where the count is expected to fall (a wrong guess costs a retry)
-                    s.tree_depth = std::min(spec_depth, s.iters_left);
-                    build_tree(s.lower, s.upper, s.tree_depth, s.tree);
-                    ProbeRequest r;
+                if (!s.use_exact && !s.has_map && s.search_rounds > 0) {
+                    // the threshold search left a narrow bracket: the rounding model starts with a map
+                    plan_map(p, s, false);
+                    s.after_map = State::kBisect;
+                    MapRequest r;
                     r.problem = b;
-                    r.bound = true;
-                    s.tree_slot.assign(s.tree.size(), -1);
-                    s.tree_sign.assign(s.tree.size(), 0);
-                    // expected count at a node: log-linear between the bracket ends (the count falls
-                    // steeply and convexly with the penalty); close calls are evaluated with both signs
-                    const bool ends_known = s.upper_count >= 0 && s.lower_count < (long long)p.n;
-                    const double c_lo = std::log((double)std::max(1LL, s.lower_count));
-                    const double c_hi = std::log((double)std::max(1LL, s.upper_count));
-                    s.tree_slot2.assign(s.tree.size(), -1);
-                    long long unused = 0;
-                    for (size_t i = 0; i < s.tree.size(); ++i) {
-                        if (analytic_count(p, s.tree[i], &unused)) {
-                            continue;
-                        }
-                        double eps = s.eps;
-                        bound_epsilon(p, s.tree[i], &eps);
-                        // where the (log-linear) count is expected to cross the target, as a fraction of
-                        // the bracket; a node well to one side of it is evaluated with one sign only
-                        const double t = (s.tree[i] - s.lower) / (s.upper - s.lower);
-                        const double tgt = std::log((double)std::max(1LL, s.target));
-                        const double t_cross = (c_lo > c_hi) ? (c_lo - tgt) / (c_lo - c_hi) : 0.5;
-                        int sign = (t < t_cross) ? +1 : -1;
-                        bool both = !ends_known || std::fabs(t - t_cross) < opt.bound_both_margin;
-                        if (i == 0 && s.retry_sign != 0) {
-                            sign = s.retry_sign;
-                            both = false;
-                        }
-                        s.tree_sign[i] = sign;
-                        s.tree_slot[i] = (int)r.lambdas.size();
-                        r.lambdas.push_back(s.tree[i] + (double)sign * eps);
-                        if (both) {
-                            s.tree_slot2[i] = (int)r.lambdas.size();
-                            r.lambdas.push_back(s.tree[i] - (double)sign * eps);
-                        }
-                    }
-                    s.bound_round = true;
-                    probes.push_back(r);
-                    probe_owner.push_back(b);
+                    r.lambda_ref = s.req_ref;
+                    r.margin = s.req_margin;
+                    maps.push_back(r);
+                    map_owner.push_back(b);
                     break;
                 }
                 if (!s.use_exact && s.has_map) {
@@ -577,7 +613,41 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
         for (size_t q = 0; q < probes.size(); ++q) {
             State &s = st[probe_owner[q]];
             const ProbeRequest &r = probes[q];
+            const ChainProblem &p = problems[probe_owner[q]];
             ++s.out.passes;
+            if (s.bound_round) {
+                ++s.search_rounds;
+                for (size_t i = 0; i < r.lambdas.size(); ++i) {
+                    const double x = r.lambdas[i];
+                    const long long c = r.results[i].count;
+                    s.evals.emplace_back(x, c);
+                    if (c > s.target) {
+                        if (!s.G_real || x - s.eps > s.G) {
+                            s.G = x - s.eps;
+                            s.cG = c;
+                            s.G_real = true;
+                        }
+                    } else if (!s.L_real || x + s.eps < s.L) {
+                        s.L = x + s.eps;
+                        s.cL = c;
+                        s.L_real = true;
+                    }
+                }
+                if (std::getenv("ROCCO_SEARCH_DEBUG") != nullptr) {
+                    std::fprintf(stderr, "[search] problem %zu round %d: G %.17g (%lld) L %.17g (%lld) width %.3g eps %.3g\n",
+                                 probe_owner[q], s.search_rounds, s.G, s.cG, s.L, s.cL, s.L - s.G, s.eps);
+                }
+                const long long blocks = (long long)(p.n / 8192) + 1;
+                const bool few_left = s.G_real && s.L_real && (double)(s.cG - s.cL) <= opt.search_gate * (double)blocks;
+                if (few_left || s.L - s.G <= 8.0 * s.eps || s.search_rounds >= 48) {
+                    // few loci can still change between the thresholds: from here on the rounding model
+                    // with its frozen blocks (rounds that skip the settled parts) is cheaper
+                    s.searching = false;
+                    advance_analytic(p, s);
+                    bracket_counts_from_evals(p, s);
+                }
+                continue;
+            }
             if (s.phase == State::kLowerBracket || s.phase == State::kUpperBracket) {
                 const Outcome o = classify(r.results[0], s.target);
                 if (o == Outcome::kUncertain) {
@@ -596,68 +666,6 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                         s.upper += std::max(1.0, std::fabs(s.upper));
                     } else {
                         s.phase = State::kBisect;
-                    }
-                }
-                continue;
-            }
-            const ChainProblem &p = problems[probe_owner[q]];
-            if (s.bound_round) {
-                // node + eps counted above the target: the reference's count is above it too;
-                // node - eps counted at or below it: so is the reference's.  Anything else says nothing.
-                size_t i = 0;
-                for (int level = 0; level < s.tree_depth; ++level) {
-                    Outcome o = Outcome::kUncertain;
-                    long long c = 0;
-                    bool both_failed = false;
-                    if (s.tree_slot[i] < 0) {
-                        analytic_count(p, s.tree[i], &c);
-                        o = (c > s.target) ? Outcome::kGreater : Outcome::kLessEqual;
-                    } else {
-                        c = r.results[(size_t)s.tree_slot[i]].count;
-                        if (s.tree_sign[i] > 0 && c > s.target) {
-                            o = Outcome::kGreater;
-                        } else if (s.tree_sign[i] < 0 && c <= s.target) {
-                            o = Outcome::kLessEqual;
-                        } else if (s.tree_slot2[i] >= 0) {
-                            const long long c2 = r.results[(size_t)s.tree_slot2[i]].count;  // the opposite sign
-                            if (s.tree_sign[i] < 0 && c2 > s.target) {
-                                o = Outcome::kGreater;
-                                c = c2;
-                            } else if (s.tree_sign[i] > 0 && c2 <= s.target) {
-                                o = Outcome::kLessEqual;
-                                c = c2;
-                            } else {
-                                both_failed = true;
-                            }
-                        }
-                    }
-                    if (std::getenv("ROCCO_SEARCH_DEBUG") != nullptr) {
-                        std::fprintf(stderr, "[bound] level-in-round %d node %.17g sign %d eval-count %lld target %lld -> %s (eps %.3g)\n",
-                                     level, s.tree[i], s.tree_slot[i] < 0 ? 0 : s.tree_sign[i], c, s.target,
-                                     o == Outcome::kGreater ? "greater" : (o == Outcome::kLessEqual ? "lessequal" : "unknown"), s.eps);
-                    }
-                    if (o == Outcome::kUncertain) {
-                        if (both_failed || (level == 0 && s.retry_sign != 0)) {
-                            // both signs tried: the target lies inside the bracketing counts -> from here
-                            // on the rounding model proper decides (binade maps, windows, spine)
-                            s.bound_ok = false;
-                            s.retry_sign = 0;
-                        } else {
-                            s.retry_sign = -s.tree_sign[i];
-                        }
-                        break;
-                    }
-                    s.retry_sign = 0;
-                    ++s.out.evaluations;
-                    --s.iters_left;
-                    if (o == Outcome::kGreater) {
-                        s.lower = s.tree[i];
-                        s.lower_count = c;
-                        i = 2 * i + 2;
-                    } else {
-                        s.upper = s.tree[i];
-                        s.upper_count = c;
-                        i = 2 * i + 1;
                     }
                 }
                 continue;

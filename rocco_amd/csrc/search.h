@@ -172,7 +172,7 @@ struct SearchOptions {
     double tiny_round_loci = 0.3e6;     // below: spec_depth + 3 levels per round
     double map_rebuild_ratio = 0.8;    // rebuild a bracket map when its margin would shrink below this ratio
     bool exact_penalty = true;         // settle a lone open decision through the spine (penalty bit-exact)
-    double bound_both_margin = 0.15;   // bound probes: both signs when the node is this close (bracket fraction) to the expected crossing
+    double search_gate = 0.015;        // the threshold search stops when (loci that can still change) <= gate * workgroups
     bool use_bounds = true;            // decide early bisection steps with shifted exact-arithmetic counts
     double survey_gate = 0.5;          // survey a bracket when (loci that can still change) <= gate * workgroups
     int exact_depth = 6;    // same for the exact kernel (63 lanes)
