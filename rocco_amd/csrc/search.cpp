@@ -117,6 +117,20 @@ bool known_count(const ChainProblem &p, const State &s, double lambda, long long
     return false;
 }
 
+// Lowest penalty the device can still be asked about: below the certified threshold G every outcome is
+// known ("more than the target"), so maps, surveys and windows only need to hold from here to `upper`.
+double eff_lower(const State &s)
+{
+    return (s.G_real && s.G > s.lower) ? s.G : s.lower;
+}
+
+// Highest penalty the device is still asked about while bisecting (at and above L every outcome is
+// known).  Only the final window must reach up to `upper` itself.
+double eff_upper(const State &s)
+{
+    return (s.L_real && s.L < s.upper) ? s.L : s.upper;
+}
+
 // Counts bounding the reference's count at the ends of the current bracket, from the evaluations of
 // the search (count_q is non-increasing and brackets the reference's count within eps).
 void bracket_counts_from_evals(const ChainProblem &p, State &s)
@@ -181,11 +195,13 @@ void advance_analytic(const ChainProblem &p, State &s)
 }
 
 // Replay the remaining bisection steps when count > target  <=>  mid < critical.
-void replay_with_critical(State &s, double critical)
+void replay_with_critical(const ChainProblem &p, State &s, double critical)
 {
     while (s.iters_left > 0) {
         const double mid = (s.lower + s.upper) / 2.0;
-        if (mid < critical) {
+        long long c = 0;
+        const bool greater = known_count(p, s, mid, &c) ? (c > s.target) : (mid < critical);
+        if (greater) {
             s.lower = mid;
         } else {
             s.upper = mid;
@@ -199,13 +215,15 @@ void replay_with_critical(State &s, double critical)
 // the running values cannot move much inside it, otherwise a point map at the next midpoint.
 void plan_map(const ChainProblem &p, State &s, bool force_bracket)
 {
-    const double width = s.upper - s.lower;
+    const double lo = eff_lower(s);
+    const double hi = force_bracket ? s.upper : eff_upper(s);  // (forced: for the final window)
+    const double width = hi - lo;
     const double reach = p.cost_max + (p.score_max - p.score_min) + 2.0;
     const double drift = 2.0 * width * (double)s.lower_count;
     if (force_bracket || drift <= 4.0 * reach) {
-        s.req_ref = (s.lower + s.upper) / 2.0;
-        s.req_lo = s.lower;
-        s.req_hi = s.upper;
+        s.req_ref = (lo + hi) / 2.0;
+        s.req_lo = lo;
+        s.req_hi = hi;
         s.req_margin = reach + drift + 2.0;
         s.point_pending = false;
     } else {
@@ -420,6 +438,11 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     SpineRequest r;
                     r.problem = b;
                     r.lambdas = s.tree;
+                    for (double &lam : r.lambdas) {
+                        // a node below the certified threshold selects more than the target, and so does
+                        // the threshold itself: ask about that one (it lies inside the surveyed interval)
+                        lam = std::max(lam, std::min(eff_lower(s), s.upper));
+                    }
                     if (s.tree_depth == s.iters_left && s.tree.size() < 64) {
                         // the last tree: let the evaluator also pick and materialise the answer
                         r.lambdas.push_back(s.upper);
@@ -443,9 +466,9 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     break;
                 }
                 if (!s.use_exact && s.has_map) {
-                    const double width = s.upper - s.lower;
+                    const double width = eff_upper(s) - eff_lower(s);
                     const double mid = (s.lower + s.upper) / 2.0;
-                    const bool inside = (s.map_lo <= s.lower && s.upper <= s.map_hi);
+                    const bool inside = (s.map_lo <= eff_lower(s) && eff_upper(s) <= s.map_hi);
                     const bool point_ok = s.point_pending && s.map_lo == mid && s.map_hi == mid;
                     // a map built for a much wider bracket carries a larger hazard margin than needed:
                     // rebuild it once that margin would shrink materially
@@ -468,7 +491,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     }
                 }
                 if (!s.use_exact && s.has_map && !s.point_pending && s.map_lo < s.map_hi && s.upper_count >= 0 &&
-                    (s.survey_width < 0.0 || s.survey_width > 16.0 * (s.upper - s.lower))) {
+                    (s.survey_width < 0.0 || s.survey_width > 16.0 * (eff_upper(s) - eff_lower(s)))) {
                     // the map covers the whole bracket: when few loci can still change inside it, let the
                     // evaluator find the settled parts so that later rounds skip them
                     const long long diffs = s.lower_count - s.upper_count;
@@ -476,10 +499,10 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     if ((double)diffs <= opt.survey_gate * (double)blocks) {
                         WindowRequest w;
                         w.problem = b;
-                        w.lambda_lo = s.lower;
-                        w.lambda_hi = s.upper;
+                        w.lambda_lo = eff_lower(s);
+                        w.lambda_hi = eff_upper(s);
                         surveys.push_back(w);
-                        s.survey_width = s.upper - s.lower;
+                        s.survey_width = eff_upper(s) - eff_lower(s);
                     }
                 }
                 s.tree_depth = std::min(s.use_exact ? opt.exact_depth : spec_depth, s.iters_left);
@@ -499,7 +522,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     s.tree_slot.assign(s.tree.size(), -1);
                     long long unused = 0;
                     for (size_t i = 0; i < s.tree.size(); ++i) {
-                        if (!analytic_count(p, s.tree[i], &unused)) {
+                        if (!known_count(p, s, s.tree[i], &unused)) {
                             s.tree_slot[i] = (int)r.lambdas.size();
                             r.lambdas.push_back(s.tree[i]);
                         }
@@ -521,7 +544,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
             case State::kZone: {
                 WindowRequest r;
                 r.problem = b;
-                r.lambda_lo = s.lower;
+                r.lambda_lo = std::min(eff_lower(s), s.upper);  // below it every outcome is known already
                 r.lambda_hi = s.upper;
                 windows.push_back(r);
                 window_owner.push_back(b);
@@ -588,10 +611,10 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 ++s.out.evaluations;
                 --s.iters_left;
                 if (r.counts[i] > s.target) {
-                    s.lower = r.lambdas[i];
+                    s.lower = s.tree[i];
                     i = 2 * i + 2;
                 } else {
-                    s.upper = r.lambdas[i];
+                    s.upper = s.tree[i];
                     answer = i;
                     i = 2 * i + 1;
                 }
@@ -676,7 +699,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 Outcome o;
                 long long analytic = 0;
                 if (s.tree_slot[i] < 0) {
-                    analytic_count(p, s.tree[i], &analytic);
+                    known_count(p, s, s.tree[i], &analytic);
                     o = (analytic > s.target) ? Outcome::kGreater : Outcome::kLessEqual;
                 } else {
                     o = classify(r.results[(size_t)s.tree_slot[i]], s.target);
@@ -685,7 +708,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     // the uncertain node is the midpoint of the current bracket
                     const double mid = s.tree[i];
                     const bool is_point_here = s.has_map && s.map_lo == mid && s.map_hi == mid;
-                    const bool covers = s.has_map && s.map_lo <= s.lower && s.upper <= s.map_hi;
+                    const bool covers = s.has_map && s.map_lo <= eff_lower(s) && s.upper <= s.map_hi;
                     if (!s.has_map) {
                         plan_map(p, s, false);  // sharpen the rounding model, then ask again
                         s.after_map = State::kBisect;
@@ -760,9 +783,9 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
             bool certified = false;
             if (!w.overflow && w.n_diff == 0 && w.count_lo <= s.target) {
                 // every remaining probe selects count_lo <= target loci: upper = mid each step
-                replay_with_critical(s, -INFINITY);
+                replay_with_critical(p, s, -INFINITY);
                 certified = true;
-            } else if (!(opt.use_spine && opt.exact_penalty && s.has_map && s.map_lo <= s.lower &&
+            } else if (!(opt.use_spine && opt.exact_penalty && s.has_map && s.map_lo <= eff_lower(s) &&
                          s.upper <= s.map_hi) &&
                        !w.overflow && w.n_diff == 1 && w.diff_adjacent && w.count_lo <= s.target &&
                        w.count_hi > s.target && !w.diffs.empty()) {
@@ -776,7 +799,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 if (span > 0.0 && d.margin_lo > 0.0 && d.margin_hi <= 0.0) {
                     critical = s.lower + (d.margin_lo / span) * (s.upper - s.lower);
                 }
-                replay_with_critical(s, critical);
+                replay_with_critical(p, s, critical);
                 certified = true;
             }
             if (certified) {
@@ -784,7 +807,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 s.out.selection_penalty = s.upper;
                 s.out.path = ROCCO_HIP_PATH_CERTIFIED;
                 s.phase = State::kDone;
-            } else if (opt.use_spine && s.has_map && s.map_lo <= s.lower && s.upper <= s.map_hi) {
+            } else if (opt.use_spine && s.has_map && s.map_lo <= eff_lower(s) && s.upper <= s.map_hi) {
                 // not separable by the window: finish the reference's own steps through the exact spine
                 s.use_spine = true;
                 s.phase = (s.iters_left > 0) ? State::kBisect : State::kFinalSpine;
