@@ -88,6 +88,7 @@ struct State {
     long long cG = 0, cL = 0;   // counts behind the thresholds (cG > target >= cL)
     bool G_real = false, L_real = false;  // thresholds come from an evaluation (not from the analytic range)
     int search_rounds = 0;
+    long long open_before = 0x7FFFFFFFFFFFFFFFLL;  // cG - cL after the previous round
     std::vector<std::pair<double, long long>> evals;  // every (x, count_q(x)) evaluated so far
     long long lower_count = 0;   // selected loci at `lower` (bounds the count anywhere in the bracket)
     long long upper_count = -1;  // selected loci at `upper` (-1: not evaluated yet)
@@ -661,7 +662,12 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                                  probe_owner[q], s.search_rounds, s.G, s.cG, s.L, s.cL, s.L - s.G, s.eps);
                 }
                 const long long blocks = (long long)(p.n / 8192) + 1;
-                const bool few_left = s.G_real && s.L_real && (double)(s.cG - s.cL) <= opt.search_gate * (double)blocks;
+                // few loci can still change between the thresholds; or their number stopped falling (the
+                // count jumps by a whole run of loci at one penalty: narrowing further settles nothing)
+                const long long open_now = (s.G_real && s.L_real) ? (s.cG - s.cL) : (long long)p.n;
+                const bool stalled = open_now >= s.open_before && (double)open_now <= opt.survey_gate * (double)blocks;
+                s.open_before = open_now;
+                const bool few_left = stalled || (double)open_now <= opt.search_gate * (double)blocks;
                 if (few_left || s.L - s.G <= 8.0 * s.eps || s.search_rounds >= 48) {
                     // few loci can still change between the thresholds: from here on the rounding model
                     // with its frozen blocks (rounds that skip the settled parts) is cheaper
