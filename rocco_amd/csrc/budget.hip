@@ -79,6 +79,7 @@ public:
         bool use_frozen = false;
         int solution_index = -1;
         int select_depth = 0;
+        bool select_has_upper = true;
         long long select_target = 0;
         double margin = 0.0;
         std::vector<double> lambdas;
@@ -268,6 +269,7 @@ public:
             t.record = true;
             t.solution_index = r.solution_index;
             t.select_depth = r.select_depth;
+            t.select_has_upper = r.select_has_upper;
             t.select_target = r.select_target;
             t.lambdas = r.lambdas;
             t.spine = &r;
@@ -584,6 +586,7 @@ private:
             ft.rec_off = 0;
             ft.rec_goff = 0;
             ft.sel_depth = rt[t].record ? rt[t].select_depth : 0;
+            ft.sel_has_upper = rt[t].select_has_upper ? 1 : 0;
             ft.sel_target = rt[t].select_target;
             any_select = any_select || (ft.sel_depth > 0);
             if (rt[t].record) {

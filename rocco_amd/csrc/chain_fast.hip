@@ -2251,7 +2251,7 @@ __global__ void spine_select_kernel(FastLaunch L, int *solution_slot)
         return;
     }
     int i = 0;
-    int answer = task.slot_count - 1;  // the current upper end
+    int answer = task.sel_has_upper ? (task.slot_count - 1) : -1;  // the current upper end, if it was evaluated
     for (int level = 0; level < task.sel_depth; ++level) {
         if (L.buf.results[task.slot_begin + i].count_lo > task.sel_target) {
             i = 2 * i + 2;
@@ -2260,7 +2260,7 @@ __global__ void spine_select_kernel(FastLaunch L, int *solution_slot)
             i = 2 * i + 1;
         }
     }
-    solution_slot[t] = task.slot_begin + answer;
+    solution_slot[t] = (answer >= 0) ? (task.slot_begin + answer) : -1;
     L.buf.results[task.slot_begin].e_global = answer;  // reported to the host
 }
 

@@ -445,10 +445,16 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                         lam = std::max(lam, std::min(eff_lower(s), s.upper));
                     }
                     if (s.tree_depth == s.iters_left && s.tree.size() < 64) {
-                        // the last tree: let the evaluator also pick and materialise the answer
-                        r.lambdas.push_back(s.upper);
+                        // the last tree: let the evaluator also pick and materialise the answer.  The
+                        // current upper end joins it unless it lies above the surveyed interval (the
+                        // round would have to evaluate every block again): then, should no node of the
+                        // tree qualify, a separate pass settles the upper end.
                         r.select_depth = s.tree_depth;
                         r.select_target = s.target;
+                        r.select_has_upper = (s.upper <= eff_upper(s));
+                        if (r.select_has_upper) {
+                            r.lambdas.push_back(s.upper);
+                        }
                     }
                     spines.push_back(r);
                     spine_owner.push_back(b);
@@ -607,7 +613,8 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 continue;
             }
             size_t i = 0;
-            size_t answer = r.lambdas.size() - 1;  // index of the final penalty when this was the last tree
+            // index of the final penalty when this was the last tree (-1: the current upper end, not evaluated)
+            long long answer = (r.select_depth > 0 && !r.select_has_upper) ? -1 : (long long)r.lambdas.size() - 1;
             for (int level = 0; level < s.tree_depth; ++level) {
                 ++s.out.evaluations;
                 --s.iters_left;
@@ -616,15 +623,15 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     i = 2 * i + 2;
                 } else {
                     s.upper = s.tree[i];
-                    answer = i;
+                    answer = (long long)i;
                     i = 2 * i + 1;
                 }
             }
             if (s.iters_left <= 0) {
-                if (r.select_depth > 0 && r.selected == (int)answer) {
+                if (r.select_depth > 0 && answer >= 0 && r.selected == (int)answer) {
                     // the evaluator walked the same path and wrote that solution already
                     s.out.selection_penalty = s.upper;
-                    s.out.selected_count = r.counts[answer];
+                    s.out.selected_count = r.counts[(size_t)answer];
                     s.out.path = ROCCO_HIP_PATH_SPINE;
                     s.phase = State::kDone;
                 } else {

@@ -99,6 +99,7 @@ struct SpineRequest {
     // this node becomes the answer and the walk goes left), writes that penalty's solution and
     // reports its index in `selected`; otherwise it leaves selected = -1.
     int select_depth = 0;
+    bool select_has_upper = true;  // false: lambdas holds the tree only (selected = -1 if no node qualifies)
     long long select_target = 0;
     int selected = -1;
     std::vector<long long> counts; // filled by the evaluator
