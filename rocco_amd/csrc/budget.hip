@@ -9,6 +9,7 @@
 #include "budget.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -394,6 +395,37 @@ public:
         return ROCCO_HIP_OK;
     }
 
+    int penalized_values(const std::vector<size_t> &which, const std::vector<double> &lambdas,
+                         const std::vector<long long> &counts, std::vector<double> &values) override
+    {
+        // every objective on the stream, one synchronisation
+        const size_t W = which.size();
+        values.assign(W, 0.0);
+        size_t total = 0;
+        std::vector<size_t> off(W);
+        for (size_t i = 0; i < W; ++i) {
+            off[i] = total;
+            total += align_up(objective_scratch_bytes(probs[which[i]].n), 256);
+        }
+        int rc;
+        if ((rc = solver_->dev_misc.reserve(total + 256)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_back.reserve(W * sizeof(double) + 64)) != ROCCO_HIP_OK) return rc;
+        double *back = (double *)solver_->host_back.ptr;
+        for (size_t i = 0; i < W; ++i) {
+            const DevProblem &p = probs[which[i]];
+            rc = launch_objective(p.solution, p.scores, p.costs, p.gamma, p.n, (char *)solver_->dev_misc.ptr + off[i],
+                                  back + i, stream_, false);
+            if (rc != ROCCO_HIP_OK) {
+                return rc;
+            }
+        }
+        ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        for (size_t i = 0; i < W; ++i) {
+            values[i] = -back[i] - lambdas[i] * (double)counts[i];
+        }
+        return ROCCO_HIP_OK;
+    }
+
     // smin, smax, cmin, cmax of every problem (one stats pass over the batch)
     int compute_stats(std::vector<double> &out)
     {
@@ -445,6 +477,14 @@ public:
 
 private:
 
+public:
+    double t_prep_ = 0.0, t_launch_ = 0.0, t_wait_ = 0.0, t_consume_ = 0.0;
+    static double now_us()
+    {
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+
+private:
     int run_round(std::vector<RoundTask> &rt)
     {
         const size_t T = rt.size();
@@ -452,11 +492,13 @@ private:
             return ROCCO_HIP_OK;
         }
         ++rounds;
+        const double tt0 = now_us();
         std::vector<FastTask> tasks(T);
         std::vector<FastChain> chains;
         std::vector<FastSlot> slots;
         std::vector<int2> blockmap, blockmap_all;
         std::vector<std::vector<int>> launched(T);
+        std::vector<char> launched_all(T, 0);
         std::vector<long long> skip_off(T, -1);
         std::vector<uint8_t> skip_bytes;
         long long chain_chunks = 0, chain_blocks = 0, slot_chunks = 0, slot_blocks = 0, rec_entries = 0;
@@ -521,9 +563,7 @@ private:
                 skip.resize(align_up((size_t)nblocks, 64), 0);
                 skip_bytes.insert(skip_bytes.end(), skip.begin(), skip.end());
             } else {
-                for (int k = 0; k < nblocks; ++k) {
-                    launched[t].push_back(k);
-                }
+                launched_all[t] = 1;  // every block: the list stays empty
             }
             if (rt[t].survey) {
                 ft.frz_out = p.frz;
@@ -532,7 +572,7 @@ private:
                 const char *kind = rt[t].record ? "spine" : (rt[t].survey ? "survey" : (rt[t].window ? "window" : (rt[t].map ? "map" : "probe")));
                 std::fprintf(stderr, "[round %d] %s problem %zu: %zu lambdas (first %.17g, margin %.3g), %zu / %d blocks%s\n",
                              rounds, kind, rt[t].problem, rt[t].lambdas.size(), rt[t].lambdas[0], rt[t].margin,
-                             launched[t].size(), nblocks, p.emap ? "" : " [no map]");
+                             launched_all[t] ? (size_t)nblocks : launched[t].size(), nblocks, p.emap ? "" : " [no map]");
             }
             ft.slot_begin = (int)slots.size();
             any_costs = any_costs || (p.costs != nullptr);
@@ -599,11 +639,17 @@ private:
                     solution_slot[t] = ft.slot_begin + rt[t].solution_index;
                 }
             }
-            for (int k : launched[t]) {
-                blockmap.push_back(make_int2((int)t, k));
-            }
+            const size_t at_all = blockmap_all.size();
+            blockmap_all.resize(at_all + (size_t)nblocks);
             for (int k = 0; k < nblocks; ++k) {
-                blockmap_all.push_back(make_int2((int)t, k));
+                blockmap_all[at_all + (size_t)k] = make_int2((int)t, k);
+            }
+            if (launched_all[t]) {
+                blockmap.insert(blockmap.end(), blockmap_all.begin() + (long)at_all, blockmap_all.end());
+            } else {
+                for (int k : launched[t]) {
+                    blockmap.push_back(make_int2((int)t, k));
+                }
             }
         }
         const size_t C = chains.size(), S = slots.size(), NB = blockmap.size(), NBA = blockmap_all.size();
@@ -622,6 +668,8 @@ private:
         if ((rc = solver_->host_stage.reserve(desc_bytes)) != ROCCO_HIP_OK) return rc;
         char *h = (char *)solver_->host_stage.ptr;
         char *dd = (char *)solver_->dev_tasks.ptr;
+        const double tt1 = now_us();
+        t_prep_ += tt1 - tt0;
         for (size_t t = 0; t < T; ++t) {
             if (skip_off[t] >= 0) {  // record rounds: "not evaluated this round" instead of "frozen"
                 tasks[t].frz.flag = (uint8_t *)(dd + b_tasks + b_chains + b_slots + b_map + b_mapall + skip_off[t]);
@@ -757,7 +805,11 @@ private:
                 }
             }
         }
+        const double tt2 = now_us();
+        t_launch_ += tt2 - tt1;
         ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        const double tt3 = now_us();
+        t_wait_ += tt3 - tt2;
         const FastSlotResult *hr = (const FastSlotResult *)solver_->host_back.ptr;
         for (size_t t = 0; t < T; ++t) {
             if (!(rt[t].record && rt[t].use_frozen)) {
@@ -789,7 +841,7 @@ private:
                 }
                 // a block surveyed this round carries its new verdict; skipped (frozen) blocks stay frozen
                 std::vector<int> active;
-                const std::vector<int> *surveyed = rt[t].use_frozen ? &launched[t] : nullptr;
+                const std::vector<int> *surveyed = (rt[t].use_frozen && !launched_all[t]) ? &launched[t] : nullptr;
                 if (surveyed == nullptr) {
                     for (int k = 0; k < nb; ++k) {
                         p.frz_flags[k] = (uint8_t)hf[k];
@@ -1125,7 +1177,12 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_BOUNDS")) opt.use_bounds = std::atoi(e) != 0;
     if (const char *e = std::getenv("ROCCO_HIP_SEARCH_GATE")) opt.search_gate = std::atof(e);
     std::vector<CalibrationResult> res;
+    const double t_solve0 = HipEvaluator::now_us();
     if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
+    if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+        std::fprintf(stderr, "[host] solve %.0f us: %d rounds, prep %.0f launch %.0f wait %.0f us (rest: search logic, other calls)\n",
+                     HipEvaluator::now_us() - t_solve0, ev.rounds, ev.t_prep_, ev.t_launch_, ev.t_wait_);
+    }
     for (size_t t = 0; t < n_tasks; ++t) {
         results[t].selection_penalty = res[t].selection_penalty;
         results[t].penalized_value = res[t].penalized_value;

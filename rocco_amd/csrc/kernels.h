@@ -37,7 +37,7 @@ int launch_decode_runs(const uint8_t *solution_dev, size_t n, int64_t *run_begin
 size_t objective_scratch_bytes(size_t n);
 int launch_objective(const uint8_t *solution_dev, const double *scores_dev,
                      const double *switch_costs_dev, double gamma, size_t n, void *scratch_dev,
-                     double *objective_host_pinned, hipStream_t stream);
+                     double *objective_host_pinned, hipStream_t stream, bool synchronize = true);
 
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,

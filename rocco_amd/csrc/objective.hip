@@ -90,7 +90,7 @@ size_t objective_scratch_bytes(size_t n)
 
 int launch_objective(const uint8_t *solution_dev, const double *scores_dev,
                      const double *switch_costs_dev, double gamma, size_t n, void *scratch_dev,
-                     double *objective_host_pinned, hipStream_t stream)
+                     double *objective_host_pinned, hipStream_t stream, bool synchronize)
 {
     if (n == 0) {
         *objective_host_pinned = 0.0;
@@ -105,7 +105,9 @@ int launch_objective(const uint8_t *solution_dev, const double *scores_dev,
     ROCCO_HIP_TRY(hipGetLastError());
     ROCCO_HIP_TRY(hipMemcpyAsync(objective_host_pinned, out, sizeof(double), hipMemcpyDeviceToHost,
                                  stream));
-    ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+    if (synchronize) {
+        ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+    }
     return ROCCO_HIP_OK;
 }
 

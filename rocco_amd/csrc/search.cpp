@@ -883,16 +883,28 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
     }
 
     results.resize(B);
+    std::vector<size_t> which;
+    std::vector<double> lams, values;
+    std::vector<long long> counts;
     for (size_t b = 0; b < B; ++b) {
-        State &s = st[b];
+        const State &s = st[b];
         if (s.out.path == ROCCO_HIP_PATH_CERTIFIED || s.out.path == ROCCO_HIP_PATH_SPINE) {
-            const int rc = ev.penalized_value(b, s.out.selection_penalty, s.out.selected_count,
-                                              &s.out.penalized_value);
-            if (rc != ROCCO_HIP_OK) {
-                return rc;
-            }
+            which.push_back(b);
+            lams.push_back(s.out.selection_penalty);
+            counts.push_back(s.out.selected_count);
         }
-        results[b] = s.out;
+    }
+    if (!which.empty()) {
+        const int rc = ev.penalized_values(which, lams, counts, values);
+        if (rc != ROCCO_HIP_OK) {
+            return rc;
+        }
+        for (size_t i = 0; i < which.size(); ++i) {
+            st[which[i]].out.penalized_value = values[i];
+        }
+    }
+    for (size_t b = 0; b < B; ++b) {
+        results[b] = st[b].out;
     }
     return ROCCO_HIP_OK;
 }

@@ -150,6 +150,17 @@ public:
     virtual int exact(std::vector<ExactRequest> &reqs) = 0;
     // penalised value  sum (s - lambda) z - sum c |dz|  of the solution currently in the buffer
     virtual int penalized_value(size_t problem, double lambda, long long count, double *value_out) = 0;
+    // the same for several problems at once (an evaluator may run them concurrently)
+    virtual int penalized_values(const std::vector<size_t> &which, const std::vector<double> &lambdas,
+                                 const std::vector<long long> &counts, std::vector<double> &values)
+    {
+        values.assign(which.size(), 0.0);
+        for (size_t i = 0; i < which.size(); ++i) {
+            const int rc = penalized_value(which[i], lambdas[i], counts[i], &values[i]);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
 };
 
 struct CalibrationResult {
