@@ -18,6 +18,7 @@ Prints one JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -102,6 +103,10 @@ def main():
 
     for _ in range(args.warmup):
         res, merged = one_step()
+    # a full (generation-2) pass of Python's cyclic GC costs ~30 ms here and would otherwise fire once,
+    # a few steps into the run: take it now and keep the survivors out of later passes
+    gc.collect()
+    gc.freeze()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
