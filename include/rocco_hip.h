@@ -187,6 +187,15 @@ int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev,
  * DESIGN.md section 7 (5-decimal background + planted peaks with per-sample dropout); the same
  * integer arithmetic is restated in NumPy in rocco_amd/synth.py so any slice can be regenerated
  * on the host bit-for-bit. */
+/* Cross-fit Whittaker baseline of every row of a row-major rows x cols matrix.
+ * Replaces rocco_crossfit_whittaker_baseline_matrix_f64 (rocco/native/baseline_backend.h:12-23,
+ * baseline_backend.c:305-334) as called through rocco/_baseline.c:16-104 from rocco/inference.py:185-209,
+ * on device buffers: same arguments, same results bit for bit, cols < 25 -> zeros.  matrix_dev and
+ * baseline_out_dev must not overlap.  Returns 0, ROCCO_HIP_ENOMEM (the reference's -1) or EINVAL / EHIP. */
+int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, const double *matrix_dev,
+                                                     size_t rows, size_t cols, double penalty_lambda,
+                                                     double *baseline_out_dev, void *stream);
+
 int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
                            size_t row_stride, uint64_t seed, void *stream);
 

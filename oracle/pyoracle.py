@@ -120,6 +120,9 @@ def lib() -> ctypes.CDLL:
         _lib.oracle_median_columns.restype = ctypes.c_int
         _lib.oracle_median_columns.argtypes = [
             ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_double_p]
+        _lib.oracle_crossfit_whittaker_baseline_matrix_f64.restype = ctypes.c_int
+        _lib.oracle_crossfit_whittaker_baseline_matrix_f64.argtypes = [
+            _c_double_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, _c_double_p]
     return _lib
 
 
@@ -387,3 +390,16 @@ def combine_records(per_chrom_records: Sequence[Sequence[Record]]) -> List[Recor
     for recs in per_chrom_records:
         allr.extend(recs)
     return merge_bed_records(allr)
+
+
+def crossfit_whittaker_baseline(values, penalty_lambda: float) -> np.ndarray:
+    """rocco/_baseline.c:16-104 over rocco/native/baseline_backend.c:252-334 (1-D or 2-D input)."""
+    m = np.ascontiguousarray(values, dtype=np.float64)
+    if m.ndim not in (1, 2):
+        raise ValueError("`values` must be one-dimensional or two-dimensional")
+    out = np.empty_like(m)
+    rows, cols = (1, m.shape[0]) if m.ndim == 1 else m.shape
+    if m.size:
+        _check(lib().oracle_crossfit_whittaker_baseline_matrix_f64(
+            _dptr(m), rows, cols, float(penalty_lambda), _dptr(out)))
+    return out

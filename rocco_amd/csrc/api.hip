@@ -290,6 +290,27 @@ int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev,
     return rc;
 }
 
+int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, const double *matrix_dev,
+                                                     size_t rows, size_t cols, double penalty_lambda,
+                                                     double *baseline_out_dev, void *stream)
+{
+    if (solver == nullptr || ((matrix_dev == nullptr || baseline_out_dev == nullptr) && rows * cols > 0)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_misc.reserve(whittaker_scratch_bytes(rows, cols))) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    rc = launch_crossfit_whittaker(matrix_dev, rows, cols, penalty_lambda, baseline_out_dev, solver->dev_misc.ptr,
+                                   (hipStream_t)stream);
+    if (rc != ROCCO_HIP_OK) {
+        return rc;
+    }
+    ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the scratch buffer is the solver's
+    return ROCCO_HIP_OK;
+}
+
 int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
                            size_t row_stride, uint64_t seed, void *stream)
 {

@@ -39,6 +39,12 @@ int launch_objective(const uint8_t *solution_dev, const double *scores_dev,
                      const double *switch_costs_dev, double gamma, size_t n, void *scratch_dev,
                      double *objective_host_pinned, hipStream_t stream, bool synchronize = true);
 
+// ---- whittaker.hip --------------------------------------------------------------------------
+// scratch: at least whittaker_scratch_bytes(rows, cols) bytes; matrix and output must not overlap
+size_t whittaker_scratch_bytes(size_t rows, size_t cols);
+int launch_crossfit_whittaker(const double *matrix_dev, size_t rows, size_t cols, double penalty_lambda,
+                              double *baseline_out_dev, void *scratch_dev, hipStream_t stream);
+
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
                  hipStream_t stream);

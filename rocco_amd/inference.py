@@ -1,0 +1,92 @@
+"""Count-path scoring pieces of rocco/inference.py on the MI355X.
+
+Built so far: the cross-fit Whittaker baseline (row a3) -- ``crossfit_whittaker_baseline`` is the
+device replacement of the reference's ``rocco._baseline.crossfit_whittaker_baseline``
+(rocco/_baseline.c:16-104 over rocco/native/baseline_backend.c) and
+``_estimate_local_background_matrix`` mirrors rocco/inference.py:185-229 around it.  Results are the
+reference's bit for bit.  There is no CPU fallback: without the library or a GPU these raise.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+from . import _native
+from . import dp as _dp
+
+
+def _resolve_local_baseline_window(n_loci: int, target_window: int = 101) -> int:
+    """rocco/inference.py:49-62: odd window <= n_loci, 0 when fewer than 25 loci."""
+    n_loci = int(n_loci)
+    if n_loci < 25:
+        return 0
+    window = int(max(3, target_window))
+    if window > n_loci:
+        window = n_loci
+    if (window % 2) == 0:
+        window = window - 1 if window == n_loci else window + 1
+    return int(max(0, window))
+
+
+def _consenrich_whittaker_lambda(block_size: int) -> float:
+    """rocco/inference.py:65-76: smoothing block size -> Whittaker penalty."""
+    block = int(max(3, block_size))
+    if (block % 2) == 0:
+        block += 1
+    w_hat = float(block) * 0.15915494
+    return float(7.0 * (w_hat**4))
+
+
+def crossfit_whittaker_baseline_device(values_t, penalty_lambda: float, out_t=None):
+    """Device-resident form: ``values_t`` is a contiguous float64 CUDA tensor [rows, cols] (or [cols]);
+    returns a new tensor of the same shape (or fills ``out_t``, which must not alias the input)."""
+    import torch
+
+    if values_t.dim() not in (1, 2):
+        raise ValueError("`values` must be one-dimensional or two-dimensional")
+    if values_t.dtype != torch.float64 or not values_t.is_cuda or not values_t.is_contiguous():
+        raise ValueError("values_t must be a contiguous float64 CUDA tensor")
+    rows = 1 if values_t.dim() == 1 else int(values_t.shape[0])
+    cols = int(values_t.shape[-1])
+    if out_t is None:
+        out_t = torch.empty_like(values_t)
+    elif out_t.shape != values_t.shape or out_t.dtype != torch.float64 or not out_t.is_contiguous() \
+            or out_t.data_ptr() == values_t.data_ptr():
+        raise ValueError("out_t must be a distinct contiguous float64 tensor of the same shape")
+    if rows * cols == 0:
+        return out_t
+    solver = _native.solver_for(values_t.device.index)
+    _native.check(_native.load().rocco_hip_crossfit_whittaker_baseline_matrix_f64(
+        solver.handle, values_t.data_ptr(), rows, cols, float(penalty_lambda), out_t.data_ptr(),
+        _dp._stream_ptr(values_t)), "rocco_hip_crossfit_whittaker_baseline_matrix_f64")
+    return out_t
+
+
+def crossfit_whittaker_baseline(values, penalty_lambda: float) -> np.ndarray:
+    """Same call as the reference's extension (rocco/_baseline.c:16-104): ``values`` 1-D or 2-D,
+    returns a float64 array of the same shape with the cross-fit baseline of every row."""
+    _native.load()
+    arr = np.ascontiguousarray(values, dtype=np.float64)
+    if arr.ndim not in (1, 2):
+        raise ValueError("`values` must be one-dimensional or two-dimensional")
+    if arr.size == 0:
+        return np.zeros(arr.shape, dtype=np.float64)
+    values_t = _dp._to_device_f64(arr.reshape(-1)).reshape(arr.shape)
+    return crossfit_whittaker_baseline_device(values_t, float(penalty_lambda)).cpu().numpy()
+
+
+def _estimate_local_background_matrix(centered_matrix, target_window: int = 101) -> Tuple[np.ndarray, int, float]:
+    """rocco/inference.py:185-229: (local baselines [K, n], window, penalty)."""
+    matrix = np.asarray(centered_matrix, dtype=np.float64)
+    if matrix.ndim != 2:
+        raise ValueError("`centered_matrix` must be two-dimensional")
+    _, n_loci = matrix.shape
+    window = _resolve_local_baseline_window(n_loci, target_window=target_window)
+    if window == 0:
+        return np.zeros_like(matrix, dtype=np.float64), 0, 0.0
+    penalty_lambda = _consenrich_whittaker_lambda(window)
+    local_baselines = crossfit_whittaker_baseline(matrix, penalty_lambda=penalty_lambda)
+    if not np.all(np.isfinite(local_baselines)):
+        raise ValueError("Local baseline fit produced non-finite values")
+    return local_baselines, window, penalty_lambda

@@ -1,0 +1,50 @@
+"""GPU: cross-fit Whittaker baseline through the C ABI (rocco_hip_crossfit_whittaker_baseline_matrix_f64)
+against the golden vectors of the reference's backend and against the CPU oracle: bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "baseline_vectors.npz")
+
+
+def test_golden_baselines_bit_for_bit(gpu):
+    from rocco_amd.inference import crossfit_whittaker_baseline
+
+    gold = np.load(GOLD)
+    for name in gold["names"]:
+        got = crossfit_whittaker_baseline(gold[f"{name}_matrix"], float(gold[f"{name}_lambda"]))
+        assert got.dtype == np.float64 and got.shape == gold[f"{name}_matrix"].shape
+        assert got.tobytes() == gold[f"{name}_baseline"].tobytes(), name
+    # one-dimensional input (rocco/_baseline.c:74-81)
+    name = str(gold["names"][-1])
+    row = gold[f"{name}_matrix"][0]
+    one = crossfit_whittaker_baseline(row, float(gold[f"{name}_lambda"]))
+    assert one.shape == row.shape and one.tobytes() == gold[f"{name}_baseline"][0].tobytes()
+    with pytest.raises(ValueError):
+        crossfit_whittaker_baseline(np.zeros((2, 2, 2)), 1.0)
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 25), (3, 63), (5, 64), (7, 65), (64, 129), (65, 4097), (130, 20001), (2, 300007)])
+def test_random_matrices_match_oracle(gpu, oracle, rows, cols):
+    from rocco_amd.inference import _consenrich_whittaker_lambda, crossfit_whittaker_baseline
+
+    rng = np.random.default_rng(rows * 1000 + cols)
+    m = rng.normal(0.0, 1.5, size=(rows, cols))
+    m[rng.random(m.shape) < 0.1] = 0.0
+    for block in (3, 101):
+        lam = _consenrich_whittaker_lambda(min(block, cols))
+        assert crossfit_whittaker_baseline(m, lam).tobytes() == oracle.crossfit_whittaker_baseline(m, lam).tobytes(), (rows, cols, block)
+
+
+def test_local_background_matrix(gpu, oracle):
+    from rocco_amd.inference import _estimate_local_background_matrix
+
+    rng = np.random.default_rng(3)
+    m = rng.normal(size=(4, 2000))
+    base, window, lam = _estimate_local_background_matrix(m)
+    assert window == 101 and lam == 7.0 * ((101.0 * 0.15915494) ** 4)
+    assert base.tobytes() == oracle.crossfit_whittaker_baseline(m, lam).tobytes()
+    z, w0, l0 = _estimate_local_background_matrix(rng.normal(size=(2, 24)))
+    assert w0 == 0 and l0 == 0.0 and not z.any()
