@@ -113,6 +113,7 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->dev_solution.release();
     solver->dev_maps.release();
     solver->dev_frozen.release();
+    solver->dev_factor.release();
     solver->host_stage.release();
     solver->host_back.release();
     delete solver;
@@ -302,8 +303,24 @@ int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, c
     if ((rc = solver->dev_misc.reserve(whittaker_scratch_bytes(rows, cols))) != ROCCO_HIP_OK) {
         return rc;
     }
-    rc = launch_crossfit_whittaker(matrix_dev, rows, cols, penalty_lambda, baseline_out_dev, solver->dev_misc.ptr,
-                                   (hipStream_t)stream);
+    if (rows > 0 && cols >= 25 &&
+        !(solver->factor_cap >= cols && solver->factor_lambda == penalty_lambda)) {
+        // the factor depends on the penalty and (at its last two entries only) on the length: keep the
+        // one of the longest rows seen with this penalty
+        const size_t cap = (solver->factor_lambda == penalty_lambda && solver->factor_cap > cols) ? solver->factor_cap : cols;
+        solver->factor_cap = 0;
+        if ((rc = solver->dev_factor.reserve(6 * cap * sizeof(double))) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        if ((rc = launch_whittaker_factor(cap, penalty_lambda, (double *)solver->dev_factor.ptr, (hipStream_t)stream)) !=
+            ROCCO_HIP_OK) {
+            return rc;
+        }
+        solver->factor_cap = cap;
+        solver->factor_lambda = penalty_lambda;
+    }
+    rc = launch_crossfit_whittaker(matrix_dev, rows, cols, penalty_lambda, (const double *)solver->dev_factor.ptr,
+                                   solver->factor_cap, baseline_out_dev, solver->dev_misc.ptr, (hipStream_t)stream);
     if (rc != ROCCO_HIP_OK) {
         return rc;
     }

@@ -57,6 +57,9 @@ struct rocco_hip_solver {
     rocco::DeviceBuffer dev_solution; // solution scratch when the caller wants counts only
     rocco::DeviceBuffer dev_maps;     // per-chunk binade maps of the problems being solved
     rocco::DeviceBuffer dev_frozen;   // per-block frozen summaries of the problems being solved
+    rocco::DeviceBuffer dev_factor;   // Whittaker LDL^T factor of the longest row seen (whittaker.hip)
+    double factor_lambda = 0.0;       // ... its penalty
+    size_t factor_cap = 0;            // ... and length (0: none)
     rocco::PinnedBuffer host_stage;   // pinned staging for uploads
     rocco::PinnedBuffer host_back;    // pinned staging for readbacks
 };

@@ -40,10 +40,14 @@ int launch_objective(const uint8_t *solution_dev, const double *scores_dev,
                      double *objective_host_pinned, hipStream_t stream, bool synchronize = true);
 
 // ---- whittaker.hip --------------------------------------------------------------------------
-// scratch: at least whittaker_scratch_bytes(rows, cols) bytes; matrix and output must not overlap
+// factor_dev: 6 * factor_cap doubles filled by launch_whittaker_factor for a length factor_cap >= cols and
+// the same penalty; scratch: at least whittaker_scratch_bytes(rows, cols) bytes; matrix and output must
+// not overlap
 size_t whittaker_scratch_bytes(size_t rows, size_t cols);
+int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_dev, hipStream_t stream);
 int launch_crossfit_whittaker(const double *matrix_dev, size_t rows, size_t cols, double penalty_lambda,
-                              double *baseline_out_dev, void *scratch_dev, hipStream_t stream);
+                              const double *factor_dev, size_t factor_cap, double *baseline_out_dev,
+                              void *scratch_dev, hipStream_t stream);
 
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
