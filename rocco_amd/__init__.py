@@ -11,6 +11,7 @@ from .dp import (  # noqa: F401
     solve_chrom_exact,
     solve_penalized_chain,
 )
+from .inference import crossfit_whittaker_baseline  # noqa: F401  (rocco/_baseline.c:16-104)
 from .rocco import (  # noqa: F401
     chrom_solution_to_bed,
     combine_chrom_results,
