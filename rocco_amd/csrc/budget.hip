@@ -1176,6 +1176,8 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_MAP_REBUILD")) opt.map_rebuild_ratio = std::atof(e);
     if (const char *e = std::getenv("ROCCO_HIP_BOUNDS")) opt.use_bounds = std::atoi(e) != 0;
     if (const char *e = std::getenv("ROCCO_HIP_SEARCH_GATE")) opt.search_gate = std::atof(e);
+    if (const char *e = std::getenv("ROCCO_HIP_SEARCH_POINTS")) opt.search_points = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("ROCCO_HIP_SEARCH_INTERP")) opt.search_interpolate = std::atoi(e) != 0;
     std::vector<CalibrationResult> res;
     const double t_solve0 = HipEvaluator::now_us();
     if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;

@@ -358,8 +358,11 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 // threshold search: a few exact-arithmetic counts inside (G, L); every one of them moves
                 // G or L (quartiles, plus the log-linear estimate of the crossing once both ends are real)
                 const double width = s.L - s.G;
-                std::vector<double> fr = {0.25, 0.5, 0.75};
-                if (s.G_real && s.L_real && s.cG > s.cL && s.cL > 0) {
+                std::vector<double> fr;
+                for (int k = 1; k <= opt.search_points; ++k) {
+                    fr.push_back((double)k / (double)(opt.search_points + 1));
+                }
+                if (opt.search_interpolate && s.G_real && s.L_real && s.cG > s.cL && s.cL > 0) {
                     const double lg = std::log((double)s.cG), ll = std::log((double)s.cL);
                     const double lt = std::log((double)std::max(1LL, s.target));
                     fr.push_back(std::min(0.98, std::max(0.02, (lg - lt) / (lg - ll))));

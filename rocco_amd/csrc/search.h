@@ -184,6 +184,8 @@ struct SearchOptions {
     double tiny_round_loci = 0.3e6;     // below: spec_depth + 3 levels per round
     double map_rebuild_ratio = 0.8;    // rebuild a bracket map when its margin would shrink below this ratio
     bool exact_penalty = true;         // settle a lone open decision through the spine (penalty bit-exact)
+    int search_points = 2;             // evaluations per round of the threshold search (equally spaced)
+    bool search_interpolate = false;   // ... plus one at the log-linear estimate of the crossing (does not pay)
     double search_gate = 0.015;        // the threshold search stops when (loci that can still change) <= gate * workgroups
     bool use_bounds = true;            // decide early bisection steps with shifted exact-arithmetic counts
     double survey_gate = 0.5;          // survey a bracket when (loci that can still change) <= gate * workgroups
