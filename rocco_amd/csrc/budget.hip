@@ -625,6 +625,7 @@ private:
             ft.slot_count = (int)slots.size() - ft.slot_begin;
             ft.rec_off = 0;
             ft.rec_goff = 0;
+            ft.pre_round = rt[t].bound ? 1 : 0;
             ft.sel_depth = rt[t].record ? rt[t].select_depth : 0;
             ft.sel_has_upper = rt[t].select_has_upper ? 1 : 0;
             ft.sel_target = rt[t].select_target;

@@ -55,6 +55,7 @@ struct FastTask {
     int n_blocks;
     long long rec_off;   // record slots: offset of this task in the [chunk][slot] record arrays
     long long rec_goff;  // ... and in the [group of 32 chunks][slot] summary arrays
+    int pre_round;          // every slot of the task is a bound slot: the staged tile holds rn_q(score)
     int sel_has_upper;      // record slots: the last slot is the current upper end (else: the tree only)
     int sel_depth;          // record slots: > 0 = slots are a bisection tree (heap order) [+ the current upper end];
     long long sel_target;   //   the spine launch walks it against this target and materialises the answer

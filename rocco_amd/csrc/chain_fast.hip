@@ -162,9 +162,18 @@ __device__ __forceinline__ void stage_tile(const FastTask &task, int local_block
                       v12 = src[12 * kFastThreads], v13 = src[13 * kFastThreads], v14 = src[14 * kFastThreads],
                       v15 = src[15 * kFastThreads];
         static_assert(kChunk / 2 == 16, "tile staging is written out for 16 loads per lane");
+        // bound rounds (exact arithmetic on the grid q at penalties that are multiples of q): round the
+        // scores once here instead of once per step and penalty -- rn_q(s - x) == rn_q(s) - x
+        const bool pre = task.pre_round != 0;
+        const double mq = task.magic;
         auto put = [&](int r, const double2 &v) {
             const int e = 2 * (r * kFastThreads + (int)threadIdx.x);
-            *reinterpret_cast<double2 *>(lds_s + (e >> 5) * kLdsStride + (e & 31)) = v;
+            double2 w = v;
+            if (pre) {
+                w.x = (v.x + mq) - mq;
+                w.y = (v.y + mq) - mq;
+            }
+            *reinterpret_cast<double2 *>(lds_s + (e >> 5) * kLdsStride + (e & 31)) = w;
         };
         put(0, v0); put(1, v1); put(2, v2); put(3, v3); put(4, v4); put(5, v5); put(6, v6); put(7, v7);
         put(8, v8); put(9, v9); put(10, v10); put(11, v11); put(12, v12); put(13, v13); put(14, v14); put(15, v15);
@@ -181,6 +190,10 @@ __device__ __forceinline__ void stage_tile(const FastTask &task, int local_block
         } else {
             if (j < n) v.x = s[j];
             if (j + 1 < n) v.y = s[j + 1];
+        }
+        if (task.pre_round != 0) {
+            v.x = (v.x + task.magic) - task.magic;
+            v.y = (v.y + task.magic) - task.magic;
         }
         *reinterpret_cast<double2 *>(lds_s + (e >> 5) * kLdsStride + (e & 31)) = v;
         if (HAS_COSTS) {
@@ -242,6 +255,42 @@ __device__ __forceinline__ int chunk_code(const FastTask &task, const FastSlot &
 // with the last locus) that are clean and free of tolerance weight, and map rounds certify nothing at
 // all.  For those the per-step work collapses to the recursion itself; the general loops below
 // (same results, every corner case) run for the remaining wavefronts.
+
+// K1 of a bound slot (exact arithmetic, nothing to certify): the tile already holds rn_q(score) and the
+// penalty is a multiple of q, so a step input is one subtraction.
+template <bool HAS_COSTS>
+__device__ __forceinline__ void bound_aggregate_steps(const double *__restrict__ sv, const double *__restrict__ cv,
+                                                      double c_prev0_raw, double gamma, double mq, double lambda,
+                                                      double big, Fn &f, int &pstar)
+{
+    const double c_const = (gamma + mq) - mq;
+    double c_prev = HAS_COSTS ? ((c_prev0_raw + mq) - mq) : c_const;
+    bool known = false;
+    int ps = kChunk;
+    double fa = 0.0, lo = -big, hi = big;
+#pragma unroll 1
+    for (int i0 = 0; i0 < kChunk; i0 += 8) {
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const int i = i0 + ii;
+            const double a = sv[i] - lambda;
+            fa = fmin(fmax(fa + a, -big), big);
+            lo = fmin(fmax(lo, -c_prev), c_prev) + a;
+            hi = fmin(fmax(hi, -c_prev), c_prev) + a;
+            if (!known && lo == hi) {
+                known = true;
+                ps = i;
+            }
+            if (HAS_COSTS) {
+                c_prev = (cv[i] + mq) - mq;
+            }
+        }
+    }
+    f.a = fa;
+    f.lo = lo;
+    f.hi = hi;
+    pstar = ps;
+}
 
 // K1, one chain, any interior chunk.  Per-lane parameters select the arithmetic: a = rn_mg(s - sub) + add
 // is rn_u(s) + rn_u(-lambda) for a clean chunk (sub = 0) and rn_q(s - lambda) for a hazard chunk
@@ -366,7 +415,7 @@ __device__ __forceinline__ void mid_apply_steps(const double *__restrict__ sv, c
 }
 
 // K3, one chain: the recursion from the true incoming delta, classes, optional gain.
-template <bool CLEAN, bool HAS_COSTS, bool GAIN, bool CLASSES>
+template <bool CLEAN, bool HAS_COSTS, bool GAIN, bool CLASSES, bool PRE = false>
 __device__ __forceinline__ void lean_apply_steps(const double *__restrict__ sv, const double *__restrict__ cv,
                                                  double c_prev0_raw, double gamma, double mg, double nl, double &delta,
                                                  double &gain, unsigned &D, unsigned &V)
@@ -381,7 +430,8 @@ __device__ __forceinline__ void lean_apply_steps(const double *__restrict__ sv, 
     for (int ii = 0; ii < 8; ++ii) {
         const int i = i0 + ii;
         const double sj = sv[i];
-        const double a = CLEAN ? (((sj + mg) - mg) + nl) : (((sj - nl) + mg) - mg);
+        // PRE: the tile holds rn_q(score) and nl (the penalty) is a multiple of q
+        const double a = PRE ? (sj - nl) : (CLEAN ? (((sj + mg) - mg) + nl) : (((sj - nl) + mg) - mg));
         const double cj = HAS_COSTS ? ((cv[i] + mg) - mg) : c_const;
         if (GAIN) {
             g += fmax(0.0, dl - c_prev);
@@ -456,7 +506,12 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
     if (NCH == 1) {
         const bool interior = valid && j0 > 0 && (j0 + kChunk < n);
         const bool noise_all = __all(need_noise);
-        if (__all(interior) && (noise_all || !__any(need_noise))) {
+        if (slot.mode == kModeBound && task.pre_round != 0 && __all(interior)) {
+            bound_aggregate_steps<HAS_COSTS>(d.sv, d.cv, d.c_prev0, task.gamma, magic, lam[0], big, f[0], pstar[0]);
+            known[0] = pstar[0] < kChunk;
+            done = true;
+            anyw = true;  // (bound slots carry no tolerance model at all; K3 never consults this)
+        } else if (__all(interior) && (noise_all || !__any(need_noise))) {
             const bool clean = mode[0].clean;
             const double mg = clean ? mode[0].magic_u : magic;
             const double sub = clean ? 0.0 : lam[0];
@@ -1108,7 +1163,10 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
         if (__all(lane_lean)) {
             done = true;
             validmask = 0xFFFFFFFFU;
-            if (bound_round) {
+            if (bound_round && task.pre_round != 0) {
+                lean_apply_steps<false, HAS_COSTS, false, true, true>(d.sv, d.cv, d.c_prev0, task.gamma, magic,
+                                                                      lam[0], delta[0], gain, D_lo, V_lo);
+            } else if (bound_round) {
                 lean_apply_steps<false, HAS_COSTS, false, true>(d.sv, d.cv, d.c_prev0, task.gamma, magic, lam[0],
                                                                 delta[0], gain, D_lo, V_lo);
             } else if (map_round) {

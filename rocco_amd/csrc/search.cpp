@@ -243,6 +243,18 @@ void plan_map(const ChainProblem &p, State &s, bool force_bracket)
 // running value (same constants and the same bound on the running values as the hazard mode of
 // oracle/delta_oracle.c, with sum |s| in place of the sum of the positive parts).  With eps >= w + slack, a
 // multiple of q:  count_q(lambda + eps) <= count_reference(lambda) <= count_q(lambda - eps).
+static int bound_grid_exponent(const ChainProblem &p)
+{
+    const double r = std::max(p.cost_max, 0.0) + (p.score_max - p.score_min) + 2.0;
+    return (int)std::ceil(std::log2(8.0 * r)) - 52;
+}
+
+// nearest multiple of q = 2^qexp (bound evaluations run on scores rounded to that grid once per tile)
+static double snap_to_grid(double x, int qexp)
+{
+    return std::ldexp(std::nearbyint(std::ldexp(x, -qexp)), qexp);
+}
+
 static bool bound_epsilon(const ChainProblem &p, double lambda, double *eps_out)
 {
     // sum_j max(0, s_j - lambda) <= sum |s_j| + n * max(0, -lambda)
@@ -370,8 +382,9 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 ProbeRequest r;
                 r.problem = b;
                 r.bound = true;
+                const int qexp = bound_grid_exponent(p);
                 for (double f : fr) {
-                    const double x = s.G + f * width;
+                    const double x = snap_to_grid(s.G + f * width, qexp);
                     if (x - s.eps > s.G && x + s.eps < s.L) {
                         r.lambdas.push_back(x);
                     }
