@@ -370,9 +370,13 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 // threshold search: a few exact-arithmetic counts inside (G, L); every one of them moves
                 // G or L (quartiles, plus the log-linear estimate of the crossing once both ends are real)
                 const double width = s.L - s.G;
+                // evaluations per round: a pass over many loci is dominated by the evaluations themselves
+                // (two per round are cheapest per bit), a small one by its fixed launch + sync cost
+                const int points = (round_loci > 30.0e6) ? opt.search_points
+                                                         : ((round_loci > 12.0e6) ? opt.search_points + 1 : opt.search_points + 3);
                 std::vector<double> fr;
-                for (int k = 1; k <= opt.search_points; ++k) {
-                    fr.push_back((double)k / (double)(opt.search_points + 1));
+                for (int k = 1; k <= points; ++k) {
+                    fr.push_back((double)k / (double)(points + 1));
                 }
                 if (opt.search_interpolate && s.G_real && s.L_real && s.cG > s.cL && s.cL > 0) {
                     const double lg = std::log((double)s.cG), ll = std::log((double)s.cL);
