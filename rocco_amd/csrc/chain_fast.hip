@@ -1944,21 +1944,35 @@ __global__ __launch_bounds__(64) void spine_kernel(FastLaunch L)
             double dv[kGroup + 1];
             double gv[kGroup];
 #pragma unroll
+            // unconditional loads from clamped (always valid) addresses, masked afterwards: loads inside
+            // per-element conditionals would be waited for one by one
             for (int c = 0; c <= kGroup; ++c) {
                 const bool in = active && (k + c < nchunks);
-                const long long a2 = task.rec_off + (in ? (k + c) : 0) * S + (active ? lane : 0);
-                fl[c] = in ? buf.rec_flags[a2] : 1U;
-                dv[c] = in ? buf.rec_din[a2] : 0.0;
+                const long long kc = (k + c < nchunks) ? (k + c) : (nchunks - 1);
+                const long long a2 = task.rec_off + kc * S + (active ? lane : 0);
+                const unsigned flv = buf.rec_flags[a2];
+                const double dvv = buf.rec_din[a2];
+                fl[c] = in ? flv : 1U;
+                dv[c] = in ? dvv : 0.0;
                 if (c < kGroup) {
-                    gv[c] = in ? buf.rec_gain[a2] : 0.0;
+                    const double gvv = buf.rec_gain[a2];
+                    gv[c] = in ? gvv : 0.0;
                 }
             }
             double sv[kGroupLoci / 64], cv[kGroupLoci / 64];
 #pragma unroll
             for (int qq = 0; qq < kGroupLoci / 64; ++qq) {
                 const long long j = g0 + qq * 64 + lane;
-                sv[qq] = (j < n) ? sc[j] : 0.0;
-                cv[qq] = has_costs ? ((j > 0 && j < n) ? cs[j - 1] : 0.0) : task.gamma;
+                const long long jc = (j < n) ? j : (n - 1);
+                const double svv = sc[jc];
+                sv[qq] = (j < n) ? svv : 0.0;
+                if (has_costs) {
+                    const long long jj = (jc > 0) ? (jc - 1) : 0;
+                    const double cvv = cs[(jj < n - 1) ? jj : ((n > 1) ? (n - 2) : 0)];
+                    cv[qq] = (j > 0 && j < n) ? cvv : 0.0;
+                } else {
+                    cv[qq] = task.gamma;
+                }
             }
             const long long jx = g0 + kGroupLoci;
             const double s_x = (jx < n) ? sc[jx] : 0.0;
