@@ -162,7 +162,7 @@ def main():
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 semantics) ----
     cpu_baseline = None
     parity = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle as po
 
