@@ -59,10 +59,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (rocco_amd has no CPU path)")
+    # one process per GPU over RCCL; ROCCO_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with
+    # fewer GPUs than ranks (ranks then share devices; timings of such a run mean nothing)
+    backend = os.environ.get("ROCCO_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     names = [c for c in args.chroms.split(",") if c] or None
     genome = synth.chrom_loci(args.step_bp, names)  # [(name, n)]
@@ -92,7 +100,7 @@ def main():
         for idx, c in zip(mine, counts):
             local[idx] = flat[at:at + c]
             at += c
-        merged = shard.gather_intervals(local, device=device) if world > 1 else local
+        merged = shard.gather_intervals(local, device=device if backend == "nccl" else None) if world > 1 else local
         return res, merged
 
     def sync_all():
