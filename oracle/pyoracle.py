@@ -120,6 +120,11 @@ def lib() -> ctypes.CDLL:
         _lib.oracle_median_columns.restype = ctypes.c_int
         _lib.oracle_median_columns.argtypes = [
             ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_double_p]
+        _lib.oracle_score_centered_wls_f64.restype = ctypes.c_int
+        _lib.oracle_score_centered_wls_f64.argtypes = [
+            _c_double_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+            ctypes.c_int, ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
+            _c_double_p, _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int)]
         _lib.oracle_crossfit_whittaker_baseline_matrix_f64.restype = ctypes.c_int
         _lib.oracle_crossfit_whittaker_baseline_matrix_f64.argtypes = [
             _c_double_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, _c_double_p]
@@ -403,3 +408,21 @@ def crossfit_whittaker_baseline(values, penalty_lambda: float) -> np.ndarray:
         _check(lib().oracle_crossfit_whittaker_baseline_matrix_f64(
             _dptr(m), rows, cols, float(penalty_lambda), _dptr(out)))
     return out
+
+
+def score_centered_wls(centered_matrix, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
+                       spatial_window: int = 31, precision_floor_ratio: float = 0.01):
+    """rocco/_wls.c `score_centered_wls` over rocco/native/wls_backend.c:744-947: returns
+    (scores, mean, raw_variance, prior_variance, moderated_variance, standard_error, total_df, window)."""
+    m = np.ascontiguousarray(centered_matrix, dtype=np.float64)
+    if m.ndim != 2 or m.shape[0] == 0 or m.shape[1] == 0:
+        raise ValueError("`centered_matrix` must be a non-empty two-dimensional array")
+    K, n = m.shape
+    tracks = [np.empty(n, dtype=np.float64) for _ in range(6)]
+    df, win = ctypes.c_double(), ctypes.c_int()
+    _check(lib().oracle_score_centered_wls_f64(
+        _dptr(m), K, n, float(lower_bound_z), float(prior_df), float(0.0 if min_effect is None else min_effect),
+        0 if min_effect is None else 1, int(spatial_window), float(precision_floor_ratio),
+        *[_dptr(t) for t in tracks], ctypes.byref(df), ctypes.byref(win)))
+    mean, raw, prior, mod, se, scores = tracks
+    return scores, mean, raw, prior, mod, se, float(df.value), int(win.value)

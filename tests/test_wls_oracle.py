@@ -1,0 +1,53 @@
+"""CPU: the oracle's restatement of the centred-WLS backend (oracle/wls_oracle.c) against the golden
+vectors written from the reference's own backend, and against that backend itself when its build
+(oracle/_ref/libwls_ref.so) is present."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "wls_vectors.npz")
+
+
+def run_case(oracle, gold, name):
+    lbz, pdf, me, use_me, win, pfr = gold[f"{name}_params"]
+    res = oracle.score_centered_wls(gold[f"{name}_matrix"], lower_bound_z=lbz, prior_df=pdf,
+                                    min_effect=(me if use_me else None), spatial_window=int(win),
+                                    precision_floor_ratio=pfr)
+    scores, mean, raw, prior, mod, se, df, window = res
+    return np.stack([mean, raw, prior, mod, se, scores]), np.array([df, window])
+
+
+def test_oracle_reproduces_golden_wls_tracks_bit_for_bit(oracle):
+    gold = np.load(GOLD)
+    for name in gold["names"]:
+        tracks, dfw = run_case(oracle, gold, name)
+        assert tracks.tobytes() == gold[f"{name}_tracks"].tobytes(), name
+        assert np.array_equal(dfw, gold[f"{name}_df_window"]), name
+
+
+def test_oracle_matches_compiled_reference_backend(oracle):
+    path = os.path.join(ROOT, "oracle", "_ref", "libwls_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libwls_ref.so not built (reference not present)")
+    dp = ctypes.POINTER(ctypes.c_double)
+    ref = ctypes.CDLL(path).rocco_score_centered_wls_f64
+    ref.argtypes = [dp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                    ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, dp, dp, dp, dp, dp, dp,
+                    ctypes.POINTER(ctypes.c_int)]
+    ref.restype = ctypes.c_int
+    rng = np.random.default_rng(11)
+    for n in (1, 4, 5, 33, 1000, 50001):
+        for K in (1, 4):
+            m = np.ascontiguousarray(np.round(rng.normal(0, 1, (K, n)), 2))  # rounded: plenty of ties
+            tracks = [np.empty(n) for _ in range(6)]
+            df, win = ctypes.c_double(), ctypes.c_int()
+            assert ref(m.ctypes.data_as(dp), K, n, 1.0, 5.0, 0.0, 0, 31, 0.01,
+                       *[t.ctypes.data_as(dp) for t in tracks], ctypes.byref(df), ctypes.byref(win)) == 0
+            got = oracle.score_centered_wls(m)
+            want = (tracks[5], tracks[0], tracks[1], tracks[2], tracks[3], tracks[4])
+            for g, w in zip(got[:6], want):
+                assert g.tobytes() == w.tobytes(), (n, K)
+            assert got[6] == df.value and got[7] == win.value
