@@ -182,11 +182,7 @@ int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev,
                           int64_t *run_begin_dev, int64_t *run_end_dev, size_t capacity,
                           size_t *n_runs_out, void *stream);
 
-/* ---- synthetic signal matrices (benchmark / test support, device-resident) -------------------
- * Fills a row-major [K][n] matrix with the counter-based synthetic tracks described in
- * DESIGN.md section 7 (5-decimal background + planted peaks with per-sample dropout); the same
- * integer arithmetic is restated in NumPy in rocco_amd/synth.py so any slice can be regenerated
- * on the host bit-for-bit. */
+/* ---- row baselines ------------------------------------------------ */
 /* Cross-fit Whittaker baseline of every row of a row-major rows x cols matrix.
  * Replaces rocco_crossfit_whittaker_baseline_matrix_f64 (rocco/native/baseline_backend.h:12-23,
  * baseline_backend.c:305-334) as called through rocco/_baseline.c:16-104 from rocco/inference.py:185-209,
@@ -196,6 +192,26 @@ int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, c
                                                      size_t rows, size_t cols, double penalty_lambda,
                                                      double *baseline_out_dev, void *stream);
 
+/* ---- centred-WLS locus scores ------------------------------------
+ * Replaces rocco_score_centered_wls_f64 (rocco/native/wls_backend.h:11-28, wls_backend.c:744-947) as
+ * called through rocco/_wls.c from rocco/inference.py:231-299 (`_score_centered_wls_matrix`), on device
+ * buffers: centered_dev is the row-major K x n matrix of baseline-subtracted tracks; the six outputs are
+ * n doubles each; *df_out / *window_out (host, may be NULL) receive the degrees of freedom and the
+ * spatial window used.  Same arguments and, on finite input, the same results bit for bit.  Differences:
+ * non-finite values are rejected with EINVAL (the reference drops such pairs from the trend fit);
+ * spatial windows above 63 loci are rejected with EINVAL (the reference's caller always passes 31).
+ * Returns 0, ROCCO_HIP_ENOMEM (the reference's -1), EINVAL (its -2) or EHIP. */
+int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *centered_dev, size_t K, size_t n,
+                                     double lower_bound_z, double prior_df, double min_effect, int use_min_effect,
+                                     int spatial_window, double precision_floor_ratio, double *mean_dev,
+                                     double *raw_var_dev, double *prior_var_dev, double *mod_var_dev, double *se_dev,
+                                     double *scores_dev, double *df_out, int *window_out, void *stream);
+
+/* ---- synthetic signal matrices (benchmark / test support, device-resident) -------------------
+ * Fills a row-major [K][n] matrix with the counter-based synthetic tracks described in
+ * DESIGN.md section 7 (5-decimal background + planted peaks with per-sample dropout); the same
+ * integer arithmetic is restated in NumPy in rocco_amd/synth.py so any slice can be regenerated
+ * on the host bit-for-bit. */
 int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
                            size_t row_stride, uint64_t seed, void *stream);
 

@@ -12,6 +12,7 @@ from .dp import (  # noqa: F401
     solve_penalized_chain,
 )
 from .inference import crossfit_whittaker_baseline  # noqa: F401  (rocco/_baseline.c:16-104)
+from .inference import score_centered_wls  # noqa: F401  (rocco/_wls.c)
 from .rocco import (  # noqa: F401
     chrom_solution_to_bed,
     combine_chrom_results,

@@ -113,6 +113,10 @@ PROTOTYPES = [
     ("rocco_hip_crossfit_whittaker_baseline_matrix_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_void_p,
       ctypes.c_void_p]),
+    ("rocco_hip_score_centered_wls_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_double,
+      ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_int_p, ctypes.c_void_p]),
     ("rocco_hip_synth_matrix", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
       ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]),

@@ -328,6 +328,30 @@ int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, c
     return ROCCO_HIP_OK;
 }
 
+int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *centered_dev, size_t K, size_t n,
+                                     double lower_bound_z, double prior_df, double min_effect, int use_min_effect,
+                                     int spatial_window, double precision_floor_ratio, double *mean_dev,
+                                     double *raw_var_dev, double *prior_var_dev, double *mod_var_dev, double *se_dev,
+                                     double *scores_dev, double *df_out, int *window_out, void *stream)
+{
+    // argument checks of rocco_score_centered_wls_f64 (wls_backend.c:770-776)
+    if (solver == nullptr || centered_dev == nullptr || mean_dev == nullptr || raw_var_dev == nullptr ||
+        prior_var_dev == nullptr || mod_var_dev == nullptr || se_dev == nullptr || scores_dev == nullptr || K == 0 ||
+        n == 0 || n > (size_t)0x7fffffff) {
+        set_last_error("rocco_hip_score_centered_wls_f64: null buffer, empty matrix or more than 2^31-1 loci");
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_misc.reserve(wls_scratch_bytes(K, n))) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    return launch_score_centered_wls(centered_dev, K, n, lower_bound_z, prior_df, min_effect, use_min_effect,
+                                     spatial_window, precision_floor_ratio, mean_dev, raw_var_dev, prior_var_dev,
+                                     mod_var_dev, se_dev, scores_dev, solver->dev_misc.ptr, df_out, window_out,
+                                     (hipStream_t)stream);
+}
+
 int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
                            size_t row_stride, uint64_t seed, void *stream)
 {

@@ -49,6 +49,17 @@ int launch_crossfit_whittaker(const double *matrix_dev, size_t rows, size_t cols
                               const double *factor_dev, size_t factor_cap, double *baseline_out_dev,
                               void *scratch_dev, hipStream_t stream);
 
+// ---- wls.hip --------------------------------------------------------------------------------
+// scratch: at least wls_scratch_bytes(K, n) bytes; synchronises the stream before returning
+int wls_spatial_window(size_t n, int requested);
+int wls_max_window();
+size_t wls_scratch_bytes(size_t K, size_t n);
+int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, double lower_bound_z, double prior_df,
+                              double min_effect, int use_min_effect, int spatial_window,
+                              double precision_floor_ratio, double *mean_dev, double *raw_var_dev,
+                              double *prior_var_dev, double *mod_var_dev, double *se_dev, double *scores_dev,
+                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream);
+
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
                  hipStream_t stream);

@@ -1,0 +1,648 @@
+// rocco_amd/csrc/wls.hip -- centred-WLS scoring of a K x n matrix, gfx950.
+//
+// Replaces rocco_score_centered_wls_f64 (rocco/native/wls_backend.c:744-947; wrapper rocco/_wls.c; caller
+// rocco/inference.py:231-299).  Results equal the reference's bit for bit on finite inputs, so every
+// order-dependent sum keeps the reference's order:
+//   * rolling AR(1) innovation variance (610-742): the three running sums are updated by subtract-then-add
+//     along the row -- one lane per row runs them in sequence (16 rows per workgroup, tiles of 256 start
+//     positions through LDS), then all 64 lanes turn the sums of the tile into variances (the divisions
+//     are not part of the dependent chain);
+//   * monotone variance trend (394-608): the reference sorts the (|value|, variance) pairs of a row with
+//     qsort under a total order (x, then y), so the sorted sequence is unique: two stable device radix
+//     sorts (by y, then by x) give the same sequence; bin medians are order statistics, taken from a
+//     segmented sort of each bin's variances; pooling (262-339) and knots run in one thread per row;
+//   * rows are accumulated into the per-locus precision sums in row order (858-910), one launch per row.
+#include "kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+
+namespace rocco {
+
+namespace {
+
+constexpr int kTile = 512;   // start positions per tile of the rolling kernel
+constexpr int kLanes = 64;
+constexpr int kHelpers = 3 * kLanes;  // lanes of the helper wavefronts of the rolling kernel
+constexpr int kMaxWindow = 63;
+constexpr int kStream = kTile + kMaxWindow + 9;  // values a tile of start positions touches (+ one prefetched batch)
+static_assert(kTile % 16 == 0, "two batches of 8 start positions per trip");
+constexpr int kStage = (kStream + kHelpers - 1) / kHelpers;
+constexpr int kMaxBins = 64;
+
+// ---- rolling AR(1) innovation variance (wls_backend.c:610-742) --------------------------------------
+// vas[row][s] for s = 0 .. max_start (the caller indexes it with clamp(i - half, 0, max_start), 727-738).
+// One workgroup of four wavefronts per row.  The three running sums of the reference are independent
+// chains  s <- (s - P[t]) + P[t + off]  over the streams  P0 = v, P1 = v*v, P2 = v[i]*v[i+1]
+// (off = window, window, window - 1): lanes 0..2 of the first wavefront run one chain each -- two dependent
+// additions per start position, the order of the reference (711-722) -- while the other three wavefronts
+// turn the previous tile's sums into variances (667-709; its divisions are off the chain) and stage the
+// next tile's streams in a third LDS buffer (loads issued before, stored after the variance arithmetic).
+struct RollingTile {
+    double P[3][kStream];
+    double S[3][kTile];
+};
+
+struct StagedValues {
+    double v[kStage], nx[kStage];
+};
+
+__device__ __forceinline__ void rolling_stage_load(StagedValues &r, const double *__restrict__ row, long long n,
+                                                   long long base, int hl)
+{
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) {
+        const long long i = base + hl + j * kHelpers;
+        const long long i0 = (i < n) ? i : (n - 1), i1 = (i + 1 < n) ? (i + 1) : (n - 1);  // loads without branches
+        const double v = row[i0], nx = row[i1];
+        r.v[j] = (i < n) ? v : 0.0;
+        r.nx[j] = (i + 1 < n) ? nx : 0.0;
+    }
+}
+
+__device__ __forceinline__ void rolling_stage_store(RollingTile &tile, const StagedValues &r, int hl)
+{
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) {
+        const int c = hl + j * kHelpers;
+        if (c < kStream) {
+            tile.P[0][c] = r.v[j];
+            tile.P[1][c] = r.v[j] * r.v[j];
+            tile.P[2][c] = r.v[j] * r.nx[j];
+        }
+    }
+}
+
+__device__ __forceinline__ void rolling_variances(const RollingTile &tile, double *__restrict__ out, int T, int window,
+                                                  int hl)
+{
+    const double wd = (double)window, pair_count = (double)(window - 1);
+    for (int t = hl; t < T; t += kHelpers) {
+        const double sy = tile.S[0][t], ssq = tile.S[1][t], slag = tile.S[2][t];
+        const double leaving = tile.P[0][t], entering = tile.P[0][t + window - 1];
+        const double sum_x_seq = sy - entering, sum_y_seq = sy - leaving;
+        const double mean_all = sy / wd;
+        double g0n = ssq - (wd * mean_all * mean_all);
+        if (g0n < 0.0) {
+            g0n = 0.0;
+        }
+        const double g1n = slag - (mean_all * sum_x_seq) - (mean_all * sum_y_seq) + (pair_count * mean_all * mean_all);
+        const double lambda_eff = 1.0 / (wd + 1.0);
+        const double scale_floor = 1.0e-4 * (g0n + 1.0);
+        const double denom = (g0n * (1.0 + lambda_eff)) + scale_floor;
+        const double eps = 1.0e-12 * (g0n + 1.0);
+        double beta1 = 0.0;
+        if (denom > eps) {
+            beta1 = g1n / denom;
+        }
+        if (beta1 > 0.99) {
+            beta1 = 0.99;
+        } else if (beta1 < 0.0) {
+            beta1 = 0.0;
+        }
+        const double gamma0 = g0n / wd;
+        double omb = 1.0 - (beta1 * beta1);
+        if (omb < 0.0) {
+            omb = 0.0;
+        }
+        out[t] = fmax(gamma0 * omb, 0.0);
+    }
+}
+
+__global__ __launch_bounds__(kLanes + kHelpers) void wls_rolling_kernel(const double *__restrict__ matrix, long long n,
+                                                                       int window, double *__restrict__ vas)
+{
+    __shared__ RollingTile tiles[3];  // the tile the chains run on, the previous one (variances), the next one (staging)
+    const int lane = threadIdx.x, hl = (int)threadIdx.x - kLanes;
+    const bool helper = hl >= 0;
+    const double *__restrict__ row = matrix + (long long)blockIdx.x * n;
+    const long long max_start = n - window;
+    double *__restrict__ out = vas + (long long)blockIdx.x * (max_start + 1);
+    const long long n_tiles = (max_start + kTile) / kTile;  // ceil((max_start + 1) / kTile)
+    StagedValues staged;
+    if (helper) {
+        rolling_stage_load(staged, row, n, 0, hl);
+        rolling_stage_store(tiles[0], staged, hl);
+    }
+    __syncthreads();
+    double sum = 0.0;
+    const int off = (lane == 2) ? (window - 1) : window;
+    const int chain = (lane < 3) ? lane : 0;
+    if (lane < 3) {
+        // wls_backend.c:652-661
+        const int terms = (lane == 2) ? (window - 1) : window;
+        for (int i = 0; i < terms; ++i) {
+            sum += tiles[0].P[chain][i];
+        }
+    }
+    for (long long tile = 0; tile < n_tiles; ++tile) {
+        RollingTile &cur = tiles[tile % 3], &prev = tiles[(tile + 2) % 3], &next = tiles[(tile + 1) % 3];
+        if (!helper) {
+            if (lane < 3) {
+                const double *__restrict__ P = cur.P[chain];
+                double *__restrict__ S = cur.S[chain];
+                // (past the row's last start the update reads staged zeros and its result is not used)
+                double a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    a[u] = P[u];
+                    b[u] = P[u + off];
+                }
+#pragma unroll 1
+                for (int t = 0; t < kTile; t += 16) {
+                    // two batches per trip, the operand registers ping-pong: the next batch's operands are
+                    // fetched while this batch's chain runs
+                    double a2[8], b2[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        a2[u] = P[t + 8 + u];
+                        b2[u] = P[t + 8 + u + off];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        S[t + u] = sum;
+                        sum = (sum - a[u]) + b[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        a[u] = P[t + 16 + u];
+                        b[u] = P[t + 16 + u + off];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        S[t + 8 + u] = sum;
+                        sum = (sum - a2[u]) + b2[u];
+                    }
+                }
+            }
+        } else {
+            rolling_stage_load(staged, row, n, (tile + 1) * kTile, hl);  // (zeros past the row's end)
+            if (tile > 0) {
+                rolling_variances(prev, out + (tile - 1) * kTile, kTile, window, hl);
+            }
+            rolling_stage_store(next, staged, hl);
+        }
+        __syncthreads();
+    }
+    if (helper) {
+        const long long last = n_tiles - 1;
+        rolling_variances(tiles[last % 3], out + last * kTile, (int)(max_start + 1 - last * kTile), window, hl);
+    }
+}
+
+__device__ __forceinline__ double obs_variance_at(const double *__restrict__ vas_row, long long i, long long half,
+                                                  long long max_start)
+{
+    // wls_backend.c:727-738 then 865-868
+    long long c = (i < half) ? 0 : (i - half);
+    if (c > max_start) {
+        c = max_start;
+    }
+    return fmax(vas_row[c], 1.0e-8);
+}
+
+// pairs of one row: keys (bit patterns of non-negative doubles order like the numbers)
+__global__ __launch_bounds__(256) void wls_pairs_kernel(const double *__restrict__ row, const double *__restrict__ vas_row,
+                                                       long long n, long long half, long long max_start,
+                                                       unsigned long long *__restrict__ key_y,
+                                                       unsigned long long *__restrict__ val_x, int *__restrict__ bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const double x = fabs(row[i]);
+    const double y = fmax(obs_variance_at(vas_row, i, half, max_start), 1.0e-8);  // wls_backend.c:429-430
+    if (!isfinite(x) || !isfinite(y)) {
+        atomicOr(bad, 1);
+    }
+    key_y[i] = (unsigned long long)__double_as_longlong(y);
+    val_x[i] = (unsigned long long)__double_as_longlong(x);
+}
+
+__global__ __launch_bounds__(256) void wls_iota_kernel(unsigned *__restrict__ idx, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        idx[i] = (unsigned)i;
+    }
+}
+
+// perm[r] = position in the y-sorted sequence of the pair of rank r in (x, y) order; the pair's trend bin
+// is the b with (b n) / bins <= r < ((b + 1) n) / bins (wls_backend.c:474-476)
+__global__ __launch_bounds__(256) void wls_bin_scatter_kernel(const unsigned *__restrict__ perm, long long n, int bins,
+                                                             unsigned char *__restrict__ bin_of_yrank)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) {
+        return;
+    }
+    long long b = (r * bins) / n;
+    while (b + 1 < bins && ((b + 1) * n) / bins <= r) {
+        ++b;
+    }
+    while (b > 0 && (b * n) / bins > r) {
+        --b;
+    }
+    bin_of_yrank[perm[r]] = (unsigned char)b;
+}
+
+struct TrendFit {
+    int mode;         // 0: constant `value`, 2: interpolate the knots
+    int knots;
+    double value;
+    double kc[kMaxBins], kv[kMaxBins];
+};
+
+__device__ __forceinline__ double bits_to_double(unsigned long long b) { return __longlong_as_double((long long)b); }
+
+// one thread: bins -> pooled fit -> knots (wls_backend.c:436-439, 472-565)
+__global__ void wls_knots_kernel(const unsigned long long *__restrict__ ys_sorted_all,  // all y ascending
+                                 const unsigned long long *__restrict__ xs,             // x of the (x, y)-sorted pairs
+                                 const unsigned long long *__restrict__ ys_bins,        // y sorted inside each bin
+                                 long long n, int bins, TrendFit *fit)
+{
+    __shared__ double s_bc[kMaxBins], s_bv[kMaxBins], s_bw[kMaxBins];
+    __shared__ double s_fallback;
+    {
+        // one lane per bin fetches the bin's medians (wls_backend.c:472-520)
+        const int b = threadIdx.x;
+        if (b < bins) {
+            const long long left = ((long long)b * n) / bins, right = ((long long)(b + 1) * n) / bins;
+            const long long width = right - left;
+            double c = 0.0, v = 0.0;
+            if (width > 0) {
+                if (width & 1LL) {
+                    c = bits_to_double(xs[left + width / 2]);
+                    v = bits_to_double(ys_bins[left + width / 2]);
+                } else {
+                    c = 0.5 * (bits_to_double(xs[left + width / 2 - 1]) + bits_to_double(xs[left + width / 2]));
+                    v = 0.5 * (bits_to_double(ys_bins[left + width / 2 - 1]) + bits_to_double(ys_bins[left + width / 2]));
+                }
+            }
+            s_bc[b] = c;
+            s_bv[b] = v;
+            s_bw[b] = (double)width;
+        }
+        if (b == kMaxBins - 1) {
+            // fallback: median of every y (wls_backend.c:436-439)
+            double f;
+            if (n & 1LL) {
+                f = bits_to_double(ys_sorted_all[n / 2]);
+            } else {
+                f = 0.5 * (bits_to_double(ys_sorted_all[n / 2 - 1]) + bits_to_double(ys_sorted_all[n / 2]));
+            }
+            s_fallback = fmax(f, 1.0e-8);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) {
+        return;
+    }
+    const double fallback = s_fallback;
+    double bc[kMaxBins], bv[kMaxBins], bw[kMaxBins], fitv[kMaxBins];
+    long long bl[kMaxBins];
+    int used = 0;
+    for (int b = 0; b < bins; ++b) {
+        if (s_bw[b] > 0.0) {
+            bc[used] = s_bc[b];
+            bv[used] = s_bv[b];
+            bw[used] = s_bw[b];
+            ++used;
+        }
+    }
+    fit->mode = 0;
+    fit->knots = 0;
+    if (used == 0) {
+        fit->value = fallback;
+        return;
+    }
+    if (used == 1) {
+        fit->value = fmax(bv[0], 1.0e-8);
+        return;
+    }
+    // pool adjacent violators (wls_backend.c:262-339)
+    int nb = 0;
+    for (int i = 0; i < used; ++i) {
+        fitv[nb] = bv[i];
+        bw[nb] = fmax(bw[i], 1.0e-8);
+        bl[nb] = 1;
+        ++nb;
+        while (nb >= 2 && fitv[nb - 2] > fitv[nb - 1]) {
+            const double tw = bw[nb - 2] + bw[nb - 1];
+            const double mv = ((fitv[nb - 2] * bw[nb - 2]) + (fitv[nb - 1] * bw[nb - 1])) / tw;
+            fitv[nb - 2] = mv;
+            bw[nb - 2] = tw;
+            bl[nb - 2] += bl[nb - 1];
+            --nb;
+        }
+    }
+    // expand blocks and build the knots (wls_backend.c:541-552)
+    int knots = 0;
+    int idx = 0;
+    for (int b = 0; b < nb; ++b) {
+        for (long long r = 0; r < bl[b]; ++r, ++idx) {
+            const double cv = bc[idx], vv = fmax(fitv[b], 1.0e-8);
+            if (knots > 0 && cv <= fit->kc[knots - 1]) {
+                fit->kv[knots - 1] = fmax(fit->kv[knots - 1], vv);
+                continue;
+            }
+            fit->kc[knots] = cv;
+            fit->kv[knots] = vv;
+            ++knots;
+        }
+    }
+    fit->knots = knots;
+    if (knots == 0) {
+        fit->value = fallback;
+    } else if (knots == 1) {
+        fit->value = fmax(fit->kv[0], 1.0e-8);
+    } else {
+        fit->mode = 2;
+    }
+}
+
+// wls_backend.c:341-392
+__device__ __forceinline__ double linear_interp(const double *xs, const double *ys, int count, double t)
+{
+    if (count == 1 || t <= xs[0]) {
+        return ys[0];
+    }
+    if (t >= xs[count - 1]) {
+        return ys[count - 1];
+    }
+    int left = 0, right = count - 1;
+    while (right - left > 1) {
+        const int mid = left + (right - left) / 2;
+        if (xs[mid] <= t) {
+            left = mid;
+        } else {
+            right = mid;
+        }
+    }
+    if (xs[right] <= xs[left]) {
+        return fmax(ys[right], ys[left]);
+    }
+    const double w = (t - xs[left]) / (xs[right] - xs[left]);
+    return ys[left] + (w * (ys[right] - ys[left]));
+}
+
+// one row into the per-locus sums (wls_backend.c:885-910); sums = weighted | precision | raw | prior, n each
+__global__ __launch_bounds__(256) void wls_accumulate_kernel(const double *__restrict__ row, const double *__restrict__ vas_row,
+                                                            long long n, long long half, long long max_start,
+                                                            const TrendFit *__restrict__ fit, double local_df,
+                                                            double prior_df, double total_df, double floor_ratio,
+                                                            double *__restrict__ sums)
+{
+    __shared__ double kc[kMaxBins], kv[kMaxBins];
+    const int mode = fit->mode, knots = fit->knots;
+    if (threadIdx.x < kMaxBins) {
+        kc[threadIdx.x] = fit->kc[threadIdx.x];
+        kv[threadIdx.x] = fit->kv[threadIdx.x];
+    }
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const double value = row[i];
+    const double obs_value = fmax(obs_variance_at(vas_row, i, half, max_start), 1.0e-8);
+    double prior_track = fit->value;
+    if (mode == 2) {
+        prior_track = fmax(linear_interp(kc, kv, knots, fabs(value)), 1.0e-8);  // wls_backend.c:590-592
+    }
+    const double prior_value = fmax(prior_track, 1.0e-8);
+    double posterior_variance = ((local_df * obs_value) + (prior_df * prior_value)) / fmax(total_df, 1.0);
+    const double variance_floor = floor_ratio * prior_value;
+    if (posterior_variance < variance_floor) {
+        posterior_variance = variance_floor;
+    }
+    posterior_variance = fmax(posterior_variance, 1.0e-8);
+    const double posterior_precision = 1.0 / posterior_variance;
+    sums[2 * n + i] += 1.0 / obs_value;
+    sums[3 * n + i] += 1.0 / prior_value;
+    sums[1 * n + i] += posterior_precision;
+    sums[0 * n + i] += posterior_precision * value;
+}
+
+// rows of fewer than 5 loci (no window): robust scale of the row for every locus (wls_backend.c:834-851)
+__global__ void wls_tiny_kernel(const double *__restrict__ matrix, long long rows, long long n, double local_df,
+                                double prior_df, double total_df, double floor_ratio, double *__restrict__ sums)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) {
+        return;
+    }
+    for (long long k = 0; k < rows; ++k) {
+        double w[4];
+        for (long long i = 0; i < n; ++i) {
+            w[i] = matrix[k * n + i];
+        }
+        auto median_small = [&](double *v) {  // order statistics of at most 4 values
+            for (int a = 1; a < (int)n; ++a) {
+                const double key = v[a];
+                int b = a;
+                while (b > 0 && v[b - 1] > key) {
+                    v[b] = v[b - 1];
+                    --b;
+                }
+                v[b] = key;
+            }
+            if (n == 1) {
+                return v[0];
+            }
+            return (n & 1LL) ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]);
+        };
+        const double med = median_small(w);
+        for (long long i = 0; i < n; ++i) {
+            w[i] = fabs(matrix[k * n + i] - med);
+        }
+        // (the reference takes |work - median| of the partially ordered work buffer: same multiset)
+        double mad = median_small(w);
+        mad *= 1.4826;
+        double sf = (mad > 1.0e-6) ? mad : 1.0e-6;
+        sf = fmax(sf * sf, 1.0e-8);
+        for (long long i = 0; i < n; ++i) {
+            const double obs_value = fmax(sf, 1.0e-8), prior_value = fmax(sf, 1.0e-8);
+            double pv = ((local_df * obs_value) + (prior_df * prior_value)) / fmax(total_df, 1.0);
+            const double vf = floor_ratio * prior_value;
+            if (pv < vf) {
+                pv = vf;
+            }
+            pv = fmax(pv, 1.0e-8);
+            const double prec = 1.0 / pv;
+            sums[2 * n + i] += 1.0 / obs_value;
+            sums[3 * n + i] += 1.0 / prior_value;
+            sums[1 * n + i] += prec;
+            sums[0 * n + i] += prec * matrix[k * n + i];
+        }
+    }
+}
+
+// wls_backend.c:913-937
+__global__ __launch_bounds__(256) void wls_final_kernel(const double *__restrict__ sums, long long n, double sample_count,
+                                                       double lower_bound_z, double min_effect, int use_min_effect,
+                                                       double *__restrict__ mean, double *__restrict__ raw_var,
+                                                       double *__restrict__ prior_var, double *__restrict__ mod_var,
+                                                       double *__restrict__ se, double *__restrict__ scores)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const double locus_precision = fmax(sums[1 * n + i], 1.0e-8);
+    const double m = sums[0 * n + i] / locus_precision;
+    mean[i] = m;
+    raw_var[i] = sample_count / fmax(sums[2 * n + i], 1.0e-8);
+    prior_var[i] = sample_count / fmax(sums[3 * n + i], 1.0e-8);
+    mod_var[i] = sample_count / locus_precision;
+    const double s = sqrt(1.0 / locus_precision);
+    se[i] = s;
+    const double z = m / fmax(s, 1.0e-8);
+    if (use_min_effect != 0) {
+        scores[i] = (m - fmax(min_effect, 0.0)) / fmax(s, 1.0e-8);
+    } else {
+        scores[i] = z - lower_bound_z;
+    }
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+int wls_spatial_window(size_t n, int requested)
+{
+    // wls_backend.c:232-260
+    if (n < 5) {
+        return 0;
+    }
+    size_t w = requested > 0 ? (size_t)requested : 31U;
+    if (w < 5) {
+        w = 5;
+    }
+    if (w > n) {
+        w = n;
+    }
+    if ((w & 1U) == 0) {
+        w = (w == n) ? (w - 1) : (w + 1);
+    }
+    return (w < 5) ? 0 : (int)w;
+}
+
+int wls_max_window() { return kMaxWindow; }
+
+int trend_bins(size_t n)
+{
+    // wls_backend.c:461 -- the same expression, evaluated on the host like the reference's
+    return (int)std::fmax(4.0, std::floor(1.0 + (std::log((double)n + 1.0) / std::log(2.0))));
+}
+
+using u64 = unsigned long long;
+
+size_t sort_temp_bytes(size_t n)
+{
+    size_t a = 0, b = 0, c = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const u64 *)nullptr, (u64 *)nullptr, (const u64 *)nullptr,
+                                             (u64 *)nullptr, (int)n);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const u64 *)nullptr, (u64 *)nullptr, (const unsigned *)nullptr,
+                                             (unsigned *)nullptr, (int)n);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, c, (const unsigned char *)nullptr, (unsigned char *)nullptr,
+                                             (const u64 *)nullptr, (u64 *)nullptr, (int)n, 0, 6);
+    return align_up(std::max(a, std::max(b, c)), 256);
+}
+
+size_t wls_scratch_bytes(size_t K, size_t n)
+{
+    return align_up(K * n * 8, 256) + 6 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256) + 2 * align_up(n, 256) +
+           align_up(4 * n * 8, 256) + sort_temp_bytes(n) + 4096;
+}
+
+int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, double lower_bound_z, double prior_df,
+                              double min_effect, int use_min_effect, int spatial_window,
+                              double precision_floor_ratio, double *mean_dev, double *raw_var_dev,
+                              double *prior_var_dev, double *mod_var_dev, double *se_dev, double *scores_dev,
+                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream)
+{
+    const double pdf = std::fmax(prior_df, 0.0), floor_ratio = std::fmax(precision_floor_ratio, 0.0);
+    const int window = wls_spatial_window(n, spatial_window);
+    const double local_df = window > 0 ? std::fmax(4.0, (double)window - 3.0) : 1.0;
+    const double total_df = local_df + pdf;
+    if (df_out != nullptr) {
+        *df_out = total_df;
+    }
+    if (window_out != nullptr) {
+        *window_out = window;
+    }
+    if (window > kMaxWindow) {
+        set_last_error("rocco_hip_score_centered_wls_f64: spatial windows above 63 loci are not supported");
+        return ROCCO_HIP_EINVAL;
+    }
+    const long long nn = (long long)n;
+    char *sc = (char *)scratch_dev;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        char *p = sc + off;
+        off += align_up(bytes, 256);
+        return p;
+    };
+    double *vas = (double *)carve(K * n * 8);
+    u64 *key_a = (u64 *)carve(n * 8), *key_b = (u64 *)carve(n * 8), *val_a = (u64 *)carve(n * 8);
+    u64 *val_b = (u64 *)carve(n * 8), *key_c = (u64 *)carve(n * 8), *key_d = (u64 *)carve(n * 8);
+    unsigned *iota = (unsigned *)carve(n * 4), *perm = (unsigned *)carve(n * 4);
+    unsigned char *bin_a = (unsigned char *)carve(n), *bin_b = (unsigned char *)carve(n);
+    double *sums = (double *)carve(4 * n * 8);
+    TrendFit *fit = (TrendFit *)carve(sizeof(TrendFit));
+    int *bad = (int *)carve(256);
+    void *tmp = sc + off;
+    const size_t tmp_bytes = sort_temp_bytes(n);
+    ROCCO_HIP_TRY(hipMemsetAsync(sums, 0, 4 * n * 8, stream));
+    ROCCO_HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), stream));
+    const unsigned blocks256 = (unsigned)((n + 255) / 256);
+    if (window == 0 || n < 4) {
+        hipLaunchKernelGGL(wls_tiny_kernel, dim3(1), dim3(64), 0, stream, centered_dev, (long long)K, nn, local_df, pdf,
+                           total_df, floor_ratio, sums);
+    } else {
+        const long long half = window / 2, max_start = nn - window;
+        const size_t vas_stride = (size_t)(max_start + 1);
+        hipLaunchKernelGGL(wls_rolling_kernel, dim3((unsigned)K), dim3(kLanes + kHelpers), 0, stream, centered_dev, nn, window, vas);
+        const int bins = trend_bins(n);
+        if (bins > kMaxBins) {
+            set_last_error("rocco_hip_score_centered_wls_f64: more than 64 trend bins");
+            return ROCCO_HIP_EINVAL;
+        }
+        hipLaunchKernelGGL(wls_iota_kernel, dim3(blocks256), dim3(256), 0, stream, iota, nn);
+        for (size_t k = 0; k < K; ++k) {
+            const double *row = centered_dev + k * n;
+            const double *vas_row = vas + k * vas_stride;
+            hipLaunchKernelGGL(wls_pairs_kernel, dim3(blocks256), dim3(256), 0, stream, row, vas_row, nn, half, max_start,
+                               key_a, val_a, bad);
+            // The reference sorts the pairs under the total order (x, then y): the sorted sequence is unique.
+            // By y carrying x (key_b = every y ascending, also the fallback median) ...
+            size_t t = tmp_bytes;
+            ROCCO_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, t, key_a, key_b, val_a, val_b, (int)n, 0, 64, stream));
+            // ... then -- stable -- by x carrying the y-rank: key_c = x in (x, y) order, perm = y-rank by (x, y)-rank
+            t = tmp_bytes;
+            ROCCO_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, t, val_b, key_c, iota, perm, (int)n, 0, 64, stream));
+            // bin medians of y: a stable sort of the y-sorted sequence by bin leaves every bin's y ascending
+            hipLaunchKernelGGL(wls_bin_scatter_kernel, dim3(blocks256), dim3(256), 0, stream, perm, nn, bins, bin_a);
+            t = tmp_bytes;
+            ROCCO_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, t, bin_a, bin_b, key_b, key_d, (int)n, 0, 6, stream));
+            hipLaunchKernelGGL(wls_knots_kernel, dim3(1), dim3(kMaxBins), 0, stream, key_b, key_c, key_d, nn, bins, fit);
+            hipLaunchKernelGGL(wls_accumulate_kernel, dim3(blocks256), dim3(256), 0, stream, row, vas_row, nn, half,
+                               max_start, fit, local_df, pdf, total_df, floor_ratio, sums);
+        }
+    }
+    hipLaunchKernelGGL(wls_final_kernel, dim3(blocks256), dim3(256), 0, stream, sums, nn, (double)K, lower_bound_z,
+                       min_effect, use_min_effect, mean_dev, raw_var_dev, prior_var_dev, mod_var_dev, se_dev, scores_dev);
+    ROCCO_HIP_TRY(hipGetLastError());
+    int bad_host = 0;
+    ROCCO_HIP_TRY(hipMemcpyAsync(&bad_host, bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize(stream));  // also: the scratch buffer is the solver's
+    if (bad_host != 0) {
+        set_last_error("rocco_hip_score_centered_wls_f64: non-finite values in the centred matrix");
+        return ROCCO_HIP_EINVAL;
+    }
+    return ROCCO_HIP_OK;
+}
+
+}  // namespace rocco

@@ -3,8 +3,10 @@
 Built so far: the cross-fit Whittaker baseline (row a3) -- ``crossfit_whittaker_baseline`` is the
 device replacement of the reference's ``rocco._baseline.crossfit_whittaker_baseline``
 (rocco/_baseline.c:16-104 over rocco/native/baseline_backend.c) and
-``_estimate_local_background_matrix`` mirrors rocco/inference.py:185-229 around it.  Results are the
-reference's bit for bit.  There is no CPU fallback: without the library or a GPU these raise.
+``_estimate_local_background_matrix`` mirrors rocco/inference.py:185-229 around it -- and the centred-WLS
+scores (row a4): ``score_centered_wls`` replaces ``rocco._wls.score_centered_wls`` (rocco/_wls.c over
+rocco/native/wls_backend.c:744-947), ``_score_centered_wls_matrix`` mirrors rocco/inference.py:231-299.
+Results are the reference's bit for bit.  There is no CPU fallback: without the library or a GPU these raise.
 """
 from __future__ import annotations
 
@@ -90,3 +92,75 @@ def _estimate_local_background_matrix(centered_matrix, target_window: int = 101)
     if not np.all(np.isfinite(local_baselines)):
         raise ValueError("Local baseline fit produced non-finite values")
     return local_baselines, window, penalty_lambda
+
+
+def score_centered_wls_device(centered_t, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
+                              spatial_window: int = 31, precision_floor_ratio: float = 0.01):
+    """Device-resident form of the reference extension's ``score_centered_wls`` (rocco/_wls.c over
+    rocco/native/wls_backend.c:744-947): ``centered_t`` is a contiguous float64 CUDA tensor [K, n]; returns
+    (scores, mean, raw_variance, prior_variance, moderated_variance, standard_error, total_df, window)
+    with the six tracks as CUDA tensors of n doubles."""
+    import ctypes
+
+    import torch
+
+    if centered_t.dim() != 2:
+        raise ValueError("`centered_matrix` must be two-dimensional")
+    if centered_t.dtype != torch.float64 or not centered_t.is_cuda or not centered_t.is_contiguous():
+        raise ValueError("centered_t must be a contiguous float64 CUDA tensor")
+    K, n = int(centered_t.shape[0]), int(centered_t.shape[1])
+    if K == 0 or n == 0:
+        raise ValueError("`centered_matrix` must be non-empty")
+    tracks = torch.empty((6, n), dtype=torch.float64, device=centered_t.device)
+    df, win = ctypes.c_double(), ctypes.c_int()
+    solver = _native.solver_for(centered_t.device.index)
+    _native.check(_native.load().rocco_hip_score_centered_wls_f64(
+        solver.handle, centered_t.data_ptr(), K, n, float(lower_bound_z), float(prior_df),
+        float(0.0 if min_effect is None else min_effect), 0 if min_effect is None else 1, int(spatial_window),
+        float(precision_floor_ratio), *[tracks[i].data_ptr() for i in range(6)], ctypes.byref(df), ctypes.byref(win),
+        _dp._stream_ptr(centered_t)), "rocco_hip_score_centered_wls_f64")
+    mean, raw, prior, mod, se, scores = (tracks[i] for i in range(6))
+    return scores, mean, raw, prior, mod, se, float(df.value), int(win.value)
+
+
+def score_centered_wls(centered_matrix, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
+                       spatial_window: int = 31, precision_floor_ratio: float = 0.01):
+    """Same call as the reference's extension ``rocco._wls.score_centered_wls`` on a host array."""
+    _native.load()
+    arr = np.ascontiguousarray(centered_matrix, dtype=np.float64)
+    if arr.ndim != 2 or arr.shape[0] == 0 or arr.shape[1] == 0:
+        raise ValueError("`centered_matrix` must be a non-empty two-dimensional array")
+    centered_t = _dp._to_device_f64(arr.reshape(-1)).reshape(arr.shape)
+    out = score_centered_wls_device(centered_t, lower_bound_z, prior_df, min_effect, spatial_window,
+                                    precision_floor_ratio)
+    return tuple(t.cpu().numpy() for t in out[:6]) + out[6:]
+
+
+def _score_centered_wls_matrix(centered_matrix, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
+                               spatial_window=None, precision_floor_ratio: float = 0.01):
+    """rocco/inference.py:231-299: (scores, details) of the EB-moderated centred WLS."""
+    centered = np.asarray(centered_matrix, dtype=np.float64)
+    if centered.ndim != 2:
+        raise ValueError("`centered_matrix` must be two-dimensional")
+    if centered.shape[0] == 0 or centered.shape[1] == 0:
+        raise ValueError("`centered_matrix` must be non-empty")
+    precision_floor_ratio_ = float(max(precision_floor_ratio, 0.0))
+    scores, mean, raw, prior, mod, se, total_df, window = score_centered_wls(
+        centered, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df), min_effect=min_effect,
+        spatial_window=31 if spatial_window is None else int(spatial_window),
+        precision_floor_ratio=precision_floor_ratio_)
+    details = {
+        "mean": mean,
+        "raw_variance": raw,
+        "prior_variance": prior,
+        "moderated_variance": mod,
+        "standard_error": se,
+        "z_scores": mean / np.maximum(se, 1.0e-8),
+        "min_effect": float(0.0 if min_effect is None else max(min_effect, 0.0)),
+        "precision_floor_ratio": float(precision_floor_ratio_),
+        "degrees_of_freedom": np.full(centered.shape[1], float(total_df), dtype=np.float64),
+        "prior_spatial_window": float(window),
+    }
+    if not all(np.all(np.isfinite(a)) for a in (scores, mean, raw, prior, mod, se, details["z_scores"])):
+        raise ValueError("EB scoring produced non-finite values")
+    return scores, details

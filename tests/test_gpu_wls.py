@@ -1,0 +1,88 @@
+"""GPU: centred-WLS locus scores through the C ABI (rocco_hip_score_centered_wls_f64) against the golden
+vectors of the reference's backend and against the CPU oracle: every track bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wls_vectors.npz")
+ORDER = ("mean", "raw", "prior", "mod", "se", "scores")
+
+
+def stack(res):
+    scores, mean, raw, prior, mod, se, df, window = res
+    return np.stack([mean, raw, prior, mod, se, scores]), np.array([df, window])
+
+
+def test_golden_wls_tracks_bit_for_bit(gpu):
+    from rocco_amd.inference import score_centered_wls
+
+    gold = np.load(GOLD)
+    for name in gold["names"]:
+        lbz, pdf, me, use_me, win, pfr = gold[f"{name}_params"]
+        tracks, dfw = stack(score_centered_wls(gold[f"{name}_matrix"], lower_bound_z=lbz, prior_df=pdf,
+                                               min_effect=(me if use_me else None), spatial_window=int(win),
+                                               precision_floor_ratio=pfr))
+        want = gold[f"{name}_tracks"]
+        for t, label in enumerate(ORDER):
+            assert tracks[t].tobytes() == want[t].tobytes(), (name, label)
+        assert np.array_equal(dfw, gold[f"{name}_df_window"]), name
+
+
+@pytest.mark.parametrize("K,n", [(1, 5), (2, 31), (3, 32), (17, 257), (16, 287), (33, 4099), (5, 70001), (3, 1200003)])
+def test_random_matrices_match_oracle(gpu, oracle, K, n):
+    from rocco_amd.inference import score_centered_wls
+
+    rng = np.random.default_rng(K * 7919 + n)
+    m = rng.normal(0.0, 1.0, size=(K, n)) * np.exp(rng.normal(0.0, 0.5, size=(1, n)))
+    cases = [(m, {}), (np.round(m, 1), {"min_effect": 0.25}),  # rounded: ties in |value| and in the variances
+             (m, {"spatial_window": 7, "prior_df": 0.0, "precision_floor_ratio": 0.5}),
+             (m, {"spatial_window": 63, "lower_bound_z": 0.0})]
+    if n > 100000:
+        cases = cases[:2]
+    for mat, kw in cases:
+        got, dfw = stack(score_centered_wls(mat, **kw))
+        want, dfw_o = stack(oracle.score_centered_wls(mat, **kw))
+        for t, label in enumerate(ORDER):
+            assert got[t].tobytes() == want[t].tobytes(), (K, n, kw, label)
+        assert np.array_equal(dfw, dfw_o)
+
+
+def test_constant_and_zero_rows(gpu, oracle):
+    from rocco_amd.inference import score_centered_wls
+
+    m = np.zeros((3, 500))
+    m[1] = 2.5
+    m[2, 100:200] = np.linspace(-1, 1, 100)
+    got, _ = stack(score_centered_wls(m))
+    want, _ = stack(oracle.score_centered_wls(m))
+    assert got.tobytes() == want.tobytes()
+
+
+def test_argument_errors(gpu):
+    from rocco_amd.inference import _score_centered_wls_matrix, score_centered_wls
+
+    with pytest.raises(ValueError):
+        score_centered_wls(np.zeros((0, 5)))
+    with pytest.raises(ValueError):
+        _score_centered_wls_matrix(np.zeros(5))
+    bad = np.ones((2, 100))
+    bad[1, 7] = np.nan
+    with pytest.raises(ValueError):
+        score_centered_wls(bad)
+    with pytest.raises(ValueError):
+        score_centered_wls(np.ones((2, 1000)), spatial_window=101)
+
+
+def test_wrapper_details(gpu, oracle):
+    from rocco_amd.inference import _score_centered_wls_matrix
+
+    rng = np.random.default_rng(5)
+    m = rng.normal(size=(6, 3000))
+    scores, details = _score_centered_wls_matrix(m, min_effect=0.1)
+    o = oracle.score_centered_wls(m, min_effect=0.1)
+    assert scores.tobytes() == o[0].tobytes()
+    assert details["mean"].tobytes() == o[1].tobytes() and details["standard_error"].tobytes() == o[5].tobytes()
+    assert details["prior_spatial_window"] == 31.0 and details["min_effect"] == 0.1
+    assert np.all(details["degrees_of_freedom"] == o[6])
