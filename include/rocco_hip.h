@@ -207,6 +207,23 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
                                      double *raw_var_dev, double *prior_var_dev, double *mod_var_dev, double *se_dev,
                                      double *scores_dev, double *df_out, int *window_out, void *stream);
 
+/* ---- count-path glue of score_loci_wls ---------------------------------
+ * Replaces the NumPy statements of rocco/inference.py:40-47 (`_log_scale_wls_matrix`) and 330-331 (pilot
+ * offset): centered_out[k][i] = log2(max(counts[k][i], 0) + pseudocount) - median_i(log2(...)[k][:]).
+ * The row medians are exact order statistics (np.median: mean of the two middle values for even n); the
+ * logarithm is the device's, which may differ from NumPy's by one unit in the last place (NumPy's own
+ * log2 differs between its SVML and libm builds), so this row is checked to a tolerance.  centered_out_dev
+ * may alias counts_dev; row_offsets_out_dev (K doubles, may be NULL) receives the medians.  Non-finite
+ * input -> EINVAL (the reference raises ValueError). */
+int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *counts_dev, size_t K, size_t n,
+                                        double pseudocount, double *centered_out_dev, double *row_offsets_out_dev,
+                                        void *stream);
+
+/* out = a - b, element by element (rocco/inference.py:335 `centered = global_centered - local_baselines`);
+ * out_dev may alias a_dev or b_dev. */
+int rocco_hip_subtract_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,
+                           size_t count, void *stream);
+
 /* ---- synthetic signal matrices (benchmark / test support, device-resident) -------------------
  * Fills a row-major [K][n] matrix with the counter-based synthetic tracks described in
  * DESIGN.md section 7 (5-decimal background + planted peaks with per-sample dropout); the same

@@ -426,3 +426,43 @@ def score_centered_wls(centered_matrix, lower_bound_z: float = 1.0, prior_df: fl
         *[_dptr(t) for t in tracks], ctypes.byref(df), ctypes.byref(win)))
     mean, raw, prior, mod, se, scores = tracks
     return scores, mean, raw, prior, mod, se, float(df.value), int(win.value)
+
+
+def score_loci_wls(chrom_matrix, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
+                   precision_floor_ratio: float = 0.01, log_matrix=None):
+    """rocco/inference.py:302-379 restated over the oracle's backends: NumPy for the log scale (40-47), the
+    pilot offset (330-331) and the subtraction (335); `crossfit_whittaker_baseline` (185-229) and
+    `score_centered_wls` (231-299) for the rest.  `log_matrix` replaces the log-scaled matrix (tests use it
+    to separate the one-ulp freedom of log2 from everything downstream).  Returns (scores, details)."""
+    if log_matrix is None:
+        counts = np.asarray(chrom_matrix, dtype=np.float64)
+        if np.any(~np.isfinite(counts)):
+            raise ValueError("`chrom_matrix` contains non-finite values")
+        matrix = np.log2(np.clip(counts, 0.0, None) + 1.0)
+    else:
+        matrix = np.asarray(log_matrix, dtype=np.float64)
+    if matrix.ndim != 2 or matrix.shape[0] == 0 or matrix.shape[1] == 0:
+        raise ValueError("`chrom_matrix` must be a non-empty two-dimensional array")
+    global_centered = matrix - np.median(matrix, axis=1, keepdims=True)
+    n = matrix.shape[1]
+    window, lam = 0, 0.0
+    if n >= 25:  # inference.py:49-62 with target_window 101
+        window = min(101, n)
+        if window % 2 == 0:
+            window = window - 1 if window == n else window + 1
+        block = max(3, window)
+        block += 1 if block % 2 == 0 else 0
+        lam = float(7.0 * ((float(block) * 0.15915494) ** 4))  # inference.py:65-76
+        centered = global_centered - crossfit_whittaker_baseline(global_centered, lam)
+    else:
+        centered = global_centered - np.zeros_like(global_centered)
+    scores, mean, raw, prior, mod, se, df, win = score_centered_wls(
+        centered, lower_bound_z=lower_bound_z, prior_df=prior_df, min_effect=min_effect, spatial_window=31,
+        precision_floor_ratio=max(precision_floor_ratio, 0.0))
+    details = {"input_scale": "log2p1", "local_baseline_window": int(window), "local_baseline_lambda": lam,
+               "mean": mean, "raw_variance": raw, "prior_variance": prior, "moderated_variance": mod,
+               "standard_error": se, "z_scores": mean / np.maximum(se, 1.0e-8),
+               "min_effect": float(0.0 if min_effect is None else max(min_effect, 0.0)),
+               "precision_floor_ratio": float(max(precision_floor_ratio, 0.0)), "prior_spatial_window": int(win),
+               "degrees_of_freedom": np.full(n, float(df)), "centered_matrix": centered}
+    return scores, details

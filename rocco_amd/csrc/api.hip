@@ -352,6 +352,34 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
                                      (hipStream_t)stream);
 }
 
+int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *counts_dev, size_t K, size_t n,
+                                        double pseudocount, double *centered_out_dev, double *row_offsets_out_dev,
+                                        void *stream)
+{
+    if (solver == nullptr || counts_dev == nullptr || centered_out_dev == nullptr || K == 0 || n == 0 ||
+        n > (size_t)0x7fffffff) {
+        set_last_error("rocco_hip_log_scale_center_rows_f64: null buffer, empty matrix or more than 2^31-1 loci");
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_misc.reserve(log_scale_scratch_bytes(K, n))) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    return launch_log_scale_center_rows(counts_dev, K, n, pseudocount, centered_out_dev, row_offsets_out_dev,
+                                        solver->dev_misc.ptr, (hipStream_t)stream);
+}
+
+int rocco_hip_subtract_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,
+                           size_t count, void *stream)
+{
+    if (solver == nullptr || ((a_dev == nullptr || b_dev == nullptr || out_dev == nullptr) && count > 0)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_subtract(a_dev, b_dev, out_dev, count, (hipStream_t)stream);
+}
+
 int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
                            size_t row_stride, uint64_t seed, void *stream)
 {

@@ -60,6 +60,13 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
                               double *prior_var_dev, double *mod_var_dev, double *se_dev, double *scores_dev,
                               void *scratch_dev, double *df_out, int *window_out, hipStream_t stream);
 
+// row a2 glue (wls.hip): log2(max(x, 0) + pseudocount), row medians subtracted; out may alias the input
+size_t log_scale_scratch_bytes(size_t K, size_t n);
+int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount,
+                                 double *centered_out_dev, double *row_offsets_out_dev, void *scratch_dev,
+                                 hipStream_t stream);
+int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream);
+
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
                  hipStream_t stream);

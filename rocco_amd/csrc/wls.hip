@@ -506,6 +506,68 @@ __global__ __launch_bounds__(256) void wls_final_kernel(const double *__restrict
     }
 }
 
+// ---- row a2 glue: log scale, pilot offset, centring (rocco/inference.py:40-47, 330-336) ----------------
+__global__ __launch_bounds__(256) void log_scale_kernel(const double *__restrict__ in, double *__restrict__ out,
+                                                       long long count, double pseudocount, int *__restrict__ bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) {
+        return;
+    }
+    const double v = in[i];
+    if (!isfinite(v)) {
+        atomicOr(bad, 1);
+    }
+    out[i] = log2(fmax(v, 0.0) + pseudocount);  // np.log2(np.clip(matrix, 0.0, None) + pseudocount)
+}
+
+// order-preserving key of a double (negative values: all bits flipped, others: sign bit set)
+__global__ __launch_bounds__(256) void order_key_kernel(const double *__restrict__ in, unsigned long long *__restrict__ key,
+                                                       long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(in[i]);
+        key[i] = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+    }
+}
+
+__device__ __forceinline__ double key_to_double(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// np.median of one sorted row: the middle value, or the mean of the two middle values
+__global__ void row_median_kernel(const unsigned long long *__restrict__ sorted_keys, long long n, double *__restrict__ med)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n & 1LL) {
+            *med = key_to_double(sorted_keys[n / 2]);
+        } else {
+            *med = (key_to_double(sorted_keys[n / 2 - 1]) + key_to_double(sorted_keys[n / 2])) / 2.0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void subtract_row_offset_kernel(double *__restrict__ matrix, const double *__restrict__ med,
+                                                                 long long n, long long count)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        matrix[i] = matrix[i] - med[i / n];
+    }
+}
+
+__global__ __launch_bounds__(256) void subtract_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                                                      double *__restrict__ out, long long count)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        out[i] = a[i] - b[i];
+    }
+}
+
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
@@ -642,6 +704,61 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
         set_last_error("rocco_hip_score_centered_wls_f64: non-finite values in the centred matrix");
         return ROCCO_HIP_EINVAL;
     }
+    return ROCCO_HIP_OK;
+}
+
+size_t log_scale_scratch_bytes(size_t K, size_t n)
+{
+    size_t t = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t, (const u64 *)nullptr, (u64 *)nullptr, (int)n);
+    return 2 * align_up(n * 8, 256) + align_up(K * 8, 256) + align_up(t, 256) + 512;
+}
+
+int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount,
+                                 double *centered_out_dev, double *row_offsets_out_dev, void *scratch_dev,
+                                 hipStream_t stream)
+{
+    const long long count = (long long)(K * n), nn = (long long)n;
+    char *sc = (char *)scratch_dev;
+    u64 *key_a = (u64 *)sc, *key_b = (u64 *)(sc + align_up(n * 8, 256));
+    double *med = (double *)(sc + 2 * align_up(n * 8, 256));
+    int *bad = (int *)(sc + 2 * align_up(n * 8, 256) + align_up(K * 8, 256));
+    void *tmp = (char *)bad + 256;
+    size_t tmp_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, key_a, key_b, (int)n);
+    ROCCO_HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), stream));
+    const unsigned blocks_all = (unsigned)((count + 255) / 256), blocks_row = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(log_scale_kernel, dim3(blocks_all), dim3(256), 0, stream, counts_dev, centered_out_dev, count,
+                       pseudocount, bad);
+    for (size_t k = 0; k < K; ++k) {
+        hipLaunchKernelGGL(order_key_kernel, dim3(blocks_row), dim3(256), 0, stream, centered_out_dev + k * n, key_a, nn);
+        size_t t = tmp_bytes;
+        ROCCO_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(tmp, t, key_a, key_b, (int)n, 0, 64, stream));
+        hipLaunchKernelGGL(row_median_kernel, dim3(1), dim3(64), 0, stream, key_b, nn, med + k);
+    }
+    hipLaunchKernelGGL(subtract_row_offset_kernel, dim3(blocks_all), dim3(256), 0, stream, centered_out_dev, med, nn, count);
+    if (row_offsets_out_dev != nullptr) {
+        ROCCO_HIP_TRY(hipMemcpyAsync(row_offsets_out_dev, med, K * 8, hipMemcpyDeviceToDevice, stream));
+    }
+    ROCCO_HIP_TRY(hipGetLastError());
+    int bad_host = 0;
+    ROCCO_HIP_TRY(hipMemcpyAsync(&bad_host, bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize(stream));  // also: the scratch buffer is the solver's
+    if (bad_host != 0) {
+        set_last_error("`chrom_matrix` contains non-finite values");
+        return ROCCO_HIP_EINVAL;
+    }
+    return ROCCO_HIP_OK;
+}
+
+int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream)
+{
+    if (count == 0) {
+        return ROCCO_HIP_OK;
+    }
+    hipLaunchKernelGGL(subtract_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, a_dev, b_dev, out_dev,
+                       (long long)count);
+    ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }
 

@@ -164,3 +164,104 @@ def _score_centered_wls_matrix(centered_matrix, lower_bound_z: float = 1.0, prio
     if not all(np.all(np.isfinite(a)) for a in (scores, mean, raw, prior, mod, se, details["z_scores"])):
         raise ValueError("EB scoring produced non-finite values")
     return scores, details
+
+
+def log_scale_center_rows_device(counts_t, pseudocount: float = 1.0, out_t=None):
+    """rocco/inference.py:40-47 + 330-331 on the device: log2(max(counts, 0) + pseudocount) with every row's
+    median subtracted.  Returns (centred tensor [K, n], row medians [K])."""
+    import torch
+
+    if counts_t.dim() != 2:
+        raise ValueError("`chrom_matrix` must be two-dimensional")
+    if counts_t.dtype != torch.float64 or not counts_t.is_cuda or not counts_t.is_contiguous():
+        raise ValueError("counts_t must be a contiguous float64 CUDA tensor")
+    K, n = int(counts_t.shape[0]), int(counts_t.shape[1])
+    if K == 0 or n == 0:
+        raise ValueError("`chrom_matrix` must be non-empty")
+    if out_t is None:
+        out_t = torch.empty_like(counts_t)
+    offsets = torch.empty(K, dtype=torch.float64, device=counts_t.device)
+    solver = _native.solver_for(counts_t.device.index)
+    _native.check(_native.load().rocco_hip_log_scale_center_rows_f64(
+        solver.handle, counts_t.data_ptr(), K, n, float(pseudocount), out_t.data_ptr(), offsets.data_ptr(),
+        _dp._stream_ptr(counts_t)), "rocco_hip_log_scale_center_rows_f64")
+    return out_t, offsets
+
+
+def score_loci_wls_device(counts_t, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
+                          precision_floor_ratio: float = 0.01, overwrite_input: bool = False):
+    """Device-resident rocco/inference.py:302-379: ``counts_t`` is a contiguous float64 CUDA tensor [K, n].
+    Returns (score tensor [n], details) where the details hold CUDA tensors (``centered_matrix`` included)."""
+    import torch
+
+    global_centered, _ = log_scale_center_rows_device(counts_t, 1.0, counts_t if overwrite_input else None)
+    K, n = int(global_centered.shape[0]), int(global_centered.shape[1])
+    window = _resolve_local_baseline_window(n, target_window=101)
+    penalty_lambda = 0.0
+    solver = _native.solver_for(counts_t.device.index)
+    if window == 0:
+        centered = global_centered  # zero baselines (rocco/inference.py:195-196)
+    else:
+        penalty_lambda = _consenrich_whittaker_lambda(window)
+        baselines = crossfit_whittaker_baseline_device(global_centered, penalty_lambda)
+        if not bool(torch.isfinite(baselines).all()):
+            raise ValueError("Local baseline fit produced non-finite values")
+        _native.check(_native.load().rocco_hip_subtract_f64(
+            solver.handle, global_centered.data_ptr(), baselines.data_ptr(), global_centered.data_ptr(), K * n,
+            _dp._stream_ptr(global_centered)), "rocco_hip_subtract_f64")
+        centered = global_centered
+        del baselines
+    precision_floor_ratio_ = float(max(precision_floor_ratio, 0.0))
+    scores, mean, raw, prior, mod, se, total_df, resolved_window = score_centered_wls_device(
+        centered, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df), min_effect=min_effect,
+        spatial_window=31, precision_floor_ratio=precision_floor_ratio_)
+    z_scores = mean / torch.clamp_min(se, 1.0e-8)
+    tracks = torch.stack([scores, mean, raw, prior, mod, se, z_scores])
+    if not bool(torch.isfinite(tracks).all()):
+        raise ValueError("EB scoring produced non-finite values")
+    details = {
+        "input_scale": "log2p1",
+        "local_baseline_window": int(window),
+        "local_baseline_lambda": float(penalty_lambda),
+        "mean": mean,
+        "raw_variance": raw,
+        "prior_variance": prior,
+        "moderated_variance": mod,
+        "standard_error": se,
+        "z_scores": z_scores,
+        "min_effect": float(0.0 if min_effect is None else max(min_effect, 0.0)),
+        "precision_floor_ratio": float(precision_floor_ratio_),
+        "prior_spatial_window": int(resolved_window),
+        "degrees_of_freedom": torch.full((n,), float(total_df), dtype=torch.float64, device=counts_t.device),
+        "centered_matrix": centered,
+    }
+    return scores, details
+
+
+def score_loci_wls(chrom_matrix, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
+                   precision_floor_ratio: float = 0.01, low_memory: bool = False, return_details: bool = False):
+    """rocco/inference.py:302-379 with the same signature, NumPy in and out."""
+    import torch
+
+    _native.load()
+    matrix = np.ascontiguousarray(chrom_matrix, dtype=np.float64)
+    if matrix.ndim != 2:
+        raise ValueError("`chrom_matrix` must be two-dimensional")
+    if matrix.shape[0] == 0 or matrix.shape[1] == 0:
+        raise ValueError("`chrom_matrix` must be non-empty")
+    counts_t = _dp._to_device_f64(matrix.reshape(-1)).reshape(matrix.shape)
+    scores_t, details_t = score_loci_wls_device(counts_t, lower_bound_z=lower_bound_z, prior_df=prior_df,
+                                                min_effect=min_effect, precision_floor_ratio=precision_floor_ratio,
+                                                overwrite_input=True)
+    scores = scores_t.cpu().numpy()
+    if not return_details:
+        return scores
+    details = {}
+    for key, value in details_t.items():
+        if isinstance(value, torch.Tensor):
+            if key == "centered_matrix" and low_memory:
+                value = value.to(torch.float32)
+            details[key] = value.cpu().numpy()
+        else:
+            details[key] = value
+    return scores, details

@@ -1,0 +1,87 @@
+"""GPU: the count-path scoring glue `score_loci_wls` (rocco/inference.py:302-379).
+
+Everything downstream of the logarithm equals the reference bit for bit, so counts of the form 2^k - 1
+(log2(count + 1) is exact on any platform) must reproduce the oracle's composition exactly.  On general counts
+the device's log2 may differ from NumPy's in the last place (NumPy's own log2 differs between its SVML and
+libm builds): tolerance 4 ulp on the log scale, 1e-6 relative on the tracks."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TRACKS = ("mean", "raw_variance", "prior_variance", "moderated_variance", "standard_error", "z_scores",
+          "degrees_of_freedom", "centered_matrix")
+
+
+def test_reference_known_answers(gpu):
+    """tests/test_rocco.py:235-260 of the reference."""
+    from rocco_amd.inference import score_loci_wls
+
+    scores, details = score_loci_wls(np.array([[1.0, 15.0]]), lower_bound_z=0.0, return_details=True)
+    assert details["input_scale"] == "log2p1"
+    assert "sample_intercepts" not in details and "sample_baselines" not in details
+    assert np.allclose(details["mean"], np.array([-1.5, 1.5]))
+    assert np.allclose(details["z_scores"], np.array([-0.67449076, 0.67449076]))
+    assert np.allclose(scores, np.array([-0.67449076, 0.67449076]))
+    scores, details = score_loci_wls(np.array([[1.0, 15.0]]), min_effect=0.5, return_details=True)
+    assert np.isclose(details["min_effect"], 0.5)
+    assert scores[1] < details["z_scores"][1] and scores[0] < details["z_scores"][0]
+    scores, details = score_loci_wls(np.array([[1.0, 3.0, 7.0], [1.2, 2.8, 6.5]]), low_memory=True, return_details=True)
+    assert scores.dtype == np.float64 and details["centered_matrix"].dtype == np.float32
+    assert np.all(np.isfinite(details["centered_matrix"]))
+    assert score_loci_wls(np.array([[1.0, 3.0, 7.0]])).shape == (3,)
+
+
+@pytest.mark.parametrize("K,n", [(1, 2), (2, 24), (3, 25), (4, 26), (5, 1000), (7, 40001), (3, 600000)])
+def test_power_of_two_counts_bit_for_bit(gpu, oracle, K, n):
+    from rocco_amd.inference import score_loci_wls
+
+    rng = np.random.default_rng(K * 31 + n)
+    peaks = rng.random(n) < 0.05
+    k = rng.integers(0, 6, size=(K, n)) + peaks[None, :] * rng.integers(2, 9, size=(K, n))
+    counts = np.ldexp(1.0, k) - 1.0
+    counts[rng.random(counts.shape) < 0.01] *= -1.0  # negative counts are clipped to zero
+    for kw in ({}, {"min_effect": 0.3, "prior_df": 2.0, "precision_floor_ratio": 0.2}):
+        got, gd = score_loci_wls(counts, return_details=True, **kw)
+        want, wd = oracle.score_loci_wls(counts, **kw)
+        assert got.tobytes() == want.tobytes(), (K, n, kw)
+        for key in TRACKS:
+            assert np.asarray(gd[key]).tobytes() == np.asarray(wd[key]).tobytes(), (K, n, kw, key)
+        for key in ("input_scale", "local_baseline_window", "local_baseline_lambda", "min_effect",
+                    "precision_floor_ratio", "prior_spatial_window"):
+            assert gd[key] == wd[key], key
+
+
+def test_log_scale_and_pilot_offset(gpu):
+    import torch
+
+    from rocco_amd.inference import log_scale_center_rows_device
+
+    rng = np.random.default_rng(2)
+    for n in (1, 2, 7, 1000, 100001):
+        counts = rng.gamma(0.7, 8.0, size=(4, n))
+        counts[0, :: 3] = 0.0
+        counts[1] = -counts[1]
+        c_t, off_t = log_scale_center_rows_device(torch.from_numpy(counts).cuda())
+        log_ref = np.log2(np.clip(counts, 0.0, None) + 1.0)
+        med = np.median(log_ref, axis=1)
+        assert np.allclose(off_t.cpu().numpy(), med, rtol=0, atol=4 * np.spacing(np.abs(med).max() + 1.0))
+        recon = c_t.cpu().numpy() + off_t.cpu().numpy()[:, None]
+        assert np.all(np.abs(recon - log_ref) <= 4 * np.spacing(np.maximum(np.abs(log_ref), np.abs(med)[:, None]) + 1.0))
+    with pytest.raises(ValueError):
+        log_scale_center_rows_device(torch.tensor([[1.0, float("inf")]], dtype=torch.float64).cuda())
+
+
+def test_general_counts_within_tolerance(gpu, oracle):
+    from rocco_amd.inference import score_loci_wls
+
+    rng = np.random.default_rng(9)
+    K, n = 6, 50000
+    counts = rng.gamma(0.8, 6.0, size=(K, n)) * (1.0 + 4.0 * (rng.random(n) < 0.03))[None, :]
+    got, gd = score_loci_wls(counts, return_details=True)
+    want, wd = oracle.score_loci_wls(counts)
+    # tolerance: 1e-6 relative to the track's scale (a last-place change of one log value may move one pair across
+    # a trend-bin border; the tracks are continuous in everything else)
+    for key in ("mean", "raw_variance", "prior_variance", "moderated_variance", "standard_error"):
+        scale = np.abs(wd[key]).max()
+        assert np.abs(gd[key] - wd[key]).max() <= 1e-6 * scale, key
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()

@@ -51,3 +51,15 @@ def test_oracle_matches_compiled_reference_backend(oracle):
             for g, w in zip(got[:6], want):
                 assert g.tobytes() == w.tobytes(), (n, K)
             assert got[6] == df.value and got[7] == win.value
+
+
+def test_oracle_score_loci_wls_known_answers(oracle):
+    """The reference's own expectations for `score_loci_wls` (tests/test_rocco.py:235-260)."""
+    scores, details = oracle.score_loci_wls(np.array([[1.0, 15.0]]), lower_bound_z=0.0)
+    assert details["input_scale"] == "log2p1"
+    assert np.allclose(details["mean"], np.array([-1.5, 1.5]))
+    assert np.allclose(details["z_scores"], np.array([-0.67449076, 0.67449076]))
+    assert np.allclose(scores, np.array([-0.67449076, 0.67449076]))
+    scores, details = oracle.score_loci_wls(np.array([[1.0, 15.0]]), min_effect=0.5)
+    assert np.isclose(details["min_effect"], 0.5)
+    assert scores[1] < details["z_scores"][1] and scores[0] < details["z_scores"][0]
