@@ -213,11 +213,12 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
  * The row medians are exact order statistics (np.median: mean of the two middle values for even n); the
  * logarithm is the device's, which may differ from NumPy's by one unit in the last place (NumPy's own
  * log2 differs between its SVML and libm builds), so this row is checked to a tolerance.  centered_out_dev
- * may alias counts_dev; row_offsets_out_dev (K doubles, may be NULL) receives the medians.  Non-finite
+ * may alias counts_dev; row_offsets_out_dev (K doubles, may be NULL) receives the medians.  apply_log2 == 0
+ * takes the matrix as already log-scaled (only the pilot offset is removed; bit-exact).  Non-finite
  * input -> EINVAL (the reference raises ValueError). */
 int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *counts_dev, size_t K, size_t n,
-                                        double pseudocount, double *centered_out_dev, double *row_offsets_out_dev,
-                                        void *stream);
+                                        double pseudocount, int apply_log2, double *centered_out_dev,
+                                        double *row_offsets_out_dev, void *stream);
 
 /* out = a - b, element by element (rocco/inference.py:335 `centered = global_centered - local_baselines`);
  * out_dev may alias a_dev or b_dev. */

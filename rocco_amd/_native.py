@@ -118,8 +118,8 @@ PROTOTYPES = [
       ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_int_p, ctypes.c_void_p]),
     ("rocco_hip_log_scale_center_rows_f64", ctypes.c_int,
-     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_void_p,
-      ctypes.c_void_p, ctypes.c_void_p]),
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
+      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ("rocco_hip_subtract_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("rocco_hip_synth_matrix", ctypes.c_int,

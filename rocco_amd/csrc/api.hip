@@ -353,8 +353,8 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
 }
 
 int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *counts_dev, size_t K, size_t n,
-                                        double pseudocount, double *centered_out_dev, double *row_offsets_out_dev,
-                                        void *stream)
+                                        double pseudocount, int apply_log2, double *centered_out_dev,
+                                        double *row_offsets_out_dev, void *stream)
 {
     if (solver == nullptr || counts_dev == nullptr || centered_out_dev == nullptr || K == 0 || n == 0 ||
         n > (size_t)0x7fffffff) {
@@ -366,7 +366,7 @@ int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *
     if ((rc = solver->dev_misc.reserve(log_scale_scratch_bytes(K, n))) != ROCCO_HIP_OK) {
         return rc;
     }
-    return launch_log_scale_center_rows(counts_dev, K, n, pseudocount, centered_out_dev, row_offsets_out_dev,
+    return launch_log_scale_center_rows(counts_dev, K, n, pseudocount, apply_log2, centered_out_dev, row_offsets_out_dev,
                                         solver->dev_misc.ptr, (hipStream_t)stream);
 }
 

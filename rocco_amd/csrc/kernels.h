@@ -62,7 +62,7 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
 
 // row a2 glue (wls.hip): log2(max(x, 0) + pseudocount), row medians subtracted; out may alias the input
 size_t log_scale_scratch_bytes(size_t K, size_t n);
-int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount,
+int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount, int apply_log,
                                  double *centered_out_dev, double *row_offsets_out_dev, void *scratch_dev,
                                  hipStream_t stream);
 int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream);

@@ -508,7 +508,8 @@ __global__ __launch_bounds__(256) void wls_final_kernel(const double *__restrict
 
 // ---- row a2 glue: log scale, pilot offset, centring (rocco/inference.py:40-47, 330-336) ----------------
 __global__ __launch_bounds__(256) void log_scale_kernel(const double *__restrict__ in, double *__restrict__ out,
-                                                       long long count, double pseudocount, int *__restrict__ bad)
+                                                       long long count, double pseudocount, int apply_log,
+                                                       int *__restrict__ bad)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) {
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(256) void log_scale_kernel(const double *__restrict
     if (!isfinite(v)) {
         atomicOr(bad, 1);
     }
-    out[i] = log2(fmax(v, 0.0) + pseudocount);  // np.log2(np.clip(matrix, 0.0, None) + pseudocount)
+    out[i] = apply_log ? log2(fmax(v, 0.0) + pseudocount) : v;  // np.log2(np.clip(matrix, 0.0, None) + pseudocount)
 }
 
 // order-preserving key of a double (negative values: all bits flipped, others: sign bit set)
@@ -714,7 +715,7 @@ size_t log_scale_scratch_bytes(size_t K, size_t n)
     return 2 * align_up(n * 8, 256) + align_up(K * 8, 256) + align_up(t, 256) + 512;
 }
 
-int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount,
+int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount, int apply_log,
                                  double *centered_out_dev, double *row_offsets_out_dev, void *scratch_dev,
                                  hipStream_t stream)
 {
@@ -729,7 +730,7 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
     ROCCO_HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), stream));
     const unsigned blocks_all = (unsigned)((count + 255) / 256), blocks_row = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(log_scale_kernel, dim3(blocks_all), dim3(256), 0, stream, counts_dev, centered_out_dev, count,
-                       pseudocount, bad);
+                       pseudocount, apply_log, bad);
     for (size_t k = 0; k < K; ++k) {
         hipLaunchKernelGGL(order_key_kernel, dim3(blocks_row), dim3(256), 0, stream, centered_out_dev + k * n, key_a, nn);
         size_t t = tmp_bytes;

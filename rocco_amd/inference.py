@@ -166,9 +166,10 @@ def _score_centered_wls_matrix(centered_matrix, lower_bound_z: float = 1.0, prio
     return scores, details
 
 
-def log_scale_center_rows_device(counts_t, pseudocount: float = 1.0, out_t=None):
+def log_scale_center_rows_device(counts_t, pseudocount: float = 1.0, out_t=None, apply_log2: bool = True):
     """rocco/inference.py:40-47 + 330-331 on the device: log2(max(counts, 0) + pseudocount) with every row's
-    median subtracted.  Returns (centred tensor [K, n], row medians [K])."""
+    median subtracted (``apply_log2=False``: the matrix is already log-scaled).  Returns (centred tensor
+    [K, n], row medians [K])."""
     import torch
 
     if counts_t.dim() != 2:
@@ -183,18 +184,24 @@ def log_scale_center_rows_device(counts_t, pseudocount: float = 1.0, out_t=None)
     offsets = torch.empty(K, dtype=torch.float64, device=counts_t.device)
     solver = _native.solver_for(counts_t.device.index)
     _native.check(_native.load().rocco_hip_log_scale_center_rows_f64(
-        solver.handle, counts_t.data_ptr(), K, n, float(pseudocount), out_t.data_ptr(), offsets.data_ptr(),
+        solver.handle, counts_t.data_ptr(), K, n, float(pseudocount), 1 if apply_log2 else 0, out_t.data_ptr(),
+        offsets.data_ptr(),
         _dp._stream_ptr(counts_t)), "rocco_hip_log_scale_center_rows_f64")
     return out_t, offsets
 
 
 def score_loci_wls_device(counts_t, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
-                          precision_floor_ratio: float = 0.01, overwrite_input: bool = False):
+                          precision_floor_ratio: float = 0.01, overwrite_input: bool = False,
+                          input_scale: str = "counts"):
     """Device-resident rocco/inference.py:302-379: ``counts_t`` is a contiguous float64 CUDA tensor [K, n].
-    Returns (score tensor [n], details) where the details hold CUDA tensors (``centered_matrix`` included)."""
+    Returns (score tensor [n], details) where the details hold CUDA tensors (``centered_matrix`` included).
+    ``input_scale="log2p1"`` (not in the reference) takes a matrix that is already log2(count + 1)."""
     import torch
 
-    global_centered, _ = log_scale_center_rows_device(counts_t, 1.0, counts_t if overwrite_input else None)
+    if input_scale not in ("counts", "log2p1"):
+        raise ValueError("input_scale must be 'counts' or 'log2p1'")
+    global_centered, _ = log_scale_center_rows_device(counts_t, 1.0, counts_t if overwrite_input else None,
+                                                      apply_log2=(input_scale == "counts"))
     K, n = int(global_centered.shape[0]), int(global_centered.shape[1])
     window = _resolve_local_baseline_window(n, target_window=101)
     penalty_lambda = 0.0
@@ -239,8 +246,10 @@ def score_loci_wls_device(counts_t, lower_bound_z: float = 1.0, prior_df: float 
 
 
 def score_loci_wls(chrom_matrix, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
-                   precision_floor_ratio: float = 0.01, low_memory: bool = False, return_details: bool = False):
-    """rocco/inference.py:302-379 with the same signature, NumPy in and out."""
+                   precision_floor_ratio: float = 0.01, low_memory: bool = False, return_details: bool = False,
+                   input_scale: str = "counts"):
+    """rocco/inference.py:302-379 with the same signature, NumPy in and out (``input_scale``: see
+    ``score_loci_wls_device``)."""
     import torch
 
     _native.load()
@@ -252,7 +261,7 @@ def score_loci_wls(chrom_matrix, lower_bound_z: float = 1.0, prior_df: float = 5
     counts_t = _dp._to_device_f64(matrix.reshape(-1)).reshape(matrix.shape)
     scores_t, details_t = score_loci_wls_device(counts_t, lower_bound_z=lower_bound_z, prior_df=prior_df,
                                                 min_effect=min_effect, precision_floor_ratio=precision_floor_ratio,
-                                                overwrite_input=True)
+                                                overwrite_input=True, input_scale=input_scale)
     scores = scores_t.cpu().numpy()
     if not return_details:
         return scores

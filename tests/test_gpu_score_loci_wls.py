@@ -85,3 +85,28 @@ def test_general_counts_within_tolerance(gpu, oracle):
         scale = np.abs(wd[key]).max()
         assert np.abs(gd[key] - wd[key]).max() <= 1e-6 * scale, key
     assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+
+
+def test_golden_vectors_of_the_reference_function(gpu):
+    """tests/golden/score_loci_wls_vectors.npz (the reference's own `score_loci_wls`): bit for bit from the
+    log-scaled matrix on, and from the counts wherever log2(count + 1) is exact ("pow2" cases)."""
+    import os
+
+    from rocco_amd.inference import score_loci_wls
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "score_loci_wls_vectors.npz"))
+    for name in gold["names"]:
+        name = str(name)
+        lbz, pdf, me, pfr = gold[f"{name}_params"]
+        kw = dict(lower_bound_z=lbz, prior_df=pdf, min_effect=None if np.isnan(me) else me, precision_floor_ratio=pfr)
+        runs = [(gold[f"{name}_log"], "log2p1")]
+        if "_pow2_" in name:
+            runs.append((gold[f"{name}_counts"], "counts"))
+        for matrix, scale in runs:
+            scores, details = score_loci_wls(matrix, return_details=True, input_scale=scale, **kw)
+            assert scores.tobytes() == gold[f"{name}_scores"].tobytes(), (name, scale)
+            for key in TRACKS:
+                assert np.asarray(details[key], dtype=np.float64).tobytes() == gold[f"{name}_{key}"].tobytes(), (name, scale, key)
+            scalars = np.array([details["local_baseline_window"], details["local_baseline_lambda"], details["min_effect"],
+                                details["precision_floor_ratio"], details["prior_spatial_window"]], dtype=np.float64)
+            assert np.array_equal(scalars, gold[f"{name}_scalars"]), name

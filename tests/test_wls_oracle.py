@@ -63,3 +63,20 @@ def test_oracle_score_loci_wls_known_answers(oracle):
     scores, details = oracle.score_loci_wls(np.array([[1.0, 15.0]]), min_effect=0.5)
     assert np.isclose(details["min_effect"], 0.5)
     assert scores[1] < details["z_scores"][1] and scores[0] < details["z_scores"][0]
+
+
+def test_oracle_reproduces_the_reference_score_loci_wls(oracle):
+    """tests/golden/score_loci_wls_vectors.npz was written by the reference's own `score_loci_wls`."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "score_loci_wls_vectors.npz"))
+    tracks = ("mean", "raw_variance", "prior_variance", "moderated_variance", "standard_error", "z_scores",
+              "degrees_of_freedom", "centered_matrix")
+    for name in gold["names"]:
+        lbz, pdf, me, pfr = gold[f"{name}_params"]
+        kw = dict(lower_bound_z=lbz, prior_df=pdf, min_effect=None if np.isnan(me) else me, precision_floor_ratio=pfr)
+        scores, details = oracle.score_loci_wls(gold[f"{name}_counts"], **kw)
+        assert scores.tobytes() == gold[f"{name}_scores"].tobytes(), name
+        for key in tracks:
+            assert np.asarray(details[key], dtype=np.float64).tobytes() == gold[f"{name}_{key}"].tobytes(), (name, key)
+        scalars = np.array([details["local_baseline_window"], details["local_baseline_lambda"], details["min_effect"],
+                            details["precision_floor_ratio"], details["prior_spatial_window"]], dtype=np.float64)
+        assert np.array_equal(scalars, gold[f"{name}_scalars"]), name
