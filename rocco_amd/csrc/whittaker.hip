@@ -11,25 +11,20 @@
 //     length n except for the last two loci (the bands differ only there): it is computed ONCE per
 //     penalty for the longest length seen (one lane per parity; the reference recomputes it for every
 //     row), kept in the solver, and a tiny kernel recomputes the two end entries for each length;
-//   * the diagonal solve z = f / d is elementwise: a separate, fully parallel kernel (a division inside
-//     a dependent chain costs more than the chain);
-//   * the rows are independent: forward and backward substitution run with one lane per row, both
-//     parities in the same lane (two dependent chains interleave).  A workgroup takes 16 rows and moves
-//     them through LDS in tiles of 256 loci with coalesced 512-byte accesses (a lane reading its own row
-//     directly would touch one cache line per lane per instruction), all 64 lanes moving data, 16 of
-//     them running chains: the chains are latency-bound by construction (multiply, subtract, subtract
-//     per locus and parity), so narrow workgroups on many CUs beat wide ones.
+//   * the diagonal solve z = f / d and the cross-fit average are elementwise: they ride on the write-back
+//     of the sweeps (a division inside a dependent chain costs more than the chain);
+//   * the rows are independent and so are the two parities: one workgroup per row, one wavefront per
+//     parity running the recurrence in a single lane, two more wavefronts feeding them through LDS (see
+//     "forward / backward substitution" below).  The chains are issue-bound by construction (two multiplies
+//     and two subtractions per locus, a lone wavefront issues one FP64 instruction per ~2.6 ns), so the
+//     design keeps everything else off the chain wavefront and lets K rows x 2 parities run side by side.
 #include "kernels.h"
 
 namespace rocco {
 
 namespace {
 
-constexpr int kRows = 16;             // rows (chains) per workgroup
-constexpr int kTile = 256;            // loci per tile
-constexpr int kStride = kTile + 1;    // LDS row stride (odd multiple of 8 bytes: no bank conflicts)
 constexpr int kLanes = 64;
-constexpr int kMoves = kRows * kTile / kLanes;  // 8-byte elements each lane moves per tile
 
 __device__ __forceinline__ double band_a0(long long i, long long n, int parity, double lambda)
 {
@@ -177,256 +172,179 @@ __device__ __forceinline__ double chain_step(double v, double c1, double c2, dou
     return v - t1 - t2;
 }
 
-// move a tile between global memory (row-major, row length n) and LDS ([row][kStride]); every instruction
-// of the wavefront touches 64 consecutive loci of one row
-template <bool TO_LDS>
-__device__ __forceinline__ void move_tile(double *__restrict__ lds, double *__restrict__ global, long long row0,
-                                          int nrows, long long n, long long base, int T)
+// ---- forward / backward substitution ------------------------------------------------------------------
+// One workgroup per row: wavefront p (p = 0, 1) runs the recurrence of parity p in lane 0 -- a lone wavefront
+// issues about one FP64 instruction per 2.6 ns whether 1 or 64 lanes are active, so the sweep time is
+// (instructions per locus of the chain wavefront) x n and everything that is not the chain is moved off it:
+// wavefronts 2 and 3 stage the next tile's inputs AND factor entries in LDS (coalesced loads issued before,
+// stored after their other work; a load issued by the chain wavefront itself would put a memory latency into
+// every batch) and carry the previous tile's results to global memory, applying the elementwise steps on the
+// way (z = f / d after the forward sweep, baseline_backend.c:153-156; 0.5 (x0 + x1) after the backward sweep,
+// 296-299).  The end cases of the recurrences are staged as zero coefficients (x - 0 * 0 - 0 * 0 == x exactly,
+// signed zeros included), and so are the loci past the row's end, so the chain wavefront runs the same
+// branch-free loop on every tile.  Three LDS tiles rotate (chain / write-back / staging), one barrier per tile.
+constexpr int kSweepTile = 512;
+constexpr int kSweepHelpers = 2 * kLanes;
+constexpr int kSweepMoves = kSweepTile / kSweepHelpers;
+
+struct SweepTile {
+    double in[2][kSweepTile];
+    double coef[2][kSweepTile][2];  // the multipliers of the previous and the one-before-previous value
+    double out[2][kSweepTile];
+};
+
+template <bool BACKWARD>
+__device__ __forceinline__ void sweep_chain(SweepTile &tile, int parity, double &p1, double &p2)
 {
-    const int lane = threadIdx.x;
-    if (nrows == kRows && T == kTile) {
-        // full tile (workgroup-uniform): unconditional accesses, all in flight together -- loads inside
-        // per-element conditionals are waited for one by one
-        if (TO_LDS) {
-            double v[kMoves];
+    const double *__restrict__ in = tile.in[parity];
+    const double(*__restrict__ coef)[2] = tile.coef[parity];
+    double *__restrict__ out = tile.out[parity];
+    // batches of 8 loci; batch j covers [t(j), t(j) + 8), in sweep order
+    auto batch_start = [](int j) { return BACKWARD ? (kSweepTile - 8 - 8 * j) : (8 * j); };
+    constexpr int kBatches = kSweepTile / 8;
+    double v[8], a[8], b[8], v2[8], a2[8], b2[8], r[8];
+    auto fetch = [&](double(&vv)[8], double(&aa)[8], double(&bb)[8], int j) {
+        const int t0 = batch_start((j < kBatches) ? j : (kBatches - 1));  // (past the tile's end: re-read the last batch)
 #pragma unroll
-            for (int k = 0; k < kMoves; ++k) {
-                const int e = k * kLanes + lane;
-                v[k] = global[(row0 + e / kTile) * n + base + e % kTile];
-            }
+        for (int k = 0; k < 8; ++k) {
+            vv[k] = in[t0 + k];
+            aa[k] = coef[t0 + k][0];
+            bb[k] = coef[t0 + k][1];
+        }
+    };
+    auto run = [&](const double(&vv)[8], const double(&aa)[8], const double(&bb)[8], int j) {
+        const int t0 = batch_start(j);
 #pragma unroll
-            for (int k = 0; k < kMoves; ++k) {
-                const int e = k * kLanes + lane;
-                lds[(e / kTile) * kStride + e % kTile] = v[k];
+        for (int k = 0; k < 8; ++k) {
+            const int kk = BACKWARD ? (7 - k) : k;
+            r[kk] = chain_step(vv[kk], aa[kk], bb[kk], p1, p2);
+            p2 = p1;
+            p1 = r[kk];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            out[t0 + k] = r[k];
+        }
+    };
+    fetch(v, a, b, 0);
+#pragma unroll 1
+    for (int j = 0; j < kBatches; j += 2) {
+        // two batches per trip, the operand registers ping-pong: the next batch's operands are fetched while
+        // this batch's chain runs
+        fetch(v2, a2, b2, j + 1);
+        run(v, a, b, j);
+        fetch(v, a, b, j + 2);
+        run(v2, a2, b2, j + 1);
+    }
+}
+
+// forward (BACKWARD = false): src0 = the matrix (rhs = W_p y), dst0 / dst1 = z of parity 0 / 1 (f / d);
+// backward: src0 / src1 = z of parity 0 / 1, dst0 = the baseline (dst0 may be src0: every tile is read
+// before it is written)
+template <bool BACKWARD>
+__global__ __launch_bounds__(2 * kLanes + kSweepHelpers) void whittaker_sweep_kernel(
+    const double *src0, const double *src1, long long n, long long cap, const double *__restrict__ factor,
+    const double *__restrict__ tail, double *dst0, double *dst1)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    SweepTile *tiles = reinterpret_cast<SweepTile *>(smem);  // [3]
+    const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
+    const bool helper = wave >= 2;
+    const int hl = (int)threadIdx.x - 2 * kLanes;
+    const long long row_off = (long long)blockIdx.x * n;
+    const Factor f0 = factor_of(factor, tail, n, cap, 0), f1 = factor_of(factor, tail, n, cap, 1);
+    const long long n_tiles = (n + kSweepTile - 1) / kSweepTile;
+    // tile k of the sweep covers loci [base(k), base(k) + T(k))
+    auto tile_base = [&](long long k) { return (BACKWARD ? (n_tiles - 1 - k) : k) * kSweepTile; };
+    double s0[kSweepMoves], s1[kSweepMoves], ca[2][kSweepMoves], cb[2][kSweepMoves];
+    auto stage_load = [&](long long k) {
+        const long long b = tile_base(k);
+#pragma unroll
+        for (int j = 0; j < kSweepMoves; ++j) {
+            const long long i = b + hl + j * kSweepHelpers;
+            const long long ii = (i < n) ? i : (n - 1);  // loads without branches
+            s0[j] = src0[row_off + ii];
+            s1[j] = BACKWARD ? src1[row_off + ii] : 0.0;
+            // the multipliers of locus i, end cases as zeros: forward l1[i-1], l2[i-2] (baseline_backend.c:142-151),
+            // backward l1[i], l2[i] (158-172); Factor::ll1 / ll2 hold the entries that depend on the length
+            const long long i1 = BACKWARD ? ii : ((ii >= 1) ? (ii - 1) : 0), i2 = BACKWARD ? ii : ((ii >= 2) ? (ii - 2) : 0);
+            const bool has1 = BACKWARD ? (i < n - 1) : (i >= 1 && i < n), has2 = BACKWARD ? (i < n - 2) : (i >= 2 && i < n);
+            const double a0 = f0.ll1(i1), a1 = f1.ll1(i1), b0 = f0.ll2(i2), b1 = f1.ll2(i2);
+            ca[0][j] = has1 ? a0 : 0.0;
+            ca[1][j] = has1 ? a1 : 0.0;
+            cb[0][j] = has2 ? b0 : 0.0;
+            cb[1][j] = has2 ? b1 : 0.0;
+        }
+    };
+    auto stage_store = [&](long long k) {
+        SweepTile &t = tiles[k % 3];
+        const long long b = tile_base(k);
+#pragma unroll
+        for (int j = 0; j < kSweepMoves; ++j) {
+            const int c = hl + j * kSweepHelpers;
+            const long long i = b + c;
+            const bool inside = i < n;
+            const long long ic = inside ? i : (n - 1);
+            if (BACKWARD) {
+                t.in[0][c] = inside ? s0[j] : 0.0;
+                t.in[1][c] = inside ? s1[j] : 0.0;
+            } else {
+                t.in[0][c] = inside ? rhs_value(s0[j], ic, n, 0) : 0.0;
+                t.in[1][c] = inside ? rhs_value(s0[j], ic, n, 1) : 0.0;
             }
+            t.coef[0][c][0] = ca[0][j];
+            t.coef[0][c][1] = cb[0][j];
+            t.coef[1][c][0] = ca[1][j];
+            t.coef[1][c][1] = cb[1][j];
+        }
+    };
+    auto write_back = [&](long long k) {
+        const SweepTile &t = tiles[k % 3];
+        const long long b = tile_base(k);
+#pragma unroll
+        for (int j = 0; j < kSweepMoves; ++j) {
+            const int c = hl + j * kSweepHelpers;
+            const long long i = b + c;
+            if (i < n) {
+                if (BACKWARD) {
+                    dst0[row_off + i] = 0.5 * (t.out[0][c] + t.out[1][c]);
+                } else {
+                    dst0[row_off + i] = t.out[0][c] / f0.dd(i);
+                    dst1[row_off + i] = t.out[1][c] / f1.dd(i);
+                }
+            }
+        }
+    };
+    if (helper) {
+        stage_load(0);
+        stage_store(0);
+    }
+    __syncthreads();
+    double p1 = 0.0, p2 = 0.0;
+    for (long long k = 0; k < n_tiles; ++k) {
+        if (!helper) {
+#ifndef SWEEP_NO_CHAIN
+            if (lane == 0) {
+                sweep_chain<BACKWARD>(tiles[k % 3], wave, p1, p2);
+            }
+#endif
         } else {
-#pragma unroll
-            for (int k = 0; k < kMoves; ++k) {
-                const int e = k * kLanes + lane;
-                global[(row0 + e / kTile) * n + base + e % kTile] = lds[(e / kTile) * kStride + e % kTile];
+#ifndef SWEEP_NO_HELPER
+            if (k + 1 < n_tiles) {
+                stage_load(k + 1);
             }
-        }
-        return;
-    }
-#pragma unroll 8
-    for (int k = 0; k < kMoves; ++k) {
-        const int e = k * kLanes + lane;
-        const int r = e / kTile, c = e % kTile;
-        if (r < nrows && c < T) {
-            if (TO_LDS) {
-                lds[r * kStride + c] = global[(row0 + r) * n + base + c];
-            } else {
-                global[(row0 + r) * n + base + c] = lds[r * kStride + c];
+            if (k > 0) {
+                write_back(k - 1);
             }
-        }
-    }
-}
-
-// forward substitution L f = rhs for both parities (baseline_backend.c:142-151): f of parity 0 -> fa_out
-// (the output buffer), parity 1 -> fb_out (scratch)
-__global__ __launch_bounds__(kLanes) void whittaker_forward_kernel(const double *__restrict__ matrix, long long rows,
-                                                                  long long n, long long cap,
-                                                                  const double *__restrict__ factor,
-                                                                  const double *__restrict__ tail,
-                                                                  double *__restrict__ fa_out, double *__restrict__ fb_out)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *tile_y = smem;
-    double *tile_a = tile_y + kRows * kStride;
-    double *tile_b = tile_a + kRows * kStride;
-    double *coef = tile_b + kRows * kStride;  // [4][kTile]: l1(i-1), l2(i-2) of parity 0, then of parity 1
-    const int lane = threadIdx.x;
-    const long long row0 = (long long)blockIdx.x * kRows;
-    const int nrows = (int)((rows - row0 < kRows) ? (rows - row0) : kRows);
-    const Factor f0 = factor_of(factor, tail, n, cap, 0), f1 = factor_of(factor, tail, n, cap, 1);
-    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;  // f[i-1], f[i-2] of parity 0 / 1
-    for (long long base = 0; base < n; base += kTile) {
-        const int T = (int)((n - base < kTile) ? (n - base) : kTile);
-        __syncthreads();
-        move_tile<true>(tile_y, const_cast<double *>(matrix), row0, nrows, n, base, T);
-        for (int c = lane; c < T; c += kLanes) {
-            const long long i = base + c;
-            coef[0 * kTile + c] = (i >= 1) ? f0.ll1(i - 1) : 0.0;
-            coef[1 * kTile + c] = (i >= 2) ? f0.ll2(i - 2) : 0.0;
-            coef[2 * kTile + c] = (i >= 1) ? f1.ll1(i - 1) : 0.0;
-            coef[3 * kTile + c] = (i >= 2) ? f1.ll2(i - 2) : 0.0;
-        }
-        __syncthreads();
-        if (lane < nrows) {
-            const double *__restrict__ yrow = tile_y + lane * kStride;
-            double *__restrict__ arow = tile_a + lane * kStride;
-            double *__restrict__ brow = tile_b + lane * kStride;
-            if (T == kTile && base >= 2 && base + kTile + 2 <= n) {
-                // interior tile: no end cases; unrolled so that the LDS reads run ahead of the chains.
-                // rhs = w * y, w = 1 on the locus' own parity and 0 on the other (baseline_backend.c:208-209)
-                // Inputs of eight loci are read into registers first: LDS reads issued one by one between
-                // the (possibly aliasing) LDS writes would each cost a full LDS round trip inside the chain.
-#pragma unroll 1
-                for (int t0 = 0; t0 < kTile; t0 += 8) {
-                    double yv[8], c0[8], c1[8], c2[8], c3[8], fa[8], fb[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        // the factor is the same for every lane: wave-uniform (scalar) loads, no LDS traffic
-                        const long long i = base + t0 + k;
-                        yv[k] = yrow[t0 + k];
-                        c0[k] = f0.l1[i - 1];
-                        c1[k] = f0.l2[i - 2];
-                        c2[k] = f1.l1[i - 1];
-                        c3[k] = f1.l2[i - 2];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        // even loci (t0 is even) carry weight 1 for parity 0 and 0 for parity 1; odd the reverse
-                        const double wa = (k & 1) ? 0.0 : 1.0, wb = (k & 1) ? 1.0 : 0.0;
-                        fa[k] = chain_step(wa * yv[k], c0[k], c1[k], a1, a2);
-                        fb[k] = chain_step(wb * yv[k], c2[k], c3[k], b1, b2);
-                        a2 = a1;
-                        a1 = fa[k];
-                        b2 = b1;
-                        b1 = fb[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        arow[t0 + k] = fa[k];
-                        brow[t0 + k] = fb[k];
-                    }
-                }
-            } else {
-                for (int t = 0; t < T; ++t) {
-                    const long long i = base + t;
-                    const double y = yrow[t];
-                    const double ra = rhs_value(y, i, n, 0), rb = rhs_value(y, i, n, 1);
-                    double fa, fb;
-                    if (i == 0) {
-                        fa = ra;
-                        fb = rb;
-                    } else if (i == 1) {
-                        fa = ra - (coef[0 * kTile + t] * a1);
-                        fb = rb - (coef[2 * kTile + t] * b1);
-                    } else {
-                        fa = chain_step(ra, coef[0 * kTile + t], coef[1 * kTile + t], a1, a2);
-                        fb = chain_step(rb, coef[2 * kTile + t], coef[3 * kTile + t], b1, b2);
-                    }
-                    arow[t] = fa;
-                    brow[t] = fb;
-                    a2 = a1;
-                    a1 = fa;
-                    b2 = b1;
-                    b1 = fb;
-                }
+            if (k + 1 < n_tiles) {
+                stage_store(k + 1);
             }
+#endif
         }
         __syncthreads();
-        move_tile<false>(tile_a, fa_out, row0, nrows, n, base, T);
-        move_tile<false>(tile_b, fb_out, row0, nrows, n, base, T);
     }
-}
-
-// diagonal solve z = f / d (baseline_backend.c:153-156), every element independently
-__global__ __launch_bounds__(256) void whittaker_diagonal_kernel(long long rows, long long n, long long cap,
-                                                                 const double *__restrict__ factor,
-                                                                 const double *__restrict__ tail,
-                                                                 double *__restrict__ z0, double *__restrict__ z1)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
-        return;
-    }
-    const double d0 = factor_of(factor, tail, n, cap, 0).dd(i), d1 = factor_of(factor, tail, n, cap, 1).dd(i);
-    for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
-        z0[r * n + i] = z0[r * n + i] / d0;
-        z1[r * n + i] = z1[r * n + i] / d1;
-    }
-}
-
-// backward substitution L^T x = z for both parities and the cross-fit average
-// (baseline_backend.c:158-172, 296-299); out holds z of parity 0 on entry, the baseline on exit
-__global__ __launch_bounds__(kLanes) void whittaker_backward_kernel(long long rows, long long n, long long cap,
-                                                                   const double *__restrict__ factor,
-                                                                   const double *__restrict__ tail,
-                                                                   double *__restrict__ out, const double *__restrict__ z1)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *tile_a = smem;
-    double *tile_b = tile_a + kRows * kStride;
-    double *coef = tile_b + kRows * kStride;  // [4][kTile]: l1(i), l2(i) of parity 0, then of parity 1
-    const int lane = threadIdx.x;
-    const long long row0 = (long long)blockIdx.x * kRows;
-    const int nrows = (int)((rows - row0 < kRows) ? (rows - row0) : kRows);
-    const Factor f0 = factor_of(factor, tail, n, cap, 0), f1 = factor_of(factor, tail, n, cap, 1);
-    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;  // x[i+1], x[i+2] of parity 0 / 1
-    const long long last_base = ((n - 1) / kTile) * kTile;
-    for (long long base = last_base; base >= 0; base -= kTile) {
-        const int T = (int)((n - base < kTile) ? (n - base) : kTile);
-        __syncthreads();
-        move_tile<true>(tile_a, out, row0, nrows, n, base, T);
-        move_tile<true>(tile_b, const_cast<double *>(z1), row0, nrows, n, base, T);
-        for (int c = lane; c < T; c += kLanes) {
-            const long long i = base + c;
-            coef[0 * kTile + c] = f0.ll1(i);
-            coef[1 * kTile + c] = f0.ll2(i);
-            coef[2 * kTile + c] = f1.ll1(i);
-            coef[3 * kTile + c] = f1.ll2(i);
-        }
-        __syncthreads();
-        if (lane < nrows) {
-            double *__restrict__ arow = tile_a + lane * kStride;
-            const double *__restrict__ brow = tile_b + lane * kStride;
-            if (T == kTile && base + kTile + 2 <= n) {
-                // interior tile: x[i] = z[i] - l1[i] x[i+1] - l2[i] x[i+2]
-#pragma unroll 1
-                for (int t0 = kTile - 8; t0 >= 0; t0 -= 8) {
-                    double za[8], zb[8], c0[8], c1[8], c2[8], c3[8], xm[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const long long i = base + t0 + k;
-                        za[k] = arow[t0 + k];
-                        zb[k] = brow[t0 + k];
-                        c0[k] = f0.l1[i];
-                        c1[k] = f0.l2[i];
-                        c2[k] = f1.l1[i];
-                        c3[k] = f1.l2[i];
-                    }
-#pragma unroll
-                    for (int k = 7; k >= 0; --k) {
-                        const double xa = chain_step(za[k], c0[k], c1[k], a1, a2);
-                        const double xb = chain_step(zb[k], c2[k], c3[k], b1, b2);
-                        xm[k] = 0.5 * (xa + xb);
-                        a2 = a1;
-                        a1 = xa;
-                        b2 = b1;
-                        b1 = xb;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        arow[t0 + k] = xm[k];
-                    }
-                }
-            } else {
-                for (int t = T - 1; t >= 0; --t) {
-                    const long long i = base + t;
-                    const double za = arow[t], zb = brow[t];
-                    double xa, xb;
-                    if (i == n - 1) {
-                        xa = za;
-                        xb = zb;
-                    } else if (i == n - 2) {
-                        xa = za - (coef[0 * kTile + t] * a1);
-                        xb = zb - (coef[2 * kTile + t] * b1);
-                    } else {
-                        xa = chain_step(za, coef[0 * kTile + t], coef[1 * kTile + t], a1, a2);
-                        xb = chain_step(zb, coef[2 * kTile + t], coef[3 * kTile + t], b1, b2);
-                    }
-                    arow[t] = 0.5 * (xa + xb);
-                    a2 = a1;
-                    a1 = xa;
-                    b2 = b1;
-                    b1 = xb;
-                }
-            }
-        }
-        __syncthreads();
-        move_tile<false>(tile_a, out, row0, nrows, n, base, T);
+    if (helper) {
+        write_back(n_tiles - 1);
     }
 }
 
@@ -472,29 +390,23 @@ int launch_crossfit_whittaker(const double *matrix_dev, size_t rows, size_t cols
     }
     double *tail = (double *)scratch_dev;  // 6 doubles
     double *z1 = tail + 8;
-    const unsigned row_groups = (unsigned)((rows + kRows - 1) / kRows);
-    const size_t lds_fwd = (size_t)(3 * kRows * kStride + 4 * kTile) * sizeof(double);
-    const size_t lds_bwd = (size_t)(2 * kRows * kStride + 4 * kTile) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_forward_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
-        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_backward_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
-        attr_set = true;
-    }
     const long long n = (long long)cols, cap = (long long)factor_cap;
     hipLaunchKernelGGL(whittaker_tail_kernel, dim3(1), dim3(64), 0, stream, n, cap, penalty_lambda, factor_dev, tail);
-    hipLaunchKernelGGL(whittaker_forward_kernel, dim3(row_groups), dim3(kLanes), lds_fwd, stream, matrix_dev,
-                       (long long)rows, n, cap, factor_dev, tail, baseline_out_dev, z1);
-    {
-        const unsigned gx = (unsigned)((cols + 255) / 256);
-        const unsigned gy = (unsigned)((rows < 64) ? rows : 64);
-        hipLaunchKernelGGL(whittaker_diagonal_kernel, dim3(gx, gy), dim3(256), 0, stream, (long long)rows, n, cap,
-                           factor_dev, tail, baseline_out_dev, z1);
+    const dim3 block(2 * kLanes + kSweepHelpers);
+    const size_t lds = 3 * sizeof(SweepTile);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_sweep_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_sweep_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
     }
-    hipLaunchKernelGGL(whittaker_backward_kernel, dim3(row_groups), dim3(kLanes), lds_bwd, stream, (long long)rows, n,
-                       cap, factor_dev, tail, baseline_out_dev, z1);
+    hipLaunchKernelGGL(whittaker_sweep_kernel<false>, dim3((unsigned)rows), block, lds, stream, matrix_dev,
+                       (const double *)nullptr, n, cap, factor_dev, tail, baseline_out_dev, z1);
+    hipLaunchKernelGGL(whittaker_sweep_kernel<true>, dim3((unsigned)rows), block, lds, stream,
+                       (const double *)baseline_out_dev, (const double *)z1, n, cap, factor_dev, tail, baseline_out_dev,
+                       (double *)nullptr);
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }
