@@ -225,6 +225,22 @@ int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *
 int rocco_hip_subtract_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,
                            size_t count, void *stream);
 
+/* ---- narrowPeak summit offsets ---------------------------------------
+ * Replaces the per-peak NumPy statements of rocco/rocco.py:838-872 (`_write_narrowpeak_summit_offsets`) over the
+ * summit track of rocco/rocco.py:809-835 (`_cpy_narrowpeak_summit_track`), for the peaks of one chromosome:
+ * intervals_dev = the chromosome's locus starts (ascending, n_intervals of them), effect_mean_dev = the WLS mean
+ * per locus (n_mean doubles, rounded to float32 inside as the reference stores it), peaks as half-open base-pair
+ * intervals.  offsets_out[p] = clip(centre of the first locus with the largest non-NaN mean among the loci
+ * starting in [start, end) - start, 0, end - start - 1), or -1 when the peak is empty, holds no locus or no
+ * finite value.  centers_dev == NULL: the centre of locus i is (intervals[i] + intervals[i+1]) // 2 and the last
+ * entry of intervals only closes the last locus (rocco.py:816-822); otherwise intervals_dev / centers_dev are the
+ * `starts` / `centers` arrays of a stored summit track (rocco.py:855-857), n_intervals each.  Exact (integer /
+ * compare work). */
+int rocco_hip_narrowpeak_summit_offsets(rocco_hip_solver *solver, const int64_t *intervals_dev, size_t n_intervals,
+                                        const int64_t *centers_dev, const double *effect_mean_dev, size_t n_mean, const int64_t *peak_start_dev,
+                                        const int64_t *peak_end_dev, size_t n_peaks, int64_t *offsets_out_dev,
+                                        void *stream);
+
 /* ---- synthetic signal matrices (benchmark / test support, device-resident) -------------------
  * Fills a row-major [K][n] matrix with the counter-based synthetic tracks described in
  * DESIGN.md section 7 (5-decimal background + planted peaks with per-sample dropout); the same

@@ -466,3 +466,36 @@ def score_loci_wls(chrom_matrix, lower_bound_z: float = 1.0, prior_df: float = 5
                "precision_floor_ratio": float(max(precision_floor_ratio, 0.0)), "prior_spatial_window": int(win),
                "degrees_of_freedom": np.full(n, float(df)), "centered_matrix": centered}
     return scores, details
+
+
+def narrowpeak_summit_track(intervals, effect_mean):
+    """rocco/rocco.py:809-835 without the temporary file: (starts, centers, float32 mean) or None."""
+    intervals_ = np.asarray(intervals, dtype=np.int64)
+    effect_mean_ = np.asarray(effect_mean, dtype=np.float32)
+    usable = int(min(max(intervals_.shape[0] - 1, 0), effect_mean_.shape[0]))
+    if usable <= 0:
+        return None
+    centers = (intervals_[:usable].astype(np.int64) + intervals_[1:usable + 1].astype(np.int64)) // 2
+    return intervals_[:usable].copy(), centers, effect_mean_[:usable].copy()
+
+
+def narrowpeak_summit_offsets(records: Sequence[Record], tracks: Dict[str, Optional[tuple]]) -> List[Tuple[str, int]]:
+    """rocco/rocco.py:838-872 as a list of (peak name, offset); `tracks[chrom]` is the summit track or None."""
+    out = []
+    for chrom, start, end in records:
+        summit_offset = -1
+        track = tracks.get(chrom)
+        peak_length = int(end) - int(start)
+        if track is not None and peak_length > 0:
+            starts, centers = np.asarray(track[0], dtype=np.int64), np.asarray(track[1], dtype=np.int64)
+            mean_track = np.asarray(track[2], dtype=np.float64)
+            left = int(np.searchsorted(starts, int(start), side="left"))
+            right = int(np.searchsorted(starts, int(end), side="left"))
+            if right > left:
+                local_mean = mean_track[left:right]
+                if np.any(np.isfinite(local_mean)):
+                    local_idx = int(np.nanargmax(local_mean))
+                    summit_bp = int(centers[left + local_idx])
+                    summit_offset = int(np.clip(summit_bp - int(start), 0, max(peak_length - 1, 0)))
+        out.append((f"{chrom}_{start}_{end}", summit_offset))
+    return out

@@ -122,6 +122,9 @@ PROTOTYPES = [
       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ("rocco_hip_subtract_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("rocco_hip_narrowpeak_summit_offsets", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     ("rocco_hip_synth_matrix", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
       ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]),

@@ -380,6 +380,21 @@ int rocco_hip_subtract_f64(rocco_hip_solver *solver, const double *a_dev, const 
     return launch_subtract(a_dev, b_dev, out_dev, count, (hipStream_t)stream);
 }
 
+int rocco_hip_narrowpeak_summit_offsets(rocco_hip_solver *solver, const int64_t *intervals_dev, size_t n_intervals,
+                                        const int64_t *centers_dev, const double *effect_mean_dev, size_t n_mean, const int64_t *peak_start_dev,
+                                        const int64_t *peak_end_dev, size_t n_peaks, int64_t *offsets_out_dev,
+                                        void *stream)
+{
+    if (solver == nullptr ||
+        (n_peaks > 0 && (peak_start_dev == nullptr || peak_end_dev == nullptr || offsets_out_dev == nullptr)) ||
+        (n_intervals > 0 && intervals_dev == nullptr) || (n_mean > 0 && effect_mean_dev == nullptr)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_summit_offsets(intervals_dev, n_intervals, centers_dev, effect_mean_dev, n_mean, peak_start_dev, peak_end_dev,
+                                 n_peaks, offsets_out_dev, (hipStream_t)stream);
+}
+
 int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
                            size_t row_stride, uint64_t seed, void *stream)
 {

@@ -67,6 +67,12 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
                                  hipStream_t stream);
 int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream);
 
+// ---- summit.hip -----------------------------------------------------------------------------
+int launch_summit_offsets(const int64_t *intervals_dev, size_t n_intervals, const int64_t *centers_dev,
+                          const double *effect_mean_dev, size_t n_mean,
+                          const int64_t *peak_start_dev, const int64_t *peak_end_dev, size_t n_peaks,
+                          int64_t *offsets_out_dev, hipStream_t stream);
+
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
                  hipStream_t stream);

@@ -10,6 +10,8 @@ reference's `rocco/rocco.py`:
     solve_cached_chromosomes       rocco/rocco.py:890-930, 1146-1196 (one process per GPU, every
                                    chromosome of the rank batched into the same device passes,
                                    instead of a fork pool of <= 4 workers)
+    _cpy_narrowpeak_summit_track   rocco/rocco.py:809-835
+    _write_narrowpeak_summit_offsets  rocco/rocco.py:838-872 (per-peak arg-max on the device)
 
 The K x n -> n scoring, the chain solve and the run-length decode run in librocco_hip.so; text
 formatting / file writing of the (small) interval lists stays on the host as in the reference.
@@ -241,6 +243,92 @@ def chrom_solution_to_bed(chromosome, intervals, solution, ID=None, check_gaps_i
                                      min_length_bp=min_length_bp)
     output_file = f"rocco_{chromosome}.bed" if ID is None else f"rocco_{ID}_{chromosome}.bed"
     return _write_bed_records(records, output_file)
+
+
+# --------------------------------------------------------------------------------------------
+# narrowPeak summit offsets
+# --------------------------------------------------------------------------------------------
+
+def narrowpeak_summit_offsets_device(intervals_t, effect_mean_t, peak_start_t, peak_end_t, centers_t=None):
+    """Summit offsets of the peaks of one chromosome (rocco/rocco.py:852-870) as an int64 CUDA tensor:
+    ``intervals_t`` int64 locus starts, ``effect_mean_t`` float64 WLS mean per locus, peaks in base pairs.
+    With ``centers_t`` the pair (intervals_t, centers_t) is a stored summit track's (starts, centers)."""
+    import torch
+
+    checks = [(intervals_t, torch.int64), (effect_mean_t, torch.float64), (peak_start_t, torch.int64),
+              (peak_end_t, torch.int64)]
+    if centers_t is not None:
+        checks.append((centers_t, torch.int64))
+        if centers_t.shape != intervals_t.shape:
+            raise ValueError("starts and centers of a summit track must have the same length")
+    for t, dt in checks:
+        if t.dtype != dt or not t.is_cuda or not t.is_contiguous() or t.dim() != 1:
+            raise ValueError("summit inputs must be contiguous one-dimensional CUDA tensors (int64 / float64)")
+    if peak_start_t.shape != peak_end_t.shape:
+        raise ValueError("peak starts and ends must have the same length")
+    out_t = torch.empty_like(peak_start_t)
+    solver = _native.solver_for(intervals_t.device.index)
+    _native.check(_native.load().rocco_hip_narrowpeak_summit_offsets(
+        solver.handle, intervals_t.data_ptr(), int(intervals_t.shape[0]),
+        None if centers_t is None else centers_t.data_ptr(), effect_mean_t.data_ptr(),
+        int(effect_mean_t.shape[0]), peak_start_t.data_ptr(), peak_end_t.data_ptr(), int(peak_start_t.shape[0]),
+        out_t.data_ptr(), _dp._stream_ptr(intervals_t)), "rocco_hip_narrowpeak_summit_offsets")
+    return out_t
+
+
+def _cpy_narrowpeak_summit_track(chrom: str, intervals, effect_mean) -> Optional[str]:
+    """rocco/rocco.py:809-835: the per-chromosome summit track (starts, centres, float32 mean) as a temporary
+    .npz file, or None when there is no usable locus."""
+    import tempfile
+
+    intervals_ = np.asarray(intervals, dtype=np.int64)
+    effect_mean_ = np.asarray(effect_mean, dtype=np.float32)
+    usable = int(min(max(intervals_.shape[0] - 1, 0), effect_mean_.shape[0]))
+    if usable <= 0:
+        return None
+    starts = intervals_[:usable]
+    centers = (intervals_[:usable].astype(np.int64) + intervals_[1:usable + 1].astype(np.int64)) // 2
+    fd, summit_track_file = tempfile.mkstemp(prefix=f"rocco_summit_track_{chrom}_", suffix=".npz")
+    os.close(fd)
+    np.savez(summit_track_file, starts=starts.astype(np.int64, copy=False),
+             centers=centers.astype(np.int64, copy=False), mean=effect_mean_[:usable].astype(np.float32, copy=False))
+    return summit_track_file
+
+
+def _write_narrowpeak_summit_offsets(peak_file: str, chrom_cache: dict, output_file: str) -> str:
+    """rocco/rocco.py:838-872: one line ``{chrom}_{start}_{end}\t{offset}`` per peak of ``peak_file``.  The peaks
+    of a chromosome go to the device together (binary searches + first arg-max per peak in one launch)."""
+    import torch
+
+    _native.load()
+    records, _ = _read_bed_records(peak_file)
+    offsets = [-1] * len(records)
+    by_chrom: Dict[str, List[int]] = {}
+    for idx, (chrom, _start, _end) in enumerate(records):
+        by_chrom.setdefault(chrom, []).append(idx)
+    device = f"cuda:{_dp._device_index()}"
+    for chrom, indices in by_chrom.items():
+        summit_track_file = chrom_cache.get(chrom, {}).get("summit_track_file")
+        if summit_track_file is None:
+            continue
+        with np.load(summit_track_file) as summit_track:
+            starts = np.asarray(summit_track["starts"], dtype=np.int64)
+            centers = np.asarray(summit_track["centers"], dtype=np.int64)
+            mean_track = np.asarray(summit_track["mean"], dtype=np.float64)
+        if starts.shape[0] == 0:
+            continue
+        peak_start = np.array([records[i][1] for i in indices], dtype=np.int64)
+        peak_end = np.array([records[i][2] for i in indices], dtype=np.int64)
+        out_t = narrowpeak_summit_offsets_device(
+            torch.from_numpy(np.ascontiguousarray(starts)).to(device),
+            torch.from_numpy(np.ascontiguousarray(mean_track)).to(device), torch.from_numpy(peak_start).to(device),
+            torch.from_numpy(peak_end).to(device), centers_t=torch.from_numpy(np.ascontiguousarray(centers)).to(device))
+        for i, value in zip(indices, out_t.cpu().numpy().tolist()):
+            offsets[i] = int(value)
+    with open(output_file, "w", encoding="utf-8") as handle:
+        for (chrom, start, end), summit_offset in zip(records, offsets):
+            handle.write(f"{chrom}_{start}_{end}\t{summit_offset}\n")
+    return output_file
 
 
 # --------------------------------------------------------------------------------------------

@@ -80,3 +80,12 @@ def test_oracle_reproduces_the_reference_score_loci_wls(oracle):
         scalars = np.array([details["local_baseline_window"], details["local_baseline_lambda"], details["min_effect"],
                             details["precision_floor_ratio"], details["prior_spatial_window"]], dtype=np.float64)
         assert np.array_equal(scalars, gold[f"{name}_scalars"]), name
+
+
+def test_oracle_summit_offsets_known_answer(oracle):
+    """The reference's expectation for `_write_narrowpeak_summit_offsets` (tests/test_rocco.py:301-325)."""
+    tracks = {"chr1": (np.array([100, 150, 200]), np.array([125, 175, 225]), np.array([1.0, 5.0, 2.0], dtype=np.float32)),
+              "chr2": None}
+    got = oracle.narrowpeak_summit_offsets([("chr1", 100, 250), ("chr1", 150, 250), ("chr2", 0, 50)], tracks)
+    assert got == [("chr1_100_250", 75), ("chr1_150_250", 25), ("chr2_0_50", -1)]
+    assert oracle.narrowpeak_summit_track(np.array([5]), np.array([1.0])) is None
