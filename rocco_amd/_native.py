@@ -7,8 +7,10 @@ There is no CPU fallback: if the library or a GPU is missing, every call fails l
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
+import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -197,10 +199,27 @@ class Solver:
 
 
 _solvers: dict = {}
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def use_solver(solver: Solver):
+    """Calls made by this thread inside the block use `solver` (its scratch buffers) instead of the process-wide
+    handle of its device: concurrent host threads need one solver each (rocco_amd.pipeline)."""
+    previous = getattr(_tls, "solver", None)
+    _tls.solver = solver
+    try:
+        yield solver
+    finally:
+        _tls.solver = previous
 
 
 def solver_for(device: int) -> Solver:
-    """Process-wide solver handle per device (scratch buffers are reused across calls)."""
+    """Process-wide solver handle per device (scratch buffers are reused across calls), or the calling
+    thread's own (`use_solver`)."""
+    own = getattr(_tls, "solver", None)
+    if own is not None and own.device == int(device):
+        return own
     s = _solvers.get(int(device))
     if s is None:
         s = Solver(int(device))

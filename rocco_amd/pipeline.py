@@ -8,12 +8,33 @@ interval lists (a few thousand index pairs per chromosome) come back to the host
 """
 from __future__ import annotations
 
+import concurrent.futures
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import _native
 from . import dp as _dp
 from . import rocco as _rocco
+from . import shard as _shard
+
+# The calibration is a sequence of short device passes separated by host decisions: latency-bound once the
+# active set has shrunk.  Chromosomes are independent, so a rank's chromosomes are split into groups that
+# calibrate side by side -- one host thread, HIP stream and solver handle (scratch buffers) per group; the
+# native call releases the GIL -- and fill each other's gaps.  Results do not depend on the grouping.
+SOLVE_GROUPS = int(os.environ.get("ROCCO_SOLVE_GROUPS", "4"))
+_pool: Optional[concurrent.futures.ThreadPoolExecutor] = None
+_group_state: Dict[Tuple[int, int], tuple] = {}  # (device, group) -> (Solver, torch.cuda.Stream)
+
+
+def _group_resources(device_index: int, group: int):
+    import torch
+
+    key = (int(device_index), int(group))
+    if key not in _group_state:
+        _group_state[key] = (_native.Solver(int(device_index)), torch.cuda.Stream(device=int(device_index)))
+    return _group_state[key]
 
 
 class ChromWork:
@@ -29,21 +50,8 @@ class ChromWork:
         self.n = int(matrix_t.shape[1])
 
 
-def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None):
-    """Score, solve and decode every chromosome of this rank.
-
-    Returns a list of dicts: name, n, selected_count, selection_penalty, penalized_objective, path,
-    begin / end (int64 CUDA tensors: half-open locus index pairs of the merged runs) and the
-    solution tensor.
-    """
-    import torch
-
-    scores = []
-    for c in chroms:
-        s_t = _rocco.score_central_tendency_chrom_device(c.matrix_t)
-        scores.append(s_t)
-    if scores_out is not None:
-        scores_out.extend(scores)
+def _solve_group(chroms: Sequence[ChromWork], scores: list) -> list:
+    """Calibrate and decode the given chromosomes on the calling thread's current stream / solver."""
     targets = [int(np.floor(c.n * c.budget)) for c in chroms]  # rocco/dp.py:197
     solved = _dp.calibrate_batch_device(scores, [c.gamma for c in chroms], targets)
     out = []
@@ -54,6 +62,49 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None):
             "penalized_objective": value, "path": info["path"], "info": info,
             "begin": begin_t, "end": end_t, "solution": sol_t, "step": c.step, "start": c.start,
         })
+    return out
+
+
+def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, groups: Optional[int] = None):
+    """Score, solve and decode every chromosome of this rank.
+
+    Returns a list of dicts: name, n, selected_count, selection_penalty, penalized_objective, path,
+    begin / end (int64 CUDA tensors: half-open locus index pairs of the merged runs) and the
+    solution tensor.  `groups` (default ROCCO_SOLVE_GROUPS): how many groups of chromosomes calibrate
+    side by side (see SOLVE_GROUPS above).
+    """
+    import torch
+
+    global _pool
+    scores = []
+    for c in chroms:
+        s_t = _rocco.score_central_tendency_chrom_device(c.matrix_t)
+        scores.append(s_t)
+    if scores_out is not None:
+        scores_out.extend(scores)
+    n_groups = max(1, min(int(groups if groups is not None else SOLVE_GROUPS), len(chroms)))
+    if n_groups == 1:
+        return _solve_group(chroms, scores)
+    device = scores[0].device
+    scored = torch.cuda.Event()
+    scored.record()
+    members = _shard.lpt_partition([c.n for c in chroms], n_groups)
+
+    def work(group: int):
+        solver, stream = _group_resources(device.index, group)
+        idx = members[group]
+        with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
+            stream.wait_event(scored)
+            res = _solve_group([chroms[i] for i in idx], [scores[i] for i in idx])
+            stream.synchronize()
+        return idx, res
+
+    if _pool is None:
+        _pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-solve")
+    out: List[Optional[dict]] = [None] * len(chroms)
+    for idx, res in _pool.map(work, range(n_groups)):
+        for i, r in zip(idx, res):
+            out[i] = r
     return out
 
 
