@@ -241,6 +241,21 @@ int rocco_hip_narrowpeak_summit_offsets(rocco_hip_solver *solver, const int64_t 
                                         const int64_t *peak_end_dev, size_t n_peaks, int64_t *offsets_out_dev,
                                         void *stream);
 
+/* ---- signal matrix assembly --------------------------------------------
+ * The NumPy statements at the end of generate_chrom_matrix (rocco/readtracks.py:614-633) on device buffers.
+ * rocco_hip_union_intervals: unique_out = np.sort(np.unique(values)) (capacity `count`), *n_unique_out = its
+ * length, *fixed_step_out (may be NULL) = 1 iff np.unique(np.diff(unique_out)).size <= 1 (the bigWig check,
+ * readtracks.py:615-620).
+ * rocco_hip_scatter_tracks: matrix[k, np.searchsorted(common, intervals_k)] = vals_k on a zero matrix (K x m,
+ * row-major, out_dtype 0 = float64, 1 = float32 as with low_memory); track k owns the entries
+ * offsets_host[k] .. offsets_host[k+1] of the concatenated interval / value arrays; repeated loci inside a
+ * track keep the last value, as NumPy's fancy-index assignment does.  Exact. */
+int rocco_hip_union_intervals(rocco_hip_solver *solver, const int64_t *values_dev, size_t count,
+                              int64_t *unique_out_dev, size_t *n_unique_out, int *fixed_step_out, void *stream);
+int rocco_hip_scatter_tracks(rocco_hip_solver *solver, const int64_t *common_dev, size_t m,
+                             const int64_t *intervals_concat_dev, const double *vals_concat_dev,
+                             const size_t *offsets_host, size_t K, int out_dtype, void *matrix_out_dev, void *stream);
+
 /* ---- synthetic signal matrices (benchmark / test support, device-resident) -------------------
  * Fills a row-major [K][n] matrix with the counter-based synthetic tracks described in
  * DESIGN.md section 7 (5-decimal background + planted peaks with per-sample dropout); the same

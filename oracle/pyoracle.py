@@ -499,3 +499,18 @@ def narrowpeak_summit_offsets(records: Sequence[Record], tracks: Dict[str, Optio
                     summit_offset = int(np.clip(summit_bp - int(start), 0, max(peak_length - 1, 0)))
         out.append((f"{chrom}_{start}_{end}", summit_offset))
     return out
+
+
+def assemble_chrom_matrix(interval_matrix, vals_matrix, track_type: str = "bam", low_memory: bool = False,
+                          chromosome: str = ""):
+    """The tail of generate_chrom_matrix (rocco/readtracks.py:614-633), NumPy statement by NumPy statement."""
+    common_intervals = np.sort(np.unique(np.concatenate(interval_matrix, axis=0)))
+    if track_type == "bigwig" and common_intervals.size > 1:
+        if np.unique(np.diff(common_intervals)).size != 1:
+            raise ValueError(f"bigWig inputs for {chromosome} do not share one fixed binning scheme")
+    matrix_dtype = np.float32 if low_memory else np.float64
+    count_matrix = np.zeros((len(interval_matrix), len(common_intervals)), dtype=matrix_dtype)
+    for i, (intervals_, vals_) in enumerate(zip(interval_matrix, vals_matrix)):
+        idx = np.searchsorted(common_intervals, intervals_)
+        count_matrix[i, idx] = np.asarray(vals_, dtype=matrix_dtype)
+    return np.array(common_intervals).astype(int), count_matrix

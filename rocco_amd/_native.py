@@ -127,6 +127,11 @@ PROTOTYPES = [
     ("rocco_hip_narrowpeak_summit_offsets", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_union_intervals", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, c_size_p, c_int_p, ctypes.c_void_p]),
+    ("rocco_hip_scatter_tracks", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, c_size_p, ctypes.c_size_t,
+      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     ("rocco_hip_synth_matrix", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
       ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]),

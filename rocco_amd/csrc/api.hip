@@ -395,6 +395,57 @@ int rocco_hip_narrowpeak_summit_offsets(rocco_hip_solver *solver, const int64_t 
                                  n_peaks, offsets_out_dev, (hipStream_t)stream);
 }
 
+int rocco_hip_union_intervals(rocco_hip_solver *solver, const int64_t *values_dev, size_t count,
+                              int64_t *unique_out_dev, size_t *n_unique_out, int *fixed_step_out, void *stream)
+{
+    if (solver == nullptr || n_unique_out == nullptr || count > (size_t)0x7fffffff ||
+        (count > 0 && (values_dev == nullptr || unique_out_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    *n_unique_out = 0;
+    if (fixed_step_out != nullptr) {
+        *fixed_step_out = 1;
+    }
+    if (count == 0) {
+        return ROCCO_HIP_OK;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_misc.reserve(union_scratch_bytes(count))) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    return launch_union_intervals(values_dev, count, unique_out_dev, n_unique_out, fixed_step_out, solver->dev_misc.ptr,
+                                  (hipStream_t)stream);
+}
+
+int rocco_hip_scatter_tracks(rocco_hip_solver *solver, const int64_t *common_dev, size_t m,
+                             const int64_t *intervals_concat_dev, const double *vals_concat_dev,
+                             const size_t *offsets_host, size_t K, int out_dtype, void *matrix_out_dev, void *stream)
+{
+    if (solver == nullptr || offsets_host == nullptr || (out_dtype != 0 && out_dtype != 1) ||
+        (K * m > 0 && (common_dev == nullptr || matrix_out_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    for (size_t k = 0; k < K; ++k) {
+        if (offsets_host[k + 1] < offsets_host[k] || offsets_host[k + 1] - offsets_host[k] >= (size_t)0xffffffff) {
+            return ROCCO_HIP_EINVAL;
+        }
+    }
+    if (K > 0 && offsets_host[K] > 0 && (intervals_concat_dev == nullptr || vals_concat_dev == nullptr)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    if (K * m == 0) {
+        return ROCCO_HIP_OK;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_misc.reserve(scatter_scratch_bytes(K, m))) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    return launch_scatter_tracks(common_dev, m, intervals_concat_dev, vals_concat_dev, offsets_host, K, out_dtype,
+                                 matrix_out_dev, solver->dev_misc.ptr, (hipStream_t)stream);
+}
+
 int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
                            size_t row_stride, uint64_t seed, void *stream)
 {

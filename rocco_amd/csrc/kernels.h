@@ -73,6 +73,15 @@ int launch_summit_offsets(const int64_t *intervals_dev, size_t n_intervals, cons
                           const int64_t *peak_start_dev, const int64_t *peak_end_dev, size_t n_peaks,
                           int64_t *offsets_out_dev, hipStream_t stream);
 
+// ---- assemble.hip ---------------------------------------------------------------------------
+size_t union_scratch_bytes(size_t count);
+int launch_union_intervals(const int64_t *values_dev, size_t count, int64_t *unique_out_dev, size_t *n_unique_out,
+                           int *fixed_step_out, void *scratch_dev, hipStream_t stream);
+size_t scatter_scratch_bytes(size_t K, size_t m);
+int launch_scatter_tracks(const int64_t *common_dev, size_t m, const int64_t *intervals_concat_dev,
+                          const double *vals_concat_dev, const size_t *offsets_host, size_t K, int out_dtype,
+                          void *matrix_out_dev, void *scratch_dev, hipStream_t stream);
+
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
                  hipStream_t stream);
