@@ -40,7 +40,13 @@ def _group_resources(device_index: int, group: int):
 class ChromWork:
     """One chromosome owned by this rank."""
 
-    def __init__(self, name: str, matrix_t, budget: float, gamma: float, step: int = 50, start: int = 0):
+    def __init__(self, name: str, matrix_t, budget: float, gamma: float, step: int = 50, start: int = 0,
+                 scoring: str = "median", wls_params: Optional[dict] = None):
+        """`scoring`: "median" -- column medians of signal tracks, the bigWig branch of `_build_chrom_cache`
+        (rocco/rocco.py:977-991); "wls" -- `score_loci_wls` on a count matrix, its BAM branch (1009-1018), with
+        `wls_params` = lower_bound_z / prior_df / min_effect / precision_floor_ratio."""
+        if scoring not in ("median", "wls"):
+            raise ValueError("scoring must be 'median' or 'wls'")
         self.name = name
         self.matrix_t = matrix_t  # [K, n] float64 / float32 CUDA tensor
         self.budget = float(budget)
@@ -48,6 +54,8 @@ class ChromWork:
         self.step = int(step)
         self.start = int(start)
         self.n = int(matrix_t.shape[1])
+        self.scoring = scoring
+        self.wls_params = dict(wls_params or {})
 
 
 def _solve_group(chroms: Sequence[ChromWork], scores: list) -> list:
@@ -61,6 +69,7 @@ def _solve_group(chroms: Sequence[ChromWork], scores: list) -> list:
             "name": c.name, "n": c.n, "selected_count": count, "selection_penalty": penalty,
             "penalized_objective": value, "path": info["path"], "info": info,
             "begin": begin_t, "end": end_t, "solution": sol_t, "step": c.step, "start": c.start,
+            "effect_mean": getattr(c, "_effect_mean", None),
         })
     return out
 
@@ -78,7 +87,14 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
     global _pool
     scores = []
     for c in chroms:
-        s_t = _rocco.score_central_tendency_chrom_device(c.matrix_t)
+        if c.scoring == "wls":
+            from . import inference as _inference
+
+            s_t, details = _inference.score_loci_wls_device(c.matrix_t.to(torch.float64), **c.wls_params)
+            c._effect_mean = details["mean"]  # rocco/rocco.py:1090 `effect_mean`, the summit track's source
+        else:
+            s_t = _rocco.score_central_tendency_chrom_device(c.matrix_t)
+            c._effect_mean = s_t  # rocco/rocco.py:995-997: the bigWig branch uses the scores themselves
         scores.append(s_t)
     if scores_out is not None:
         scores_out.extend(scores)
@@ -119,3 +135,22 @@ def runs_to_records(result: dict, min_length_bp: Optional[int] = None) -> List[T
         if min_length_bp is None or (e_bp - s_bp) >= int(min_length_bp):
             recs.append((result["name"], int(s_bp), int(e_bp)))
     return recs
+
+
+def summit_offsets(result: dict, min_length_bp: Optional[int] = None) -> List[Tuple[str, int]]:
+    """(peak name, summit offset) of every record of `runs_to_records(result)` -- what
+    `_write_narrowpeak_summit_offsets` (rocco/rocco.py:838-872) writes for this chromosome -- from the result's
+    `effect_mean` track, all on the device."""
+    import torch
+
+    records = runs_to_records(result, min_length_bp=min_length_bp)
+    if not records:
+        return []
+    dev = result["begin"].device
+    n, step, start = result["n"], result["step"], result["start"]
+    intervals_t = start + step * torch.arange(n, dtype=torch.int64, device=dev)
+    starts_t = torch.tensor([r[1] for r in records], dtype=torch.int64, device=dev)
+    ends_t = torch.tensor([r[2] for r in records], dtype=torch.int64, device=dev)
+    mean_t = result["effect_mean"].to(torch.float64).contiguous()
+    off = _rocco.narrowpeak_summit_offsets_device(intervals_t, mean_t, starts_t, ends_t).cpu().numpy().tolist()
+    return [(f"{c}_{s}_{e}", int(o)) for (c, s, e), o in zip(records, off)]

@@ -110,3 +110,37 @@ def test_golden_vectors_of_the_reference_function(gpu):
             scalars = np.array([details["local_baseline_window"], details["local_baseline_lambda"], details["min_effect"],
                                 details["precision_floor_ratio"], details["prior_spatial_window"]], dtype=np.float64)
             assert np.array_equal(scalars, gold[f"{name}_scalars"]), name
+
+
+def test_count_path_pipeline_end_to_end(gpu, oracle):
+    """Counts -> score_loci_wls -> budgeted solve -> BED3 records -> summit offsets, every step in HBM
+    (rocco/rocco.py:1009-1018, 890-930, 139-191, 809-872), against the oracle's composition.  The counts are
+    2^k - 1 so that log2(count + 1) is exact and everything downstream must agree bit for bit."""
+    import torch
+
+    from rocco_amd import pipeline
+
+    rng = np.random.default_rng(21)
+    K, n, step, budget, gamma = 6, 120000, 50, 0.03, 1.0
+    peaks = np.zeros(n, dtype=bool)
+    for c in rng.integers(0, n - 60, size=n // 1500):
+        peaks[c:c + int(rng.integers(4, 40))] = True
+    k = rng.integers(0, 4, size=(K, n)) + peaks[None, :] * rng.integers(2, 7, size=(K, n))
+    counts = np.ldexp(1.0, k) - 1.0
+    params = {"lower_bound_z": 1.0, "prior_df": 5.0, "min_effect": None, "precision_floor_ratio": 0.01}
+    work = pipeline.ChromWork("chrC", torch.from_numpy(counts).cuda(), budget, gamma, step=step, start=1000,
+                              scoring="wls", wls_params=params)
+    scores = []
+    res = pipeline.solve_rank([work], scores_out=scores)[0]
+    o_scores, o_details = oracle.score_loci_wls(counts, **params)
+    assert scores[0].cpu().numpy().tobytes() == o_scores.tobytes()
+    o_sol, _o_obj, o_det = oracle.solve_chrom_exact(o_scores, budget=budget, gamma=gamma, return_details=True)
+    assert res["selection_penalty"] == o_det["selection_penalty"] and res["selected_count"] == o_det["selected_count"]
+    assert np.array_equal(res["solution"].cpu().numpy(), o_sol)
+    intervals = 1000 + step * np.arange(n, dtype=np.int64)
+    want_records = oracle.chrom_solution_records("chrC", intervals, o_sol)
+    assert pipeline.runs_to_records(res) == want_records and len(want_records) > 10
+    track = oracle.narrowpeak_summit_track(intervals, o_details["mean"])
+    want_offsets = oracle.narrowpeak_summit_offsets(want_records, {"chrC": track})
+    assert pipeline.summit_offsets(res) == want_offsets
+    assert any(off > 0 for _, off in want_offsets)
