@@ -256,6 +256,27 @@ int rocco_hip_scatter_tracks(rocco_hip_solver *solver, const int64_t *common_dev
                              const int64_t *intervals_concat_dev, const double *vals_concat_dev,
                              const size_t *offsets_host, size_t K, int out_dtype, void *matrix_out_dev, void *stream);
 
+/* ---- the K x n part of the wild-bootstrap budget null -------------------
+ * The random multipliers stay with NumPy on the host (rocco/inference.py:540-571 draws them from
+ * np.random.default_rng streams); what moves to the device is what the reference does with them per draw
+ * (rocco/inference.py:628-685 `_compute_budget_null_draw`): the K x n product, the WLS rescoring
+ * (rocco_hip_score_centered_wls_f64) and the four means -- and the residual template they start from (688-722).
+ * rocco_hip_numpy_sum_f64: np.sum of a contiguous float64 vector in NumPy's own order (8192-element buffer chunks,
+ *   pairwise summation inside a chunk, running total over the chunks), bit for bit.
+ * rocco_hip_budget_null_draw_stats_f64: stats_out[0..4) = np.mean(pos), np.mean(pos / null_soft_scale),
+ *   np.mean(pos > 0), np.mean(scores > null_threshold) with pos = np.clip(scores - null_center, 0, None)
+ *   (inference.py:676-684), summed in NumPy's order.
+ * rocco_hip_multiply_f64: out = a * b elementwise (inference.py:665).
+ * rocco_hip_subtract_positive_row_f64: out[k][i] = matrix[k][i] - max(row[i], 0) (inference.py:717-721). */
+int rocco_hip_numpy_sum_f64(rocco_hip_solver *solver, const double *x_dev, size_t n, double *sum_out, void *stream);
+int rocco_hip_budget_null_draw_stats_f64(rocco_hip_solver *solver, const double *scores_dev, size_t n,
+                                         double null_center, double null_soft_scale, double null_threshold,
+                                         double *stats_out, void *stream);
+int rocco_hip_multiply_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,
+                           size_t count, void *stream);
+int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *matrix_dev, const double *row_dev,
+                                        size_t K, size_t n, double *out_dev, void *stream);
+
 /* ---- synthetic signal matrices (benchmark / test support, device-resident) -------------------
  * Fills a row-major [K][n] matrix with the counter-based synthetic tracks described in
  * DESIGN.md section 7 (5-decimal background + planted peaks with per-sample dropout); the same

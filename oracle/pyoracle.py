@@ -514,3 +514,26 @@ def assemble_chrom_matrix(interval_matrix, vals_matrix, track_type: str = "bam",
         idx = np.searchsorted(common_intervals, intervals_)
         count_matrix[i, idx] = np.asarray(vals_, dtype=matrix_dtype)
     return np.array(common_intervals).astype(int), count_matrix
+
+
+def fit_budget_null_residual_template(centered_matrix, lower_bound_z=1.0, prior_df=5.0, min_effect=None,
+                                      precision_floor_ratio=0.01):
+    """rocco/inference.py:688-722: (residual_template, observed_scores, positive_consensus)."""
+    centered = np.asarray(centered_matrix, dtype=np.float64)
+    res = score_centered_wls(centered, lower_bound_z=lower_bound_z, prior_df=prior_df, min_effect=min_effect,
+                             spatial_window=31, precision_floor_ratio=max(precision_floor_ratio, 0.0))
+    positive_consensus = np.clip(res[1], 0.0, None)
+    return centered - positive_consensus[None, :], res[0].astype(np.float64), positive_consensus
+
+
+def compute_budget_null_draw(residual_template, wild_weights, lower_bound_z, prior_df, min_effect,
+                             precision_floor_ratio, null_center, null_soft_scale, null_threshold):
+    """rocco/inference.py:656-685 given the draw's multipliers (one row per sample)."""
+    bootstrap_centered = np.asarray(residual_template, dtype=np.float64) * np.asarray(wild_weights, dtype=np.float64)
+    scores = score_centered_wls(bootstrap_centered, lower_bound_z=lower_bound_z, prior_df=prior_df,
+                                min_effect=(None if min_effect is None else float(max(min_effect, 0.0))),
+                                spatial_window=31, precision_floor_ratio=max(precision_floor_ratio, 0.0))[0]
+    residual = np.asarray(scores, dtype=np.float64) - null_center
+    positive = np.clip(residual, 0.0, None)
+    return (float(np.mean(positive)), float(np.mean(positive / null_soft_scale)), float(np.mean(positive > 0.0)),
+            float(np.mean(scores > null_threshold)))

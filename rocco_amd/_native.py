@@ -132,6 +132,16 @@ PROTOTYPES = [
     ("rocco_hip_scatter_tracks", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, c_size_p, ctypes.c_size_t,
       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_numpy_sum_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, c_double_p, ctypes.c_void_p]),
+    ("rocco_hip_budget_null_draw_stats_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+      c_double_p, ctypes.c_void_p]),
+    ("rocco_hip_multiply_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("rocco_hip_subtract_positive_row_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
+      ctypes.c_void_p]),
     ("rocco_hip_synth_matrix", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
       ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]),

@@ -446,6 +446,68 @@ int rocco_hip_scatter_tracks(rocco_hip_solver *solver, const int64_t *common_dev
                                  matrix_out_dev, solver->dev_misc.ptr, (hipStream_t)stream);
 }
 
+int rocco_hip_numpy_sum_f64(rocco_hip_solver *solver, const double *x_dev, size_t n, double *sum_out, void *stream)
+{
+    if (solver == nullptr || sum_out == nullptr || (n > 0 && x_dev == nullptr)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    *sum_out = 0.0;
+    if (n == 0) {
+        return ROCCO_HIP_OK;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_misc.reserve(npsum_scratch_bytes(n))) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    const int mode = 0;
+    return launch_numpy_sums(x_dev, n, &mode, 1, 0.0, 1.0, 0.0, solver->dev_misc.ptr, sum_out, (hipStream_t)stream);
+}
+
+int rocco_hip_budget_null_draw_stats_f64(rocco_hip_solver *solver, const double *scores_dev, size_t n,
+                                         double null_center, double null_soft_scale, double null_threshold,
+                                         double *stats_out, void *stream)
+{
+    if (solver == nullptr || stats_out == nullptr || scores_dev == nullptr || n == 0) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_misc.reserve(npsum_scratch_bytes(n))) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    const int modes[4] = {1, 2, 3, 4};
+    double sums[4];
+    if ((rc = launch_numpy_sums(scores_dev, n, modes, 4, null_center, null_soft_scale, null_threshold,
+                                solver->dev_misc.ptr, sums, (hipStream_t)stream)) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    for (int i = 0; i < 4; ++i) {
+        stats_out[i] = sums[i] / (double)n;  // np.mean: the sum divided by the count
+    }
+    return ROCCO_HIP_OK;
+}
+
+int rocco_hip_multiply_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,
+                           size_t count, void *stream)
+{
+    if (solver == nullptr || ((a_dev == nullptr || b_dev == nullptr || out_dev == nullptr) && count > 0)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_multiply(a_dev, b_dev, out_dev, count, (hipStream_t)stream);
+}
+
+int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *matrix_dev, const double *row_dev,
+                                        size_t K, size_t n, double *out_dev, void *stream)
+{
+    if (solver == nullptr || ((matrix_dev == nullptr || row_dev == nullptr || out_dev == nullptr) && K * n > 0)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_subtract_positive_row(matrix_dev, row_dev, K, n, out_dev, (hipStream_t)stream);
+}
+
 int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
                            size_t row_stride, uint64_t seed, void *stream)
 {

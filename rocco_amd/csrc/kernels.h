@@ -82,6 +82,14 @@ int launch_scatter_tracks(const int64_t *common_dev, size_t m, const int64_t *in
                           const double *vals_concat_dev, const size_t *offsets_host, size_t K, int out_dtype,
                           void *matrix_out_dev, void *scratch_dev, hipStream_t stream);
 
+// ---- npsum.hip ------------------------------------------------------------------------------
+size_t npsum_scratch_bytes(size_t n);
+int launch_numpy_sums(const double *x_dev, size_t n, const int *modes, int n_modes, double center, double scale,
+                      double threshold, void *scratch_dev, double *sums_out_host, hipStream_t stream);
+int launch_multiply(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream);
+int launch_subtract_positive_row(const double *matrix_dev, const double *row_dev, size_t K, size_t n, double *out_dev,
+                                 hipStream_t stream);
+
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
                  hipStream_t stream);

@@ -274,3 +274,76 @@ def score_loci_wls(chrom_matrix, lower_bound_z: float = 1.0, prior_df: float = 5
         else:
             details[key] = value
     return scores, details
+
+
+# --------------------------------------------------------------------------------------------
+# the K x n part of the wild-bootstrap budget null (rocco/inference.py:628-722)
+# --------------------------------------------------------------------------------------------
+
+def numpy_sum_device(x_t) -> float:
+    """np.sum of a contiguous one-dimensional float64 CUDA tensor in NumPy's own summation order (bit for bit)."""
+    import ctypes
+
+    import torch
+
+    if x_t.dim() != 1 or x_t.dtype != torch.float64 or not x_t.is_cuda or not x_t.is_contiguous():
+        raise ValueError("x_t must be a contiguous one-dimensional float64 CUDA tensor")
+    out = ctypes.c_double(0.0)
+    solver = _native.solver_for(x_t.device.index)
+    _native.check(_native.load().rocco_hip_numpy_sum_f64(solver.handle, x_t.data_ptr(), int(x_t.shape[0]),
+                                                         ctypes.byref(out), _dp._stream_ptr(x_t)),
+                  "rocco_hip_numpy_sum_f64")
+    return float(out.value)
+
+
+def fit_budget_null_residual_template_device(centered_t, lower_bound_z: float = 1.0, prior_df: float = 5.0,
+                                             min_effect=None, precision_floor_ratio: float = 0.01):
+    """rocco/inference.py:688-722 on the device: (residual_template [K, n], observed_scores [n],
+    positive_consensus [n]) with residual = centered - max(mu_hat, 0)."""
+    import torch
+
+    scores, mean, _raw, _prior, _mod, _se, _df, _win = score_centered_wls_device(
+        centered_t, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df), min_effect=min_effect,
+        spatial_window=31, precision_floor_ratio=float(max(precision_floor_ratio, 0.0)))
+    K, n = int(centered_t.shape[0]), int(centered_t.shape[1])
+    residual = torch.empty_like(centered_t)
+    solver = _native.solver_for(centered_t.device.index)
+    _native.check(_native.load().rocco_hip_subtract_positive_row_f64(
+        solver.handle, centered_t.data_ptr(), mean.data_ptr(), K, n, residual.data_ptr(),
+        _dp._stream_ptr(centered_t)), "rocco_hip_subtract_positive_row_f64")
+    return residual, scores, torch.clamp_min(mean, 0.0)
+
+
+def compute_budget_null_draw_device(residual_template_t, wild_weights_t, lower_bound_z: float, prior_df: float,
+                                    min_effect, precision_floor_ratio: float, null_center: float,
+                                    null_soft_scale: float, null_threshold: float, work_t=None):
+    """One draw of the budget null given its multipliers (rocco/inference.py:656-685; the multipliers of 646-664
+    come from NumPy's generator on the host): bootstrap = residual_template * wild_weights, WLS rescoring, and the
+    four means -- mean positive excess, the same in null-scale units, fraction positive, fraction above the null
+    threshold -- summed in NumPy's order."""
+    import ctypes
+
+    import torch
+
+    if residual_template_t.shape != wild_weights_t.shape or residual_template_t.dim() != 2:
+        raise ValueError("residual template and multipliers must be [K, n] tensors of the same shape")
+    for t in (residual_template_t, wild_weights_t):
+        if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("residual template and multipliers must be contiguous float64 CUDA tensors")
+    K, n = int(residual_template_t.shape[0]), int(residual_template_t.shape[1])
+    boot = work_t if work_t is not None else torch.empty_like(residual_template_t)
+    lib, solver, stream = _native.load(), _native.solver_for(residual_template_t.device.index), \
+        _dp._stream_ptr(residual_template_t)
+    _native.check(lib.rocco_hip_multiply_f64(solver.handle, residual_template_t.data_ptr(), wild_weights_t.data_ptr(),
+                                             boot.data_ptr(), K * n, stream), "rocco_hip_multiply_f64")
+    scores = score_centered_wls_device(boot, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df),
+                                       min_effect=(None if min_effect is None else float(max(min_effect, 0.0))),
+                                       spatial_window=31,
+                                       precision_floor_ratio=float(max(precision_floor_ratio, 0.0)))[0]
+    if not bool(torch.isfinite(scores).all()):
+        raise ValueError("EB scoring produced non-finite values")
+    stats = (ctypes.c_double * 4)()
+    _native.check(lib.rocco_hip_budget_null_draw_stats_f64(solver.handle, scores.data_ptr(), n, float(null_center),
+                                                           float(null_soft_scale), float(null_threshold), stats,
+                                                           stream), "rocco_hip_budget_null_draw_stats_f64")
+    return float(stats[0]), float(stats[1]), float(stats[2]), float(stats[3])

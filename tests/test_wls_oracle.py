@@ -89,3 +89,19 @@ def test_oracle_summit_offsets_known_answer(oracle):
     got = oracle.narrowpeak_summit_offsets([("chr1", 100, 250), ("chr1", 150, 250), ("chr2", 0, 50)], tracks)
     assert got == [("chr1_100_250", 75), ("chr1_150_250", 25), ("chr2_0_50", -1)]
     assert oracle.narrowpeak_summit_track(np.array([5]), np.array([1.0])) is None
+
+
+def test_oracle_reproduces_the_reference_budget_null_draws(oracle):
+    """tests/golden/budget_null_vectors.npz was written by the reference's `_fit_budget_null_residual_template` and
+    `_compute_budget_null_draw` (with the multipliers of each draw stored)."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "budget_null_vectors.npz"))
+    for name in gold["names"]:
+        lbz, pdf, me, pfr, center, soft_scale, threshold = gold[f"{name}_params"]
+        me = None if np.isnan(me) else float(me)
+        template, scores, positive = oracle.fit_budget_null_residual_template(gold[f"{name}_centered"], lbz, pdf, me, pfr)
+        assert template.tobytes() == gold[f"{name}_template"].tobytes(), name
+        assert scores.tobytes() == gold[f"{name}_fitted_scores"].tobytes() and positive.tobytes() == gold[f"{name}_positive"].tobytes()
+        for draw in range(2):
+            stats = oracle.compute_budget_null_draw(template, gold[f"{name}_draw{draw}_weights"], lbz, pdf, me, pfr, center,
+                                                    soft_scale, threshold)
+            assert np.array(stats).tobytes() == gold[f"{name}_draw{draw}_stats"].tobytes(), (name, draw)
