@@ -212,6 +212,33 @@ def main():
             "path": g["path"],
         }
 
+    # ---- the count-path scoring rows on the same sample: reported beside the headline, not part of it ----
+    next_rows = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from rocco_amd import inference
+
+        counts_t = (m_t * 20.0).contiguous()  # count-like magnitudes from the sample's tracks
+        inference.score_loci_wls_device(counts_t)  # first call: Whittaker factor for this penalty, scratch buffers
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wls_scores, _ = inference.score_loci_wls_device(counts_t)
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t0
+        ks, ns = min(K, 4), min(n_s, 200000)
+        sub = counts_t[:ks, :ns].contiguous()
+        sub_h = sub.cpu().numpy()
+        t0 = time.perf_counter()
+        o_scores, _ = po.score_loci_wls(sub_h)
+        t_cpu = time.perf_counter() - t0
+        g_scores = inference.score_loci_wls_device(sub)[0].cpu().numpy()
+        next_rows = {"score_loci_wls": {
+            "value": round(n_s / t_gpu, 1), "unit": "loci/s", "workload": f"{sample} (n={n_s}), K={K} count matrix",
+            "cpu_oracle_values_per_s": round(sub_h.size / t_cpu, 1), "cpu_sample": f"{ks} x {ns}",
+            "gpu_values_per_s": round(K * n_s / t_gpu, 1),
+            "max_rel_score_diff_vs_oracle": float(np.abs(g_scores - o_scores).max() / np.abs(o_scores).max()),
+            "note": "log2 differs from NumPy's in the last place; everything downstream is bit-exact (tests)"}}
+        del counts_t, wls_scores
+
     if rank == 0:
         line = {
             "metric": "loci/sec to converged solve, hg38 50bp K=%d; BED3 intervals bit-exact" % K,
@@ -233,6 +260,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity": parity,
+            "next_rows": next_rows,
             "solve_paths": paths,
         }
         print(json.dumps(line))
