@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import concurrent.futures
 import os
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -26,6 +27,7 @@ from . import shard as _shard
 SOLVE_GROUPS = int(os.environ.get("ROCCO_SOLVE_GROUPS", "4"))
 _pool: Optional[concurrent.futures.ThreadPoolExecutor] = None
 _group_state: Dict[Tuple[int, int], tuple] = {}  # (device, group) -> (Solver, torch.cuda.Stream)
+_group_lock = threading.Lock()  # the groups' solver handles are per process: one grouped solve at a time
 
 
 def _group_resources(device_index: int, group: int):
@@ -115,12 +117,13 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
             stream.synchronize()
         return idx, res
 
-    if _pool is None:
-        _pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-solve")
     out: List[Optional[dict]] = [None] * len(chroms)
-    for idx, res in _pool.map(work, range(n_groups)):
-        for i, r in zip(idx, res):
-            out[i] = r
+    with _group_lock:
+        if _pool is None:
+            _pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-solve")
+        for idx, res in _pool.map(work, range(n_groups)):
+            for i, r in zip(idx, res):
+                out[i] = r
     return out
 
 
