@@ -60,8 +60,21 @@ class ChromWork:
         self.wls_params = dict(wls_params or {})
 
 
+def _score_wls(c: ChromWork):
+    import torch
+
+    from . import inference as _inference
+
+    s_t, details = _inference.score_loci_wls_device(c.matrix_t.to(torch.float64), **c.wls_params)
+    c._effect_mean = details["mean"]  # rocco/rocco.py:1090 `effect_mean`, the summit track's source
+    return s_t
+
+
 def _solve_group(chroms: Sequence[ChromWork], scores: list) -> list:
-    """Calibrate and decode the given chromosomes on the calling thread's current stream / solver."""
+    """Calibrate and decode the given chromosomes on the calling thread's current stream / solver; count-path
+    chromosomes (scores[i] is None) are scored here first, so that the groups' chain kernels -- one latency-bound
+    wavefront per row and parity -- run side by side as well."""
+    scores = [s if s is not None else _score_wls(c) for c, s in zip(chroms, scores)]
     targets = [int(np.floor(c.n * c.budget)) for c in chroms]  # rocco/dp.py:197
     solved = _dp.calibrate_batch_device(scores, [c.gamma for c in chroms], targets)
     out = []
@@ -71,7 +84,7 @@ def _solve_group(chroms: Sequence[ChromWork], scores: list) -> list:
             "name": c.name, "n": c.n, "selected_count": count, "selection_penalty": penalty,
             "penalized_objective": value, "path": info["path"], "info": info,
             "begin": begin_t, "end": end_t, "solution": sol_t, "step": c.step, "start": c.start,
-            "effect_mean": getattr(c, "_effect_mean", None),
+            "effect_mean": getattr(c, "_effect_mean", None), "scores": s_t,
         })
     return out
 
@@ -80,50 +93,49 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
     """Score, solve and decode every chromosome of this rank.
 
     Returns a list of dicts: name, n, selected_count, selection_penalty, penalized_objective, path,
-    begin / end (int64 CUDA tensors: half-open locus index pairs of the merged runs) and the
-    solution tensor.  `groups` (default ROCCO_SOLVE_GROUPS): how many groups of chromosomes calibrate
-    side by side (see SOLVE_GROUPS above).
+    begin / end (int64 CUDA tensors: half-open locus index pairs of the merged runs), the solution and the
+    score tensors.  `groups` (default ROCCO_SOLVE_GROUPS): how many groups of chromosomes calibrate side by
+    side (see SOLVE_GROUPS above).  Median scoring (bandwidth-bound) runs first, alone on the device; count-path
+    scoring (latency-bound chain kernels) runs inside the groups.
     """
     import torch
 
     global _pool
-    scores = []
+    scores: List[Optional[object]] = []
     for c in chroms:
         if c.scoring == "wls":
-            from . import inference as _inference
-
-            s_t, details = _inference.score_loci_wls_device(c.matrix_t.to(torch.float64), **c.wls_params)
-            c._effect_mean = details["mean"]  # rocco/rocco.py:1090 `effect_mean`, the summit track's source
+            scores.append(None)
         else:
             s_t = _rocco.score_central_tendency_chrom_device(c.matrix_t)
             c._effect_mean = s_t  # rocco/rocco.py:995-997: the bigWig branch uses the scores themselves
-        scores.append(s_t)
-    if scores_out is not None:
-        scores_out.extend(scores)
+            scores.append(s_t)
     n_groups = max(1, min(int(groups if groups is not None else SOLVE_GROUPS), len(chroms)))
-    if n_groups == 1:
-        return _solve_group(chroms, scores)
-    device = scores[0].device
-    scored = torch.cuda.Event()
-    scored.record()
-    members = _shard.lpt_partition([c.n for c in chroms], n_groups)
-
-    def work(group: int):
-        solver, stream = _group_resources(device.index, group)
-        idx = members[group]
-        with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
-            stream.wait_event(scored)
-            res = _solve_group([chroms[i] for i in idx], [scores[i] for i in idx])
-            stream.synchronize()
-        return idx, res
-
     out: List[Optional[dict]] = [None] * len(chroms)
-    with _group_lock:
-        if _pool is None:
-            _pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-solve")
-        for idx, res in _pool.map(work, range(n_groups)):
-            for i, r in zip(idx, res):
-                out[i] = r
+    if n_groups == 1:
+        out = _solve_group(chroms, scores)
+    else:
+        device = chroms[0].matrix_t.device
+        scored = torch.cuda.Event()
+        scored.record()
+        members = _shard.lpt_partition([c.n for c in chroms], n_groups)
+
+        def work(group: int):
+            solver, stream = _group_resources(device.index, group)
+            idx = members[group]
+            with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
+                stream.wait_event(scored)
+                res = _solve_group([chroms[i] for i in idx], [scores[i] for i in idx])
+                stream.synchronize()
+            return idx, res
+
+        with _group_lock:
+            if _pool is None:
+                _pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-solve")
+            for idx, res in _pool.map(work, range(n_groups)):
+                for i, r in zip(idx, res):
+                    out[i] = r
+    if scores_out is not None:
+        scores_out.extend(r["scores"] for r in out)
     return out
 
 
