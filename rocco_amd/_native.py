@@ -155,6 +155,10 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime: load it first, so that this library binds to the same one
+    # (two HIP runtimes in one process do not see each other's devices, streams or allocations)
+    import torch  # noqa: F401
+
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(
             "Make sure native HIP extension is built and available "
