@@ -44,7 +44,8 @@ int launch_objective(const uint8_t *solution_dev, const double *scores_dev,
 // the same penalty; scratch: at least whittaker_scratch_bytes(rows, cols) bytes; matrix and output must
 // not overlap
 size_t whittaker_scratch_bytes(size_t rows, size_t cols);
-int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_dev, hipStream_t stream);
+int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_dev, hipStream_t stream,
+                            const double *old_factor_dev = nullptr, size_t old_cap = 0);
 int launch_crossfit_whittaker(const double *matrix_dev, size_t rows, size_t cols, double penalty_lambda,
                               const double *factor_dev, size_t factor_cap, double *baseline_out_dev,
                               void *scratch_dev, hipStream_t stream);

@@ -45,8 +45,10 @@ __device__ __forceinline__ double band_a1(long long i, long long n, double lambd
     return (i == 0 || i == n - 2) ? (-2.0 * lambda) : (-4.0 * lambda);
 }
 
-// factor[p] = d | l1 | l2, each `cap` doubles, computed for length `cap` (baseline_backend.c:105-140)
-__global__ __launch_bounds__(64) void whittaker_factor_kernel(long long cap, double lambda, double *factor)
+// factor[p] = d | l1 | l2, each `cap` doubles, computed for length `cap` (baseline_backend.c:105-140).
+// start > 0 resumes a factor whose entries 0 .. start-1 are already in place and do not depend on the length
+// (start <= the previous length - 2: the last two entries of a factor carry its end bands).
+__global__ __launch_bounds__(64) void whittaker_factor_kernel(long long cap, double lambda, double *factor, long long start)
 {
     const int parity = threadIdx.x;
     if (parity >= 2) {
@@ -56,19 +58,30 @@ __global__ __launch_bounds__(64) void whittaker_factor_kernel(long long cap, dou
     double *__restrict__ d = factor + (long long)parity * 3 * cap;
     double *__restrict__ l1 = d + cap;
     double *__restrict__ l2 = l1 + cap;
-    double d_m2 = band_a0(0, n, parity, lambda);
-    double l1_m2 = band_a1(0, n, lambda) / d_m2;
-    double l2_m2 = lambda / d_m2;
+    double d_m2, l1_m2, l2_m2, d_m1, l1_m1, l2_m1;
+    long long first = 2;
+    if (start >= 4) {
+        first = start;
+        d_m2 = d[start - 2];
+        l2_m2 = l2[start - 2];
+        d_m1 = d[start - 1];
+        l1_m1 = l1[start - 1];
+        l2_m1 = l2[start - 1];
+    } else {
+    d_m2 = band_a0(0, n, parity, lambda);
+    l1_m2 = band_a1(0, n, lambda) / d_m2;
+    l2_m2 = lambda / d_m2;
     d[0] = d_m2;
     l1[0] = l1_m2;
     l2[0] = l2_m2;
-    double d_m1 = band_a0(1, n, parity, lambda) - ((l1_m2 * l1_m2) * d_m2);
-    double l1_m1 = (band_a1(1, n, lambda) - ((l2_m2 * d_m2) * l1_m2)) / d_m1;
-    double l2_m1 = (n > 3) ? (lambda / d_m1) : 0.0;
+    d_m1 = band_a0(1, n, parity, lambda) - ((l1_m2 * l1_m2) * d_m2);
+    l1_m1 = (band_a1(1, n, lambda) - ((l2_m2 * d_m2) * l1_m2)) / d_m1;
+    l2_m1 = (n > 3) ? (lambda / d_m1) : 0.0;
     d[1] = d_m1;
     l1[1] = l1_m1;
     l2[1] = l2_m1;
-    for (long long i = 2; i < n; ++i) {
+    }
+    for (long long i = first; i < n; ++i) {
         double t1 = ((l1_m1 * l1_m1) * d_m1);
         const double t2 = ((l2_m2 * l2_m2) * d_m2);
         const double di = band_a0(i, n, parity, lambda) - t1 - t2;
@@ -363,10 +376,20 @@ size_t whittaker_scratch_bytes(size_t rows, size_t cols)
     return (rows * cols + 8) * sizeof(double) + 256;
 }
 
-int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_dev, hipStream_t stream)
+int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_dev, hipStream_t stream,
+                            const double *old_factor_dev, size_t old_cap)
 {
+    // a longer factor of the same penalty continues the old one: its entries 0 .. old_cap-3 carry over
+    long long start = 0;
+    if (old_factor_dev != nullptr && old_cap >= 8 && old_cap < cap) {
+        start = (long long)old_cap - 2;
+        for (int a = 0; a < 6; ++a) {
+            ROCCO_HIP_TRY(hipMemcpyAsync(factor_dev + (size_t)a * cap, old_factor_dev + (size_t)a * old_cap,
+                                         (size_t)start * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+    }
     hipLaunchKernelGGL(whittaker_factor_kernel, dim3(1), dim3(64), 0, stream, (long long)cap, penalty_lambda,
-                       factor_dev);
+                       factor_dev, start);
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }

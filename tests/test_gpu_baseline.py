@@ -48,3 +48,15 @@ def test_local_background_matrix(gpu, oracle):
     assert base.tobytes() == oracle.crossfit_whittaker_baseline(m, lam).tobytes()
     z, w0, l0 = _estimate_local_background_matrix(rng.normal(size=(2, 24)))
     assert w0 == 0 and l0 == 0.0 and not z.any()
+
+
+def test_factor_is_extended_for_longer_rows(gpu, oracle):
+    """The LDL^T factor is kept per penalty and EXTENDED when a longer matrix arrives (its entries do not depend on
+    the length except the last two): ascending, descending and mixed lengths must all reproduce the oracle."""
+    from rocco_amd.inference import _consenrich_whittaker_lambda, crossfit_whittaker_baseline
+
+    rng = np.random.default_rng(12)
+    lam = _consenrich_whittaker_lambda(57)  # a penalty no other test uses: the factor starts from scratch here
+    for cols in (25, 26, 31, 600, 599, 40000, 8, 40001, 1000, 250000, 30):
+        m = rng.normal(size=(3, cols))
+        assert crossfit_whittaker_baseline(m, lam).tobytes() == oracle.crossfit_whittaker_baseline(m, lam).tobytes(), cols
