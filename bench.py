@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--chroms", type=str, default="", help="comma list (default: whole genome)")
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=str, default="chr21")
+    ap.add_argument("--cpu-sample", type=str, default="chr1")
     return ap.parse_args()
 
 
