@@ -277,6 +277,19 @@ int rocco_hip_multiply_f64(rocco_hip_solver *solver, const double *a_dev, const 
 int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *matrix_dev, const double *row_dev,
                                         size_t K, size_t n, double *out_dev, void *stream);
 
+/* bigWig dense fill: the NumPy statements of get_bigwig_chrom_scores after the file has been read
+ * (rocco/readtracks.py:141-186) for one track's intervals in ascending order (as pyBigWig returns them).
+ * *flags_out: bit 0 non-finite value (147-150), bit 1 non-positive width (153-156), bit 2 variable width (158-161),
+ * bit 3 start off the fixed grid (165-168), bit 4 overlapping / duplicate / out-of-order bins (170-173); nothing is
+ * written when a flag is set.  Otherwise *first_start_out, *step_out and *n_full_out describe
+ * np.arange(starts[0], starts[-1] + step, step); with full_out_dev != NULL and capacity >= *n_full_out it receives
+ * np.round(scatter(vals) * const_scale, round_digits) (no scaling for const_scale < 0; rounding as NumPy does it:
+ * multiply by 10**d, round half to even, divide).  Call once with full_out_dev == NULL for the size.  Exact. */
+int rocco_hip_bigwig_dense_fill_f64(rocco_hip_solver *solver, const int64_t *starts_dev, const int64_t *ends_dev,
+                                    const double *vals_dev, size_t count, double const_scale, int round_digits,
+                                    double *full_out_dev, size_t capacity, int64_t *first_start_out, int64_t *step_out,
+                                    size_t *n_full_out, int *flags_out, void *stream);
+
 /* ---- synthetic signal matrices (benchmark / test support, device-resident) -------------------
  * Fills a row-major [K][n] matrix with the counter-based synthetic tracks described in
  * DESIGN.md section 7 (5-decimal background + planted peaks with per-sample dropout); the same

@@ -537,3 +537,34 @@ def compute_budget_null_draw(residual_template, wild_weights, lower_bound_z, pri
     positive = np.clip(residual, 0.0, None)
     return (float(np.mean(positive)), float(np.mean(positive / null_soft_scale)), float(np.mean(positive > 0.0)),
             float(np.mean(scores > null_threshold)))
+
+
+def bigwig_dense_fill(starts, ends, vals, const_scale: float = 1.0, round_digits: int = 5, bigwig_file: str = "",
+                      chromosome: str = ""):
+    """get_bigwig_chrom_scores after the file has been read (rocco/readtracks.py:141-186), NumPy statement by
+    NumPy statement."""
+    starts = np.asarray(starts, dtype=np.int64)
+    ends = np.asarray(ends, dtype=np.int64)
+    vals = np.asarray(vals, dtype=np.float64)
+    if not np.all(np.isfinite(vals)):
+        raise ValueError(f"bigWig values for {bigwig_file} {chromosome} contain non-finite entries")
+    widths = ends - starts
+    if np.any(widths <= 0):
+        raise ValueError(f"bigWig intervals for {bigwig_file} {chromosome} contain non-positive widths")
+    step = int(widths[0])
+    if np.any(widths != step):
+        raise ValueError(f"bigWig file {bigwig_file} uses variable-width bins on {chromosome}; ROCCO expects a "
+                         "fixed-width binning scheme")
+    offset = int(starts[0])
+    idx = starts - offset
+    if np.any(idx % step != 0):
+        raise ValueError(f"bigWig starts for {bigwig_file} {chromosome} are not aligned to a single fixed binning scheme")
+    idx = (idx // step).astype(np.int64, copy=False)
+    if np.unique(idx).size != idx.size:
+        raise ValueError(f"bigWig file {bigwig_file} has overlapping or duplicate bins on {chromosome}")
+    full_intervals = np.arange(int(starts[0]), int(starts[-1]) + step, step, dtype=np.int64)
+    full_vals = np.zeros(full_intervals.size, dtype=np.float64)
+    full_vals[idx] = vals
+    if const_scale >= 0:
+        full_vals = full_vals * float(const_scale)
+    return full_intervals.astype(int), np.round(full_vals, round_digits)

@@ -142,6 +142,9 @@ PROTOTYPES = [
     ("rocco_hip_subtract_positive_row_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
       ctypes.c_void_p]),
+    ("rocco_hip_bigwig_dense_fill_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
+      ctypes.c_void_p, ctypes.c_size_t, c_ll_p, c_ll_p, c_size_p, c_int_p, ctypes.c_void_p]),
     ("rocco_hip_synth_matrix", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
       ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]),

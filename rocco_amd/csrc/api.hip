@@ -519,6 +519,26 @@ int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *
     return launch_subtract_positive_row(matrix_dev, row_dev, K, n, out_dev, (hipStream_t)stream);
 }
 
+int rocco_hip_bigwig_dense_fill_f64(rocco_hip_solver *solver, const int64_t *starts_dev, const int64_t *ends_dev,
+                                    const double *vals_dev, size_t count, double const_scale, int round_digits,
+                                    double *full_out_dev, size_t capacity, int64_t *first_start_out, int64_t *step_out,
+                                    size_t *n_full_out, int *flags_out, void *stream)
+{
+    if (solver == nullptr || starts_dev == nullptr || ends_dev == nullptr || vals_dev == nullptr || count == 0 ||
+        first_start_out == nullptr || step_out == nullptr || n_full_out == nullptr || flags_out == nullptr ||
+        round_digits > 22 || round_digits < -22) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_misc.reserve(256)) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    return launch_bigwig_dense_fill(starts_dev, ends_dev, vals_dev, count, const_scale, round_digits, full_out_dev,
+                                    capacity, first_start_out, step_out, n_full_out, flags_out, solver->dev_misc.ptr,
+                                    (hipStream_t)stream);
+}
+
 int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype, size_t K, size_t n,
                            size_t row_stride, uint64_t seed, void *stream)
 {

@@ -132,3 +132,124 @@ int launch_scatter_tracks(const int64_t *common_dev, size_t m, const int64_t *in
 }
 
 }  // namespace rocco
+
+// ---- bigWig dense fill (rocco/readtracks.py:141-186) ----------------------------------------------------------
+namespace rocco {
+
+namespace {
+
+enum { kBwNonFinite = 1, kBwBadWidth = 2, kBwVarWidth = 4, kBwMisaligned = 8, kBwDuplicate = 16 };
+
+__global__ __launch_bounds__(256) void bigwig_check_kernel(const long long *__restrict__ starts, const long long *__restrict__ ends,
+                                                          const double *__restrict__ vals, long long count,
+                                                          int *__restrict__ flags)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) {
+        return;
+    }
+    const long long step = ends[0] - starts[0], offset = starts[0];
+    int f = 0;
+    if (!isfinite(vals[i])) {
+        f |= kBwNonFinite;
+    }
+    const long long w = ends[i] - starts[i];
+    if (w <= 0) {
+        f |= kBwBadWidth;
+    }
+    if (w != step) {
+        f |= kBwVarWidth;
+    }
+    if (step > 0) {
+        if ((starts[i] - offset) % step != 0) {
+            f |= kBwMisaligned;
+        }
+        // np.unique(idx).size != idx.size: pyBigWig returns intervals in ascending order, so a repeated or
+        // out-of-order start shows up next to its neighbour
+        if (i > 0 && starts[i] <= starts[i - 1]) {
+            f |= kBwDuplicate;
+        }
+    }
+    if (f != 0) {
+        atomicOr(flags, f);
+    }
+}
+
+__global__ __launch_bounds__(256) void bigwig_scatter_kernel(const long long *__restrict__ starts, const double *__restrict__ vals,
+                                                            long long count, long long step, double *__restrict__ full)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        full[(starts[i] - starts[0]) / step] = vals[i];
+    }
+}
+
+// full = np.round(full * const_scale (if const_scale >= 0), round_digits): np.round multiplies by 10**d, rounds
+// half to even (np.rint) and divides by 10**d (d >= 0), or divides, rounds and multiplies (d < 0)
+__global__ __launch_bounds__(256) void scale_round_kernel(double *__restrict__ full, long long n, double const_scale,
+                                                         int apply_scale, double pow10, int digits)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    double v = full[i];
+    if (apply_scale) {
+        v = v * const_scale;
+    }
+    if (digits > 0) {
+        v = rint(v * pow10) / pow10;
+    } else if (digits == 0) {
+        v = rint(v);
+    } else {
+        v = rint(v / pow10) * pow10;
+    }
+    full[i] = v;
+}
+
+}  // namespace
+
+int launch_bigwig_dense_fill(const int64_t *starts_dev, const int64_t *ends_dev, const double *vals_dev, size_t count,
+                             double const_scale, int round_digits, double *full_out_dev, size_t capacity,
+                             int64_t *first_start_out, int64_t *step_out, size_t *n_full_out, int *flags_out,
+                             void *scratch_dev, hipStream_t stream)
+{
+    int *flags = (int *)scratch_dev;
+    long long ends_host[1], starts_host[2];
+    ROCCO_HIP_TRY(hipMemsetAsync(flags, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(bigwig_check_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
+                       (const long long *)starts_dev, (const long long *)ends_dev, vals_dev, (long long)count, flags);
+    ROCCO_HIP_TRY(hipGetLastError());
+    ROCCO_HIP_TRY(hipMemcpyAsync(&starts_host[0], starts_dev, 8, hipMemcpyDeviceToHost, stream));
+    ROCCO_HIP_TRY(hipMemcpyAsync(&starts_host[1], starts_dev + (count - 1), 8, hipMemcpyDeviceToHost, stream));
+    ROCCO_HIP_TRY(hipMemcpyAsync(&ends_host[0], ends_dev, 8, hipMemcpyDeviceToHost, stream));
+    ROCCO_HIP_TRY(hipMemcpyAsync(flags_out, flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+    const long long step = ends_host[0] - starts_host[0];
+    *first_start_out = starts_host[0];
+    *step_out = step;
+    *n_full_out = 0;
+    if (*flags_out != 0 || step <= 0) {
+        return ROCCO_HIP_OK;  // the caller raises the reference's ValueError for the flag
+    }
+    const size_t n_full = (size_t)((starts_host[1] - starts_host[0]) / step) + 1;  // np.arange(first, last + step, step)
+    *n_full_out = n_full;
+    if (full_out_dev == nullptr || capacity < n_full) {
+        return ROCCO_HIP_OK;  // size query
+    }
+    ROCCO_HIP_TRY(hipMemsetAsync(full_out_dev, 0, n_full * sizeof(double), stream));
+    hipLaunchKernelGGL(bigwig_scatter_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
+                       (const long long *)starts_dev, vals_dev, (long long)count, step, full_out_dev);
+    const int digits = round_digits;
+    double pow10 = 1.0;
+    for (int d = 0; d < (digits < 0 ? -digits : digits); ++d) {
+        pow10 *= 10.0;  // 10**|d| as NumPy's integer power converted to float64 (exact up to 10**22)
+    }
+    hipLaunchKernelGGL(scale_round_kernel, dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream, full_out_dev,
+                       (long long)n_full, const_scale, const_scale >= 0.0 ? 1 : 0, pow10, digits);
+    ROCCO_HIP_TRY(hipGetLastError());
+    ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+    return ROCCO_HIP_OK;
+}
+
+}  // namespace rocco

@@ -91,6 +91,11 @@ int launch_multiply(const double *a_dev, const double *b_dev, double *out_dev, s
 int launch_subtract_positive_row(const double *matrix_dev, const double *row_dev, size_t K, size_t n, double *out_dev,
                                  hipStream_t stream);
 
+int launch_bigwig_dense_fill(const int64_t *starts_dev, const int64_t *ends_dev, const double *vals_dev, size_t count,
+                             double const_scale, int round_digits, double *full_out_dev, size_t capacity,
+                             int64_t *first_start_out, int64_t *step_out, size_t *n_full_out, int *flags_out,
+                             void *scratch_dev, hipStream_t stream);
+
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
                  hipStream_t stream);

@@ -72,3 +72,61 @@ def assemble_chrom_matrix(interval_matrix: Sequence, vals_matrix: Sequence, trac
     common_t, matrix_t = assemble_chrom_matrix_device(interval_matrix, vals_matrix, track_type=track_type,
                                                       low_memory=low_memory, chromosome=chromosome)
     return common_t.cpu().numpy().astype(int), matrix_t.cpu().numpy()
+
+
+_BW_ERRORS = (
+    (1, "bigWig values for {f} {c} contain non-finite entries"),
+    (2, "bigWig intervals for {f} {c} contain non-positive widths"),
+    (4, "bigWig file {f} uses variable-width bins on {c}; ROCCO expects a fixed-width binning scheme"),
+    (8, "bigWig starts for {f} {c} are not aligned to a single fixed binning scheme"),
+    (16, "bigWig file {f} has overlapping or duplicate bins on {c}"),
+)
+
+
+def bigwig_dense_fill_device(starts, ends, vals, const_scale: float = 1.0, round_digits: int = 5,
+                             bigwig_file: str = "", chromosome: str = "", device=None):
+    """What ``get_bigwig_chrom_scores`` does with a track's intervals once pyBigWig has returned them
+    (rocco/readtracks.py:141-186), on the device: validation (same ValueErrors, same order), dense fill of the
+    fixed-step grid between the first and the last start, constant scaling, ``np.round(..., round_digits)``.
+    ``starts`` must ascend (as pyBigWig returns them).  Returns (first_start, step, values CUDA tensor)."""
+    import torch
+
+    _native.load()
+    dev = torch.device(device) if device is not None else torch.device(f"cuda:{_dp._device_index()}")
+
+    def to_dev(a, dtype, np_dtype):
+        if _dp._is_tensor(a):
+            return a.to(device=dev, dtype=dtype).contiguous().reshape(-1)
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=np_dtype)).to(dev)
+
+    starts_t, ends_t = to_dev(starts, torch.int64, np.int64), to_dev(ends, torch.int64, np.int64)
+    vals_t = to_dev(vals, torch.float64, np.float64)
+    count = int(starts_t.shape[0])
+    if count == 0 or int(ends_t.shape[0]) != count or int(vals_t.shape[0]) != count:
+        raise ValueError("starts, ends and values must be non-empty and of one length")
+    lib, solver, stream = _native.load(), _native.solver_for(dev.index), _dp._stream_ptr(starts_t)
+    first, step = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    n_full, flags = ctypes.c_size_t(0), ctypes.c_int(0)
+
+    def call(out_t, capacity):
+        _native.check(lib.rocco_hip_bigwig_dense_fill_f64(
+            solver.handle, starts_t.data_ptr(), ends_t.data_ptr(), vals_t.data_ptr(), count, float(const_scale),
+            int(round_digits), None if out_t is None else out_t.data_ptr(), capacity, ctypes.byref(first),
+            ctypes.byref(step), ctypes.byref(n_full), ctypes.byref(flags), stream), "rocco_hip_bigwig_dense_fill_f64")
+        for bit, message in _BW_ERRORS:
+            if flags.value & bit:
+                raise ValueError(message.format(f=bigwig_file, c=chromosome))
+
+    call(None, 0)
+    full_t = torch.empty(int(n_full.value), dtype=torch.float64, device=dev)
+    call(full_t, int(n_full.value))
+    return int(first.value), int(step.value), full_t
+
+
+def bigwig_dense_fill(starts, ends, vals, const_scale: float = 1.0, round_digits: int = 5, bigwig_file: str = "",
+                      chromosome: str = "") -> Tuple[np.ndarray, np.ndarray]:
+    """NumPy in and out: the (full_intervals, rounded full_vals) pair ``get_bigwig_chrom_scores`` returns
+    (rocco/readtracks.py:175-186)."""
+    first, step, full_t = bigwig_dense_fill_device(starts, ends, vals, const_scale, round_digits, bigwig_file, chromosome)
+    full_intervals = np.arange(first, first + step * int(full_t.shape[0]), step, dtype=np.int64)
+    return full_intervals.astype(int), full_t.cpu().numpy()

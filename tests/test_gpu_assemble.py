@@ -67,3 +67,41 @@ def test_assembled_matrix_feeds_the_scoring_kernel(gpu):
     scores = score_central_tendency_chrom_device(matrix_t).cpu().numpy()
     assert np.array_equal(scores, np.median(matrix_t.cpu().numpy(), axis=0))
     assert common_t.dtype == torch.int64 and common_t.shape[0] == matrix_t.shape[1]
+
+
+@pytest.mark.parametrize("n,step,gaps", [(1, 50, False), (7, 50, True), (1000, 10, True), (200000, 50, True), (50000, 25, False)])
+def test_bigwig_dense_fill_equals_numpy_statements(gpu, oracle, n, step, gaps):
+    from rocco_amd.readtracks import bigwig_dense_fill
+
+    rng = np.random.default_rng(n + step)
+    grid = 3000 + step * np.arange(n, dtype=np.int64)
+    keep = np.ones(n, dtype=bool)
+    if gaps and n > 3:
+        keep[1:-1] = rng.random(n - 2) > 0.3  # missing bins are filled with zeros
+    starts = grid[keep]
+    vals = rng.gamma(1.0, 3.0, size=starts.size) * 10.0 ** rng.integers(-6, 3, size=starts.size)
+    vals[rng.random(vals.size) < 0.05] = 0.125  # exact ties for round-half-to-even
+    for const_scale, digits in ((1.0, 5), (0.37, 2), (-1.0, 0), (2.5, -1), (0.0, 3)):
+        want_i, want_v = oracle.bigwig_dense_fill(starts, starts + step, vals, const_scale, digits)
+        got_i, got_v = bigwig_dense_fill(starts, starts + step, vals, const_scale, digits)
+        assert got_i.dtype == want_i.dtype and np.array_equal(got_i, want_i)
+        assert got_v.tobytes() == want_v.tobytes(), (n, const_scale, digits)
+
+
+def test_bigwig_dense_fill_errors_like_the_reference(gpu, oracle):
+    from rocco_amd.readtracks import bigwig_dense_fill
+
+    s = np.array([0, 50, 100, 150], dtype=np.int64)
+    v = np.ones(4)
+    cases = {
+        "non-finite": (s, s + 50, np.array([1.0, np.nan, 1.0, 1.0])),
+        "non-positive widths": (s, np.array([50, 50, 150, 200]), v),
+        "variable-width": (s, np.array([50, 100, 160, 200]), v),
+        "not aligned": (np.array([0, 50, 110, 160]), np.array([50, 100, 160, 210]), v),
+        "overlapping or duplicate": (np.array([0, 50, 50, 100]), np.array([50, 100, 100, 150]), v),
+    }
+    for needle, (a, b, c) in cases.items():
+        with pytest.raises(ValueError, match=needle):
+            oracle.bigwig_dense_fill(a, b, c, bigwig_file="t.bw", chromosome="chrZ")
+        with pytest.raises(ValueError, match=needle):
+            bigwig_dense_fill(a, b, c, bigwig_file="t.bw", chromosome="chrZ")
