@@ -60,6 +60,15 @@ int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long va
 int rocco_hip_score_median(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K,
                            size_t n, size_t row_stride, double *scores_dev, void *stream);
 
+/* The other branches of score_central_tendency_chrom (not reached from the reference's driver): the nearest-rank
+ * quantile of rocco.py:267-272 -- `rank` (0-based position in the sorted column) is computed by the caller with
+ * NumPy's own rule, np.quantile(np.arange(K), q, method="nearest") -- and the column mean of rocco.py:298-299
+ * (rows added in order, one division).  Same matrix conventions as rocco_hip_score_median; NaN in a column gives NaN. */
+int rocco_hip_score_order_statistic(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K, size_t n,
+                                    size_t row_stride, int rank, double *scores_dev, void *stream);
+int rocco_hip_score_mean(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K, size_t n,
+                         size_t row_stride, double *scores_dev, void *stream);
+
 /* ---- chain solve at a fixed selection penalty ----------------------------------------------
  * Replaces rocco/_chain_dp.c:9-213 `solve_penalized_chain` (Python wrapper rocco/dp.py:49-86).
  * `switch_costs_dev` has n-1 entries, or is NULL to use the scalar `gamma` at every boundary

@@ -88,6 +88,12 @@ PROTOTYPES = [
     ("rocco_hip_score_median", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
       ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_score_order_statistic", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+      ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_score_mean", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+      ctypes.c_void_p, ctypes.c_void_p]),
     ("rocco_hip_solve_penalized_chain_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t,
       ctypes.c_double, ctypes.c_void_p, c_double_p, c_ll_p, c_int_p, ctypes.c_void_p]),

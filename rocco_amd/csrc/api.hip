@@ -152,6 +152,28 @@ int rocco_hip_score_median(rocco_hip_solver *solver, const void *matrix_dev, int
     return launch_median(matrix_dev, dtype, K, n, row_stride, scores_dev, (hipStream_t)stream);
 }
 
+int rocco_hip_score_order_statistic(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K, size_t n,
+                                    size_t row_stride, int rank, double *scores_dev, void *stream)
+{
+    if (solver == nullptr || (n > 0 && (matrix_dev == nullptr || scores_dev == nullptr)) || K == 0 || row_stride < n ||
+        (dtype != 0 && dtype != 1) || rank < 0 || (size_t)rank >= K) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_order_statistic(matrix_dev, dtype, K, n, row_stride, rank, scores_dev, (hipStream_t)stream);
+}
+
+int rocco_hip_score_mean(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K, size_t n,
+                         size_t row_stride, double *scores_dev, void *stream)
+{
+    if (solver == nullptr || (n > 0 && (matrix_dev == nullptr || scores_dev == nullptr)) || K == 0 || row_stride < n ||
+        (dtype != 0 && dtype != 1)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_column_mean(matrix_dev, dtype, K, n, row_stride, scores_dev, (hipStream_t)stream);
+}
+
 int rocco_hip_solve_penalized_chain_f64(rocco_hip_solver *solver, const double *scores_dev,
                                         const double *switch_costs_dev, double gamma, size_t n,
                                         double selection_penalty, uint8_t *solution_dev,

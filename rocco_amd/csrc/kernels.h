@@ -26,6 +26,11 @@ int launch_chain_exact(const ExactTask *tasks_dev, int n_tasks, hipStream_t stre
 int launch_median(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride,
                   double *scores_dev, hipStream_t stream);
 
+int launch_order_statistic(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, int rank,
+                           double *scores_dev, hipStream_t stream);
+int launch_column_mean(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, double *scores_dev,
+                       hipStream_t stream);
+
 // ---- decode.hip -----------------------------------------------------------------------------
 // scratch: at least decode_scratch_bytes(n) bytes
 size_t decode_scratch_bytes(size_t n);

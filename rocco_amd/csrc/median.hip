@@ -151,6 +151,53 @@ __global__ __launch_bounds__(256) void median_rank_kernel(const T *__restrict__ 
     out[j] = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : ((K & 1) ? lo : (lo + hi) / 2.0);
 }
 
+// The branches of score_central_tendency_chrom the reference's driver does not reach (rocco.py:267-272, 298-299):
+// nearest-rank quantile (the rank comes from the host, computed by NumPy's own rule) and the column mean.
+template <typename T>
+__global__ __launch_bounds__(256) void order_statistic_kernel(const T *__restrict__ m, int K, long long n, long long stride,
+                                                             int rank, double *__restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) {
+        return;
+    }
+    double found = 0.0;
+    bool has_nan = false;
+    for (int a = 0; a < K; ++a) {
+        const double x = (double)m[(long long)a * stride + j];
+        if (is_nan_bits(x)) {
+            has_nan = true;
+            continue;
+        }
+        int less = 0, equal = 0;
+        for (int b = 0; b < K; ++b) {
+            const double y = (double)m[(long long)b * stride + j];
+            less += (y < x);
+            equal += (y == x);
+        }
+        if (rank >= less && rank < less + equal) {  // x occupies the sorted positions [less, less + equal)
+            found = x;
+        }
+    }
+    out[j] = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : found;
+}
+
+// np.mean(matrix, axis=0): the rows are added one after the other, then one division by K
+template <typename T>
+__global__ __launch_bounds__(256) void column_mean_kernel(const T *__restrict__ m, int K, long long n, long long stride,
+                                                         double *__restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) {
+        return;
+    }
+    double acc = (double)m[j];
+    for (int a = 1; a < K; ++a) {
+        acc += (double)m[(long long)a * stride + j];
+    }
+    out[j] = acc / (double)K;
+}
+
 template <typename T, int KP>
 void launch_kp(const T *m, int K, long long n, long long stride, double *out, hipStream_t stream)
 {
@@ -225,6 +272,42 @@ int launch_median(const void *matrix_dev, int dtype, size_t K, size_t n, size_t 
         return dispatch<double>((const double *)matrix_dev, K, n, row_stride, scores_dev, stream);
     }
     return dispatch<float>((const float *)matrix_dev, K, n, row_stride, scores_dev, stream);
+}
+
+int launch_order_statistic(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, int rank,
+                           double *scores_dev, hipStream_t stream)
+{
+    if (n == 0) {
+        return ROCCO_HIP_OK;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == 0) {
+        hipLaunchKernelGGL(order_statistic_kernel<double>, grid, block, 0, stream, (const double *)matrix_dev, (int)K,
+                           (long long)n, (long long)row_stride, rank, scores_dev);
+    } else {
+        hipLaunchKernelGGL(order_statistic_kernel<float>, grid, block, 0, stream, (const float *)matrix_dev, (int)K,
+                           (long long)n, (long long)row_stride, rank, scores_dev);
+    }
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_column_mean(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, double *scores_dev,
+                       hipStream_t stream)
+{
+    if (n == 0) {
+        return ROCCO_HIP_OK;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == 0) {
+        hipLaunchKernelGGL(column_mean_kernel<double>, grid, block, 0, stream, (const double *)matrix_dev, (int)K,
+                           (long long)n, (long long)row_stride, scores_dev);
+    } else {
+        hipLaunchKernelGGL(column_mean_kernel<float>, grid, block, 0, stream, (const float *)matrix_dev, (int)K,
+                           (long long)n, (long long)row_stride, scores_dev);
+    }
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
 }
 
 }  // namespace rocco

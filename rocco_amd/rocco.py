@@ -105,8 +105,9 @@ def combine_chrom_results(chrom_bed_files: list, output_file: str, name_features
 # scoring
 # --------------------------------------------------------------------------------------------
 
-def score_central_tendency_chrom_device(matrix_t, out_t=None):
-    """Column-wise median of a [K, n] float64/float32 CUDA tensor -> float64 CUDA tensor [n]."""
+def score_central_tendency_chrom_device(matrix_t, out_t=None, method: str = "median", rank: int = 0):
+    """Column-wise median of a [K, n] float64/float32 CUDA tensor -> float64 CUDA tensor [n]
+    (``method="rank"``: the order statistic `rank`; ``method="mean"``: the column mean)."""
     import torch
 
     if matrix_t.ndim != 2:
@@ -122,18 +123,28 @@ def score_central_tendency_chrom_device(matrix_t, out_t=None):
         return out_t
     solver = _native.solver_for(matrix_t.device.index)
     row_stride = int(matrix_t.stride(0)) if K > 1 else n
-    _native.check(_native.load().rocco_hip_score_median(
-        solver.handle, matrix_t.data_ptr(), 0 if matrix_t.dtype == torch.float64 else 1, K, n,
-        max(row_stride, n), out_t.data_ptr(), _dp._stream_ptr(matrix_t)), "rocco_hip_score_median")
+    dtype = 0 if matrix_t.dtype == torch.float64 else 1
+    lib, stream = _native.load(), _dp._stream_ptr(matrix_t)
+    if method == "rank":
+        _native.check(lib.rocco_hip_score_order_statistic(solver.handle, matrix_t.data_ptr(), dtype, K, n,
+                                                          max(row_stride, n), int(rank), out_t.data_ptr(), stream),
+                      "rocco_hip_score_order_statistic")
+    elif method == "mean":
+        _native.check(lib.rocco_hip_score_mean(solver.handle, matrix_t.data_ptr(), dtype, K, n, max(row_stride, n),
+                                               out_t.data_ptr(), stream), "rocco_hip_score_mean")
+    else:
+        _native.check(lib.rocco_hip_score_median(solver.handle, matrix_t.data_ptr(), dtype, K, n, max(row_stride, n),
+                                                 out_t.data_ptr(), stream), "rocco_hip_score_median")
     return out_t
 
 
 def score_central_tendency_chrom(chrom_matrix, method="quantile", quantile=0.50, tprop=0.05, power=1.0):
     r"""Return a column-wise location summary across samples (rocco/rocco.py:243-304).
 
-    The median branch -- the only one the reference's driver reaches (rocco/rocco.py:983-991) --
-    runs on the GPU.  The other branches of the reference (nearest quantile, trimmed mean, mean,
-    and `power` != 1) are not on the accelerated path and raise NotImplementedError here.
+    The median branch -- the only one the reference's driver reaches (rocco/rocco.py:983-991) -- runs the
+    selection-network kernel; the nearest-rank quantile and the mean run simple kernels.  The trimmed mean (its
+    summation order is SciPy's masked-array business) and `power` != 1 (libm `pow`) are not reproduced and raise
+    NotImplementedError.
     """
     import torch
 
@@ -150,22 +161,29 @@ def score_central_tendency_chrom(chrom_matrix, method="quantile", quantile=0.50,
             raise ValueError("`chrom_matrix` must be a 2D array.")
         matrix_t = torch.from_numpy(np.ascontiguousarray(arr)).to(f"cuda:{_dp._device_index()}")
     method_ = str(method).strip().lower().replace("-", "").replace("_", "")
+    kernel, rank = "median", 0
     if matrix_t.shape[0] > 1:
         if method_ == "quantile":
             if not 0.0 <= quantile <= 1.0:
                 logger.warning("`quantile` must be in [0, 1]. Using the median instead.")
                 quantile = 0.50
             if quantile != 0.50:
-                raise NotImplementedError("only the median (quantile=0.5) runs on the accelerated path")
-        elif method_ in ("tmean", "mean"):
-            raise NotImplementedError(f"method {method!r} is not on the accelerated path")
+                # the sorted position np.quantile(..., method="nearest") picks, by NumPy's own rounding rule
+                K = int(matrix_t.shape[0])
+                kernel, rank = "rank", int(np.quantile(np.arange(K, dtype=float), quantile, method="nearest"))
+        elif method_ == "mean":
+            kernel = "mean"
+        elif method_ == "tmean":
+            raise NotImplementedError("method 'tmean' is not on the accelerated path")
         else:
             raise ValueError(f"Central tendency method not recognized: {method}")
     if power != 1.0:
         raise NotImplementedError("`power` != 1.0 is not on the accelerated path")
     if not matrix_t.is_cuda:
         matrix_t = matrix_t.to(f"cuda:{_dp._device_index()}")
-    out = score_central_tendency_chrom_device(matrix_t)
+    if kernel != "median" and matrix_t.dtype != torch.float64:
+        matrix_t = matrix_t.to(torch.float64)  # np.asarray(chrom_matrix, dtype=float), rocco/rocco.py:251
+    out = score_central_tendency_chrom_device(matrix_t, method=kernel, rank=rank)
     return out.cpu().numpy()
 
 

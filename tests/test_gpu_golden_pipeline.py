@@ -60,9 +60,30 @@ def test_median_expectation_and_validation(gpu, gold):
     with pytest.raises(ValueError):
         score_central_tendency_chrom(np.zeros((3, 4)), method="no-such-method")
     with pytest.raises(NotImplementedError):
-        score_central_tendency_chrom(np.zeros((3, 4)), method="mean")
+        score_central_tendency_chrom(np.zeros((3, 4)), method="tmean")
+    with pytest.raises(NotImplementedError):
+        score_central_tendency_chrom(np.zeros((3, 4)), power=2.0)
     one = np.arange(5.0)[None, :]
     assert np.array_equal(score_central_tendency_chrom(one), one[0])
+
+
+@pytest.mark.parametrize("K", [2, 3, 5, 10, 33, 100, 101])
+def test_quantile_and_mean_branches_equal_numpy(gpu, K):
+    """rocco/rocco.py:267-272 (np.quantile(..., method="nearest")) and 298-299 (np.mean(axis=0)): bit for bit."""
+    from rocco_amd import score_central_tendency_chrom
+
+    rng = np.random.default_rng(K)
+    n = 20011
+    m = np.round(rng.gamma(1.0, 0.3, size=(K, n)), 2)  # plenty of ties
+    m[rng.integers(0, K), rng.integers(0, n, size=20)] = np.nan
+    for q in (0.0, 0.1, 0.25, 0.37, 0.5 + 1e-9, 0.75, 0.9, 0.995, 1.0):
+        want = np.quantile(m, q, axis=0, method="nearest")
+        got = score_central_tendency_chrom(m, method="quantile", quantile=q)
+        assert np.array_equal(got, want, equal_nan=True), (K, q)
+    for mat in (m, m.astype(np.float32)):
+        want = np.mean(np.asarray(mat, dtype=float), axis=0)
+        got = score_central_tendency_chrom(mat, method="mean")
+        assert got.tobytes() == want.tobytes(), K
 
 
 @pytest.mark.parametrize("K", [2, 3, 4, 5, 7, 8, 9, 10, 11, 16, 17, 25, 33, 50, 51, 64, 77, 100, 101, 130])
