@@ -13,6 +13,8 @@ from .dp import (  # noqa: F401
 )
 from .inference import crossfit_whittaker_baseline  # noqa: F401  (rocco/_baseline.c:16-104)
 from .inference import score_centered_wls  # noqa: F401  (rocco/_wls.c)
+from .inference import score_loci_wls  # noqa: F401  (rocco/inference.py:302-379)
+from .readtracks import assemble_chrom_matrix, bigwig_dense_fill  # noqa: F401  (rocco/readtracks.py:141-186, 614-633)
 from .rocco import (  # noqa: F401
     chrom_solution_to_bed,
     combine_chrom_results,
