@@ -722,6 +722,42 @@ __device__ __forceinline__ void aggregate_slot(const FastTask &task, const FastS
     __syncthreads();
 }
 
+// The slot and chain descriptors of a task, fetched by the first lanes while the tile is being staged (two
+// dependent global loads per slot, which would otherwise sit at the head of every pass of the slot loop).
+struct SlotDesc {
+    FastSlot slot;
+    FastChain a, b;
+};
+constexpr int kMaxStagedSlots = 64;
+
+__device__ __forceinline__ void stage_slot_descs(const FastLaunch &L, const FastTask &task, SlotDesc *desc)
+{
+    const int t = threadIdx.x;
+    if (t < task.slot_count && t < kMaxStagedSlots) {
+        const FastSlot s = L.slots[task.slot_begin + t];
+        desc[t].slot = s;
+        desc[t].a = L.chains[s.chain_a];
+        desc[t].b = L.chains[s.chain_b];
+    }
+}
+
+// slot `si` of the task with its two chains as a local two-element table (slot.chain_a / chain_b index it)
+__device__ __forceinline__ void fetch_slot(const FastLaunch &L, const FastTask &task, const SlotDesc *desc, int si,
+                                           FastSlot &slot, FastChain (&two)[2])
+{
+    if (si < kMaxStagedSlots) {
+        slot = desc[si].slot;
+        two[0] = desc[si].a;
+        two[1] = desc[si].b;
+    } else {
+        slot = L.slots[task.slot_begin + si];
+        two[0] = L.chains[slot.chain_a];
+        two[1] = L.chains[slot.chain_b];
+    }
+    slot.chain_a = 0;
+    slot.chain_b = 1;
+}
+
 template <bool HAS_COSTS>
 __global__ __launch_bounds__(kFastThreads, 2) void fast_aggregate_kernel(FastLaunch L)
 {
@@ -736,20 +772,22 @@ __global__ __launch_bounds__(kFastThreads, 2) void fast_aggregate_kernel(FastLau
         return;
     }
     const int local_block = bm.y;
-    stage_tile<HAS_COSTS>(task, local_block, lds_s, lds_c);
+    SlotDesc *desc = reinterpret_cast<SlotDesc *>(lds_red + 64);
+    stage_slot_descs(L, task, desc);
+    stage_tile<HAS_COSTS>(task, local_block, lds_s, lds_c);  // (ends with the barrier that publishes desc too)
     const long long chunk = (long long)local_block * kFastThreads + threadIdx.x;
     const long long j0 = chunk * kChunk;
     ChunkData<HAS_COSTS> d;
     load_chunk<HAS_COSTS>(task, j0, lds_s, lds_c, d);
     for (int si = (int)(blockIdx.x % L.slot_groups); si < task.slot_count; si += L.slot_groups) {
         const int slot_index = task.slot_begin + si;
-        const FastSlot slot = L.slots[slot_index];
+        FastSlot slot;
+        FastChain two[2];
+        fetch_slot(L, task, desc, si, slot, two);
         if (slot.mode == kModeWindow) {
-            aggregate_slot<2, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block,
-                                         lds_red);
+            aggregate_slot<2, HAS_COSTS>(task, slot, slot_index, two, L.buf, d, chunk, j0, local_block, lds_red);
         } else {
-            aggregate_slot<1, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block,
-                                         lds_red);
+            aggregate_slot<1, HAS_COSTS>(task, slot, slot_index, two, L.buf, d, chunk, j0, local_block, lds_red);
         }
     }
 }
@@ -1511,18 +1549,22 @@ __global__ __launch_bounds__(kFastThreads, 2) void fast_apply_kernel(FastLaunch 
         return;
     }
     const int local_block = bm.y;
-    stage_tile<HAS_COSTS>(task, local_block, lds_s, lds_c);
+    SlotDesc *desc = reinterpret_cast<SlotDesc *>(lds_red + 64);
+    stage_slot_descs(L, task, desc);
+    stage_tile<HAS_COSTS>(task, local_block, lds_s, lds_c);  // (ends with the barrier that publishes desc too)
     const long long chunk = (long long)local_block * kFastThreads + threadIdx.x;
     const long long j0 = chunk * kChunk;
     ChunkData<HAS_COSTS> d;
     load_chunk<HAS_COSTS>(task, j0, lds_s, lds_c, d);
     for (int si = (int)(blockIdx.x % L.slot_groups); si < task.slot_count; si += L.slot_groups) {
         const int slot_index = task.slot_begin + si;
-        const FastSlot slot = L.slots[slot_index];
+        FastSlot slot;
+        FastChain two[2];
+        fetch_slot(L, task, desc, si, slot, two);
         if (slot.mode == kModeWindow) {
-            apply_slot<2, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block, lds_red);
+            apply_slot<2, HAS_COSTS>(task, slot, slot_index, two, L.buf, d, chunk, j0, local_block, lds_red);
         } else {
-            apply_slot<1, HAS_COSTS>(task, slot, slot_index, L.chains, L.buf, d, chunk, j0, local_block, lds_red);
+            apply_slot<1, HAS_COSTS>(task, slot, slot_index, two, L.buf, d, chunk, j0, local_block, lds_red);
         }
     }
 }
@@ -2267,8 +2309,9 @@ int launch_fast_round(const FastLaunch &L, hipStream_t stream)
     if (L.n_slots == 0 || L.n_blocks_total == 0) {
         return ROCCO_HIP_OK;
     }
-    const size_t lds_plain = (size_t)(kTileDoubles + 64) * sizeof(double);
-    const size_t lds_costs = (size_t)(2 * kTileDoubles + 64) * sizeof(double);
+    const size_t lds_desc = (size_t)kMaxStagedSlots * sizeof(SlotDesc);
+    const size_t lds_plain = (size_t)(kTileDoubles + 64) * sizeof(double) + lds_desc;
+    const size_t lds_costs = (size_t)(2 * kTileDoubles + 64) * sizeof(double) + lds_desc;
     static bool attr_set = false;
     if (!attr_set) {
         ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_aggregate_kernel<true>),
