@@ -142,6 +142,61 @@ __device__ __forceinline__ double step_w(const Mode &m, double s, double c_raw_p
 // The workgroup's 8192 loci are loaded with coalesced 16-B accesses and laid out one 32-locus
 // chunk per LDS row (row stride 34 doubles), so that every lane then reads its own row with
 // 16-B LDS reads without bank conflicts.
+// Tile staging in two phases, so that other loads can be put in flight between them: `issue` sends the sixteen
+// 16-byte loads of a whole in-range tile (the common case) and `commit` writes them to LDS; every other tile is staged
+// by `commit` alone.
+struct TileLoads {
+    double2 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15;
+    bool fast;
+};
+
+template <bool HAS_COSTS>
+__device__ __forceinline__ void stage_tile_issue(const FastTask &task, int local_block, TileLoads &t)
+{
+    const long long base = (long long)local_block * kFastBlockLoci;
+    const double *__restrict__ s = task.scores;
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(s) & 15U) == 0);
+    t.fast = !HAS_COSTS && aligned16 && base + kFastBlockLoci <= task.n;
+    if (t.fast) {
+        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(s + base) + threadIdx.x;
+        t.v0 = src[0 * kFastThreads]; t.v1 = src[1 * kFastThreads]; t.v2 = src[2 * kFastThreads]; t.v3 = src[3 * kFastThreads];
+        t.v4 = src[4 * kFastThreads]; t.v5 = src[5 * kFastThreads]; t.v6 = src[6 * kFastThreads]; t.v7 = src[7 * kFastThreads];
+        t.v8 = src[8 * kFastThreads]; t.v9 = src[9 * kFastThreads]; t.v10 = src[10 * kFastThreads]; t.v11 = src[11 * kFastThreads];
+        t.v12 = src[12 * kFastThreads]; t.v13 = src[13 * kFastThreads]; t.v14 = src[14 * kFastThreads]; t.v15 = src[15 * kFastThreads];
+    }
+}
+
+template <bool HAS_COSTS>
+__device__ __forceinline__ void stage_tile(const FastTask &task, int local_block, double *lds_s, double *lds_c);
+
+template <bool HAS_COSTS>
+__device__ __forceinline__ void stage_tile_commit(const FastTask &task, int local_block, double *lds_s, double *lds_c,
+                                                  const TileLoads &t)
+{
+    if (!t.fast) {
+        stage_tile<HAS_COSTS>(task, local_block, lds_s, lds_c);
+        return;
+    }
+    static_assert(kChunk / 2 == 16, "tile staging is written out for 16 loads per lane");
+    // bound rounds (exact arithmetic on the grid q at penalties that are multiples of q): round the
+    // scores once here instead of once per step and penalty -- rn_q(s - x) == rn_q(s) - x
+    const bool pre = task.pre_round != 0;
+    const double mq = task.magic;
+    auto put = [&](int r, const double2 &v) {
+        const int e = 2 * (r * kFastThreads + (int)threadIdx.x);
+        double2 w = v;
+        if (pre) {
+            w.x = (v.x + mq) - mq;
+            w.y = (v.y + mq) - mq;
+        }
+        *reinterpret_cast<double2 *>(lds_s + (e >> 5) * kLdsStride + (e & 31)) = w;
+    };
+    put(0, t.v0); put(1, t.v1); put(2, t.v2); put(3, t.v3); put(4, t.v4); put(5, t.v5); put(6, t.v6); put(7, t.v7);
+    put(8, t.v8); put(9, t.v9); put(10, t.v10); put(11, t.v11); put(12, t.v12); put(13, t.v13); put(14, t.v14);
+    put(15, t.v15);
+    __syncthreads();
+}
+
 template <bool HAS_COSTS>
 __device__ __forceinline__ void stage_tile(const FastTask &task, int local_block, double *lds_s,
                                            double *lds_c)
@@ -244,10 +299,13 @@ __device__ __forceinline__ double raw_cost_at(const FastTask &task, const ChunkD
 
 __device__ __forceinline__ int chunk_code(const FastTask &task, const FastSlot &slot, long long chunk, bool valid)
 {
+    // the load is unconditional (clamped index; the null test is uniform) so that it can be in flight together
+    // with the caller's other loads
+    const int raw = (task.emap != nullptr) ? (int)task.emap[valid ? chunk : 0] : kMapNone;
     if (!valid || slot.mode == kModeMap || slot.mode == kModeBound || task.emap == nullptr) {
         return kMapNone;
     }
-    return (int)task.emap[chunk];
+    return raw;
 }
 
 // ---- lean paths ---------------------------------------------------------------------------------
@@ -741,11 +799,12 @@ __device__ __forceinline__ void stage_slot_descs(const FastLaunch &L, const Fast
     }
 }
 
-// slot `si` of the task with its two chains as a local two-element table (slot.chain_a / chain_b index it)
+// slot `si` of the task with its two chains as a local two-element table (slot.chain_a / chain_b index it);
+// from_memory: bypass the LDS copies (before the barrier that publishes them)
 __device__ __forceinline__ void fetch_slot(const FastLaunch &L, const FastTask &task, const SlotDesc *desc, int si,
-                                           FastSlot &slot, FastChain (&two)[2])
+                                           FastSlot &slot, FastChain (&two)[2], bool from_memory = false)
 {
-    if (si < kMaxStagedSlots) {
+    if (!from_memory && si < kMaxStagedSlots) {
         slot = desc[si].slot;
         two[0] = desc[si].a;
         two[1] = desc[si].b;
@@ -773,8 +832,10 @@ __global__ __launch_bounds__(kFastThreads, 2) void fast_aggregate_kernel(FastLau
     }
     const int local_block = bm.y;
     SlotDesc *desc = reinterpret_cast<SlotDesc *>(lds_red + 64);
+    TileLoads tile;
+    stage_tile_issue<HAS_COSTS>(task, local_block, tile);  // the tile's loads first: they only need the task
     stage_slot_descs(L, task, desc);
-    stage_tile<HAS_COSTS>(task, local_block, lds_s, lds_c);  // (ends with the barrier that publishes desc too)
+    stage_tile_commit<HAS_COSTS>(task, local_block, lds_s, lds_c, tile);  // (ends with the barrier that publishes desc too)
     const long long chunk = (long long)local_block * kFastThreads + threadIdx.x;
     const long long j0 = chunk * kChunk;
     ChunkData<HAS_COSTS> d;
@@ -1011,20 +1072,12 @@ __device__ __forceinline__ FillOut block_fill(unsigned D, unsigned V, unsigned v
 
 // exclusive in-workgroup scan of the chunk functions of one chain, evaluated at the workgroup's
 // incoming delta: returns the delta entering this lane's chunk
-__device__ __forceinline__ double incoming_delta(const FastBuffers &buf, const FastChain &ch, long long chunk,
-                                                 bool valid, int local_block, double big, double *lds_red)
+// (f: this lane's chunk function, the identity for lanes past the end; din_block: the delta entering the workgroup --
+// both fetched by the caller together with everything else the slot pass needs from memory)
+__device__ __forceinline__ double incoming_delta(const Fn &f, double din_block, double big, double *lds_red)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    Fn f;
-    f.a = 0.0;
-    f.lo = -big;
-    f.hi = big;
-    if (valid) {
-        f.a = buf.agg_a[ch.chunk_off + chunk];
-        f.lo = buf.agg_lo[ch.chunk_off + chunk];
-        f.hi = buf.agg_hi[ch.chunk_off + chunk];
-    }
     Fn inc = f;
     // anything composed with a constant function is that constant: when every chunk function of the
     // wavefront has coalesced (the usual case) the inclusive scan is the functions themselves
@@ -1062,7 +1115,7 @@ __device__ __forceinline__ double incoming_delta(const FastBuffers &buf, const F
     }
     __syncthreads();
     const Fn total = compose(pre, ex, big);
-    return apply_fn(total, buf.din[ch.block_off + local_block]);
+    return apply_fn(total, din_block);
 }
 
 // exclusive in-workgroup scans of the clear-clamp index (max) and of the tolerance weight
@@ -1122,11 +1175,47 @@ __device__ __forceinline__ void incoming_clear(long long own_lc, double own_w, b
 }
 
 // ---- K3: apply ------------------------------------------------------------------------------------
+// What one K3 slot pass reads from memory (written by K1 / K2 of the same round): fetched one pass ahead, so that the
+// round trip -- 3-4 us under load -- hides behind the previous pass (or behind the tile staging for the first one).
+struct SlotInputs {
+    Fn f[2];          // this lane's chunk function per chain
+    double din[2];    // delta entering the workgroup per chain
+    int praw[2];      // pstar byte per chain
+    int lc_raw;
+    double w_raw;
+    long long lcin_b;
+    double win_b;
+    int e_global;
+    int raw_code;     // binade code of the chunk (kMapNone without a map)
+};
+
+__device__ __forceinline__ void load_slot_inputs(const FastTask &task, const FastSlot &slot, int slot_index,
+                                                 const FastChain *chains, const FastBuffers &buf, long long chunk,
+                                                 bool valid, int local_block, SlotInputs &in)
+{
+    const long long cq = valid ? chunk : 0;  // clamped indices instead of branches: the loads go out together
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const FastChain &ch = chains[k == 0 ? slot.chain_a : slot.chain_b];
+        in.f[k].a = buf.agg_a[ch.chunk_off + cq];
+        in.f[k].lo = buf.agg_lo[ch.chunk_off + cq];
+        in.f[k].hi = buf.agg_hi[ch.chunk_off + cq];
+        in.praw[k] = (int)buf.pstar[ch.chunk_off + cq];
+        in.din[k] = buf.din[ch.block_off + local_block];
+    }
+    in.lc_raw = (int)buf.lc_chunk[slot.chunk_off + cq];
+    in.w_raw = buf.w_chunk[slot.chunk_off + cq];
+    in.lcin_b = (long long)buf.lcin_block[slot.block_off + local_block];
+    in.win_b = buf.win_block[slot.block_off + local_block];
+    in.e_global = buf.results[slot_index].e_global;
+    in.raw_code = (task.emap != nullptr) ? (int)task.emap[cq] : kMapNone;
+}
+
 template <int NCH, bool HAS_COSTS>
 __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot &slot, int slot_index,
                                            const FastChain *chains, const FastBuffers &buf,
                                            const ChunkData<HAS_COSTS> &d, long long chunk, long long j0,
-                                           int local_block, double *lds_red)
+                                           int local_block, double *lds_red, const SlotInputs &in)
 {
     const long long n = task.n;
     const double magic = task.magic;
@@ -1138,46 +1227,65 @@ __device__ __forceinline__ void apply_slot(const FastTask &task, const FastSlot 
     double *lds_w = lds_red + 36;
     unsigned *lds_u = reinterpret_cast<unsigned *>(lds_red + 44);
 
-    double lam[NCH], delta[NCH], delta_in[NCH];
+    // (everything this pass needs from memory was fetched a pass ahead: `in`)
+    Fn f_in[NCH];
+    double din_block[NCH], lam[NCH];
+    int praw[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const FastChain &ch = chains[k == 0 ? slot.chain_a : slot.chain_b];
+        lam[k] = ch.lambda;
+        f_in[k] = in.f[k];
+        praw[k] = in.praw[k];
+        din_block[k] = in.din[k];
+    }
+    const int lc_raw = in.lc_raw;
+    const double w_raw = in.w_raw;
+    const long long lcin_b = in.lcin_b;
+    const double win_b = in.win_b;
+    const int e_global = in.e_global;
+    const int code = (!valid || slot.mode == kModeMap || slot.mode == kModeBound || task.emap == nullptr) ? kMapNone
+                                                                                                        : in.raw_code;
+
+    double delta[NCH], delta_in[NCH];
     double delta_in0 = 0.0;
     int pstar = 0;
     bool anyw = false;  // K1: some step of this chunk carries tolerance weight
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-        const FastChain &ch = chains[k == 0 ? slot.chain_a : slot.chain_b];
-        lam[k] = ch.lambda;
-        delta[k] = incoming_delta(buf, ch, chunk, valid, local_block, big, lds_red);
+        Fn f = f_in[k];
+        if (!valid) {
+            f.a = 0.0;
+            f.lo = -big;
+            f.hi = big;
+        }
+        delta[k] = incoming_delta(f, din_block[k], big, lds_red);
         delta_in[k] = delta[k];
         if (k == 0) {
             delta_in0 = delta[0];
         }
         if (valid) {
-            const int praw = (int)buf.pstar[ch.chunk_off + chunk];
-            const int p = praw & 0x7F;
+            const int p = praw[k] & 0x7F;
             pstar = (p > pstar) ? p : pstar;
-            anyw = anyw || (k == 0 && (praw & 0x80) != 0);
+            anyw = anyw || (k == 0 && (praw[k] & 0x80) != 0);
         }
     }
-    const int code = chunk_code(task, slot, chunk, valid);
     Mode mode[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-        mode[k] = make_mode(code, false, res.e_global, task, lam[k]);
+        mode[k] = make_mode(code, false, e_global, task, lam[k]);
     }
     if (NCH == 2 && mode[0].clean != mode[NCH - 1].clean) {
-        mode[0] = make_mode(code, true, res.e_global, task, lam[0]);
-        mode[NCH - 1] = make_mode(code, true, res.e_global, task, lam[NCH - 1]);
+        mode[0] = make_mode(code, true, e_global, task, lam[0]);
+        mode[NCH - 1] = make_mode(code, true, e_global, task, lam[NCH - 1]);
     }
     // unmapped chunks counted their weights in steps
     const double wscale = mode[0].mapped ? 1.0 : mode[0].w_step;
-    const long long own_lc =
-        (valid && buf.lc_chunk[slot.chunk_off + chunk] >= 0) ? (j0 + buf.lc_chunk[slot.chunk_off + chunk]) : -1;
-    const double own_w = valid ? buf.w_chunk[slot.chunk_off + chunk] : 0.0;
+    const long long own_lc = (valid && lc_raw >= 0) ? (j0 + lc_raw) : -1;
+    const double own_w = valid ? w_raw : 0.0;
     long long lc;
     double wacc;
-    incoming_clear(own_lc, own_w, valid && anyw && slot.mode != kModeBound,
-                   (long long)buf.lcin_block[slot.block_off + local_block],
-                   buf.win_block[slot.block_off + local_block], lds_ll, lds_w, lc, wacc);
+    incoming_clear(own_lc, own_w, valid && anyw && slot.mode != kModeBound, lcin_b, win_b, lds_ll, lds_w, lc, wacc);
     // a task is either mapped everywhere or nowhere, so one scale applies to the incoming weight too
     wacc *= wscale;
 
@@ -1549,23 +1657,45 @@ __global__ __launch_bounds__(kFastThreads, 2) void fast_apply_kernel(FastLaunch 
         return;
     }
     const int local_block = bm.y;
-    SlotDesc *desc = reinterpret_cast<SlotDesc *>(lds_red + 64);
-    stage_slot_descs(L, task, desc);
-    stage_tile<HAS_COSTS>(task, local_block, lds_s, lds_c);  // (ends with the barrier that publishes desc too)
     const long long chunk = (long long)local_block * kFastThreads + threadIdx.x;
     const long long j0 = chunk * kChunk;
+    const bool valid = j0 < task.n;
+    SlotDesc *desc = reinterpret_cast<SlotDesc *>(lds_red + 64);
+    TileLoads tile;
+    stage_tile_issue<HAS_COSTS>(task, local_block, tile);  // the tile's loads first: they only need the task
+    stage_slot_descs(L, task, desc);
+    // the first pass's inputs go out while the tile is in flight (its descriptors straight from memory: the LDS
+    // copies are not published yet), every later pass's during the pass before it
+    int si = (int)(blockIdx.x % L.slot_groups);
+    FastSlot slot;
+    FastChain two[2];
+    SlotInputs in;
+    if (si < task.slot_count) {
+        fetch_slot(L, task, desc, si, slot, two, true);
+        load_slot_inputs(task, slot, task.slot_begin + si, two, L.buf, chunk, valid, local_block, in);
+    }
+    stage_tile_commit<HAS_COSTS>(task, local_block, lds_s, lds_c, tile);  // (ends with the barrier that publishes desc too)
     ChunkData<HAS_COSTS> d;
     load_chunk<HAS_COSTS>(task, j0, lds_s, lds_c, d);
-    for (int si = (int)(blockIdx.x % L.slot_groups); si < task.slot_count; si += L.slot_groups) {
+    for (; si < task.slot_count; si += L.slot_groups) {
         const int slot_index = task.slot_begin + si;
-        FastSlot slot;
-        FastChain two[2];
-        fetch_slot(L, task, desc, si, slot, two);
-        if (slot.mode == kModeWindow) {
-            apply_slot<2, HAS_COSTS>(task, slot, slot_index, two, L.buf, d, chunk, j0, local_block, lds_red);
-        } else {
-            apply_slot<1, HAS_COSTS>(task, slot, slot_index, two, L.buf, d, chunk, j0, local_block, lds_red);
+        const int si_next = si + L.slot_groups;
+        FastSlot slot_next = slot;
+        FastChain two_next[2] = {two[0], two[1]};
+        SlotInputs in_next = in;
+        if (si_next < task.slot_count) {
+            fetch_slot(L, task, desc, si_next, slot_next, two_next);
+            load_slot_inputs(task, slot_next, task.slot_begin + si_next, two_next, L.buf, chunk, valid, local_block, in_next);
         }
+        if (slot.mode == kModeWindow) {
+            apply_slot<2, HAS_COSTS>(task, slot, slot_index, two, L.buf, d, chunk, j0, local_block, lds_red, in);
+        } else {
+            apply_slot<1, HAS_COSTS>(task, slot, slot_index, two, L.buf, d, chunk, j0, local_block, lds_red, in);
+        }
+        slot = slot_next;
+        two[0] = two_next[0];
+        two[1] = two_next[1];
+        in = in_next;
     }
 }
 
