@@ -1,7 +1,7 @@
 """Ad-hoc: time the cross-fit Whittaker baseline on a benchmark-sized matrix and a CPU sample."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
 import numpy as np, torch
 from rocco_amd import synth, inference
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 100

@@ -1,6 +1,6 @@
 """Ad-hoc: time the count-path scoring (rows a2-a4: score_loci_wls) on a benchmark-sized matrix, with a CPU sample."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch

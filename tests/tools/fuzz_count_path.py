@@ -1,6 +1,6 @@
 """Ad-hoc fuzzing: count-path kernels (rows a2-a4) on the GPU against the CPU oracle, bit for bit."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import pyoracle as po

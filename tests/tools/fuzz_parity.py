@@ -1,6 +1,6 @@
 """Ad-hoc fuzzing: random budgeted / fixed-penalty solves on the GPU against the CPU oracle, bit for bit."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
 import pyoracle as po

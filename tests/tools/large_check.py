@@ -1,7 +1,7 @@
 """One-off: parity at BASELINE config-5 scale (hg38 chr1 at 10 bp = 24.9 M loci) against the CPU oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
 import numpy as np, torch
 from rocco_amd import synth, dp, rocco as rr
 import pyoracle
