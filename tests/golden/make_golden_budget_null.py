@@ -29,7 +29,7 @@ assert inf._wls_native is not None
 
 rng0 = np.random.default_rng(31337)
 out, names = {}, []
-for K, n in ((1, 40), (3, 500), (2, 8191), (2, 8200), (1, 16400)):
+for K, n in ((1, 40), (3, 500), (1, 8191), (1, 8200), (1, 16400)):
     for label, kw in (("default", dict(lower_bound_z=1.0, prior_df=5.0, min_effect=None, precision_floor_ratio=0.01)),
                       ("tuned", dict(lower_bound_z=0.5, prior_df=2.0, min_effect=0.2, precision_floor_ratio=0.1))):
         centered = rng0.normal(0.0, 0.7, size=(K, n)) + 1.5 * (rng0.random((1, n)) < 0.04)

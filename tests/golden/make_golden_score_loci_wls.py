@@ -33,7 +33,7 @@ TRACKS = ("mean", "raw_variance", "prior_variance", "moderated_variance", "stand
           "degrees_of_freedom", "centered_matrix")
 rng = np.random.default_rng(777)
 out, names = {}, []
-for K, n in ((1, 2), (2, 3), (1, 24), (3, 25), (2, 26), (4, 300), (3, 2001), (3, 6000)):
+for K, n in ((1, 2), (2, 3), (1, 24), (3, 25), (2, 26), (4, 300), (2, 1201), (2, 3000)):
     for variant in ("counts", "pow2", "fractional"):
         lam = rng.gamma(2.0, 2.0, size=(K, 1)) * (1.0 + 6.0 * (rng.random((1, n)) < 0.05))
         counts = rng.poisson(lam).astype(np.float64)
