@@ -78,6 +78,17 @@ def crossfit_whittaker_baseline(values, penalty_lambda: float) -> np.ndarray:
     return crossfit_whittaker_baseline_device(values_t, float(penalty_lambda)).cpu().numpy()
 
 
+def _consenrich_crossfit_whittaker_baseline(y_vals, block_size: int = 101) -> np.ndarray:
+    """rocco/inference.py:135-165: broad local baseline of one track (zeros for fewer than 25 loci)."""
+    y_arr = np.asarray(y_vals, dtype=np.float64)
+    if y_arr.ndim != 1:
+        raise ValueError("`y_vals` must be one-dimensional")
+    window = _resolve_local_baseline_window(int(y_arr.size), target_window=block_size)
+    if window == 0:
+        return np.zeros_like(y_arr, dtype=np.float64)
+    return crossfit_whittaker_baseline(y_arr, penalty_lambda=_consenrich_whittaker_lambda(window))
+
+
 def _estimate_local_background_matrix(centered_matrix, target_window: int = 101) -> Tuple[np.ndarray, int, float]:
     """rocco/inference.py:185-229: (local baselines [K, n], window, penalty)."""
     matrix = np.asarray(centered_matrix, dtype=np.float64)
