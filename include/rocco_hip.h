@@ -160,6 +160,18 @@ int rocco_hip_delta_window_f64(rocco_hip_solver *solver, const double *scores_de
                                const uint8_t *emap_dev, double lambda_lo, double lambda_hi,
                                uint8_t *solution_dev, rocco_hip_window_stats *stats_out, void *stream);
 
+/* Count-only evaluation in exact arithmetic on the problem's grid q (the "bound" evaluation of DESIGN.md
+ * section 4.4: no rounding model; shifted by -/+ eps it brackets what rocco/_chain_dp.c returns as
+ * best_count), in `n_rounds` rounds of up to 32 penalties each (round r holds round_sizes[r] of them).  A round
+ * whose penalties all lie at or above a penalty of the round before it runs on the loci that one selected
+ * (the selected sets are nested in the penalty) -- the counts are the same, the
+ * work is not.  lambdas_used_out: the penalties as evaluated (snapped to the grid); level_len_out[r]: loci
+ * of the array round r ran on (n = the caller's).  Scalar switch cost only. */
+int rocco_hip_delta_bound_rounds_f64(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n,
+                                     const double *lambdas, const int *round_sizes, int n_rounds,
+                                     double *lambdas_used_out, long long *counts_out, long long *level_len_out,
+                                     void *stream);
+
 /* Exact counts (and optionally one exact solution) for up to 64 penalties through the "spine":
  * the parallel kernels record per-chunk state, then one wavefront per chromosome carries the
  * reference's running values exactly -- stepping only through the chunks where the parallel

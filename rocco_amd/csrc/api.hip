@@ -114,6 +114,11 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->dev_maps.release();
     solver->dev_frozen.release();
     solver->dev_factor.release();
+    solver->dev_lean_pool.release();
+    solver->dev_lean_round.release();
+    solver->dev_lean_desc.release();
+    solver->host_lean_stage.release();
+    solver->host_lean_back.release();
     solver->host_stage.release();
     solver->host_back.release();
     delete solver;
@@ -134,6 +139,8 @@ int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long va
         solver->spec_depth = (int)value;
     } else if (k == "active_set") {
         solver->active_set = value ? 1 : 0;
+    } else if (k == "lean") {
+        solver->lean = value ? 1 : 0;
     } else {
         set_last_error("rocco_hip_solver_set: unknown key " + k);
         return ROCCO_HIP_EINVAL;
@@ -217,6 +224,21 @@ int rocco_hip_delta_probe_f64(rocco_hip_solver *solver, const double *scores_dev
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
     return delta_probe(solver, scores_dev, switch_costs_dev, gamma, n, emap_dev, lambdas, n_lambdas,
                        stats_out, (hipStream_t)stream);
+}
+
+int rocco_hip_delta_bound_rounds_f64(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n,
+                                     const double *lambdas, const int *round_sizes, int n_rounds,
+                                     double *lambdas_used_out, long long *counts_out, long long *level_len_out,
+                                     void *stream)
+{
+    if (solver == nullptr || scores_dev == nullptr || n < 2 || n >= ((size_t)1 << 31) || n_rounds < 0 ||
+        (n_rounds > 0 && (lambdas == nullptr || round_sizes == nullptr || lambdas_used_out == nullptr ||
+                          counts_out == nullptr || level_len_out == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return delta_bound_rounds(solver, scores_dev, gamma, n, lambdas, round_sizes, n_rounds, lambdas_used_out, counts_out,
+                              level_len_out, (hipStream_t)stream);
 }
 
 int rocco_hip_delta_spine_f64(rocco_hip_solver *solver, const double *scores_dev,

@@ -29,6 +29,10 @@ int delta_build_map(rocco_hip_solver *solver, const double *scores_dev, const do
                     double gamma, size_t n, double lambda_ref, double margin, uint8_t *emap_dev,
                     hipStream_t stream);
 
+int delta_bound_rounds(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n,
+                       const double *lambdas, const int *round_sizes, int n_rounds, double *lambdas_used_out,
+                       long long *counts_out, long long *level_len_out, hipStream_t stream);
+
 int delta_window(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
                  double gamma, size_t n, const uint8_t *emap_dev, double lambda_lo, double lambda_hi,
                  uint8_t *solution_dev, rocco_hip_window_stats *stats_out, hipStream_t stream);

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "chain_fast.h"
+#include "lean.h"
 #include "search.h"
 
 namespace rocco {
@@ -36,6 +37,51 @@ struct DevProblem {
     double frz_lo = 0.0, frz_hi = 0.0;  // the (latest) surveyed bracket
     std::vector<uint8_t> frz_flags;
     std::vector<int> active_blocks;
+    double smin = 0.0, smax = 0.0;
+    // compaction (lean.h): once `compacted`, scores / n / solution above are the compacted problem's and
+    // these are the caller's
+    bool compacted = false;
+    bool solution_in_orig = false;  // the exact evaluator wrote the caller's buffer directly
+    bool scattered = false;
+    const double *orig_scores = nullptr;
+    size_t orig_n = 0;
+    uint8_t *orig_solution = nullptr;
+    const int *lean_orig = nullptr;  // original locus of every compacted locus (-1: separator)
+};
+
+// Levels of one problem (lean.h): level 0 = the caller's array; every deeper level holds the loci selected
+// at its base penalty in exact arithmetic (plus separators) and serves every evaluation at or above it.
+struct LeanLevel {
+    const double *s = nullptr;
+    const int *orig = nullptr;
+    long long m = 0;
+    double base = -INFINITY;
+    bool has_eval = false;  // pts / child_len / bits / tile_off describe the latest evaluation on this level
+    std::vector<double> pts;
+    std::vector<long long> child_len;
+    unsigned *bits = nullptr;
+    unsigned *tile_off = nullptr;
+    int cap_points = 0;
+    size_t pool_mark = 0;  // the problem's pool offset before this level was created
+};
+
+struct LeanState {
+    std::vector<LeanLevel> levels;
+    size_t pool_begin = 0, pool_end = 0, pool_at = 0;
+};
+
+struct LeanReq {
+    size_t problem = 0;
+    std::vector<double> lambdas;
+    ProbeRequest *probe = nullptr;
+    CompactRequest *comp = nullptr;  // final compaction at lambdas[0]
+    int result_begin = 0;
+    // final compaction
+    double *out_s = nullptr;
+    int *out_orig = nullptr;
+    long long capacity = 0;
+    double sep = 0.0;
+    size_t mark = 0;
 };
 
 // true when -lambda lies exactly half-way between two points of a grid u = 2^(e-52) that a clean
@@ -92,6 +138,9 @@ public:
     void add_probe_tasks(std::vector<ProbeRequest> &reqs, std::vector<RoundTask> &tasks)
     {
         for (ProbeRequest &r : reqs) {
+            if (lean_takes(*this, r)) {
+                continue;  // answered by the lean evaluation of this iteration (lean_submit)
+            }
             r.results.assign(r.lambdas.size(), ProbeResult());
             if (r.lambdas.empty()) {
                 continue;
@@ -108,9 +157,17 @@ public:
 
     int probe(std::vector<ProbeRequest> &reqs) override
     {
+        std::vector<CompactRequest> none;
+        int rc;
+        if ((rc = lean_submit(none, reqs)) != ROCCO_HIP_OK) return rc;
         std::vector<RoundTask> tasks;
         add_probe_tasks(reqs, tasks);
-        return run_round(tasks);
+        if (tasks.empty()) {
+            ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        } else if ((rc = run_round(tasks)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        return lean_consume();
     }
 
     void add_window_tasks(std::vector<WindowRequest> &reqs, std::vector<RoundTask> &tasks)
@@ -317,7 +374,8 @@ public:
                 return ROCCO_HIP_EINVAL;
             }
             if (r.write_solution) {
-                words_total += (probs[r.problem].n + 30) / 32 + 1;
+                const DevProblem &pw = probs[r.problem];
+                words_total += ((pw.compacted ? pw.orig_n : pw.n) + 30) / 32 + 1;
             }
         }
         int rc;
@@ -336,7 +394,17 @@ public:
         unsigned long long *d_words = (unsigned long long *)solver_->dev_bits.ptr;
         size_t word_off = 0;
         for (size_t r = 0; r < R; ++r) {
-            const DevProblem &p = probs[reqs[r].problem];
+            DevProblem &pc = probs[reqs[r].problem];
+            // the exact evaluator is the last resort: always on the caller's own arrays
+            DevProblem p = pc;
+            if (pc.compacted) {
+                p.scores = pc.orig_scores;
+                p.n = pc.orig_n;
+                p.solution = pc.orig_solution;
+                if (reqs[r].write_solution) {
+                    pc.solution_in_orig = true;
+                }
+            }
             ExactTask &e = h_tasks[r];
             e.scores = p.scores;
             e.switch_costs = p.costs;
@@ -380,10 +448,45 @@ public:
         return ROCCO_HIP_OK;
     }
 
+    // compacted problems: copy the solution back into the caller's buffer (zero outside the kept loci)
+    int scatter_solution(size_t problem)
+    {
+        DevProblem &p = probs[problem];
+        if (!p.compacted || p.solution_in_orig || p.scattered) {
+            return ROCCO_HIP_OK;
+        }
+        ROCCO_HIP_TRY(hipMemsetAsync(p.orig_solution, 0, p.orig_n, stream_));
+        const int rc = launch_lean_scatter(p.solution, p.lean_orig, (long long)p.n, p.orig_solution, stream_);
+        p.scattered = true;
+        return rc;
+    }
+
+    int scatter_all()
+    {
+        for (size_t b = 0; b < probs.size(); ++b) {
+            const int rc = scatter_solution(b);
+            if (rc != ROCCO_HIP_OK) return rc;
+        }
+        return ROCCO_HIP_OK;
+    }
+
+    // the caller's view of a problem (what the objective is evaluated on)
+    DevProblem caller_view(size_t problem) const
+    {
+        DevProblem p = probs[problem];
+        if (p.compacted) {
+            p.scores = p.orig_scores;
+            p.n = p.orig_n;
+            p.solution = p.orig_solution;
+        }
+        return p;
+    }
+
     int penalized_value(size_t problem, double lambda, long long count, double *value_out) override
     {
-        const DevProblem &p = probs[problem];
         int rc;
+        if ((rc = scatter_solution(problem)) != ROCCO_HIP_OK) return rc;
+        const DevProblem p = caller_view(problem);
         if ((rc = solver_->dev_misc.reserve(objective_scratch_bytes(p.n))) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_back.reserve(64)) != ROCCO_HIP_OK) return rc;
         double *back = (double *)solver_->host_back.ptr;
@@ -403,16 +506,17 @@ public:
         values.assign(W, 0.0);
         size_t total = 0;
         std::vector<size_t> off(W);
-        for (size_t i = 0; i < W; ++i) {
-            off[i] = total;
-            total += align_up(objective_scratch_bytes(probs[which[i]].n), 256);
-        }
         int rc;
+        for (size_t i = 0; i < W; ++i) {
+            if ((rc = scatter_solution(which[i])) != ROCCO_HIP_OK) return rc;
+            off[i] = total;
+            total += align_up(objective_scratch_bytes(caller_view(which[i]).n), 256);
+        }
         if ((rc = solver_->dev_misc.reserve(total + 256)) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_back.reserve(W * sizeof(double) + 64)) != ROCCO_HIP_OK) return rc;
         double *back = (double *)solver_->host_back.ptr;
         for (size_t i = 0; i < W; ++i) {
-            const DevProblem &p = probs[which[i]];
+            const DevProblem p = caller_view(which[i]);
             rc = launch_objective(p.solution, p.scores, p.costs, p.gamma, p.n, (char *)solver_->dev_misc.ptr + off[i],
                                   back + i, stream_, false);
             if (rc != ROCCO_HIP_OK) {
@@ -423,6 +527,405 @@ public:
         for (size_t i = 0; i < W; ++i) {
             values[i] = -back[i] - lambdas[i] * (double)counts[i];
         }
+        return ROCCO_HIP_OK;
+    }
+
+
+    // ---- lean evaluation (lean.h): threshold-search rounds on compacted levels, final compaction ----
+    std::vector<LeanState> lean_;
+    bool lean_ready_ = false;
+    std::vector<LeanReq> lean_inflight_;
+    int lean_rounds = 0;
+    long long lean_units = 0;
+
+    bool lean_eligible(size_t problem) const
+    {
+        const DevProblem &p = probs[problem];
+        return solver_->lean != 0 && p.costs == nullptr && !p.compacted && p.n >= 2;
+    }
+
+    bool can_compact(size_t problem) const override { return lean_eligible(problem); }
+
+    int bound_points(size_t problem, int default_points) const override
+    {
+        if (!lean_eligible(problem)) {
+            return default_points;
+        }
+        long long m = (long long)probs[problem].n;
+        bool deep = false;
+        if (lean_ready_ && problem < lean_.size() && lean_[problem].levels.size() > 1) {
+            m = lean_[problem].levels.back().m;
+            deep = true;
+        }
+        int pts = (m > 8000000) ? 3 : ((m > 2000000) ? 4 : ((m > 256000) ? 8 : ((m > 32000) ? 16 : 32)));
+        if (!deep) {
+            pts = std::min(pts, 8);
+        }
+        return pts;
+    }
+
+    int lean_prepare()
+    {
+        if (lean_ready_) {
+            return ROCCO_HIP_OK;
+        }
+        lean_.assign(probs.size(), LeanState());
+        size_t total = 0;
+        for (size_t b = 0; b < probs.size(); ++b) {
+            lean_[b].pool_begin = total;
+            total += align_up(40 * probs[b].n + ((size_t)1 << 19), 256);
+            lean_[b].pool_end = total;
+            lean_[b].pool_at = lean_[b].pool_begin;
+        }
+        const int rc = solver_->dev_lean_pool.reserve(total + 256);
+        if (rc != ROCCO_HIP_OK) return rc;
+        lean_ready_ = true;
+        return ROCCO_HIP_OK;
+    }
+
+    void *lean_alloc(LeanState &ls, size_t bytes)
+    {
+        const size_t at = align_up(ls.pool_at, 256);
+        if (at + bytes > ls.pool_end) {
+            return nullptr;
+        }
+        ls.pool_at = at + bytes;
+        return (char *)solver_->dev_lean_pool.ptr + at;
+    }
+
+    static double separator_score(double base, double gamma) { return std::floor(base - 2.0 * gamma - 2.0); }
+
+    // Queue one round of lean work on the stream: compactions decided by the previous round, the evaluation of
+    // every request, the layout of its compactions, the final compactions.  lean_consume() after the stream
+    // has been synchronised.
+    int lean_enqueue(std::vector<LeanReq> &reqs)
+    {
+        lean_inflight_.clear();
+        if (reqs.empty()) {
+            return ROCCO_HIP_OK;
+        }
+        int rc;
+        if ((rc = lean_prepare()) != ROCCO_HIP_OK) return rc;
+        ++lean_rounds;
+        std::vector<LeanCompactTask> pre, post;
+        std::vector<LeanTask> tasks;
+        std::vector<double> points;
+        std::vector<size_t> post_req;
+        int units = 0, recs = 0, results = 0, pre_blocks = 0, post_blocks = 0;
+        const unsigned *pool_words = (const unsigned *)solver_->dev_lean_pool.ptr;
+        for (LeanReq &r : reqs) {
+            DevProblem &p = probs[r.problem];
+            LeanState &ls = lean_[r.problem];
+            if (ls.levels.empty()) {
+                LeanLevel l0;
+                l0.s = p.scores;
+                l0.m = (long long)p.n;
+                l0.pool_mark = ls.pool_at;
+                ls.levels.push_back(l0);
+            }
+            const double lam_min = *std::min_element(r.lambdas.begin(), r.lambdas.end());
+            while (ls.levels.size() > 1 && ls.levels.back().base > lam_min) {
+                ls.pool_at = ls.levels.back().pool_mark;
+                ls.levels.pop_back();
+            }
+            // a deeper level from the latest evaluation of this one?
+            {
+                LeanLevel &lv = ls.levels.back();
+                int best = -1;
+                if (lv.has_eval) {
+                    for (size_t i = 0; i < lv.pts.size(); ++i) {
+                        if (lv.pts[i] <= lam_min && (best < 0 || lv.pts[i] > lv.pts[(size_t)best])) {
+                            best = (int)i;
+                        }
+                    }
+                }
+                if (best >= 0 && lv.child_len[(size_t)best] >= 1 && 2 * lv.child_len[(size_t)best] <= lv.m) {
+                    const long long cl = lv.child_len[(size_t)best];
+                    const size_t mark = ls.pool_at;
+                    double *cs = (double *)lean_alloc(ls, (size_t)cl * sizeof(double));
+                    int *co = (int *)lean_alloc(ls, (size_t)cl * sizeof(int));
+                    if (cs != nullptr && co != nullptr) {
+                        const int nt = (int)((lv.m + kLeanTile - 1) / kLeanTile);
+                        LeanCompactTask ct;
+                        ct.s = lv.s;
+                        ct.orig = lv.orig;
+                        ct.m = lv.m;
+                        ct.n_tiles = nt;
+                        ct.block_begin = pre_blocks;
+                        ct.bits = lv.bits + (size_t)best * (size_t)nt * kLeanThreads;
+                        ct.tile_off = lv.tile_off + (size_t)best * (size_t)nt;
+                        ct.sep = separator_score(lv.pts[(size_t)best], p.gamma);
+                        ct.out_s = cs;
+                        ct.out_orig = co;
+                        ct.capacity = cl;
+                        pre.push_back(ct);
+                        pre_blocks += nt;
+                        LeanLevel child;
+                        child.s = cs;
+                        child.orig = co;
+                        child.m = cl;
+                        child.base = lv.pts[(size_t)best];
+                        child.pool_mark = mark;
+                        ls.levels.push_back(child);
+                    } else {
+                        ls.pool_at = mark;
+                    }
+                }
+            }
+            LeanLevel &lv = ls.levels.back();
+            const int np = (int)r.lambdas.size();
+            const int nt = (int)((lv.m + kLeanTile - 1) / kLeanTile);
+            if (lv.cap_points < np) {
+                // storage of this level's evaluations (level 0 never takes more than 8 penalties a round)
+                const int cap = std::max(np, (ls.levels.size() > 1) ? kLeanMaxPoints : 8);
+                lv.bits = (unsigned *)lean_alloc(ls, (size_t)cap * (size_t)nt * kLeanThreads * sizeof(unsigned));
+                lv.tile_off = (unsigned *)lean_alloc(ls, (size_t)cap * (size_t)nt * sizeof(unsigned));
+                if (lv.bits == nullptr || lv.tile_off == nullptr) {
+                    set_last_error("lean evaluation: level pool exhausted");
+                    return ROCCO_HIP_ENOMEM;
+                }
+                lv.cap_points = cap;
+            }
+            lv.has_eval = false;
+            LeanTask t;
+            t.s = lv.s;
+            t.m = lv.m;
+            t.c_raw = p.gamma;
+            t.magic = std::ldexp(1.5, 52 + p.qexp);
+            t.big = std::ldexp(1.0, 50 + p.qexp);
+            t.n_tiles = nt;
+            t.n_points = np;
+            t.n_groups = (np + kLeanBatch - 1) / kLeanBatch;
+            t.unit_begin = units;
+            t.point_begin = (int)points.size();
+            t.rec_begin = recs;
+            t.bits_begin = (long long)(lv.bits - pool_words);
+            t.off_begin = (long long)(lv.tile_off - pool_words);
+            t.result_begin = results;
+            t.pad = 0;
+            r.result_begin = results;
+            units += nt * t.n_groups;
+            recs += nt * np;
+            results += np;
+            points.insert(points.end(), r.lambdas.begin(), r.lambdas.end());
+            tasks.push_back(t);
+            if (r.comp != nullptr) {
+                // final compaction at lambdas[0]: its length is only known after the round
+                r.mark = ls.pool_at;
+                r.capacity = lv.m + 2;
+                r.out_s = (double *)lean_alloc(ls, (size_t)r.capacity * sizeof(double));
+                r.out_orig = (int *)lean_alloc(ls, (size_t)r.capacity * sizeof(int));
+                r.sep = separator_score(r.lambdas[0], p.gamma);
+                if (r.out_s != nullptr && r.out_orig != nullptr) {
+                    LeanCompactTask ct;
+                    ct.s = lv.s;
+                    ct.orig = lv.orig;
+                    ct.m = lv.m;
+                    ct.n_tiles = nt;
+                    ct.block_begin = post_blocks;
+                    ct.bits = lv.bits;
+                    ct.tile_off = lv.tile_off;
+                    ct.sep = r.sep;
+                    ct.out_s = r.out_s;
+                    ct.out_orig = r.out_orig;
+                    ct.capacity = r.capacity;
+                    post.push_back(ct);
+                    post_blocks += nt;
+                } else {
+                    ls.pool_at = r.mark;
+                    r.out_s = nullptr;
+                }
+            }
+        }
+        lean_units += units;
+
+        // descriptors: [pre][tasks][points][post]
+        const size_t b_pre = align_up(pre.size() * sizeof(LeanCompactTask), 256);
+        const size_t b_tasks = align_up(tasks.size() * sizeof(LeanTask), 256);
+        const size_t b_points = align_up(points.size() * sizeof(double), 256);
+        const size_t b_post = align_up(post.size() * sizeof(LeanCompactTask), 256);
+        const size_t desc = b_pre + b_tasks + b_points + b_post;
+        if ((rc = solver_->dev_lean_desc.reserve(desc + 256)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_lean_stage.reserve(desc + 256)) != ROCCO_HIP_OK) return rc;
+        char *h = (char *)solver_->host_lean_stage.ptr;
+        char *d = (char *)solver_->dev_lean_desc.ptr;
+        if (!pre.empty()) std::memcpy(h, pre.data(), pre.size() * sizeof(LeanCompactTask));
+        std::memcpy(h + b_pre, tasks.data(), tasks.size() * sizeof(LeanTask));
+        std::memcpy(h + b_pre + b_tasks, points.data(), points.size() * sizeof(double));
+        if (!post.empty()) std::memcpy(h + b_pre + b_tasks + b_points, post.data(), post.size() * sizeof(LeanCompactTask));
+        ROCCO_HIP_TRY(hipMemcpyAsync(d, h, desc, hipMemcpyHostToDevice, stream_));
+
+        // round scratch: [ticket | granules] (all-ones), [records], [results | error] (zero)
+        const size_t b_look = align_up(256 + (size_t)recs * 4 * sizeof(unsigned long long), 256);
+        const size_t b_recs = align_up((size_t)recs * sizeof(LeanTileRec), 256);
+        const size_t b_res = align_up((size_t)results * sizeof(LeanResult) + 64, 256);
+        if ((rc = solver_->dev_lean_round.reserve(b_look + b_recs + b_res)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_lean_back.reserve(b_res)) != ROCCO_HIP_OK) return rc;
+        char *sc = (char *)solver_->dev_lean_round.ptr;
+        ROCCO_HIP_TRY(hipMemsetAsync(sc, 0xFF, b_look, stream_));
+        ROCCO_HIP_TRY(hipMemsetAsync(sc + b_look + b_recs, 0, b_res, stream_));
+        unsigned *error = (unsigned *)(sc + b_look + b_recs + (size_t)results * sizeof(LeanResult));
+        if (!pre.empty()) {
+            if ((rc = launch_lean_compact((const LeanCompactTask *)d, (int)pre.size(), pre_blocks, error, stream_)) != ROCCO_HIP_OK) return rc;
+        }
+        LeanLaunch L;
+        L.tasks = (const LeanTask *)(d + b_pre);
+        L.n_tasks = (int)tasks.size();
+        L.n_units = units;
+        L.points = (const double *)(d + b_pre + b_tasks);
+        L.ticket = (unsigned *)sc;
+        L.look = (unsigned long long *)(sc + 256);
+        L.recs = (LeanTileRec *)(sc + b_look);
+        L.bits = (unsigned *)solver_->dev_lean_pool.ptr;
+        L.tile_off = (unsigned *)solver_->dev_lean_pool.ptr;
+        L.results = (LeanResult *)(sc + b_look + b_recs);
+        L.error = error;
+        if ((rc = launch_lean_eval(L, stream_)) != ROCCO_HIP_OK) return rc;
+        if ((rc = launch_lean_finish(L, results, stream_)) != ROCCO_HIP_OK) return rc;
+        if (!post.empty()) {
+            if ((rc = launch_lean_compact((const LeanCompactTask *)(d + b_pre + b_tasks + b_points), (int)post.size(), post_blocks,
+                                          error, stream_)) != ROCCO_HIP_OK) return rc;
+        }
+        ROCCO_HIP_TRY(hipMemcpyAsync(solver_->host_lean_back.ptr, sc + b_look + b_recs, (size_t)results * sizeof(LeanResult) + 8,
+                                     hipMemcpyDeviceToHost, stream_));
+        lean_result_count_ = results;
+        lean_inflight_ = reqs;
+        if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+            std::fprintf(stderr, "[lean round %d] %zu tasks, %d workgroups, %zu compactions before, %zu after\n", lean_rounds,
+                         tasks.size(), units, pre.size(), post.size());
+        }
+        return ROCCO_HIP_OK;
+    }
+
+    int lean_consume()
+    {
+        if (lean_inflight_.empty()) {
+            return ROCCO_HIP_OK;
+        }
+        const LeanResult *res = (const LeanResult *)solver_->host_lean_back.ptr;
+        const unsigned error = *(const unsigned *)((const char *)solver_->host_lean_back.ptr + (size_t)lean_result_count_ * sizeof(LeanResult));
+        if (error & 1u) {
+            set_last_error("lean evaluation: a tile waited for its predecessor beyond the spin limit");
+            return ROCCO_HIP_EHIP;
+        }
+        for (LeanReq &r : lean_inflight_) {
+            DevProblem &p = probs[r.problem];
+            LeanState &ls = lean_[r.problem];
+            LeanLevel &lv = ls.levels.back();
+            const size_t np = r.lambdas.size();
+            lv.pts = r.lambdas;
+            lv.child_len.resize(np);
+            for (size_t i = 0; i < np; ++i) {
+                lv.child_len[i] = res[r.result_begin + (int)i].child_len;
+            }
+            lv.has_eval = true;
+            if (r.probe != nullptr) {
+                r.probe->results.assign(np, ProbeResult());
+                for (size_t i = 0; i < np; ++i) {
+                    r.probe->results[i].count = res[r.result_begin + (int)i].count;
+                }
+            }
+            if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                std::fprintf(stderr, "[lean] problem %zu level %zu (m=%lld, base %.17g): %zu penalties, first %.17g -> count %lld, child %lld\n",
+                             r.problem, ls.levels.size() - 1, lv.m, lv.base, np, r.lambdas[0], res[r.result_begin].count,
+                             res[r.result_begin].child_len);
+            }
+            if (r.comp != nullptr) {
+                const long long cl = res[r.result_begin].child_len;
+                const bool fits = r.out_s != nullptr && cl >= 1 && cl <= r.capacity && !(error & 2u);
+                // worth it only when the compacted problem is much smaller than the caller's
+                if (fits && 10 * cl <= 6 * (long long)p.n) {
+                    uint8_t *sol = (uint8_t *)lean_alloc(ls, (size_t)cl);
+                    if (sol != nullptr) {
+                        p.orig_scores = p.scores;
+                        p.orig_n = p.n;
+                        p.orig_solution = p.solution;
+                        p.compacted = true;
+                        p.scores = r.out_s;
+                        p.n = (size_t)cl;
+                        p.solution = sol;
+                        p.lean_orig = r.out_orig;
+                        p.emap = nullptr;
+                        p.frz_valid = false;
+                        p.smin = std::min(p.smin, r.sep);
+                        p.sabs = std::max(p.sabs, std::fabs(r.sep));
+                        p.qexp = grid_exponent(std::max(p.cmax, 0.0), p.smin, p.smax);
+                        r.comp->done = true;
+                        r.comp->n_new = (size_t)cl;
+                        r.comp->score_floor = r.sep;
+                    }
+                }
+                if (!r.comp->done && std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                    std::fprintf(stderr, "[lean] problem %zu: final compaction declined (child %lld of %zu)\n", r.problem, cl, p.n);
+                }
+            }
+        }
+        lean_inflight_.clear();
+        return ROCCO_HIP_OK;
+    }
+
+    int lean_result_count_ = 0;
+
+    int compact(std::vector<CompactRequest> &reqs) override
+    {
+        std::vector<ProbeRequest> none;
+        int rc;
+        if ((rc = lean_submit(reqs, none)) != ROCCO_HIP_OK) return rc;
+        ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        return lean_consume();
+    }
+
+    // queue the lean part of an iteration; returns the probes that stay with the general kernels
+    int lean_submit(std::vector<CompactRequest> &compacts, std::vector<ProbeRequest> &probes)
+    {
+        std::vector<LeanReq> reqs;
+        for (CompactRequest &c : compacts) {
+            c.done = false;
+            if (!lean_eligible(c.problem)) {
+                continue;
+            }
+            LeanReq r;
+            r.problem = c.problem;
+            r.lambdas = {c.lambda_base};
+            r.comp = &c;
+            reqs.push_back(r);
+        }
+        for (ProbeRequest &q : probes) {
+            if (q.bound && !q.lambdas.empty() && q.lambdas.size() <= (size_t)kLeanMaxPoints && lean_eligible(q.problem)) {
+                LeanReq r;
+                r.problem = q.problem;
+                r.lambdas = q.lambdas;
+                r.probe = &q;
+                reqs.push_back(r);
+            }
+        }
+        return lean_enqueue(reqs);
+    }
+
+    static bool lean_takes(const HipEvaluator &ev, const ProbeRequest &q)
+    {
+        return q.bound && !q.lambdas.empty() && q.lambdas.size() <= (size_t)kLeanMaxPoints && ev.lean_eligible(q.problem);
+    }
+
+    int round_all(std::vector<CompactRequest> &compacts, std::vector<MapRequest> &maps, std::vector<WindowRequest> &surveys,
+                  std::vector<ProbeRequest> &probes, std::vector<WindowRequest> &windows,
+                  std::vector<SpineRequest> &spines) override
+    {
+        int rc;
+        if ((rc = lean_submit(compacts, probes)) != ROCCO_HIP_OK) return rc;
+        std::vector<RoundTask> tasks;
+        if ((rc = add_map_tasks(maps, tasks)) != ROCCO_HIP_OK) return rc;
+        if ((rc = add_survey_tasks(surveys, tasks)) != ROCCO_HIP_OK) return rc;
+        add_probe_tasks(probes, tasks);
+        add_window_tasks(windows, tasks);
+        if ((rc = add_spine_tasks(spines, tasks)) != ROCCO_HIP_OK) return rc;
+        if (tasks.empty()) {
+            ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        } else if ((rc = run_round(tasks)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        if ((rc = lean_consume()) != ROCCO_HIP_OK) return rc;
+        adopt_maps(maps);
         return ROCCO_HIP_OK;
     }
 
@@ -966,6 +1469,8 @@ int prepare(HipEvaluator &ev, std::vector<ChainProblem> &problems, const std::ve
             hi = std::max(hi, (*fixed_lambdas)[b]);
         }
         d.cmax = p.cost_max;
+        d.smin = p.score_min;
+        d.smax = p.score_max;
         d.sabs = std::max(std::fabs(p.score_min), std::fabs(p.score_max));
         d.qexp = (std::isfinite(lo) && std::isfinite(hi) && std::isfinite(p.cost_max))
                      ? grid_exponent(std::max(p.cost_max, 0.0), lo, hi)
@@ -1098,6 +1603,50 @@ int delta_probe(rocco_hip_solver *solver, const double *scores_dev, const double
     return ROCCO_HIP_OK;
 }
 
+int delta_bound_rounds(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n,
+                       const double *lambdas, const int *round_sizes, int n_rounds, double *lambdas_used_out,
+                       long long *counts_out, long long *level_len_out, hipStream_t stream)
+{
+    HipEvaluator ev(solver, stream);
+    DevProblem d;
+    d.scores = scores_dev;
+    d.costs = nullptr;
+    d.gamma = gamma;
+    d.n = n;
+    ev.probs.push_back(d);
+    std::vector<ChainProblem> problems(1);
+    problems[0].n = n;
+    problems[0].gamma = gamma;
+    int rc;
+    if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    if (!ev.lean_eligible(0)) {
+        set_last_error("rocco_hip_delta_bound_rounds_f64: the lean evaluation is switched off for this solver");
+        return ROCCO_HIP_EINVAL;
+    }
+    const int qexp = ev.probs[0].qexp;
+    size_t at = 0;
+    for (int r = 0; r < n_rounds; ++r) {
+        std::vector<ProbeRequest> reqs(1);
+        reqs[0].problem = 0;
+        reqs[0].bound = true;
+        for (int i = 0; i < round_sizes[r]; ++i) {
+            const double x = std::ldexp(std::nearbyint(std::ldexp(lambdas[at + (size_t)i], -qexp)), qexp);
+            reqs[0].lambdas.push_back(x);
+            lambdas_used_out[at + (size_t)i] = x;
+        }
+        if (reqs[0].lambdas.empty() || reqs[0].lambdas.size() > (size_t)kLeanMaxPoints) {
+            return ROCCO_HIP_EINVAL;
+        }
+        if ((rc = ev.probe(reqs)) != ROCCO_HIP_OK) return rc;
+        for (int i = 0; i < round_sizes[r]; ++i) {
+            counts_out[at + (size_t)i] = reqs[0].results[(size_t)i].count;
+        }
+        level_len_out[r] = ev.lean_[0].levels.back().m;
+        at += (size_t)round_sizes[r];
+    }
+    return ROCCO_HIP_OK;
+}
+
 int delta_window(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,
                  double gamma, size_t n, const uint8_t *emap_dev, double lambda_lo, double lambda_hi,
                  uint8_t *solution_dev, rocco_hip_window_stats *stats_out, hipStream_t stream)
@@ -1181,7 +1730,11 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_SEARCH_INTERP")) opt.search_interpolate = std::atoi(e) != 0;
     std::vector<CalibrationResult> res;
     const double t_solve0 = HipEvaluator::now_us();
+    if (const char *e = std::getenv("ROCCO_HIP_COMPACT")) opt.use_compaction = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ROCCO_HIP_LEAN")) solver->lean = std::atoi(e) != 0;
     if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
+    if ((rc = ev.scatter_all()) != ROCCO_HIP_OK) return rc;
+    ROCCO_HIP_TRY(hipStreamSynchronize(stream));
     if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
         std::fprintf(stderr, "[host] solve %.0f us: %d rounds, prep %.0f launch %.0f wait %.0f us (rest: search logic, other calls)\n",
                      HipEvaluator::now_us() - t_solve0, ev.rounds, ev.t_prep_, ev.t_launch_, ev.t_wait_);

@@ -48,6 +48,7 @@ struct rocco_hip_solver {
     int force_exact = 0;
     int spec_depth = 2;
     int active_set = 1;  // skip blocks that a survey proved settled for the whole bracket
+    int lean = 1;        // threshold search on compacted levels + layer-3 rounds on the compacted problem (lean.hip)
     // scratch
     rocco::DeviceBuffer dev_tasks;    // kernel task descriptors
     rocco::DeviceBuffer dev_params;   // per-launch lambda lists etc.
@@ -60,6 +61,11 @@ struct rocco_hip_solver {
     rocco::DeviceBuffer dev_factor;   // Whittaker LDL^T factor of the longest row seen (whittaker.hip)
     double factor_lambda = 0.0;       // ... its penalty
     size_t factor_cap = 0;            // ... and length (0: none)
+    rocco::DeviceBuffer dev_lean_pool;   // compacted levels of the problems being solved (lean.hip)
+    rocco::DeviceBuffer dev_lean_round;  // per-round scratch of the lean evaluation
+    rocco::DeviceBuffer dev_lean_desc;   // its descriptors
+    rocco::PinnedBuffer host_lean_stage; // ... their pinned staging
+    rocco::PinnedBuffer host_lean_back;  // ... and the readback of its results
     rocco::PinnedBuffer host_stage;   // pinned staging for uploads
     rocco::PinnedBuffer host_back;    // pinned staging for readbacks
 };

@@ -1,0 +1,96 @@
+// rocco_amd/csrc/lean.h -- count-only evaluation of the chain solve in exact arithmetic, and compaction
+// of a problem to the loci that can still be selected.
+//
+// What it computes: for a list of penalties x (multiples of the problem's grid q) the number of loci the
+// delta-form recursion of oracle/delta_oracle.c selects when every input is rounded to the grid q and no
+// rounding model is applied ("bound" evaluation):
+//     delta_0 = a_0,  delta_j = clamp(delta_{j-1}, -c, c) + a_j,  a_j = rn_q(s_j) - x,  c = rn_q(gamma)
+//     class_j = ONE if delta_j > c, ZERO if delta_j <= -c, else COPY (last locus: ONE iff delta > 0), backward fill.
+// This is the reference's forward pass and backtrack (rocco/_chain_dp.c:115-186) in exact arithmetic.  The
+// host search (search.cpp) shifts x by -/+ eps to bracket the reference's own count.
+//
+// Levels: level 0 is the caller's score array.  Because the selected sets are nested in x (minimal
+// minimisers of a parametric cut), every evaluation at x >= b only needs the loci selected at b: a deeper
+// level holds those loci, the runs separated by one "separator" locus whose score no penalty >= b can
+// select, so that a plain chain over the level reproduces every delta of the kept loci exactly.
+#pragma once
+
+#include "common.h"
+
+namespace rocco {
+
+constexpr int kLeanChunk = 32;                                // loci per lane
+constexpr int kLeanThreads = 256;                             // lanes per workgroup
+constexpr int kLeanTile = kLeanChunk * kLeanThreads;          // 8192 loci per workgroup
+constexpr int kLeanBatch = 8;                                 // penalties one workgroup carries in registers
+constexpr int kLeanMaxPoints = 32;                            // penalties per task and round
+
+// per (tile, penalty): what the finish kernel needs to close the backward fill and to place the tile's
+// loci in a compacted array
+struct LeanTileRec {
+    unsigned base;   // selected loci of the tile if the fill value entering from the right is 0
+    unsigned tail;   // loci at the tile's end that copy that value
+    unsigned cells;  // loci + separators the tile contributes to a compaction (the tile's last run end excluded)
+    unsigned flags;  // bit 0: every locus of the tile copies; bit 1: value leaving to the left (if not bit 0);
+                     // bit 2: first locus kept; bit 3: last locus kept
+};
+
+struct LeanTask {
+    const double *s;      // level array (raw scores, separators included)
+    long long m;          // its length
+    double c_raw;         // switch cost (gamma)
+    double magic;         // 1.5 * 2^(52 + qexp): (x + magic) - magic rounds x to the grid q
+    double big;           // 2^(50 + qexp)
+    int n_tiles;
+    int n_points;
+    int n_groups;         // workgroups per tile (each takes kLeanBatch penalties)
+    int unit_begin;       // first ticket of this task (tickets are tile-major: tile * n_groups + group)
+    int point_begin;      // offset of the task's penalties in the round's point list
+    int rec_begin;        // offset of the task's records: [(point) * n_tiles + tile]
+    long long bits_begin; // offset (in words) of the task's kept-locus words: [(point) * n_tiles * 256 + tile * 256 + lane]
+    long long off_begin;  // offset of the task's tile offsets: [(point) * n_tiles + tile]
+    int result_begin;     // offset of the task's results: [point]
+    int pad;
+};
+
+struct LeanResult {
+    long long count;      // selected loci
+    long long child_len;  // length of the level a compaction at this penalty would produce
+};
+
+struct LeanLaunch {
+    const LeanTask *tasks;
+    int n_tasks;
+    int n_units;                // workgroups of the evaluation launch
+    const double *points;       // penalties of every task
+    unsigned *ticket;           // one word, 0xFFFFFFFF before the launch
+    unsigned long long *look;   // [(rec index) * 4 + {lo, hi, a, out}] granules, all-ones before the launch
+    LeanTileRec *recs;
+    unsigned *bits;
+    unsigned *tile_off;
+    LeanResult *results;
+    unsigned *error;            // set when a bounded wait gave up
+};
+
+// compaction of one task at one of its evaluated penalties
+struct LeanCompactTask {
+    const double *s;          // parent level
+    const int *orig;          // parent's original-locus map (nullptr: level 0, the identity)
+    long long m;
+    int n_tiles;
+    int block_begin;          // first workgroup of this task in the launch
+    const unsigned *bits;     // kept-locus words of the chosen penalty [tile * 256 + lane]
+    const unsigned *tile_off; // offsets of the chosen penalty [tile]
+    double sep;               // separator score
+    double *out_s;
+    int *out_orig;
+    long long capacity;       // cells available at out_s / out_orig
+};
+
+int launch_lean_eval(const LeanLaunch &L, hipStream_t stream);
+int launch_lean_finish(const LeanLaunch &L, int n_pairs, hipStream_t stream);
+int launch_lean_compact(const LeanCompactTask *tasks_dev, int n_tasks, int n_blocks, unsigned *error_dev, hipStream_t stream);
+// solution_full[orig[i]] = solution_level[i] for every kept locus (the caller zeroes solution_full first)
+int launch_lean_scatter(const uint8_t *solution_level, const int *orig, long long m, uint8_t *solution_full, hipStream_t stream);
+
+}  // namespace rocco

@@ -1,0 +1,715 @@
+// rocco_amd/csrc/lean.hip -- see lean.h.  gfx950 only.
+//
+// lean_eval_kernel: one workgroup per (tile of 8192 loci, batch of <= 8 penalties), ONE launch per search
+// round for every chromosome of the batch, the scores read once from HBM:
+//   1. the tile is staged through LDS (coalesced 16-B loads, rounded to the grid q on the way; one 32-locus
+//      chunk per LDS row, row stride 34 doubles -> conflict-free 16-B LDS reads);
+//   2. every lane runs the two extreme trajectories of its chunk (from -c and from +c) for the penalties of
+//      the batch interleaved in registers (independent FP64 chains hide each other's latency), which gives
+//      the chunk's function x -> clamp(x + a, lo, hi); the functions are composed across the workgroup
+//      (wavefront shuffles, then the four wavefront aggregates through LDS);
+//   3. the tile's function is handed to the next tile through 8-byte self-flagging granules (a function
+//      with lo == hi -- nearly every tile -- fixes the outgoing delta without waiting for anything; tiles
+//      take tickets in launch order, so a tile only ever waits for one that is already running);
+//   4. every lane reruns its chunk from its true incoming delta, collects the class bits with two
+//      instructions per class and locus (sign bit of c - delta / of -delta - c shifted into a mask), and
+//      closes the backward fill of its 32 loci with one 64-bit addition (the carry chain of NZ + ONE is the
+//      fill recurrence z_j = ONE_j | (COPY_j & z_{j+1}));
+//   5. per tile and penalty: the count for an incoming fill value of 0, the length of the run that copies
+//      it, and the kept-locus bits (incoming fill value taken as 1: a superset).
+// lean_finish_kernel closes the fill across tiles (one wavefront per chromosome and penalty) and lays
+// out the compaction each penalty would give; lean_compact_kernel writes the chosen one.
+// All of it is integer / exact FP64 min-max-add work bound by HBM reads of 8 B per locus and round (level
+// 0) or by launch latency (deeper levels); no MFMA -- the path is BLAS-1.
+#include "lean.h"
+
+#include <cmath>
+
+namespace rocco {
+
+namespace {
+
+constexpr int kStride = kLeanChunk + 2;  // doubles per chunk row in LDS
+constexpr int kTileLds = kLeanThreads * kStride;
+constexpr unsigned long long kSentinel = ~0ull;  // granule not written yet (a NaN: never a value)
+constexpr unsigned kSpinLimit = 1u << 22;
+
+struct Fn {
+    double a, lo, hi;  // x -> min(max(x + a, lo), hi)
+};
+
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+
+// f first, then g
+__device__ __forceinline__ Fn compose(const Fn &f, const Fn &g)
+{
+    Fn r;
+    r.a = f.a + g.a;
+    r.lo = clampd(f.lo + g.a, g.lo, g.hi);
+    r.hi = clampd(f.hi + g.a, g.lo, g.hi);
+    return r;
+}
+
+__device__ __forceinline__ Fn shfl_up_fn(const Fn &f, int off)
+{
+    Fn r;
+    r.a = __shfl_up(f.a, off);
+    r.lo = __shfl_up(f.lo, off);
+    r.hi = __shfl_up(f.hi, off);
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void granule_store(unsigned long long *p, double v)
+{
+    __hip_atomic_store(p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// bounded wait for a granule; gives up (and reports it) rather than hang the device
+__device__ __forceinline__ double granule_wait(const unsigned long long *p, unsigned *error)
+{
+    unsigned long long v = granule_load(p);
+    unsigned spins = 0;
+    while (v == kSentinel) {
+        __builtin_amdgcn_s_sleep(2);
+        v = granule_load(p);
+        if (++spins > kSpinLimit) {
+            atomicOr(error, 1u);
+            return 0.0;
+        }
+    }
+    return __longlong_as_double((long long)v);
+}
+
+// ---- tile staging: rn_q(score) into LDS --------------------------------------------------------
+__device__ __forceinline__ void stage_tile(const double *__restrict__ s, long long m, long long base, double magic,
+                                           double *lds)
+{
+    const int t = threadIdx.x;
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(s) & 15U) == 0);
+    if (aligned16 && base + kLeanTile <= m) {
+        // whole tile in range: sixteen unconditional 16-byte loads per lane, all in flight together
+        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(s + base) + t;
+        double2 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[r] = src[r * kLeanThreads];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = 2 * (r * kLeanThreads + t);
+            double2 w;
+            w.x = (v[r].x + magic) - magic;
+            w.y = (v[r].y + magic) - magic;
+            *reinterpret_cast<double2 *>(lds + (e >> 5) * kStride + (e & 31)) = w;
+        }
+    } else {
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int e = 2 * (r * kLeanThreads + t);
+            const long long j = base + e;
+            double2 v = make_double2(0.0, 0.0);
+            if (j < m) v.x = s[j];
+            if (j + 1 < m) v.y = s[j + 1];
+            v.x = (v.x + magic) - magic;
+            v.y = (v.y + magic) - magic;
+            *reinterpret_cast<double2 *>(lds + (e >> 5) * kStride + (e & 31)) = v;
+        }
+    }
+    __syncthreads();
+}
+
+struct Scratch {
+    double wave_fn[4][kLeanBatch][3];  // wavefront aggregates
+    double tile_in[kLeanBatch];        // incoming delta of the tile
+    unsigned red[kLeanBatch][4];       // base, tail, cells, (unused)
+    unsigned char wave_pass[4][kLeanBatch], wave_v[4][kLeanBatch];
+    unsigned first_word[4][kLeanBatch];  // kept-locus word of every wavefront's first lane
+    unsigned last_word[kLeanBatch];      // ... and of the tile's last lane
+    int ticket;
+    int pad[3];
+};
+
+// One chunk, PB penalties: extreme trajectories + sum (the chunk's function).
+template <int PB>
+__device__ __forceinline__ void chunk_function(const double *__restrict__ row, const double (&x)[PB], double c,
+                                               double c_first, double big, Fn (&f)[PB])
+{
+    double lo[PB], hi[PB], fa[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        fa[p] = 0.0;
+        lo[p] = -big;
+        hi[p] = big;
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < kLeanChunk; i0 += 8) {
+        double rs[8];
+#pragma unroll
+        for (int ii = 0; ii < 8; ii += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(row + i0 + ii);
+            rs[ii] = v.x;
+            rs[ii + 1] = v.y;
+        }
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const double cc = (i0 + ii == 0) ? c_first : c;  // (clamp(+-big, -c, c) = +-c: the extremes start at the bounds)
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const double a = rs[ii] - x[p];
+                fa[p] += a;
+                lo[p] = fmin(fmax(lo[p], -cc), cc) + a;
+                hi[p] = fmin(fmax(hi[p], -cc), cc) + a;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        f[p].a = fa[p];
+        f[p].lo = lo[p];
+        f[p].hi = hi[p];
+    }
+}
+
+// One chunk, PB penalties, from the true incoming delta: class masks (locus i of the chunk at bit 31 - i).
+// `valid` = loci of the chunk that exist (32 except in the last tile); `last` = index of the chain's last locus
+// in this chunk (-1: not here).
+template <int PB, bool EDGE>
+__device__ __forceinline__ void chunk_classes(const double *__restrict__ row, const double (&x)[PB], double c,
+                                              double c_first, const double (&din)[PB], int valid, int last,
+                                              unsigned (&one)[PB], unsigned (&nz)[PB])
+{
+    double d[PB];
+    const double nc = -c;
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        one[p] = 0u;
+        nz[p] = 0u;
+        d[p] = din[p];
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < kLeanChunk; i0 += 8) {
+        double rs[8];
+#pragma unroll
+        for (int ii = 0; ii < 8; ii += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(row + i0 + ii);
+            rs[ii] = v.x;
+            rs[ii + 1] = v.y;
+        }
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const int i = i0 + ii;
+            const double cc = (i == 0) ? c_first : c;
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const double a = rs[ii] - x[p];
+                d[p] = fmin(fmax(d[p], -cc), cc) + a;
+                // sign(c - d) = 1  <=>  d > c (ONE);  sign(-c - d) = 1  <=>  d > -c (not ZERO); x - x = +0 at equality
+                double t1 = c - d[p];
+                double t2 = nc - d[p];
+                if (EDGE) {
+                    if (i == last) {  // terminal rule: ONE iff delta > 0, else ZERO
+                        t1 = 0.0 - d[p];
+                        t2 = t1;
+                    }
+                    if (i >= valid) {  // padding: ZERO
+                        t1 = 0.0;
+                        t2 = 0.0;
+                    }
+                }
+                one[p] = __builtin_amdgcn_alignbit(one[p], (unsigned)__double2hiint(t1), 31);
+                nz[p] = __builtin_amdgcn_alignbit(nz[p], (unsigned)__double2hiint(t2), 31);
+            }
+        }
+    }
+}
+
+template <int PB>
+__device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &task, int tile, int p0, int np, double *lds,
+                                          Scratch *sc)
+{
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const long long base = (long long)tile * kLeanTile;
+
+    const double c = (task.c_raw + task.magic) - task.magic;
+    const double big = task.big;
+    double x[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        x[p] = L.points[task.point_begin + p0 + min(p, np - 1)];
+    }
+    const long long j0 = base + (long long)t * kLeanChunk;
+    const double c_first = (j0 == 0) ? big : c;  // the chain's first locus takes its input unclamped
+    const double *row = lds + t * kStride;
+
+    // ---- 2. chunk functions, composed across the workgroup ----
+    Fn f[PB];
+    chunk_function<PB>(row, x, c, c_first, big, f);
+    Fn inc[PB];  // inclusive within the wavefront
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        inc[p] = f[p];
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const Fn prev = shfl_up_fn(inc[p], off);
+            if (lane >= off) {
+                inc[p] = compose(prev, inc[p]);
+            }
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            sc->wave_fn[wave][p][0] = inc[p].a;
+            sc->wave_fn[wave][p][1] = inc[p].lo;
+            sc->wave_fn[wave][p][2] = inc[p].hi;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. hand-off between tiles: one lane per penalty ----
+    if (t < np) {
+        const int p = t;
+        Fn agg;
+        agg.a = sc->wave_fn[0][p][0];
+        agg.lo = sc->wave_fn[0][p][1];
+        agg.hi = sc->wave_fn[0][p][2];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            Fn g;
+            g.a = sc->wave_fn[w][p][0];
+            g.lo = sc->wave_fn[w][p][1];
+            g.hi = sc->wave_fn[w][p][2];
+            agg = compose(agg, g);
+        }
+        const long long rec = (long long)task.rec_begin + (long long)(p0 + p) * task.n_tiles + tile;
+        unsigned long long *mine = L.look + rec * 4;
+        const bool more = (tile + 1 < task.n_tiles);
+        if (more) {
+            granule_store(mine + 0, agg.lo);
+            granule_store(mine + 1, agg.hi);
+            if (agg.lo == agg.hi) {
+                granule_store(mine + 3, agg.lo);
+            }
+        }
+        double din = 0.0;  // chain start: delta_0 = a_0 (the first clamp is the identity)
+        if (tile > 0) {
+            const unsigned long long *prev = L.look + (rec - 1) * 4;
+            const double plo = granule_wait(prev + 0, L.error);
+            const double phi = granule_wait(prev + 1, L.error);
+            din = (plo == phi) ? plo : granule_wait(prev + 3, L.error);
+        }
+        sc->tile_in[p] = din;
+        if (more && agg.lo != agg.hi) {
+            granule_store(mine + 3, clampd(din + agg.a, agg.lo, agg.hi));
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. true incoming delta of every lane, classes, fill ----
+    double din[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        // exclusive prefix: wavefronts before mine, then the lanes before mine
+        Fn e = shfl_up_fn(inc[p], 1);
+        if (lane == 0) {
+            e.a = 0.0;
+            e.lo = -big;
+            e.hi = big;
+        }
+        double v = sc->tile_in[min(p, np - 1)];
+        for (int w = 0; w < wave; ++w) {
+            v = clampd(v + sc->wave_fn[w][p][0], sc->wave_fn[w][p][1], sc->wave_fn[w][p][2]);
+        }
+        din[p] = clampd(v + e.a, e.lo, e.hi);
+    }
+    const bool edge_tile = (base + kLeanTile >= task.m);
+    const int valid = (int)max(0LL, min((long long)kLeanChunk, task.m - j0));
+    const int last = (task.m - 1 >= j0 && task.m - 1 < j0 + kLeanChunk) ? (int)(task.m - 1 - j0) : -1;
+    unsigned one[PB], nz[PB];
+    if (edge_tile) {
+        chunk_classes<PB, true>(row, x, c, c_first, din, valid, last, one, nz);
+    } else {
+        chunk_classes<PB, false>(row, x, c, c_first, din, valid, last, one, nz);
+    }
+
+    unsigned zw[PB];    // kept-locus word (fill value entering the tile taken as 1)
+    bool dep[PB];       // my incoming fill value is the tile's
+    unsigned cnt0[PB], tail[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const unsigned det = one[p] | ~nz[p];
+        const bool pass = (det == 0u);
+        tail[p] = pass ? 32u : (unsigned)__builtin_ctz(det);
+        const unsigned long long sum0 = (unsigned long long)nz[p] + (unsigned long long)one[p];
+        const unsigned z0 = (unsigned)((sum0 ^ nz[p] ^ one[p]) >> 1);
+        cnt0[p] = (unsigned)__builtin_popcount(z0);
+        const bool v = (z0 >> 31) != 0u;
+        const unsigned long long pass_b = __ballot(pass), v_b = __ballot(v);
+        // first lane to my right that does not copy
+        const unsigned long long right = (lane == 63) ? 0ull : (~pass_b & (~0ull << (lane + 1)));
+        const bool in_wave = (right != 0ull);
+        const unsigned zin_wave = in_wave ? (unsigned)((v_b >> __builtin_ctzll(right)) & 1ull) : 0u;
+        if (lane == 0) {
+            sc->wave_pass[wave][p] = (unsigned char)(pass_b == ~0ull);
+            sc->wave_v[wave][p] = (pass_b == ~0ull) ? 0 : (unsigned char)((v_b >> __builtin_ctzll(~pass_b)) & 1ull);
+        }
+        zw[p] = zin_wave;       // (temporarily: the fill value found inside the wavefront)
+        dep[p] = !in_wave;      // (temporarily: not found inside the wavefront)
+    }
+    __syncthreads();
+    unsigned cells_lane[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        unsigned zin = zw[p];
+        bool d = dep[p];
+        if (d) {
+            for (int w = wave + 1; w < 4; ++w) {
+                if (!sc->wave_pass[w][p]) {
+                    zin = sc->wave_v[w][p];
+                    d = false;
+                    break;
+                }
+            }
+        }
+        dep[p] = d;
+        const unsigned zeff = d ? 1u : zin;
+        const unsigned long long sum = (unsigned long long)nz[p] + (unsigned long long)one[p] + zeff;
+        zw[p] = (unsigned)((sum ^ nz[p] ^ one[p]) >> 1);
+        if (!d) {
+            cnt0[p] += tail[p] * zin;
+            tail[p] = 0u;
+        }
+        if (lane == 0) {
+            sc->first_word[wave][p] = zw[p];
+        }
+        if (t == kLeanThreads - 1) {
+            sc->last_word[p] = zw[p];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        // run ends inside the tile: kept locus whose right neighbour is not kept (the neighbour of the tile's
+        // last locus is taken as kept; the finish kernel settles tile borders); no separator follows the
+        // chain's last locus
+        unsigned nxt = __shfl_down(zw[p], 1);
+        if (lane == 63) {
+            nxt = (wave < 3) ? sc->first_word[wave + 1][p] : 0x80000000u;
+        }
+        unsigned ends = zw[p] & ~((zw[p] << 1) | (nxt >> 31));
+        if (last >= 0) {
+            ends &= ~(0x80000000u >> last);
+        }
+        cells_lane[p] = (unsigned)__builtin_popcount(zw[p]) + (unsigned)__builtin_popcount(ends);
+    }
+
+    // ---- 5. per tile and penalty ----
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        unsigned b = cnt0[p], tl = tail[p], ce = cells_lane[p];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            b += __shfl_down(b, off);
+            tl += __shfl_down(tl, off);
+            ce += __shfl_down(ce, off);
+        }
+        if (lane == 0 && p < np) {
+            atomicAdd(&sc->red[p][0], b);
+            atomicAdd(&sc->red[p][1], tl);
+            atomicAdd(&sc->red[p][2], ce);
+        }
+        if (p < np) {
+            L.bits[task.bits_begin + ((long long)(p0 + p) * task.n_tiles + tile) * kLeanThreads + t] = zw[p];
+        }
+    }
+    __syncthreads();
+    if (t < np) {
+        const int p = t;
+        bool all_pass = true;
+        unsigned v = 0u;
+        for (int w = 0; w < 4; ++w) {
+            if (!sc->wave_pass[w][p]) {
+                all_pass = false;
+                v = sc->wave_v[w][p];
+                break;
+            }
+        }
+        LeanTileRec r;
+        r.base = sc->red[p][0];
+        r.tail = sc->red[p][1];
+        r.cells = sc->red[p][2];
+        const unsigned firstw = sc->first_word[0][p];
+        r.flags = (all_pass ? 1u : 0u) | (v << 1) | ((firstw >> 31) << 2) | ((sc->last_word[p] & 1u) << 3);
+        L.recs[(long long)task.rec_begin + (long long)(p0 + p) * task.n_tiles + tile] = r;
+    }
+}
+
+// One wavefront per (task, penalty): close the fill across tiles, lay out the compaction.
+__global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pairs)
+{
+    const int pair = blockIdx.x;
+    if (pair >= n_pairs) {
+        return;
+    }
+    int ti = 0, acc = 0;
+    while (ti + 1 < L.n_tasks && acc + L.tasks[ti].n_points <= pair) {
+        acc += L.tasks[ti].n_points;
+        ++ti;
+    }
+    const LeanTask task = L.tasks[ti];
+    const int p = pair - acc;
+    const int lane = threadIdx.x;
+    const LeanTileRec *recs = L.recs + (long long)task.rec_begin + (long long)p * task.n_tiles;
+    const int nt = task.n_tiles;
+
+    // backward: fill value entering every tile from the right
+    unsigned carry = 0u;  // beyond the chain's end (the last locus never copies)
+    unsigned long long total = 0ull;
+    for (int hi = nt; hi > 0; hi -= 64) {
+        const int k = hi - 64 + lane;  // lanes ascend with the tiles
+        LeanTileRec r = {0u, 0u, 0u, 1u};
+        if (k >= 0) {
+            r = recs[k];
+        }
+        const bool pass = (r.flags & 1u) != 0u;
+        const bool v = (r.flags & 2u) != 0u;
+        const unsigned long long pass_b = __ballot(pass), v_b = __ballot(v);
+        const unsigned long long right = (lane == 63) ? 0ull : (~pass_b & (~0ull << (lane + 1)));
+        const unsigned zin = right ? (unsigned)((v_b >> __builtin_ctzll(right)) & 1ull) : carry;
+        unsigned long long part = (k >= 0) ? ((unsigned long long)r.base + (unsigned long long)r.tail * zin) : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            part += __shfl_down(part, off);
+        }
+        total += __shfl(part, 0);
+        if (~pass_b != 0ull) {
+            carry = (unsigned)((v_b >> __builtin_ctzll(~pass_b)) & 1ull);
+        }
+    }
+
+    // forward: offsets of the tiles in the compacted array
+    unsigned *off_out = L.tile_off + task.off_begin + (long long)p * nt;
+    const unsigned lead = ((recs[0].flags >> 2) & 1u) ? 0u : 1u;  // a separator leads unless locus 0 is kept
+    unsigned long long running = lead;
+    for (int lo = 0; lo < nt; lo += 64) {
+        const int k = lo + lane;
+        unsigned cells = 0u;
+        if (k < nt) {
+            const LeanTileRec r = recs[k];
+            cells = r.cells;
+            if (k + 1 < nt) {
+                const unsigned next_first = (recs[k + 1].flags >> 2) & 1u;
+                cells += ((r.flags >> 3) & 1u) & (next_first ^ 1u);  // run end at the tile's last locus
+            }
+        }
+        unsigned incl = cells;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned u = __shfl_up(incl, off);
+            if (lane >= off) {
+                incl += u;
+            }
+        }
+        if (k < nt) {
+            off_out[k] = (unsigned)(running + incl - cells);
+        }
+        running += __shfl(incl, 63);
+    }
+    if (lane == 0) {
+        LeanResult res;
+        res.count = (long long)total;
+        res.child_len = (long long)running;
+        L.results[task.result_begin + p] = res;
+    }
+}
+
+__global__ __launch_bounds__(kLeanThreads) void lean_compact_kernel(const LeanCompactTask *tasks, int n_tasks,
+                                                                    unsigned *error)
+{
+    __shared__ unsigned wave_sum[4];
+    int ti = 0;
+    while (ti + 1 < n_tasks && tasks[ti + 1].block_begin <= (int)blockIdx.x) {
+        ++ti;
+    }
+    const LeanCompactTask task = tasks[ti];
+    const int tile = (int)blockIdx.x - task.block_begin;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned z = task.bits[(long long)tile * kLeanThreads + t];
+    unsigned nxt;
+    if (t + 1 < kLeanThreads) {
+        nxt = task.bits[(long long)tile * kLeanThreads + t + 1];
+    } else if (tile + 1 < task.n_tiles) {
+        nxt = task.bits[(long long)(tile + 1) * kLeanThreads];
+    } else {
+        nxt = 0x80000000u;  // (beyond the chain's end: never a run end, see below)
+    }
+    const long long j0 = (long long)tile * kLeanTile + (long long)t * kLeanChunk;
+    unsigned ends = z & ~((z << 1) | (nxt >> 31));
+    if (task.m - 1 >= j0 && task.m - 1 < j0 + kLeanChunk) {
+        ends &= ~(0x80000000u >> (int)(task.m - 1 - j0));  // no separator after the chain's last locus
+    }
+    const unsigned cells = (unsigned)__builtin_popcount(z) + (unsigned)__builtin_popcount(ends);
+    unsigned incl = cells;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned u = __shfl_up(incl, off);
+        if (lane >= off) {
+            incl += u;
+        }
+    }
+    if (lane == 63) {
+        wave_sum[wave] = incl;
+    }
+    __syncthreads();
+    unsigned before = 0u;
+    for (int w = 0; w < wave; ++w) {
+        before += wave_sum[w];
+    }
+    long long pos = (long long)task.tile_off[tile] + before + incl - cells;
+    if (tile == 0 && t == 0 && pos == 1) {
+        task.out_s[0] = task.sep;  // leading separator
+        task.out_orig[0] = -1;
+    }
+    if (pos + cells > task.capacity) {
+        if (cells != 0u) {
+            atomicOr(error, 2u);
+        }
+        return;
+    }
+    unsigned rest = z;
+    while (rest != 0u) {
+        const int r = 31 - __builtin_clz(rest);
+        rest &= ~(1u << r);
+        const long long j = j0 + (31 - r);
+        task.out_s[pos] = task.s[j];
+        task.out_orig[pos] = (task.orig != nullptr) ? task.orig[j] : (int)j;
+        ++pos;
+        if ((ends >> r) & 1u) {
+            task.out_s[pos] = task.sep;
+            task.out_orig[pos] = -1;
+            ++pos;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lean_scatter_kernel(const uint8_t *__restrict__ level, const int *__restrict__ orig,
+                                                           long long m, uint8_t *__restrict__ full)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) {
+        const int o = orig[i];
+        if (o >= 0) {
+            full[o] = level[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kLeanThreads, 2) void lean_eval_kernel(LeanLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *lds = smem;
+    Scratch *sc = reinterpret_cast<Scratch *>(smem + kTileLds);
+    const int t = threadIdx.x;
+    if (t == 0) {
+        sc->ticket = (int)(atomicAdd(L.ticket, 1u) + 1u);
+    }
+    if (t < kLeanBatch * 4) {
+        (&sc->red[0][0])[t] = 0u;
+    }
+    __syncthreads();
+    const int ticket = sc->ticket;
+    if (ticket >= L.n_units) {
+        return;
+    }
+    int ti = 0;
+    while (ti + 1 < L.n_tasks && L.tasks[ti + 1].unit_begin <= ticket) {
+        ++ti;
+    }
+    const LeanTask task = L.tasks[ti];
+    const int unit = ticket - task.unit_begin;
+    const int tile = unit / task.n_groups, group = unit % task.n_groups;
+    const int p0 = group * kLeanBatch;
+    const int np = min(kLeanBatch, task.n_points - p0);
+    stage_tile(task.s, task.m, (long long)tile * kLeanTile, task.magic, lds);
+    // penalties of this workgroup, in registers: 1, 2, 4 or 8 interleaved chains per lane
+    if (np > 4) {
+        eval_body<8>(L, task, tile, p0, np, lds, sc);
+    } else if (np > 2) {
+        eval_body<4>(L, task, tile, p0, np, lds, sc);
+    } else if (np > 1) {
+        eval_body<2>(L, task, tile, p0, np, lds, sc);
+    } else {
+        eval_body<1>(L, task, tile, p0, np, lds, sc);
+    }
+}
+
+int launch_eval_all(const LeanLaunch &L, hipStream_t stream)
+{
+    static bool configured = false;
+    const size_t lds = (size_t)kTileLds * sizeof(double) + sizeof(Scratch);
+    if (!configured) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lean_eval_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(lean_eval_kernel, dim3((unsigned)L.n_units), dim3(kLeanThreads), lds, stream, L);
+    return ROCCO_HIP_OK;
+}
+
+}  // namespace
+
+int launch_lean_eval(const LeanLaunch &L, hipStream_t stream)
+{
+    if (L.n_units <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    int rc = launch_eval_all(L, stream);
+    if (rc != ROCCO_HIP_OK) {
+        return rc;
+    }
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_finish(const LeanLaunch &L, int n_pairs, hipStream_t stream)
+{
+    if (n_pairs <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    hipLaunchKernelGGL(lean_finish_kernel, dim3((unsigned)n_pairs), dim3(64), 0, stream, L, n_pairs);
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_compact(const LeanCompactTask *tasks_dev, int n_tasks, int n_blocks, unsigned *error_dev, hipStream_t stream)
+{
+    if (n_blocks <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    hipLaunchKernelGGL(lean_compact_kernel, dim3((unsigned)n_blocks), dim3(kLeanThreads), 0, stream, tasks_dev, n_tasks,
+                       error_dev);
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_scatter(const uint8_t *solution_level, const int *orig, long long m, uint8_t *solution_full, hipStream_t stream)
+{
+    if (m <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    hipLaunchKernelGGL(lean_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, solution_level, orig, m,
+                       solution_full);
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+}  // namespace rocco

@@ -82,6 +82,8 @@ struct State {
     // >= x + eps.  G / L are the best such certified thresholds; every bracket or bisection step of the
     // reference whose penalty lies outside (G, L) is then decided on the host for free.
     bool searching = false;
+    bool want_compact = false;  // the search has ended: restrict the problem to the loci that can still be selected
+    bool compacted = false;
     bool bound_round = false;  // the probe request in flight belongs to the threshold search
     double eps = 0.0;
     double G = 0.0, L = 0.0;
@@ -310,9 +312,11 @@ bool fast_path_applicable(const ChainProblem &p)
     return p.n >= 1;
 }
 
-int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
+int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     const SearchOptions &opt, std::vector<CalibrationResult> &results)
 {
+    // (a compaction replaces a problem's arrays: its length and score floor change on the way)
+    std::vector<ChainProblem> problems(problems_in);
     const size_t B = problems.size();
     std::vector<State> st(B);
     for (size_t b = 0; b < B; ++b) {
@@ -342,8 +346,9 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
         std::vector<ExactRequest> exacts;
         std::vector<MapRequest> maps;
         std::vector<SpineRequest> spines;
-        std::vector<size_t> probe_owner, window_owner, exact_owner, map_owner, spine_owner;
+        std::vector<size_t> probe_owner, window_owner, exact_owner, map_owner, spine_owner, compact_owner;
         std::vector<WindowRequest> surveys;
+        std::vector<CompactRequest> compacts;
 
         // speculation depth of this iteration's probe rounds, from the loci they will cover
         double round_loci = 0.0;
@@ -372,8 +377,9 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 const double width = s.L - s.G;
                 // evaluations per round: a pass over many loci is dominated by the evaluations themselves
                 // (two per round are cheapest per bit), a small one by its fixed launch + sync cost
-                const int points = (round_loci > 30.0e6) ? opt.search_points
-                                                         : ((round_loci > 12.0e6) ? opt.search_points + 1 : opt.search_points + 3);
+                const int points_default = (round_loci > 30.0e6) ? opt.search_points
+                                                                 : ((round_loci > 12.0e6) ? opt.search_points + 1 : opt.search_points + 3);
+                const int points = std::max(1, std::min(32, ev.bound_points(b, points_default)));
                 std::vector<double> fr;
                 for (int k = 1; k <= points; ++k) {
                     fr.push_back((double)k / (double)(points + 1));
@@ -400,8 +406,19 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     continue;
                 }
                 s.searching = false;  // (G, L) is as narrow as eps allows
+                s.want_compact = opt.use_compaction && s.G_real && !s.compacted && ev.can_compact(b);
                 advance_analytic(p, s);
                 bracket_counts_from_evals(p, s);
+            }
+            if (s.want_compact) {
+                // every penalty still to be asked about lies at or above G = (evaluated point) - eps, and the
+                // reference's selection there lies inside the exact one at G - eps
+                CompactRequest r;
+                r.problem = b;
+                r.lambda_base = s.G - s.eps;
+                compacts.push_back(r);
+                compact_owner.push_back(b);
+                continue;
             }
             advance_analytic(p, s);
             if (s.phase == State::kBisect && s.iters_left <= 0) {
@@ -599,12 +616,25 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 break;
             }
         }
-        if (probes.empty() && windows.empty() && exacts.empty() && maps.empty() && spines.empty()) {
+        if (probes.empty() && windows.empty() && exacts.empty() && maps.empty() && spines.empty() && compacts.empty()) {
             break;
         }
         int rc;
-        if ((rc = ev.round(maps, surveys, probes, windows, spines)) != ROCCO_HIP_OK) {
+        if ((rc = ev.round_all(compacts, maps, surveys, probes, windows, spines)) != ROCCO_HIP_OK) {
             return rc;
+        }
+        for (size_t q = 0; q < compacts.size(); ++q) {
+            const size_t b = compact_owner[q];
+            State &s = st[b];
+            ++s.out.passes;
+            s.want_compact = false;
+            if (compacts[q].done) {
+                s.compacted = true;
+                ChainProblem &p = problems[b];
+                p.n = compacts[q].n_new;
+                p.score_min = std::min(p.score_min, compacts[q].score_floor);
+                s.lower_count = std::min(s.lower_count, (long long)p.n);
+            }
         }
         for (size_t q = 0; q < maps.size(); ++q) {
             State &s = st[map_owner[q]];
@@ -699,6 +729,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                     // few loci can still change between the thresholds: from here on the rounding model
                     // with its frozen blocks (rounds that skip the settled parts) is cheaper
                     s.searching = false;
+                    s.want_compact = opt.use_compaction && s.G_real && !s.compacted && ev.can_compact(probe_owner[q]);
                     advance_analytic(p, s);
                     bracket_counts_from_evals(p, s);
                 }

@@ -80,6 +80,21 @@ struct MapRequest {
     double margin = 0.0;
 };
 
+// Restrict a problem to the loci that can still be selected at any penalty >= lambda_base (DESIGN.md
+// section 4.7): in exact arithmetic on the grid q the selected sets are nested in the penalty, and the
+// reference's own selection at a penalty lambda lies inside the exact one at lambda - eps.  The evaluator
+// replaces the problem's arrays by the compacted runs (separated by loci no penalty >= lambda_base can
+// select); every later request of that problem is answered on the compacted arrays, and the solution
+// is scattered back when the calibration ends.
+struct CompactRequest {
+    size_t problem = 0;
+    double lambda_base = 0.0;
+    // filled by the evaluator
+    bool done = false;
+    size_t n_new = 0;           // loci of the compacted problem (separators included)
+    double score_floor = 0.0;   // score of the separator loci (<= every other score that matters)
+};
+
 struct ExactRequest {
     size_t problem = 0;
     std::vector<double> lambdas;  // <= 64
@@ -138,6 +153,34 @@ public:
         if (!spines.empty() && (rc = spine(spines)) != 0) return rc;
         return 0;
     }
+    // Compaction (optional): an evaluator that cannot compact leaves `done` false.
+    virtual bool can_compact(size_t problem) const
+    {
+        (void)problem;
+        return false;
+    }
+    virtual int compact(std::vector<CompactRequest> &reqs)
+    {
+        (void)reqs;
+        return 0;
+    }
+    // One search iteration including compactions (which touch no other request of the iteration).
+    virtual int round_all(std::vector<CompactRequest> &compacts, std::vector<MapRequest> &maps,
+                          std::vector<WindowRequest> &surveys, std::vector<ProbeRequest> &probes,
+                          std::vector<WindowRequest> &windows, std::vector<SpineRequest> &spines)
+    {
+        int rc;
+        if (!compacts.empty() && (rc = compact(compacts)) != 0) return rc;
+        if (maps.empty() && surveys.empty() && probes.empty() && windows.empty() && spines.empty()) return 0;
+        return round(maps, surveys, probes, windows, spines);
+    }
+    // Evaluations per threshold-search round of this problem (an evaluator whose exact-arithmetic
+    // counts are cheap may ask for more than the default).
+    virtual int bound_points(size_t problem, int default_points) const
+    {
+        (void)problem;
+        return default_points;
+    }
     // Fraction of a problem's loci that rounds inside the surveyed bracket still evaluate.
     virtual double work_fraction(size_t problem) const
     {
@@ -192,6 +235,7 @@ struct SearchOptions {
     int exact_depth = 6;    // same for the exact kernel (63 lanes)
     bool force_exact = false;
     bool use_spine = true;  // finish undecided endgames through the exact spine (else the exact kernel)
+    bool use_compaction = true;  // after the threshold search: continue on the loci that can still be selected
 };
 
 // Calibrate every problem of the batch; solutions are left in the evaluator's solution buffers.

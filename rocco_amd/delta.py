@@ -42,6 +42,27 @@ def delta_probe_device(scores_t, switch_costs, lambdas: Sequence[float], emap_t=
              "max_run": int(s.max_run)} for s in stats[:len(lambdas)]]
 
 
+def delta_bound_rounds_device(scores_t, gamma: float, rounds: Sequence[Sequence[float]]):
+    """Exact-arithmetic counts (rocco_hip_delta_bound_rounds_f64) for rounds of penalties; returns per round
+    (penalties as evaluated, counts, loci of the array the round ran on)."""
+    n = int(scores_t.shape[0])
+    flat = [float(x) for r in rounds for x in r]
+    sizes = (ctypes.c_int * len(rounds))(*[len(r) for r in rounds])
+    lam = (ctypes.c_double * max(1, len(flat)))(*flat)
+    used = (ctypes.c_double * max(1, len(flat)))()
+    counts = (ctypes.c_longlong * max(1, len(flat)))()
+    lens = (ctypes.c_longlong * max(1, len(rounds)))()
+    solver = _native.solver_for(scores_t.device.index)
+    _native.check(_native.load().rocco_hip_delta_bound_rounds_f64(
+        solver.handle, scores_t.data_ptr(), float(gamma), n, lam, sizes, len(rounds), used, counts, lens,
+        _dp._stream_ptr(scores_t)), "rocco_hip_delta_bound_rounds_f64")
+    out, at = [], 0
+    for k, r in enumerate(rounds):
+        out.append((list(used[at:at + len(r)]), [int(c) for c in counts[at:at + len(r)]], int(lens[k])))
+        at += len(r)
+    return out
+
+
 def delta_window_device(scores_t, switch_costs, lambda_lo: float, lambda_hi: float, emap_t=None):
     import torch
 

@@ -25,6 +25,15 @@ struct HostProblem {
     double cmax, sabs;
     uint8_t *solution;
     std::vector<uint8_t> emap;  // empty = no map
+    // compaction (CompactRequest): the arrays above then point into these
+    const double *orig_scores = nullptr;
+    size_t orig_n = 0;
+    uint8_t *orig_solution = nullptr;
+    std::vector<double> c_scores;
+    std::vector<long long> c_orig;  // original locus of every compacted locus (-1: separator)
+    std::vector<uint8_t> c_solution;
+    bool compacted = false;
+    bool solution_in_orig = false;  // the exact evaluator wrote the original buffer directly
 };
 
 int grid_exponent(double cmax, double smin, double smax)
@@ -37,6 +46,113 @@ class OracleEvaluator : public Evaluator {
 public:
     std::vector<HostProblem> hp;
     long long probe_calls = 0, window_calls = 0, exact_calls = 0, exact_lambdas = 0, map_calls = 0, spine_calls = 0;
+    long long compact_calls = 0;
+    int compact_tile = 0;  // > 0: keep trailing COPY runs of every tile of this many loci (what the device kernels do)
+    bool allow_compact = true;
+
+    bool can_compact(size_t problem) const override
+    {
+        return allow_compact && hp[problem].costs == nullptr && !hp[problem].compacted;
+    }
+
+    // Selected set at lambda_base in exact arithmetic on the grid q (the recursion of oracle/delta_oracle.c
+    // without a map, i.e. what a bound evaluation computes), optionally widened by the trailing COPY runs of
+    // every tile; then the compacted arrays: runs of that set, separated by one locus that no penalty >=
+    // lambda_base can select.
+    int compact(std::vector<CompactRequest> &reqs) override
+    {
+        ++compact_calls;
+        for (CompactRequest &r : reqs) {
+            HostProblem &p = hp[r.problem];
+            if (p.costs != nullptr || p.compacted) {
+                continue;
+            }
+            const size_t n = p.n;
+            const double magic = std::ldexp(1.5, 52 + p.qexp);
+            auto rq = [magic](double x) {
+                volatile double t = x + magic;
+                return t - magic;
+            };
+            const double c = rq(p.gamma);
+            std::vector<uint8_t> cls(n), act(n);
+            double d = 0.0;
+            for (size_t j = 0; j < n; ++j) {
+                const double a = rq(p.scores[j] - r.lambda_base);
+                d = (j == 0) ? a : std::fmin(std::fmax(d, -c), c) + a;
+                if (j + 1 < n) {
+                    cls[j] = (d > c) ? 2 : ((d <= -c) ? 0 : 1);
+                } else {
+                    cls[j] = (d > 0.0) ? 2 : 0;
+                }
+            }
+            uint8_t state = 0;
+            for (size_t j = n; j-- > 0;) {
+                if (compact_tile > 0 && (j + 1) % (size_t)compact_tile == 0 && j + 1 < n) {
+                    state = 1;  // fill value entering a tile from the right: unknown to the device, taken as 1
+                }
+                if (cls[j] != 1) {
+                    state = (uint8_t)(cls[j] == 2);
+                }
+                act[j] = state;
+            }
+            const double sep = std::floor(r.lambda_base - 2.0 * p.cmax - 2.0);
+            p.c_scores.clear();
+            p.c_orig.clear();
+            for (size_t j = 0; j < n; ++j) {
+                if (act[j]) {
+                    if (j > 0 && !act[j - 1] && p.c_scores.empty()) {
+                        p.c_scores.push_back(sep);  // leading separator: the first run does not start the chain
+                        p.c_orig.push_back(-1);
+                    }
+                    p.c_scores.push_back(p.scores[j]);
+                    p.c_orig.push_back((long long)j);
+                    if (j + 1 < n && !act[j + 1]) {
+                        p.c_scores.push_back(sep);
+                        p.c_orig.push_back(-1);
+                    }
+                }
+            }
+            if (p.c_scores.empty()) {
+                p.c_scores.push_back(sep);
+                p.c_orig.push_back(-1);
+            }
+            p.orig_scores = p.scores;
+            p.orig_n = p.n;
+            p.orig_solution = p.solution;
+            p.c_solution.assign(p.c_scores.size(), 0);
+            p.scores = p.c_scores.data();
+            p.n = p.c_scores.size();
+            p.solution = p.c_solution.data();
+            p.emap.clear();
+            double smin = p.scores[0], smax = p.scores[0];
+            for (size_t i = 1; i < p.n; ++i) {
+                smin = std::fmin(smin, p.scores[i]);
+                smax = std::fmax(smax, p.scores[i]);
+            }
+            p.qexp = grid_exponent(p.cmax, smin, smax);
+            p.sabs = std::fmax(std::fabs(smin), std::fabs(smax));
+            p.compacted = true;
+            r.done = true;
+            r.n_new = p.n;
+            r.score_floor = sep;
+        }
+        return 0;
+    }
+
+    // compacted problems: copy the solution back to the caller's buffer (zero outside the compacted runs)
+    void scatter(size_t problem)
+    {
+        HostProblem &p = hp[problem];
+        if (!p.compacted || p.solution_in_orig) {
+            return;
+        }
+        std::memset(p.orig_solution, 0, p.orig_n);
+        for (size_t i = 0; i < p.n; ++i) {
+            if (p.c_orig[i] >= 0) {
+                p.orig_solution[p.c_orig[i]] = p.c_solution[i];
+            }
+        }
+    }
 
     int probe(std::vector<ProbeRequest> &reqs) override
     {
@@ -125,15 +241,22 @@ public:
     {
         ++exact_calls;
         for (ExactRequest &r : reqs) {
-            const HostProblem &p = hp[r.problem];
+            HostProblem &p = hp[r.problem];
             r.results.resize(r.lambdas.size());
             exact_lambdas += (long long)r.lambdas.size();
+            // the exact evaluator is the last resort: always on the caller's own arrays
+            const double *sc = p.compacted ? p.orig_scores : p.scores;
+            const size_t nn = p.compacted ? p.orig_n : p.n;
+            uint8_t *sol = p.compacted ? p.orig_solution : p.solution;
+            if (r.write_solution && p.compacted) {
+                p.solution_in_orig = true;
+            }
             for (size_t i = 0; i < r.lambdas.size(); ++i) {
                 double v = 0.0;
                 long long c = 0;
                 const int rc = oracle_solve_penalized_chain_f64(
-                    p.scores, p.costs, p.gamma, p.n, r.lambdas[i],
-                    (r.write_solution && i == 0) ? p.solution : nullptr, &v, &c);
+                    sc, p.costs, p.gamma, nn, r.lambdas[i],
+                    (r.write_solution && i == 0) ? sol : nullptr, &v, &c);
                 if (rc != 0) return rc;
                 r.results[i].value = v;
                 r.results[i].count = c;
@@ -143,7 +266,13 @@ public:
     }
     int penalized_value(size_t problem, double lambda, long long count, double *value_out) override
     {
+        scatter(problem);
         const HostProblem &p = hp[problem];
+        if (p.compacted) {
+            const double obj = oracle_objective_value_f64(p.orig_solution, p.orig_scores, p.costs, p.gamma, p.orig_n);
+            *value_out = -obj - lambda * (double)count;
+            return 0;
+        }
         const double obj = oracle_objective_value_f64(p.solution, p.scores, p.costs, p.gamma, p.n);
         *value_out = -obj - lambda * (double)count;
         return 0;
@@ -175,8 +304,17 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
         }
     }
     OracleEvaluator ev;
-    HostProblem h{scores, costs, gamma, n, grid_exponent(cmax, smin, smax), cmax,
-                  std::fmax(std::fabs(smin), std::fabs(smax)), solution, {}};
+    if (const char *e = std::getenv("ROCCO_HOSTLOGIC_COMPACT")) ev.allow_compact = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ROCCO_HOSTLOGIC_TILE")) ev.compact_tile = std::atoi(e);
+    HostProblem h;
+    h.scores = scores;
+    h.costs = costs;
+    h.gamma = gamma;
+    h.n = n;
+    h.qexp = grid_exponent(cmax, smin, smax);
+    h.cmax = cmax;
+    h.sabs = std::fmax(std::fabs(smin), std::fabs(smax));
+    h.solution = solution;
     ev.hp.push_back(h);
     ChainProblem p;
     p.n = n;
@@ -203,6 +341,8 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     std::vector<CalibrationResult> res;
     const int rc = calibrate_batch(ev, {p}, opt, res);
     if (rc != 0) return rc;
+    ev.scatter(0);
+    out_i[11] = ev.hp[0].compacted ? (long long)ev.hp[0].n : -1;
     *penalty_out = res[0].selection_penalty;
     *value_out = res[0].penalized_value;
     *count_out = res[0].selected_count;
@@ -240,8 +380,15 @@ int hostlogic_solve_fixed(const double *scores, const double *costs, double gamm
     OracleEvaluator ev;
     // penalties outside [smin - 1, smax + 1] are legal here: widen the grid range accordingly
     const double lo = std::fmin(smin, lambda), hi = std::fmax(smax, lambda);
-    HostProblem h{scores, costs, gamma, n, grid_exponent(cmax, lo, hi), cmax,
-                  std::fmax(std::fabs(smin), std::fabs(smax)), solution, {}};
+    HostProblem h;
+    h.scores = scores;
+    h.costs = costs;
+    h.gamma = gamma;
+    h.n = n;
+    h.qexp = grid_exponent(cmax, lo, hi);
+    h.cmax = cmax;
+    h.sabs = std::fmax(std::fabs(smin), std::fabs(smax));
+    h.solution = solution;
     ev.hp.push_back(h);
     ChainProblem p;
     p.n = n;

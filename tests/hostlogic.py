@@ -51,7 +51,7 @@ def calibrate(scores, gamma_or_costs, target, max_iter=60, spec_depth=2, force_e
                                    ctypes.byref(val), ctypes.byref(cnt), info)
     assert rc == 0, rc
     keys = ["path", "evaluations", "passes", "zone_iters", "n_diff", "probe_calls", "window_calls",
-            "exact_calls", "exact_lambdas", "maps", "spine_calls"]
+            "exact_calls", "exact_lambdas", "maps", "spine_calls", "compact_n"]
     return pen.value, sol, val.value, cnt.value, dict(zip(keys, [int(x) for x in info]))
 
 
