@@ -60,6 +60,13 @@ int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long va
 int rocco_hip_score_median(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K,
                            size_t n, size_t row_stride, double *scores_dev, void *stream);
 
+/* The same for `count` matrices of one K and element type in ONE launch (the chromosomes a rank owns: the
+ * call-site loop of rocco/rocco.py:948-991 over chromosomes).  matrices_dev / n / row_strides / scores_dev are
+ * host arrays of `count` entries; the results are those of `count` rocco_hip_score_median calls. */
+int rocco_hip_score_median_batch(rocco_hip_solver *solver, const void *const *matrices_dev, int dtype, size_t K,
+                                 const size_t *n, const size_t *row_strides, double *const *scores_dev, size_t count,
+                                 void *stream);
+
 /* The other branches of score_central_tendency_chrom (not reached from the reference's driver): the nearest-rank
  * quantile of rocco.py:267-272 -- `rank` (0-based position in the sorted column) is computed by the caller with
  * NumPy's own rule, np.quantile(np.arange(K), q, method="nearest") -- and the column mean of rocco.py:298-299

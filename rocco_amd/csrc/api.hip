@@ -148,6 +148,23 @@ int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long va
     return ROCCO_HIP_OK;
 }
 
+int rocco_hip_score_median_batch(rocco_hip_solver *solver, const void *const *matrices_dev, int dtype, size_t K,
+                                 const size_t *n, const size_t *row_strides, double *const *scores_dev, size_t count,
+                                 void *stream)
+{
+    if (solver == nullptr || K == 0 || (dtype != 0 && dtype != 1) ||
+        (count > 0 && (matrices_dev == nullptr || n == nullptr || row_strides == nullptr || scores_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    for (size_t i = 0; i < count; ++i) {
+        if ((n[i] > 0 && (matrices_dev[i] == nullptr || scores_dev[i] == nullptr)) || row_strides[i] < n[i]) {
+            return ROCCO_HIP_EINVAL;
+        }
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_median_batch(matrices_dev, dtype, K, n, row_strides, scores_dev, count, (hipStream_t)stream);
+}
+
 int rocco_hip_score_median(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K,
                            size_t n, size_t row_stride, double *scores_dev, void *stream)
 {

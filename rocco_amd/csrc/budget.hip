@@ -75,6 +75,8 @@ struct LeanReq {
     std::vector<double> lambdas;
     ProbeRequest *probe = nullptr;
     CompactRequest *comp = nullptr;  // final compaction at lambdas[0]
+    bool pilot = false;              // estimates from a sample of the tiles of level 0
+    double pilot_scale = 1.0;
     int result_begin = 0;
     // final compaction
     double *out_s = nullptr;
@@ -461,13 +463,39 @@ public:
         return rc;
     }
 
+    // every compacted problem of the batch in two launches (zero the callers' buffers, scatter the kept loci)
     int scatter_all()
     {
-        for (size_t b = 0; b < probs.size(); ++b) {
-            const int rc = scatter_solution(b);
-            if (rc != ROCCO_HIP_OK) return rc;
+        std::vector<LeanScatterTask> tasks;
+        int zero_blocks = 0, scatter_blocks = 0;
+        for (DevProblem &p : probs) {
+            if (!p.compacted || p.solution_in_orig || p.scattered) {
+                continue;
+            }
+            LeanScatterTask t;
+            t.level_solution = p.solution;
+            t.orig = p.lean_orig;
+            t.m = (long long)p.n;
+            t.full = p.orig_solution;
+            t.n = (long long)p.orig_n;
+            t.zero_begin = zero_blocks;
+            t.scatter_begin = scatter_blocks;
+            zero_blocks += (int)((p.orig_n + 16383) / 16384);
+            scatter_blocks += (int)((p.n + 255) / 256);
+            tasks.push_back(t);
+            p.scattered = true;
         }
-        return ROCCO_HIP_OK;
+        if (tasks.empty()) {
+            return ROCCO_HIP_OK;
+        }
+        const size_t bytes = tasks.size() * sizeof(LeanScatterTask);
+        int rc;
+        if ((rc = solver_->dev_lean_desc.reserve(bytes + 256)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_lean_stage.reserve(bytes + 256)) != ROCCO_HIP_OK) return rc;
+        std::memcpy(solver_->host_lean_stage.ptr, tasks.data(), bytes);
+        ROCCO_HIP_TRY(hipMemcpyAsync(solver_->dev_lean_desc.ptr, solver_->host_lean_stage.ptr, bytes, hipMemcpyHostToDevice, stream_));
+        return launch_lean_scatter_batch((const LeanScatterTask *)solver_->dev_lean_desc.ptr, (int)tasks.size(), zero_blocks,
+                                         scatter_blocks, stream_);
     }
 
     // the caller's view of a problem (what the objective is evaluated on)
@@ -501,35 +529,50 @@ public:
     int penalized_values(const std::vector<size_t> &which, const std::vector<double> &lambdas,
                          const std::vector<long long> &counts, std::vector<double> &values) override
     {
-        // every objective on the stream, one synchronisation
+        // every objective in two launches, on the arrays the solution lives in (a compacted problem's kept loci
+        // carry the same scores and the same transitions as the caller's array), one synchronisation; the
+        // compacted solutions are scattered to the callers' buffers on the way
         const size_t W = which.size();
         values.assign(W, 0.0);
-        size_t total = 0;
-        std::vector<size_t> off(W);
         int rc;
-        for (size_t i = 0; i < W; ++i) {
-            if ((rc = scatter_solution(which[i])) != ROCCO_HIP_OK) return rc;
-            off[i] = total;
-            total += align_up(objective_scratch_bytes(caller_view(which[i]).n), 256);
+        if ((rc = scatter_all()) != ROCCO_HIP_OK) return rc;
+        if (W == 0) {
+            return ROCCO_HIP_OK;
         }
-        if ((rc = solver_->dev_misc.reserve(total + 256)) != ROCCO_HIP_OK) return rc;
-        if ((rc = solver_->host_back.reserve(W * sizeof(double) + 64)) != ROCCO_HIP_OK) return rc;
-        double *back = (double *)solver_->host_back.ptr;
+        std::vector<ObjectiveTask> tasks(W);
+        long long tiles = 0;
         for (size_t i = 0; i < W; ++i) {
-            const DevProblem p = caller_view(which[i]);
-            rc = launch_objective(p.solution, p.scores, p.costs, p.gamma, p.n, (char *)solver_->dev_misc.ptr + off[i],
-                                  back + i, stream_, false);
-            if (rc != ROCCO_HIP_OK) {
-                return rc;
-            }
+            const DevProblem &p = probs[which[i]];
+            const bool on_level = p.compacted && !p.solution_in_orig;
+            tasks[i].solution = on_level ? p.solution : (p.compacted ? p.orig_solution : p.solution);
+            tasks[i].scores = on_level ? p.scores : (p.compacted ? p.orig_scores : p.scores);
+            tasks[i].switch_costs = p.costs;
+            tasks[i].gamma = p.gamma;
+            tasks[i].n = (long long)(on_level ? p.n : (p.compacted ? p.orig_n : p.n));
+            tasks[i].tile_begin = tiles;
+            tiles += objective_tiles((size_t)tasks[i].n);
         }
+        const size_t b_tasks = align_up(W * sizeof(ObjectiveTask), 256);
+        const size_t b_part = align_up((size_t)(2 * tiles + 2) * sizeof(double), 256);
+        const size_t b_out = align_up(W * sizeof(double), 256);
+        if ((rc = solver_->dev_misc.reserve(b_tasks + b_part + b_out)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_stage.reserve(b_tasks)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_back.reserve(b_out)) != ROCCO_HIP_OK) return rc;
+        char *dv = (char *)solver_->dev_misc.ptr;
+        std::memcpy(solver_->host_stage.ptr, tasks.data(), W * sizeof(ObjectiveTask));
+        ROCCO_HIP_TRY(hipMemcpyAsync(dv, solver_->host_stage.ptr, W * sizeof(ObjectiveTask), hipMemcpyHostToDevice, stream_));
+        if ((rc = launch_objective_batch((const ObjectiveTask *)dv, (int)W, tiles, (double *)(dv + b_tasks),
+                                         (double *)(dv + b_tasks + b_part), stream_)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        ROCCO_HIP_TRY(hipMemcpyAsync(solver_->host_back.ptr, dv + b_tasks + b_part, W * sizeof(double), hipMemcpyDeviceToHost, stream_));
         ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        const double *back = (const double *)solver_->host_back.ptr;
         for (size_t i = 0; i < W; ++i) {
             values[i] = -back[i] - lambdas[i] * (double)counts[i];
         }
         return ROCCO_HIP_OK;
     }
-
 
     // ---- lean evaluation (lean.h): threshold-search rounds on compacted levels, final compaction ----
     std::vector<LeanState> lean_;
@@ -545,6 +588,13 @@ public:
     }
 
     bool can_compact(size_t problem) const override { return lean_eligible(problem); }
+
+    static constexpr long long kPilotMinTiles = 128;
+
+    bool can_pilot(size_t problem) const override
+    {
+        return lean_eligible(problem) && (long long)((probs[problem].n + kLeanTile - 1) / kLeanTile) >= kPilotMinTiles;
+    }
 
     int bound_points(size_t problem, int default_points) const override
     {
@@ -622,6 +672,44 @@ public:
                 l0.m = (long long)p.n;
                 l0.pool_mark = ls.pool_at;
                 ls.levels.push_back(l0);
+            }
+            if (r.pilot) {
+                // every stride-th tile of the caller's array, each as a chain of its own; nothing is kept
+                const long long all_tiles = (long long)((p.n + kLeanTile - 1) / kLeanTile);
+                const int stride = (int)std::max(4LL, all_tiles / 16);  // about 16 tiles per chromosome
+                const int nt = (int)((all_tiles + stride - 1) / stride);
+                long long sampled = 0;
+                for (int k = 0; k < nt; ++k) {
+                    const long long at = (long long)k * stride * kLeanTile;
+                    sampled += std::min((long long)kLeanTile, (long long)p.n - at);
+                }
+                r.pilot_scale = (double)p.n / (double)std::max(1LL, sampled);
+                const int np = (int)r.lambdas.size();
+                LeanTask t;
+                t.s = p.scores;
+                t.m = (long long)p.n;
+                t.c_raw = p.gamma;
+                t.magic = std::ldexp(1.5, 52 + p.qexp);
+                t.big = std::ldexp(1.0, 50 + p.qexp);
+                t.n_tiles = nt;
+                t.n_points = np;
+                t.n_groups = (np + kLeanBatch - 1) / kLeanBatch;
+                t.unit_begin = units;
+                t.point_begin = (int)points.size();
+                t.rec_begin = recs;
+                t.bits_begin = 0;
+                t.off_begin = 0;
+                t.result_begin = results;
+                t.tile_stride = stride;
+                t.independent = 1;
+                t.pad = 0;
+                r.result_begin = results;
+                units += nt * t.n_groups;
+                recs += nt * np;
+                results += np;
+                points.insert(points.end(), r.lambdas.begin(), r.lambdas.end());
+                tasks.push_back(t);
+                continue;
             }
             const double lam_min = *std::min_element(r.lambdas.begin(), r.lambdas.end());
             while (ls.levels.size() > 1 && ls.levels.back().base > lam_min) {
@@ -702,6 +790,8 @@ public:
             t.bits_begin = (long long)(lv.bits - pool_words);
             t.off_begin = (long long)(lv.tile_off - pool_words);
             t.result_begin = results;
+            t.tile_stride = 1;
+            t.independent = 0;
             t.pad = 0;
             r.result_begin = results;
             units += nt * t.n_groups;
@@ -811,6 +901,13 @@ public:
         for (LeanReq &r : lean_inflight_) {
             DevProblem &p = probs[r.problem];
             LeanState &ls = lean_[r.problem];
+            if (r.pilot) {
+                r.probe->results.assign(r.lambdas.size(), ProbeResult());
+                for (size_t i = 0; i < r.lambdas.size(); ++i) {
+                    r.probe->results[i].count = (long long)std::llround((double)res[r.result_begin + (int)i].count * r.pilot_scale);
+                }
+                continue;
+            }
             LeanLevel &lv = ls.levels.back();
             const size_t np = r.lambdas.size();
             lv.pts = r.lambdas;
@@ -896,6 +993,7 @@ public:
                 r.problem = q.problem;
                 r.lambdas = q.lambdas;
                 r.probe = &q;
+                r.pilot = q.pilot && can_pilot(q.problem);
                 reqs.push_back(r);
             }
         }
@@ -1731,6 +1829,8 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     std::vector<CalibrationResult> res;
     const double t_solve0 = HipEvaluator::now_us();
     if (const char *e = std::getenv("ROCCO_HIP_COMPACT")) opt.use_compaction = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ROCCO_HIP_PILOT_ROUNDS")) opt.pilot_rounds = std::atoi(e);
+    if (const char *e = std::getenv("ROCCO_HIP_PILOT_POINTS")) opt.pilot_points = std::atoi(e);
     if (const char *e = std::getenv("ROCCO_HIP_LEAN")) solver->lean = std::atoi(e) != 0;
     if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
     if ((rc = ev.scatter_all()) != ROCCO_HIP_OK) return rc;

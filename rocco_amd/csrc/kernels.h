@@ -26,6 +26,24 @@ int launch_chain_exact(const ExactTask *tasks_dev, int n_tasks, hipStream_t stre
 int launch_median(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride,
                   double *scores_dev, hipStream_t stream);
 
+// several matrices of one K / element type in one launch (kernel-argument task table: up to kMedianBatchMax per launch)
+constexpr int kMedianBatchMax = 48;
+struct MedianTask {
+    const void *matrix;
+    double *out;
+    long long n;
+    long long stride;
+    unsigned block_begin;
+    unsigned pad;
+};
+struct MedianBatch {
+    MedianTask tasks[kMedianBatchMax];
+    int n_tasks;
+    int K;
+};
+int launch_median_batch(const void *const *matrices_dev, int dtype, size_t K, const size_t *n, const size_t *row_strides,
+                        double *const *scores_dev, size_t count, hipStream_t stream);
+
 int launch_order_statistic(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, int rank,
                            double *scores_dev, hipStream_t stream);
 int launch_column_mean(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, double *scores_dev,
@@ -43,6 +61,20 @@ size_t objective_scratch_bytes(size_t n);
 int launch_objective(const uint8_t *solution_dev, const double *scores_dev,
                      const double *switch_costs_dev, double gamma, size_t n, void *scratch_dev,
                      double *objective_host_pinned, hipStream_t stream, bool synchronize = true);
+
+// several problems at once: tasks_dev[t].tile_begin = first tile of task t (objective_tiles(n) tiles each);
+// partial_dev: 2 * total_tiles doubles; out_dev: n_tasks doubles (no copy, no synchronisation)
+struct ObjectiveTask {
+    const uint8_t *solution;
+    const double *scores;
+    const double *switch_costs;  // n-1 or nullptr
+    double gamma;
+    long long n;
+    long long tile_begin;
+};
+long long objective_tiles(size_t n);
+int launch_objective_batch(const ObjectiveTask *tasks_dev, int n_tasks, long long total_tiles, double *partial_dev,
+                           double *out_dev, hipStream_t stream);
 
 // ---- whittaker.hip --------------------------------------------------------------------------
 // factor_dev: 6 * factor_cap doubles filled by launch_whittaker_factor for a length factor_cap >= cols and

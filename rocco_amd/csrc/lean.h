@@ -50,6 +50,8 @@ struct LeanTask {
     long long bits_begin; // offset (in words) of the task's kept-locus words: [(point) * n_tiles * 256 + tile * 256 + lane]
     long long off_begin;  // offset of the task's tile offsets: [(point) * n_tiles + tile]
     int result_begin;     // offset of the task's results: [point]
+    int tile_stride;      // 1; a pilot task evaluates every tile_stride-th tile of the array ...
+    int independent;      // ... each as a chain of its own (estimates from a sample; nothing is stored)
     int pad;
 };
 
@@ -90,6 +92,18 @@ struct LeanCompactTask {
 int launch_lean_eval(const LeanLaunch &L, hipStream_t stream);
 int launch_lean_finish(const LeanLaunch &L, int n_pairs, hipStream_t stream);
 int launch_lean_compact(const LeanCompactTask *tasks_dev, int n_tasks, int n_blocks, unsigned *error_dev, hipStream_t stream);
+// every compacted problem of a batch in two launches: zero the callers' solution buffers, then scatter
+struct LeanScatterTask {
+    const uint8_t *level_solution;
+    const int *orig;
+    long long m;          // loci of the level
+    uint8_t *full;
+    long long n;          // loci of the caller's array
+    int zero_begin;       // first workgroup of this task in the zero launch (16 KiB per workgroup)
+    int scatter_begin;    // ... and in the scatter launch (256 loci of the level per workgroup)
+};
+int launch_lean_scatter_batch(const LeanScatterTask *tasks_dev, int n_tasks, int zero_blocks, int scatter_blocks,
+                              hipStream_t stream);
 // solution_full[orig[i]] = solution_level[i] for every kept locus (the caller zeroes solution_full first)
 int launch_lean_scatter(const uint8_t *solution_level, const int *orig, long long m, uint8_t *solution_full, hipStream_t stream);
 

@@ -228,13 +228,56 @@ __device__ __forceinline__ void chunk_classes(const double *__restrict__ row, co
     }
 }
 
+constexpr int kZeroBytes = 16384;  // per workgroup of the zero launch
+
+__global__ __launch_bounds__(256) void lean_zero_batch_kernel(const LeanScatterTask *__restrict__ tasks, int n_tasks)
+{
+    int ti = 0;
+    while (ti + 1 < n_tasks && tasks[ti + 1].zero_begin <= (int)blockIdx.x) {
+        ++ti;
+    }
+    const LeanScatterTask task = tasks[ti];
+    const long long at = (long long)((int)blockIdx.x - task.zero_begin) * kZeroBytes;
+    uint8_t *p = task.full + at;
+    const long long len = min((long long)kZeroBytes, task.n - at);
+    if (len == kZeroBytes && ((reinterpret_cast<uintptr_t>(p) & 15U) == 0)) {
+        uint4 *q = reinterpret_cast<uint4 *>(p);
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int r = 0; r < kZeroBytes / 16 / 256; ++r) {
+            q[r * 256 + threadIdx.x] = z;
+        }
+    } else {
+        for (long long i = threadIdx.x; i < len; i += 256) {
+            p[i] = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lean_scatter_batch_kernel(const LeanScatterTask *__restrict__ tasks, int n_tasks)
+{
+    int ti = 0;
+    while (ti + 1 < n_tasks && tasks[ti + 1].scatter_begin <= (int)blockIdx.x) {
+        ++ti;
+    }
+    const LeanScatterTask task = tasks[ti];
+    const long long i = (long long)((int)blockIdx.x - task.scatter_begin) * 256 + threadIdx.x;
+    if (i < task.m) {
+        const int o = task.orig[i];
+        if (o >= 0) {
+            task.full[o] = task.level_solution[i];
+        }
+    }
+}
+
 template <int PB>
 __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &task, int tile, int p0, int np, double *lds,
                                           Scratch *sc)
 {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const long long base = (long long)tile * kLeanTile;
+    const long long base = (long long)tile * task.tile_stride * kLeanTile;
+    const bool indep = task.independent != 0;
 
     const double c = (task.c_raw + task.magic) - task.magic;
     const double big = task.big;
@@ -244,7 +287,8 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
         x[p] = L.points[task.point_begin + p0 + min(p, np - 1)];
     }
     const long long j0 = base + (long long)t * kLeanChunk;
-    const double c_first = (j0 == 0) ? big : c;  // the chain's first locus takes its input unclamped
+    // the chain's first locus takes its input unclamped (pilot tasks: every tile is a chain of its own)
+    const double c_first = (j0 == 0 || (indep && t == 0)) ? big : c;
     const double *row = lds + t * kStride;
 
     // ---- 2. chunk functions, composed across the workgroup ----
@@ -292,7 +336,7 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
         }
         const long long rec = (long long)task.rec_begin + (long long)(p0 + p) * task.n_tiles + tile;
         unsigned long long *mine = L.look + rec * 4;
-        const bool more = (tile + 1 < task.n_tiles);
+        const bool more = (tile + 1 < task.n_tiles) && !indep;
         if (more) {
             granule_store(mine + 0, agg.lo);
             granule_store(mine + 1, agg.hi);
@@ -301,7 +345,7 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
             }
         }
         double din = 0.0;  // chain start: delta_0 = a_0 (the first clamp is the identity)
-        if (tile > 0) {
+        if (tile > 0 && !indep) {
             const unsigned long long *prev = L.look + (rec - 1) * 4;
             const double plo = granule_wait(prev + 0, L.error);
             const double phi = granule_wait(prev + 1, L.error);
@@ -427,7 +471,7 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
             atomicAdd(&sc->red[p][1], tl);
             atomicAdd(&sc->red[p][2], ce);
         }
-        if (p < np) {
+        if (p < np && !indep) {
             L.bits[task.bits_begin + ((long long)(p0 + p) * task.n_tiles + tile) * kLeanThreads + t] = zw[p];
         }
     }
@@ -519,7 +563,7 @@ __global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pai
                 incl += u;
             }
         }
-        if (k < nt) {
+        if (k < nt && task.independent == 0) {
             off_out[k] = (unsigned)(running + incl - cells);
         }
         running += __shfl(incl, 63);
@@ -535,7 +579,12 @@ __global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pai
 __global__ __launch_bounds__(kLeanThreads) void lean_compact_kernel(const LeanCompactTask *tasks, int n_tasks,
                                                                     unsigned *error)
 {
+    // one workgroup per tile of the parent level.  Every lane first lists the output cells of its 32-locus
+    // word in LDS (source locus, or -1 for the separator behind a run end) -- no memory access in that loop --,
+    // then the cells are dealt to the threads one by one: independent loads, coalesced stores.
     __shared__ unsigned wave_sum[4];
+    __shared__ unsigned total_s;
+    __shared__ int src[kLeanTile + kLeanTile / 2 + 8];  // at most one separator per two kept loci
     int ti = 0;
     while (ti + 1 < n_tasks && tasks[ti + 1].block_begin <= (int)blockIdx.x) {
         ++ti;
@@ -552,7 +601,8 @@ __global__ __launch_bounds__(kLeanThreads) void lean_compact_kernel(const LeanCo
     } else {
         nxt = 0x80000000u;  // (beyond the chain's end: never a run end, see below)
     }
-    const long long j0 = (long long)tile * kLeanTile + (long long)t * kLeanChunk;
+    const long long tile0 = (long long)tile * kLeanTile;
+    const long long j0 = tile0 + (long long)t * kLeanChunk;
     unsigned ends = z & ~((z << 1) | (nxt >> 31));
     if (task.m - 1 >= j0 && task.m - 1 < j0 + kLeanChunk) {
         ends &= ~(0x80000000u >> (int)(task.m - 1 - j0));  // no separator after the chain's last locus
@@ -560,9 +610,9 @@ __global__ __launch_bounds__(kLeanThreads) void lean_compact_kernel(const LeanCo
     const unsigned cells = (unsigned)__builtin_popcount(z) + (unsigned)__builtin_popcount(ends);
     unsigned incl = cells;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned u = __shfl_up(incl, off);
-        if (lane >= off) {
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(incl, o);
+        if (lane >= o) {
             incl += u;
         }
     }
@@ -574,29 +624,42 @@ __global__ __launch_bounds__(kLeanThreads) void lean_compact_kernel(const LeanCo
     for (int w = 0; w < wave; ++w) {
         before += wave_sum[w];
     }
-    long long pos = (long long)task.tile_off[tile] + before + incl - cells;
-    if (tile == 0 && t == 0 && pos == 1) {
+    unsigned at = before + incl - cells;
+    if (t == kLeanThreads - 1) {
+        total_s = before + incl;
+    }
+    unsigned rest = z;
+    while (rest != 0u) {
+        const int b = 31 - __builtin_clz(rest);
+        rest &= ~(1u << b);
+        src[at++] = t * kLeanChunk + (31 - b);
+        if ((ends >> b) & 1u) {
+            src[at++] = -1;
+        }
+    }
+    __syncthreads();
+    const unsigned total = total_s;
+    const long long base = (long long)task.tile_off[tile];
+    if (tile == 0 && t == 0 && base == 1) {
         task.out_s[0] = task.sep;  // leading separator
         task.out_orig[0] = -1;
     }
-    if (pos + cells > task.capacity) {
-        if (cells != 0u) {
+    if (base + total > task.capacity) {
+        if (t == 0 && total != 0u) {
             atomicOr(error, 2u);
         }
         return;
     }
-    unsigned rest = z;
-    while (rest != 0u) {
-        const int r = 31 - __builtin_clz(rest);
-        rest &= ~(1u << r);
-        const long long j = j0 + (31 - r);
-        task.out_s[pos] = task.s[j];
-        task.out_orig[pos] = (task.orig != nullptr) ? task.orig[j] : (int)j;
-        ++pos;
-        if ((ends >> r) & 1u) {
+    for (unsigned k = (unsigned)t; k < total; k += kLeanThreads) {
+        const int sidx = src[k];
+        const long long pos = base + k;
+        if (sidx < 0) {
             task.out_s[pos] = task.sep;
             task.out_orig[pos] = -1;
-            ++pos;
+        } else {
+            const long long j = tile0 + sidx;
+            task.out_s[pos] = task.s[j];
+            task.out_orig[pos] = (task.orig != nullptr) ? task.orig[j] : (int)j;
         }
     }
 }
@@ -639,7 +702,7 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_eval_kernel(LeanLaunch L
     const int tile = unit / task.n_groups, group = unit % task.n_groups;
     const int p0 = group * kLeanBatch;
     const int np = min(kLeanBatch, task.n_points - p0);
-    stage_tile(task.s, task.m, (long long)tile * kLeanTile, task.magic, lds);
+    stage_tile(task.s, task.m, (long long)tile * task.tile_stride * kLeanTile, task.magic, lds);
     // penalties of this workgroup, in registers: 1, 2, 4 or 8 interleaved chains per lane
     if (np > 4) {
         eval_body<8>(L, task, tile, p0, np, lds, sc);
@@ -697,6 +760,22 @@ int launch_lean_compact(const LeanCompactTask *tasks_dev, int n_tasks, int n_blo
     }
     hipLaunchKernelGGL(lean_compact_kernel, dim3((unsigned)n_blocks), dim3(kLeanThreads), 0, stream, tasks_dev, n_tasks,
                        error_dev);
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_scatter_batch(const LeanScatterTask *tasks_dev, int n_tasks, int zero_blocks, int scatter_blocks,
+                              hipStream_t stream)
+{
+    if (n_tasks <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    if (zero_blocks > 0) {
+        hipLaunchKernelGGL(lean_zero_batch_kernel, dim3((unsigned)zero_blocks), dim3(256), 0, stream, tasks_dev, n_tasks);
+    }
+    if (scatter_blocks > 0) {
+        hipLaunchKernelGGL(lean_scatter_batch_kernel, dim3((unsigned)scatter_blocks), dim3(256), 0, stream, tasks_dev, n_tasks);
+    }
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }

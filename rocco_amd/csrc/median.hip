@@ -50,21 +50,24 @@ __device__ __forceinline__ bool is_nan_bits(double x)
     return (__double_as_longlong(x) & 0x7FFFFFFFFFFFFFFFLL) > 0x7FF0000000000000LL;
 }
 
-// EXACT: K == KP is known at compile time (no padding, unpredicated loads).
-template <typename T, int KP, bool EXACT>
-__global__ __launch_bounds__(256) void median_kernel(const T *__restrict__ m, int K_runtime, long long n,
-                                                     long long stride, double *__restrict__ out)
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Rows are not aligned to
+// cache lines (n is arbitrary), so neighbouring workgroups share the line that straddles their
+// boundary in every row: give each XCD one contiguous range of loci so that the shared lines meet
+// in one L2 instead of being fetched from memory twice.
+__device__ __forceinline__ unsigned xcd_contiguous_block()
 {
-    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Rows are not aligned to
-    // cache lines (n is arbitrary), so neighbouring workgroups share the line that straddles their
-    // boundary in every row: give each XCD one contiguous range of loci so that the shared lines meet
-    // in one L2 instead of being fetched from memory twice.
     const unsigned nblk = gridDim.x;
     const unsigned per = nblk / 8U, rem = nblk % 8U;
     const unsigned xcd = blockIdx.x % 8U, slot = blockIdx.x / 8U;
     // XCD x owns per + (x < rem) workgroups, laid out one range after the other
-    const unsigned logical = xcd * per + (xcd < rem ? xcd : rem) + slot;
-    const long long j = (long long)logical * blockDim.x + threadIdx.x;
+    return xcd * per + (xcd < rem ? xcd : rem) + slot;
+}
+
+// EXACT: K == KP is known at compile time (no padding, unpredicated loads).
+template <typename T, int KP, bool EXACT>
+__device__ __forceinline__ void median_column(const T *__restrict__ m, int K_runtime, long long n, long long stride,
+                                              double *__restrict__ out, long long j)
+{
     if (j >= n) {
         return;
     }
@@ -102,6 +105,30 @@ __global__ __launch_bounds__(256) void median_kernel(const T *__restrict__ m, in
         r = (v[KP / 2 - 1] + v[KP / 2]) / 2.0;
     }
     out[j] = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : r;
+}
+
+template <typename T, int KP, bool EXACT>
+__global__ __launch_bounds__(256) void median_kernel(const T *__restrict__ m, int K_runtime, long long n,
+                                                     long long stride, double *__restrict__ out)
+{
+    const long long j = (long long)xcd_contiguous_block() * blockDim.x + threadIdx.x;
+    median_column<T, KP, EXACT>(m, K_runtime, n, stride, out, j);
+}
+
+// Several matrices of the same K and element type in ONE launch (the chromosomes of a rank): a launch starts
+// with every workgroup loading and then every workgroup computing -- a transient of about 0.15 ms that a
+// launch per chromosome pays 24 times per genome and this one once.
+template <typename T, int KP, bool EXACT>
+__global__ __launch_bounds__(256) void median_batch_kernel(MedianBatch batch)
+{
+    const unsigned logical = xcd_contiguous_block();
+    int ti = 0;
+    while (ti + 1 < batch.n_tasks && batch.tasks[ti + 1].block_begin <= logical) {
+        ++ti;
+    }
+    const MedianTask &task = batch.tasks[ti];
+    const long long j = (long long)(logical - task.block_begin) * blockDim.x + threadIdx.x;
+    median_column<T, KP, EXACT>((const T *)task.matrix, batch.K, task.n, task.stride, task.out, j);
 }
 
 // K == 1: copy (rocco.py:254-255; power == 1.0 is the identity)
@@ -260,7 +287,79 @@ int dispatch(const T *m, size_t K, size_t n, size_t stride, double *out, hipStre
     return ROCCO_HIP_OK;
 }
 
+template <typename T, int KP>
+void launch_batch_kp(const MedianBatch &batch, unsigned blocks, hipStream_t stream)
+{
+    if (batch.K == KP) {
+        hipLaunchKernelGGL((median_batch_kernel<T, KP, true>), dim3(blocks), dim3(256), 0, stream, batch);
+    } else {
+        hipLaunchKernelGGL((median_batch_kernel<T, KP, false>), dim3(blocks), dim3(256), 0, stream, batch);
+    }
+}
+
+template <typename T>
+bool dispatch_batch(const MedianBatch &batch, unsigned blocks, hipStream_t stream)
+{
+    const int K = batch.K;
+    if (K < 2 || K > 100) {
+        return false;
+    }
+    if (K <= 2) launch_batch_kp<T, 2>(batch, blocks, stream);
+    else if (K <= 4) launch_batch_kp<T, 4>(batch, blocks, stream);
+    else if (K <= 6) launch_batch_kp<T, 6>(batch, blocks, stream);
+    else if (K <= 8) launch_batch_kp<T, 8>(batch, blocks, stream);
+    else if (K <= 10) launch_batch_kp<T, 10>(batch, blocks, stream);
+    else if (K <= 12) launch_batch_kp<T, 12>(batch, blocks, stream);
+    else if (K <= 16) launch_batch_kp<T, 16>(batch, blocks, stream);
+    else if (K <= 20) launch_batch_kp<T, 20>(batch, blocks, stream);
+    else if (K <= 24) launch_batch_kp<T, 24>(batch, blocks, stream);
+    else if (K <= 32) launch_batch_kp<T, 32>(batch, blocks, stream);
+    else if (K <= 40) launch_batch_kp<T, 40>(batch, blocks, stream);
+    else if (K <= 50) launch_batch_kp<T, 50>(batch, blocks, stream);
+    else if (K <= 64) launch_batch_kp<T, 64>(batch, blocks, stream);
+    else if (K <= 80) launch_batch_kp<T, 80>(batch, blocks, stream);
+    else launch_batch_kp<T, 100>(batch, blocks, stream);
+    return true;
+}
+
 }  // namespace
+
+int launch_median_batch(const void *const *matrices_dev, int dtype, size_t K, const size_t *n, const size_t *row_strides,
+                        double *const *scores_dev, size_t count, hipStream_t stream)
+{
+    size_t at = 0;
+    while (at < count) {
+        MedianBatch batch;
+        batch.K = (int)K;
+        batch.n_tasks = 0;
+        unsigned blocks = 0;
+        while (at < count && batch.n_tasks < kMedianBatchMax) {
+            if (n[at] > 0) {
+                MedianTask &t = batch.tasks[batch.n_tasks++];
+                t.matrix = matrices_dev[at];
+                t.out = scores_dev[at];
+                t.n = (long long)n[at];
+                t.stride = (long long)row_strides[at];
+                t.block_begin = blocks;
+                blocks += (unsigned)((n[at] + 255) / 256);
+            }
+            ++at;
+        }
+        if (batch.n_tasks == 0) {
+            continue;
+        }
+        const bool done = (dtype == 0) ? dispatch_batch<double>(batch, blocks, stream) : dispatch_batch<float>(batch, blocks, stream);
+        if (!done) {  // K outside the network sizes: one launch per matrix
+            for (int i = 0; i < batch.n_tasks; ++i) {
+                const int rc = launch_median(batch.tasks[i].matrix, dtype, K, (size_t)batch.tasks[i].n,
+                                             (size_t)batch.tasks[i].stride, batch.tasks[i].out, stream);
+                if (rc != ROCCO_HIP_OK) return rc;
+            }
+        }
+        ROCCO_HIP_TRY(hipGetLastError());
+    }
+    return ROCCO_HIP_OK;
+}
 
 int launch_median(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride,
                   double *scores_dev, hipStream_t stream)

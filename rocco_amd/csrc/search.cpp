@@ -82,6 +82,12 @@ struct State {
     // >= x + eps.  G / L are the best such certified thresholds; every bracket or bisection step of the
     // reference whose penalty lies outside (G, L) is then decided on the host for free.
     bool searching = false;
+    // pilot: estimated counts from a sample of the loci place the first certified evaluations
+    int pilot_left = 0;
+    double pg = 0.0, pl = 0.0;
+    std::vector<std::pair<double, double>> pilot_evals;  // (x, estimated count)
+    bool pilot_round = false;
+    bool pilot_hint = false;  // the next certified round takes its points from pilot_evals
     bool want_compact = false;  // the search has ended: restrict the problem to the loci that can still be selected
     bool compacted = false;
     bool bound_round = false;  // the probe request in flight belongs to the threshold search
@@ -337,6 +343,11 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
             s.L = p.score_max + 1.0;
             s.cG = (long long)p.n;
             s.cL = 0;
+            if (opt.pilot_rounds > 0 && s.target > 0 && ev.can_pilot(b)) {
+                s.pilot_left = opt.pilot_rounds;
+                s.pg = s.G;
+                s.pl = s.L;
+            }
         }
     }
 
@@ -352,12 +363,30 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
 
         // speculation depth of this iteration's probe rounds, from the loci they will cover
         double round_loci = 0.0;
+        bool all_compacted = true;
         for (size_t b = 0; b < B; ++b) {
             if (st[b].phase != State::kDone && !st[b].use_exact) {
                 round_loci += (double)problems[b].n * ev.work_fraction(b);
+                all_compacted = all_compacted && st[b].compacted;
+            }
+        }
+        // rounds over compacted problems are launch-bound (about 110 us whatever they evaluate) until their
+        // (workgroup, penalty) pairs fill the device a few times over: speculate as deep as that allows
+        int deep = opt.spec_depth;
+        if (all_compacted) {
+            double blocks = 0.0;
+            for (size_t b = 0; b < B; ++b) {
+                if (st[b].phase != State::kDone && !st[b].use_exact) {
+                    blocks += (double)(problems[b].n / 8192 + 1);
+                }
+            }
+            deep = opt.spec_depth + 3;
+            while (deep > opt.spec_depth && blocks * (double)((1 << deep) - 1) > 1600.0) {
+                --deep;
             }
         }
         const int spec_depth =
+            all_compacted ? deep :
             (round_loci > opt.big_round_loci)
                 ? 1
                 : ((round_loci < opt.tiny_round_loci)
@@ -371,6 +400,30 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 continue;
             }
             s.bound_round = false;
+            s.pilot_round = false;
+            if (s.searching && s.pilot_left > 0) {
+                // estimated counts at equally spaced penalties inside the pilot's own interval
+                ProbeRequest r;
+                r.problem = b;
+                r.bound = true;
+                r.pilot = true;
+                const int qexp = bound_grid_exponent(p);
+                const int pts = std::max(2, std::min(32, opt.pilot_points));
+                for (int k = 1; k <= pts; ++k) {
+                    const double x = snap_to_grid(s.pg + (s.pl - s.pg) * (double)k / (double)(pts + 1), qexp);
+                    if (x > s.pg && x < s.pl && (r.lambdas.empty() || x > r.lambdas.back())) {
+                        r.lambdas.push_back(x);
+                    }
+                }
+                if (!r.lambdas.empty()) {
+                    s.pilot_round = true;
+                    probes.push_back(r);
+                    probe_owner.push_back(b);
+                    continue;
+                }
+                s.pilot_left = 0;
+                s.pilot_hint = !s.pilot_evals.empty();
+            }
             if (s.searching) {
                 // threshold search: a few exact-arithmetic counts inside (G, L); every one of them moves
                 // G or L (quartiles, plus the log-linear estimate of the crossing once both ends are real)
@@ -393,10 +446,43 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 r.problem = b;
                 r.bound = true;
                 const int qexp = bound_grid_exponent(p);
-                for (double f : fr) {
-                    const double x = snap_to_grid(s.G + f * width, qexp);
-                    if (x - s.eps > s.G && x + s.eps < s.L) {
-                        r.lambdas.push_back(x);
+                if (s.pilot_hint) {
+                    // first certified round: penalties at which the pilot's estimate crosses a few multiples of
+                    // the target (log-linear between its samples) -- two that should select more, one close to
+                    // the target, one that should select less (four: one register batch of the evaluation kernel)
+                    s.pilot_hint = false;
+                    std::sort(s.pilot_evals.begin(), s.pilot_evals.end());
+                    const double levels[4] = {2.2, 1.35, 1.08, 0.8};
+                    for (double mult : levels) {
+                        const double want = mult * (double)s.target;
+                        double x = 0.0;
+                        bool found = false;
+                        for (size_t i = 0; i + 1 < s.pilot_evals.size(); ++i) {
+                            const double c0 = s.pilot_evals[i].second, c1 = s.pilot_evals[i + 1].second;
+                            if (c0 >= want && c1 < want) {
+                                const double l0 = std::log(std::max(c0, 0.5)), l1 = std::log(std::max(c1, 0.5));
+                                const double f = (l0 > l1) ? (l0 - std::log(want)) / (l0 - l1) : 0.5;
+                                x = s.pilot_evals[i].first + f * (s.pilot_evals[i + 1].first - s.pilot_evals[i].first);
+                                found = true;
+                                break;
+                            }
+                        }
+                        if (found) {
+                            x = snap_to_grid(x, qexp);
+                            if (x - s.eps > s.G && x + s.eps < s.L &&
+                                std::find(r.lambdas.begin(), r.lambdas.end(), x) == r.lambdas.end()) {
+                                r.lambdas.push_back(x);
+                            }
+                        }
+                    }
+                    std::sort(r.lambdas.begin(), r.lambdas.end());
+                }
+                if (r.lambdas.empty()) {
+                    for (double f : fr) {
+                        const double x = snap_to_grid(s.G + f * width, qexp);
+                        if (x - s.eps > s.G && x + s.eps < s.L) {
+                            r.lambdas.push_back(x);
+                        }
                     }
                 }
                 if (!r.lambdas.empty()) {
@@ -696,6 +782,26 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
             const ProbeRequest &r = probes[q];
             const ChainProblem &p = problems[probe_owner[q]];
             ++s.out.passes;
+            if (s.pilot_round) {
+                for (size_t i = 0; i < r.lambdas.size(); ++i) {
+                    const double x = r.lambdas[i];
+                    const double c = (double)r.results[i].count;
+                    s.pilot_evals.emplace_back(x, c);
+                    if (c > (double)s.target) {
+                        s.pg = std::max(s.pg, x);
+                    } else {
+                        s.pl = std::min(s.pl, x);
+                    }
+                }
+                if (--s.pilot_left <= 0 || !(s.pl - s.pg > 64.0 * s.eps)) {
+                    s.pilot_left = 0;
+                    s.pilot_hint = true;
+                }
+                if (std::getenv("ROCCO_SEARCH_DEBUG") != nullptr) {
+                    std::fprintf(stderr, "[pilot] problem %zu: crossing estimated in (%.17g, %.17g)\n", probe_owner[q], s.pg, s.pl);
+                }
+                continue;
+            }
             if (s.bound_round) {
                 ++s.search_rounds;
                 for (size_t i = 0; i < r.lambdas.size(); ++i) {

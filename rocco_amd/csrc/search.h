@@ -61,6 +61,9 @@ struct ProbeRequest {
     // model (results carry only `count`); the caller shifts lambda by -/+ epsilon to bracket the
     // reference's count
     bool bound = false;
+    // pilot = true (with bound): the counts may be ESTIMATES from a sample of the loci; they only steer where
+    // the certified evaluations of the threshold search are placed and never decide anything
+    bool pilot = false;
     std::vector<double> lambdas;
     std::vector<ProbeResult> results;  // filled by the evaluator
 };
@@ -174,6 +177,13 @@ public:
         if (maps.empty() && surveys.empty() && probes.empty() && windows.empty() && spines.empty()) return 0;
         return round(maps, surveys, probes, windows, spines);
     }
+    // Can the evaluator estimate exact-arithmetic counts of this problem from a sample, much cheaper than it
+    // evaluates them?  (ProbeRequest::pilot)
+    virtual bool can_pilot(size_t problem) const
+    {
+        (void)problem;
+        return false;
+    }
     // Evaluations per threshold-search round of this problem (an evaluator whose exact-arithmetic
     // counts are cheap may ask for more than the default).
     virtual int bound_points(size_t problem, int default_points) const
@@ -236,6 +246,8 @@ struct SearchOptions {
     bool force_exact = false;
     bool use_spine = true;  // finish undecided endgames through the exact spine (else the exact kernel)
     bool use_compaction = true;  // after the threshold search: continue on the loci that can still be selected
+    int pilot_rounds = 3;        // sampled estimates that place the first certified evaluations (0: none)
+    int pilot_points = 16;
 };
 
 // Calibrate every problem of the batch; solutions are left in the evaluator's solution buffers.

@@ -24,7 +24,7 @@ from . import shard as _shard
 # active set has shrunk.  Chromosomes are independent, so a rank's chromosomes are split into groups that
 # calibrate side by side -- one host thread, HIP stream and solver handle (scratch buffers) per group; the
 # native call releases the GIL -- and fill each other's gaps.  Results do not depend on the grouping.
-SOLVE_GROUPS = int(os.environ.get("ROCCO_SOLVE_GROUPS", "4"))
+SOLVE_GROUPS = int(os.environ.get("ROCCO_SOLVE_GROUPS", "3"))
 _pool: Optional[concurrent.futures.ThreadPoolExecutor] = None
 _group_state: Dict[Tuple[int, int], tuple] = {}  # (device, group) -> (Solver, torch.cuda.Stream)
 _group_lock = threading.Lock()  # the groups' solver handles are per process: one grouped solve at a time
@@ -89,51 +89,93 @@ def _solve_group(chroms: Sequence[ChromWork], scores: list) -> list:
     return out
 
 
+def _group_chunks(order: List[int], n_groups: int) -> List[List[int]]:
+    """Consecutive chunks of `order` (chromosomes by descending length), about equally many chromosomes each:
+    the first groups hold the long chromosomes, the last one the shortest -- what remains to be solved once
+    the last median has been taken is as little as possible."""
+    k = len(order)
+    base, extra = divmod(k, n_groups)
+    out, at = [], 0
+    for g in range(n_groups):
+        size = base + (1 if g < extra else 0)
+        out.append(order[at:at + size])
+        at += size
+    return [c for c in out if c]
+
+
 def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, groups: Optional[int] = None):
     """Score, solve and decode every chromosome of this rank.
 
-    Returns a list of dicts: name, n, selected_count, selection_penalty, penalized_objective, path,
-    begin / end (int64 CUDA tensors: half-open locus index pairs of the merged runs), the solution and the
-    score tensors.  `groups` (default ROCCO_SOLVE_GROUPS): how many groups of chromosomes calibrate side by
-    side (see SOLVE_GROUPS above).  Median scoring (bandwidth-bound) runs first, alone on the device; count-path
-    scoring (latency-bound chain kernels) runs inside the groups.
+    Returns a list of dicts (in the order of `chroms`): name, n, selected_count, selection_penalty,
+    penalized_objective, path, begin / end (int64 CUDA tensors: half-open locus index pairs of the merged runs),
+    the solution and the score tensors.  `groups` (default ROCCO_SOLVE_GROUPS): how many groups of chromosomes
+    calibrate side by side (see SOLVE_GROUPS above).
+
+    Scoring and solving overlap: the medians (bandwidth-bound) are issued group after group on the caller's
+    stream, longest chromosomes first, and every group starts calibrating (launch-latency-bound rounds on its own
+    stream and host thread) as soon as ITS chromosomes are scored, while the later groups' medians are still
+    running.  Count-path scoring (latency-bound chain kernels) runs inside the groups.
     """
     import torch
 
     global _pool
-    scores: List[Optional[object]] = []
-    for c in chroms:
-        if c.scoring == "wls":
-            scores.append(None)
-        else:
-            s_t = _rocco.score_central_tendency_chrom_device(c.matrix_t)
-            c._effect_mean = s_t  # rocco/rocco.py:995-997: the bigWig branch uses the scores themselves
-            scores.append(s_t)
+    if len(chroms) == 0:
+        return []
+    device = chroms[0].matrix_t.device
     n_groups = max(1, min(int(groups if groups is not None else SOLVE_GROUPS), len(chroms)))
     out: List[Optional[dict]] = [None] * len(chroms)
+
+    def score_all(members: Sequence[ChromWork]) -> list:
+        # the medians of a group in one launch (count-path chromosomes are scored inside their group)
+        med = [c for c in members if c.scoring != "wls"]
+        got = dict(zip((id(c) for c in med), _rocco.score_central_tendency_chrom_batch_device([c.matrix_t for c in med])))
+        for c in med:
+            c._effect_mean = got[id(c)]  # rocco/rocco.py:995-997: the bigWig branch uses the scores themselves
+        return [got.get(id(c)) for c in members]
+
     if n_groups == 1:
-        out = _solve_group(chroms, scores)
+        out = _solve_group(chroms, score_all(chroms))
     else:
-        device = chroms[0].matrix_t.device
-        scored = torch.cuda.Event()
-        scored.record()
-        members = _shard.lpt_partition([c.n for c in chroms], n_groups)
+        order = sorted(range(len(chroms)), key=lambda i: -chroms[i].n)
+        members = _group_chunks(order, n_groups)
+        with torch.cuda.device(device):
+            caller_stream = torch.cuda.current_stream(device)
 
-        def work(group: int):
-            solver, stream = _group_resources(device.index, group)
-            idx = members[group]
-            with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
-                stream.wait_event(scored)
-                res = _solve_group([chroms[i] for i in idx], [scores[i] for i in idx])
-                stream.synchronize()
-            return idx, res
+            def work(group: int, idx: List[int], scores: list, scored):
+                solver, stream = _group_resources(device.index, group)
+                with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
+                    stream.wait_event(scored)
+                    res = _solve_group([chroms[i] for i in idx], scores)
+                    stream.synchronize()
+                # the results were allocated on the group's stream and are handed to the caller's
+                for r in res:
+                    for key in ("begin", "end", "solution", "scores", "effect_mean"):
+                        t = r.get(key)
+                        if t is not None and hasattr(t, "record_stream"):
+                            t.record_stream(caller_stream)
+                return idx, res
 
-        with _group_lock:
-            if _pool is None:
-                _pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-solve")
-            for idx, res in _pool.map(work, range(n_groups)):
-                for i, r in zip(idx, res):
-                    out[i] = r
+            with _group_lock:
+                if _pool is None:
+                    _pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-solve")
+                futures = []
+                for g, idx in enumerate(members):
+                    scores = score_all([chroms[i] for i in idx])
+                    scored = torch.cuda.Event()
+                    scored.record(caller_stream)
+                    futures.append(_pool.submit(work, g, idx, scores, scored))
+                # every group is waited for (the solver handles are shared) before any failure is reported
+                first_error = None
+                for f in futures:
+                    try:
+                        idx, res = f.result()
+                        for i, r in zip(idx, res):
+                            out[i] = r
+                    except BaseException as exc:  # noqa: BLE001
+                        if first_error is None:
+                            first_error = exc
+                if first_error is not None:
+                    raise first_error
     if scores_out is not None:
         scores_out.extend(r["scores"] for r in out)
     return out

@@ -138,6 +138,39 @@ def score_central_tendency_chrom_device(matrix_t, out_t=None, method: str = "med
     return out_t
 
 
+def score_central_tendency_chrom_batch_device(matrices):
+    """Column medians of several [K, n_i] CUDA tensors of one K and dtype in ONE launch
+    (rocco_hip_score_median_batch); returns the float64 score tensors.  Falls back to one launch each when the
+    matrices differ in K or dtype."""
+    import ctypes
+
+    import torch
+
+    matrices = list(matrices)
+    if not matrices:
+        return []
+    for m in matrices:
+        if m.ndim != 2:
+            raise ValueError("`chrom_matrix` must be a 2D array.")
+    same = all(m.dtype == matrices[0].dtype and m.shape[0] == matrices[0].shape[0] and m.stride(1) == 1
+               and m.device == matrices[0].device for m in matrices)
+    if not same or matrices[0].dtype not in (torch.float64, torch.float32) or int(matrices[0].shape[0]) < 2:
+        return [score_central_tendency_chrom_device(m) for m in matrices]
+    K = int(matrices[0].shape[0])
+    count = len(matrices)
+    outs = [torch.empty(int(m.shape[1]), dtype=torch.float64, device=m.device) for m in matrices]
+    ptrs = (ctypes.c_void_p * count)(*[m.data_ptr() for m in matrices])
+    optrs = (ctypes.c_void_p * count)(*[o.data_ptr() for o in outs])
+    ns = (ctypes.c_size_t * count)(*[int(m.shape[1]) for m in matrices])
+    strides = (ctypes.c_size_t * count)(*[max(int(m.stride(0)), int(m.shape[1])) for m in matrices])
+    solver = _native.solver_for(matrices[0].device.index)
+    dtype = 0 if matrices[0].dtype == torch.float64 else 1
+    _native.check(_native.load().rocco_hip_score_median_batch(solver.handle, ptrs, dtype, K, ns, strides, optrs, count,
+                                                              _dp._stream_ptr(matrices[0])),
+                  "rocco_hip_score_median_batch")
+    return outs
+
+
 def score_central_tendency_chrom(chrom_matrix, method="quantile", quantile=0.50, tprop=0.05, power=1.0):
     r"""Return a column-wise location summary across samples (rocco/rocco.py:243-304).
 

@@ -49,6 +49,10 @@ public:
     long long compact_calls = 0;
     int compact_tile = 0;  // > 0: keep trailing COPY runs of every tile of this many loci (what the device kernels do)
     bool allow_compact = true;
+    double pilot_noise = -1.0;  // >= 0: answer pilot requests with counts off by up to this relative error
+    long long pilot_calls = 0;
+
+    bool can_pilot(size_t problem) const override { return pilot_noise >= 0.0 && hp[problem].costs == nullptr; }
 
     bool can_compact(size_t problem) const override
     {
@@ -160,6 +164,9 @@ public:
         for (ProbeRequest &r : reqs) {
             const HostProblem &p = hp[r.problem];
             r.results.resize(r.lambdas.size());
+            if (r.pilot) {
+                ++pilot_calls;
+            }
             for (size_t i = 0; i < r.lambdas.size(); ++i) {
                 oracle_delta_stats st;
                 // bound requests: plain grid-q arithmetic (= the map-less evaluation), count only
@@ -168,6 +175,14 @@ public:
                                                       (r.bound || p.emap.empty()) ? nullptr : p.emap.data(), nullptr, &st);
                 if (rc != 0) return rc;
                 r.results[i].count = st.count;
+                if (r.pilot) {
+                    // a deliberately wrong estimate (deterministic in the penalty): the search must not depend on it
+                    unsigned long long h = 0;
+                    std::memcpy(&h, &r.lambdas[i], sizeof(h));
+                    h = (h ^ (h >> 29)) * 0x9E3779B97F4A7C15ULL;
+                    const double u = (double)(h >> 11) / 9007199254740992.0;  // [0, 1)
+                    r.results[i].count = (long long)((double)st.count * (1.0 + pilot_noise * (2.0 * u - 1.0)));
+                }
                 r.results[i].uncertain = r.bound ? 0 : st.uncertain;
                 r.results[i].effect = r.bound ? 0 : (st.overflow ? (long long)p.n + 1 : st.effect);
                 r.results[i].max_run = st.max_run;
@@ -306,6 +321,7 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     OracleEvaluator ev;
     if (const char *e = std::getenv("ROCCO_HOSTLOGIC_COMPACT")) ev.allow_compact = std::atoi(e) != 0;
     if (const char *e = std::getenv("ROCCO_HOSTLOGIC_TILE")) ev.compact_tile = std::atoi(e);
+    if (const char *e = std::getenv("ROCCO_HOSTLOGIC_PILOT")) ev.pilot_noise = std::atof(e);
     HostProblem h;
     h.scores = scores;
     h.costs = costs;
@@ -343,6 +359,7 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     if (rc != 0) return rc;
     ev.scatter(0);
     out_i[11] = ev.hp[0].compacted ? (long long)ev.hp[0].n : -1;
+    out_i[12] = ev.pilot_calls;
     *penalty_out = res[0].selection_penalty;
     *value_out = res[0].penalized_value;
     *count_out = res[0].selected_count;

@@ -44,14 +44,14 @@ def calibrate(scores, gamma_or_costs, target, max_iter=60, spec_depth=2, force_e
     sol = np.zeros(n, dtype=np.uint8)
     pen, val = ctypes.c_double(), ctypes.c_double()
     cnt = ctypes.c_longlong()
-    info = (ctypes.c_longlong * 12)()
+    info = (ctypes.c_longlong * 16)()
     rc = lib().hostlogic_calibrate(_dp(s), _dp(costs), gamma, n, int(target), total, int(max_iter),
                                    int(spec_depth), int(force_exact),
                                    sol.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(pen),
                                    ctypes.byref(val), ctypes.byref(cnt), info)
     assert rc == 0, rc
     keys = ["path", "evaluations", "passes", "zone_iters", "n_diff", "probe_calls", "window_calls",
-            "exact_calls", "exact_lambdas", "maps", "spine_calls", "compact_n"]
+            "exact_calls", "exact_lambdas", "maps", "spine_calls", "compact_n", "pilot_calls"]
     return pen.value, sol, val.value, cnt.value, dict(zip(keys, [int(x) for x in info]))
 
 
@@ -65,7 +65,7 @@ def solve_fixed(scores, gamma_or_costs, lam):
     sol = np.zeros(n, dtype=np.uint8)
     val = ctypes.c_double()
     cnt = ctypes.c_longlong()
-    info = (ctypes.c_longlong * 12)()
+    info = (ctypes.c_longlong * 16)()
     rc = lib().hostlogic_solve_fixed(_dp(s), _dp(costs), gamma, n, float(lam),
                                      sol.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(val),
                                      ctypes.byref(cnt), info)
