@@ -8,20 +8,23 @@ evaluations per chromosome, rocco/dp.py:89-164) and the run-length decode to mer
 Inputs (synthetic K x n matrices, rocco_amd/synth.py) are resident in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: the 24 chromosomes of ONE genome are assigned to ranks by LPT on their locus counts (strong
-scaling, no data-path collective); the interval lists are gathered to every rank with two small
-all_gathers over RCCL inside the timed region.
-Prints one JSON line on rank 0.
+`--gpus N` with N > 1 starts the N ranks itself (python -m torch.distributed.run, one process per GPU,
+before anything in this process touches the GPU) and relays rank 0's JSON line; under a launcher
+(WORLD_SIZE set) it runs as one rank.  N > 1: the 24 chromosomes of ONE genome are assigned to ranks by
+LPT on their locus counts (strong scaling, no data-path collective); the interval lists are gathered to
+every rank with two small all_gathers over RCCL inside the timed region.  Prints one JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import gc
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,8 +32,10 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
-def parse_args():
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -42,21 +47,146 @@ def parse_args():
     ap.add_argument("--chroms", type=str, default="", help="comma list (default: whole genome)")
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the timed steps and their roofline block only (for profiler runs: the kernel statistics then "
+                         "hold the steps' launches and nothing else)")
     ap.add_argument("--cpu-sample", type=str, default="chr1")
-    return ap.parse_args()
+    ap.add_argument("--rehearse", action="store_true",
+                    help="no device work: every rank fabricates its interval lists and runs the launch, partition, "
+                         "gather, timing and reporting code only (CPU test of the N > 1 path, backend gloo)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """Start `args.gpus` ranks as fresh processes and relay rank 0's line.  Nothing here touches the GPU."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for text in proc.stdout.splitlines():
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        else:
+            print(text, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return proc.returncode if line is not None or proc.returncode != 0 else 1
+
+
+def _cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for text in fh:
+                if text.lower().startswith("model name"):
+                    model = text.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, usable, os.cpu_count() or usable
+
+
+def _cpu_solve_worker(job):
+    """One chromosome's budgeted solve on the CPU restatement of the reference (oracle/): a process-pool worker of
+    the cpu_baseline leg (no torch, no GPU in these processes)."""
+    path, budget, gamma = job
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+
+    s = np.load(path)
+    t0 = time.perf_counter()
+    sol, obj, det = po.solve_chrom_exact(s, budget=budget, gamma=gamma, return_details=True)
+    return time.perf_counter() - t0, int(det["selected_count"])
+
+
+def _file_sha256(path):
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
+def rehearse(args, rank, world):
+    """The N > 1 host path without a device: partition, fabricated intervals, gather, timing, JSON line."""
+    import torch
+    import torch.distributed as dist
+
+    from rocco_amd import shard, synth
+
+    if world > 1:
+        dist.init_process_group(backend=os.environ.get("ROCCO_BENCH_BACKEND", "gloo"))
+    names = [c for c in args.chroms.split(",") if c] or None
+    genome = synth.chrom_loci(args.step_bp, names)
+    sizes = [n for _, n in genome]
+    owned = shard.lpt_partition(sizes, world)
+    mine = owned[rank]
+
+    def one_step():
+        local = {}
+        for idx in mine:
+            m = 3 + idx % 5  # deterministic stand-in for a chromosome's merged runs
+            local[idx] = np.stack([np.arange(m) * 1000 + idx, np.arange(m) * 1000 + idx + 50], axis=1).astype(np.int64)
+        return shard.gather_intervals(local) if world > 1 else local
+
+    for _ in range(args.warmup):
+        merged = one_step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        merged = one_step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ranks_seen = 1
+    if world > 1:
+        t = torch.tensor([elapsed, 1.0], dtype=torch.float64)
+        dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
+        elapsed, ranks_seen = float(t[0]), int(round(float(t[1])))
+    if rank == 0:
+        total = int(sum(sizes))
+        print(json.dumps({
+            "metric": "REHEARSAL (no device work): loci/sec to converged solve", "value": total / (elapsed / max(1, args.steps)),
+            "unit": "loci/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "fabricated", "rehearsal": True,
+            "config": {"workload": f"{len(genome)} chromosomes, {total} loci", "parallelism": f"chromosome-sharded x{world} (LPT)"},
+            "chromosomes_gathered": len(merged), "intervals_gathered": int(sum(v.shape[0] for v in merged.values())),
+            "shard_loci": [int(sum(sizes[i] for i in part)) for part in owned]}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # not under a launcher: start the ranks (fresh processes) before this one has touched the GPU
+        raise SystemExit(self_launch(args))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse:
+        return rehearse(args, rank, world)
+
     import torch
     import torch.distributed as dist
 
     from rocco_amd import pipeline, shard, synth
     from rocco_amd import rocco as rr
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (rocco_amd has no CPU path)")
     # one process per GPU over RCCL; ROCCO_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with
@@ -88,8 +218,10 @@ def main():
         works.append(pipeline.ChromWork(name, m_t, args.budget, args.gamma, step=args.step_bp))
     torch.cuda.synchronize()
 
-    def one_step():
-        res = pipeline.solve_rank(works)
+    median_events = []
+
+    def one_step(timing=None):
+        res = pipeline.solve_rank(works, median_timing=timing)
         # intervals of every owned chromosome to the host in ONE transfer
         counts = [int(r["begin"].numel()) for r in res]
         if sum(counts):
@@ -118,58 +250,99 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res, merged = one_step()
+        res, merged = one_step(median_events if rank == 0 else None)
     sync_all()
     elapsed = time.perf_counter() - t0
+    ranks_seen = 1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, 1.0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
+        elapsed, ranks_seen = float(t[0].item()), int(round(float(t[1].item())))
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
     value = total_loci / (elapsed / max(1, args.steps))
 
-    # ---- dominant kernel: K x n median scoring; HIP events on the stream it is launched on ----
+    # ---- roofline ----
+    # dominant kernel: the K x n median scoring, one launch per group of chromosomes (rocco_amd/pipeline.py); its
+    # launches INSIDE the timed steps were bracketed with HIP events on the stream they went to
     roofline = None
     paths = {}
-    if rank == 0 and works:
-        big = max(works, key=lambda w: w.n)
-        out = torch.empty(big.n, dtype=torch.float64, device=device)
-        for _ in range(2):
-            rr.score_central_tendency_chrom_device(big.matrix_t, out)
-        reps = 10
-        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-        for i in range(reps):
-            ev0[i].record()
-            rr.score_central_tendency_chrom_device(big.matrix_t, out)
-            ev1[i].record()
-        torch.cuda.synchronize()
-        dur_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
-        esize = big.matrix_t.element_size()
-        alg_bytes = (esize * K + 8) * big.n  # 8K read + 8 written per locus
+    if rank == 0 and works and median_events:
+        esize = works[0].matrix_t.element_size()
+        durs = [a.elapsed_time(b) for a, b, _ in median_events]  # ms
+        launches_per_step = len(median_events) // max(1, args.steps)
+        dur_ms = float(np.mean(durs))
+        alg_bytes = float(np.mean([nb for _, _, nb in median_events]))  # (8K + 8) B per locus x loci per launch
         achieved = alg_bytes / (dur_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 on gfx950 +
-        # WRITE_SIZE, separate runs; profiles/README.md) -- only when they were taken on this very launch
+        my_loci = int(sum(w.n for w in works))
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE,
+        # separate runs; profiles/README.md) -- only while they describe THIS build of the kernel and these launches
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_median.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_median.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
-            if int(pmc.get("K", -1)) == K and int(pmc.get("n", -1)) == big.n and esize == 8:
+            same_kernel = pmc.get("median_hip_sha256") == _file_sha256(os.path.join(ROOT, "rocco_amd", "csrc", "median.hip"))
+            same_work = (int(pmc.get("K", -1)) == K and int(pmc.get("loci_per_step", -1)) == my_loci and esize == 8
+                         and int(pmc.get("launches_per_step", -1)) == launches_per_step)
+            if same_kernel and same_work:
                 traffic = int(round(pmc["traffic_bytes_per_launch"]))
-                traffic_src = "profiles/r01_pmc_median.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        roofline = {"bound": "hbm", "kernel": f"median_kernel<K={K}> on {big.name} (n={big.n})",
-                    "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 4), "avg_kernel_ms": round(dur_ms, 4),
-                    "algorithmic_bytes_per_launch": int(alg_bytes), "traffic": traffic,
-                    "traffic_source": traffic_src}
+                traffic_src = "profiles/r02_pmc_median.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; same median.hip, same launches)"
+        step_bytes = (esize * K + 8 + 8 + 1) * total_loci  # scoring + one read of the scores + the solution
+        roofline = {"bound": "hbm", "kernel": f"median_batch_kernel<K={K}> ({launches_per_step} launches per step over {my_loci} loci)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(dur_ms, 4),
+                    "algorithmic_bytes_per_launch": int(alg_bytes), "traffic": traffic, "traffic_source": traffic_src,
+                    "launches_timed": len(median_events),
+                    # the whole step against the same roof: 817 B per locus at K = 100
+                    "step": {"algorithmic_bytes": int(step_bytes), "ms": round(ms_per_step, 3),
+                             "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                             "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
         for r in res:
             paths[r["name"]] = {"path": r["path"], "passes": r["info"]["passes"], "maps": r["info"].get("maps", 0),
                                 "zone_iters": r["info"].get("zone_iters", -1)}
 
+    # ---- the two halves of a step on their own (rank 0; after the timed region) ----
+    if rank == 0 and world == 1 and roofline is not None and not args.headline_only:
+        from rocco_amd import dp as _dp
+
+        mats = [w.matrix_t for w in works]
+        for _ in range(2):
+            scores = rr.score_central_tendency_chrom_batch_device(mats)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            scores = rr.score_central_tendency_chrom_batch_device(mats)
+        torch.cuda.synchronize()
+        t_med = (time.perf_counter() - t0) / reps
+        targets = [int(np.floor(w.n * w.budget)) for w in works]
+        gammas = [w.gamma for w in works]
+        _dp.calibrate_batch_device(scores, gammas, targets)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            solved = _dp.calibrate_batch_device(scores, gammas, targets)
+        torch.cuda.synchronize()
+        t_solve = (time.perf_counter() - t0) / reps
+        solve_bytes = 9 * total_loci  # compulsory: the scores once, the solution once
+        roofline["scoring_alone"] = {"ms": round(1e3 * t_med, 3), "achieved": round((esize * K + 8) * total_loci / t_med / 1e9, 1),
+                                     "frac": round((esize * K + 8) * total_loci / t_med / 1e9 / HBM_PEAK_GBS, 4),
+                                     "note": "every chromosome in one launch"}
+        roofline["solve"] = {"ms_alone_one_batch": round(1e3 * t_solve, 3), "compulsory_bytes": int(solve_bytes),
+                             "achieved": round(solve_bytes / t_solve / 1e9, 1),
+                             "frac": round(solve_bytes / t_solve / 1e9 / HBM_PEAK_GBS, 5),
+                             "passes": int(max(s[4]["passes"] for s in solved)),
+                             "note": "the calibration is a chain of launch-latency-bound rounds (DESIGN.md section 8); "
+                                     "one of them reads every score (8 B per locus), the others a few per cent of them"}
+        del scores, solved
+
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 semantics) ----
     cpu_baseline = None
     parity = None
+    m_t = None
+    if args.headline_only:
+        args.no_cpu_baseline = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle as po
@@ -177,7 +350,6 @@ def main():
         sample = args.cpu_sample if any(n == args.cpu_sample for n, _ in genome) else genome[-1][0]
         sidx = [n for n, _ in genome].index(sample)
         n_s = genome[sidx][1]
-        m_t = None
         for w in works:
             if w.name == sample:
                 m_t = w.matrix_t
@@ -195,9 +367,39 @@ def main():
         o_recs = po.chrom_solution_records(sample, intervals, o_sol)
         t_decode = time.perf_counter() - t0
         cpu_total = t_score + t_solve + t_decode
+        model, usable, logical = _cpu_info()
+        # the solve stage of the whole genome under the reference's process policies (rocco/rocco.py:792-806: at most
+        # 4 forked workers; here spawned, fork after HIP initialisation being unsafe): 1 process, 4, every usable core.
+        # The scores are the GPU's medians (bit-identical to np.median: the parity block below checks the sample's).
+        policies = {}
+        with tempfile.TemporaryDirectory(prefix="rocco_cpu_") as tmp:
+            jobs = []
+            for w in sorted(works, key=lambda w: -w.n):
+                path = os.path.join(tmp, w.name + ".npy")
+                np.save(path, rr.score_central_tendency_chrom_device(w.matrix_t).cpu().numpy())
+                jobs.append((path, args.budget, args.gamma))
+            import multiprocessing as mp
+
+            ctx = mp.get_context("spawn")
+            # (a one-GPU box's CPU share is 16 cores; there are only as many jobs as chromosomes)
+            share = max(1, min(16, usable, len(jobs)))
+            for label, procs in (("one_process", 1), ("four_processes_reference_policy", min(4, usable)), ("cpu_share_one_chromosome_per_core", share)):
+                if procs <= 4 and label.startswith("cpu_share"):
+                    continue
+                t0 = time.perf_counter()
+                if procs == 1:
+                    out = [_cpu_solve_worker(j) for j in jobs]
+                else:
+                    with ctx.Pool(procs) as pool:
+                        out = pool.map(_cpu_solve_worker, jobs, chunksize=1)
+                wall = time.perf_counter() - t0
+                policies[label] = {"processes": procs, "wall_s": round(wall, 3), "loci_per_s": round(sum(w.n for w in works) / wall, 1),
+                                   "sum_of_chromosome_solves_s": round(sum(o[0] for o in out), 3)}
         cpu_baseline = {"value": round(n_s / cpu_total, 1), "unit": "loci/s", "cores": 1, "kind": "port",
-                        "sample": f"{sample} (n={n_s}), K={K}: np.median {t_score:.2f}s + oracle chain solve "
-                                  f"(62 evaluations) {t_solve:.2f}s + python decode {t_decode:.2f}s"}
+                        "sample": f"{sample} (n={n_s}), K={K}, whole path on one core: np.median {t_score:.2f}s + oracle chain solve "
+                                  f"(62 evaluations) {t_solve:.2f}s + python decode {t_decode:.2f}s",
+                        "cpu_model": model, "cores_usable": usable, "cores_logical": logical,
+                        "solve_stage_whole_genome": policies}
         # parity of the GPU path on the same sample against the oracle
         w = pipeline.ChromWork(sample, m_t, args.budget, args.gamma, step=args.step_bp)
         scores = []
@@ -217,7 +419,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from rocco_amd import inference
 
-        counts_t = (m_t * 20.0).contiguous()  # count-like magnitudes from the sample's tracks
+        counts_t = torch.round(m_t * 20.0).contiguous()  # integer counts of count-like magnitude from the sample's tracks
         inference.score_loci_wls_device(counts_t)  # first call: Whittaker factor for this penalty, scratch buffers
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -235,8 +437,8 @@ def main():
             "value": round(n_s / t_gpu, 1), "unit": "loci/s", "workload": f"{sample} (n={n_s}), K={K} count matrix",
             "cpu_oracle_values_per_s": round(sub_h.size / t_cpu, 1), "cpu_sample": f"{ks} x {ns}",
             "gpu_values_per_s": round(K * n_s / t_gpu, 1),
-            "max_rel_score_diff_vs_oracle": float(np.abs(g_scores - o_scores).max() / np.abs(o_scores).max()),
-            "note": "log2 differs from NumPy's in the last place; everything downstream is bit-exact (tests)"}}
+            "scores_bit_exact_vs_oracle": bool(np.array_equal(g_scores, o_scores)),
+            "max_rel_score_diff_vs_oracle": float(np.abs(g_scores - o_scores).max() / np.abs(o_scores).max())}}
         del counts_t, wls_scores
 
     if rank == 0:
@@ -245,6 +447,7 @@ def main():
             "value": round(value, 1),
             "unit": "loci/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),

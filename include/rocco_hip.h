@@ -210,6 +210,13 @@ int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev,
                           int64_t *run_begin_dev, int64_t *run_end_dev, size_t capacity,
                           size_t *n_runs_out, void *stream);
 
+/* The same for `count` solutions in three launches and ONE synchronisation (the chromosomes a rank owns; the loop
+ * over chromosomes of rocco/rocco.py:1176-1196).  Host arrays of `count` entries; n_runs_out[i] may exceed
+ * capacities[i] (then only the first capacities[i] runs were written: call again with more room). */
+int rocco_hip_decode_runs_batch(rocco_hip_solver *solver, size_t count, const uint8_t *const *solutions_dev, const size_t *n,
+                                int64_t *const *run_begin_dev, int64_t *const *run_end_dev, const size_t *capacities,
+                                size_t *n_runs_out, void *stream);
+
 /* ---- row baselines ------------------------------------------------ */
 /* Cross-fit Whittaker baseline of every row of a row-major rows x cols matrix.
  * Replaces rocco_crossfit_whittaker_baseline_matrix_f64 (rocco/native/baseline_backend.h:12-23,

@@ -326,6 +326,57 @@ int rocco_hip_objective_value_f64(rocco_hip_solver *solver, const uint8_t *solut
     return rc;
 }
 
+int rocco_hip_decode_runs_batch(rocco_hip_solver *solver, size_t count, const uint8_t *const *solutions_dev, const size_t *n,
+                                int64_t *const *run_begin_dev, int64_t *const *run_end_dev, const size_t *capacities,
+                                size_t *n_runs_out, void *stream)
+{
+    if (solver == nullptr || (count > 0 && (solutions_dev == nullptr || n == nullptr || run_begin_dev == nullptr ||
+                                            run_end_dev == nullptr || capacities == nullptr || n_runs_out == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    size_t at = 0;
+    while (at < count) {
+        DecodeBatch batch;
+        batch.n_tasks = 0;
+        batch.pad = 0;
+        long long tiles = 0;
+        size_t owner[kDecodeBatchMax];
+        while (at < count && batch.n_tasks < kDecodeBatchMax) {
+            n_runs_out[at] = 0;
+            if (n[at] > 1) {
+                if (solutions_dev[at] == nullptr || (capacities[at] > 0 && (run_begin_dev[at] == nullptr || run_end_dev[at] == nullptr))) {
+                    return ROCCO_HIP_EINVAL;
+                }
+                DecodeTask &t = batch.tasks[batch.n_tasks];
+                t.solution = solutions_dev[at];
+                t.n = (long long)n[at];
+                t.tile_begin = tiles;
+                t.run_begin = run_begin_dev[at];
+                t.run_end = run_end_dev[at];
+                t.capacity = (unsigned long long)capacities[at];
+                owner[batch.n_tasks++] = at;
+                tiles += decode_tiles(n[at]);
+            }
+            ++at;
+        }
+        if (batch.n_tasks == 0) {
+            continue;
+        }
+        int rc = solver->dev_misc.reserve(decode_batch_scratch_bytes(tiles, batch.n_tasks));
+        if (rc != ROCCO_HIP_OK) return rc;
+        rc = solver->host_back.reserve((size_t)batch.n_tasks * 16 + 64);
+        if (rc != ROCCO_HIP_OK) return rc;
+        unsigned long long *back = (unsigned long long *)solver->host_back.ptr;
+        rc = launch_decode_runs_batch(batch, tiles, solver->dev_misc.ptr, back, (hipStream_t)stream);
+        if (rc != ROCCO_HIP_OK) return rc;
+        for (int i = 0; i < batch.n_tasks; ++i) {
+            n_runs_out[owner[i]] = (size_t)back[2 * i];
+        }
+    }
+    return ROCCO_HIP_OK;
+}
+
 int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev, size_t n,
                           int64_t *run_begin_dev, int64_t *run_end_dev, size_t capacity,
                           size_t *n_runs_out, void *stream)

@@ -210,7 +210,200 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(
     }
 }
 
+// ---- several solutions in three launches (the chromosomes of a group): same per-tile work, a task table in
+// the kernel arguments, one scan workgroup per task ----
+__global__ __launch_bounds__(kThreads) void decode_count_batch_kernel(DecodeBatch batch, unsigned *__restrict__ tile_counts)
+{
+    int ti = 0;
+    while (ti + 1 < batch.n_tasks && batch.tasks[ti + 1].tile_begin <= (long long)blockIdx.x) {
+        ++ti;
+    }
+    const DecodeTask &task = batch.tasks[ti];
+    const long long tile = (long long)blockIdx.x - task.tile_begin;
+    const long long i0 = (tile * kThreads + threadIdx.x) * kPerLane;
+    unsigned st = 0, en = 0;
+    if (i0 < task.n) {
+        const LaneBits b = lane_bits(task.solution, task.n, i0);
+        st = (unsigned)__popc(b.starts);
+        en = (unsigned)__popc(b.ends);
+    }
+    __shared__ unsigned s_starts[kThreads / 64];
+    __shared__ unsigned s_ends[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        st += __shfl_down(st, off);
+        en += __shfl_down(en, off);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_starts[wave] = st;
+        s_ends[wave] = en;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned a = 0, b = 0;
+        for (int w = 0; w < kThreads / 64; ++w) {
+            a += s_starts[w];
+            b += s_ends[w];
+        }
+        tile_counts[2 * blockIdx.x] = a;
+        tile_counts[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ __launch_bounds__(1024) void decode_scan_batch_kernel(DecodeBatch batch, const unsigned *__restrict__ tile_counts,
+                                                                 unsigned long long *__restrict__ tile_offsets,
+                                                                 unsigned long long *__restrict__ totals)
+{
+    const DecodeTask &task = batch.tasks[blockIdx.x];
+    const long long n_tiles = (task.n + kTileLoci - 1) / kTileLoci;
+    const unsigned *counts = tile_counts + 2 * task.tile_begin;
+    unsigned long long *offsets = tile_offsets + 2 * task.tile_begin;
+    __shared__ unsigned long long carry[2];
+    __shared__ unsigned long long wave_sums[2][16];
+    if (threadIdx.x == 0) {
+        carry[0] = 0;
+        carry[1] = 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (long long base = 0; base < n_tiles; base += blockDim.x) {
+        const long long t = base + threadIdx.x;
+        unsigned long long v0 = (t < n_tiles) ? counts[2 * t] : 0ULL;
+        unsigned long long v1 = (t < n_tiles) ? counts[2 * t + 1] : 0ULL;
+        unsigned long long i0 = v0, i1 = v1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long a = __shfl_up(i0, off);
+            const unsigned long long b = __shfl_up(i1, off);
+            if (lane >= off) {
+                i0 += a;
+                i1 += b;
+            }
+        }
+        if (lane == 63) {
+            wave_sums[0][wave] = i0;
+            wave_sums[1][wave] = i1;
+        }
+        __syncthreads();
+        unsigned long long p0 = carry[0], p1 = carry[1];
+        for (int w = 0; w < wave; ++w) {
+            p0 += wave_sums[0][w];
+            p1 += wave_sums[1][w];
+        }
+        if (t < n_tiles) {
+            offsets[2 * t] = p0 + i0 - v0;
+            offsets[2 * t + 1] = p1 + i1 - v1;
+        }
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) {
+            carry[0] = p0 + i0;
+            carry[1] = p1 + i1;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[2 * blockIdx.x] = carry[0];
+        totals[2 * blockIdx.x + 1] = carry[1];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void decode_write_batch_kernel(DecodeBatch batch,
+                                                                     const unsigned long long *__restrict__ tile_offsets)
+{
+    int ti = 0;
+    while (ti + 1 < batch.n_tasks && batch.tasks[ti + 1].tile_begin <= (long long)blockIdx.x) {
+        ++ti;
+    }
+    const DecodeTask &task = batch.tasks[ti];
+    const long long tile = (long long)blockIdx.x - task.tile_begin;
+    const long long i0 = (tile * kThreads + threadIdx.x) * kPerLane;
+    LaneBits b = {0U, 0U};
+    if (i0 < task.n) {
+        b = lane_bits(task.solution, task.n, i0);
+    }
+    const unsigned ns = (unsigned)__popc(b.starts);
+    const unsigned ne = (unsigned)__popc(b.ends);
+    unsigned is = ns, ie = ne;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned a = __shfl_up(is, off);
+        const unsigned c = __shfl_up(ie, off);
+        if (lane >= off) {
+            is += a;
+            ie += c;
+        }
+    }
+    __shared__ unsigned ws[kThreads / 64], we[kThreads / 64];
+    if (lane == 63) {
+        ws[wave] = is;
+        we[wave] = ie;
+    }
+    __syncthreads();
+    unsigned long long ps = tile_offsets[2 * blockIdx.x];
+    unsigned long long pe = tile_offsets[2 * blockIdx.x + 1];
+    for (int w = 0; w < wave; ++w) {
+        ps += ws[w];
+        pe += we[w];
+    }
+    ps += is - ns;
+    pe += ie - ne;
+    unsigned sb = b.starts;
+    while (sb) {
+        const int t = __ffs(sb) - 1;
+        sb &= sb - 1;
+        if (ps < task.capacity) {
+            task.run_begin[ps] = (int64_t)(i0 + t);
+        }
+        ++ps;
+    }
+    unsigned eb = b.ends;
+    while (eb) {
+        const int t = __ffs(eb) - 1;
+        eb &= eb - 1;
+        if (pe < task.capacity) {
+            task.run_end[pe] = (int64_t)(i0 + t + 1);
+        }
+        ++pe;
+    }
+}
+
 }  // namespace
+
+long long decode_tiles(size_t n) { return (long long)((n + kTileLoci - 1) / kTileLoci); }
+
+size_t decode_batch_scratch_bytes(long long total_tiles, int n_tasks)
+{
+    return (size_t)total_tiles * (2 * sizeof(unsigned) + 2 * sizeof(unsigned long long)) + (size_t)n_tasks * 16 + 256;
+}
+
+int launch_decode_runs_batch(const DecodeBatch &batch, long long total_tiles, void *scratch_dev,
+                             unsigned long long *totals_host_pinned, hipStream_t stream)
+{
+    if (batch.n_tasks <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    char *base = (char *)scratch_dev;
+    unsigned long long *totals = (unsigned long long *)base;
+    unsigned long long *offsets = (unsigned long long *)(base + (((size_t)batch.n_tasks * 16 + 255) / 256) * 256);
+    unsigned *counts = (unsigned *)((char *)offsets + (size_t)total_tiles * 2 * sizeof(unsigned long long));
+    if (total_tiles > 0) {
+        hipLaunchKernelGGL(decode_count_batch_kernel, dim3((unsigned)total_tiles), dim3(kThreads), 0, stream, batch, counts);
+    }
+    hipLaunchKernelGGL(decode_scan_batch_kernel, dim3((unsigned)batch.n_tasks), dim3(1024), 0, stream, batch, counts, offsets,
+                       totals);
+    if (total_tiles > 0) {
+        hipLaunchKernelGGL(decode_write_batch_kernel, dim3((unsigned)total_tiles), dim3(kThreads), 0, stream, batch, offsets);
+    }
+    ROCCO_HIP_TRY(hipGetLastError());
+    ROCCO_HIP_TRY(hipMemcpyAsync(totals_host_pinned, totals, (size_t)batch.n_tasks * 2 * sizeof(unsigned long long),
+                                 hipMemcpyDeviceToHost, stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+    return ROCCO_HIP_OK;
+}
 
 size_t decode_scratch_bytes(size_t n)
 {

@@ -56,6 +56,27 @@ int launch_decode_runs(const uint8_t *solution_dev, size_t n, int64_t *run_begin
                        int64_t *run_end_dev, size_t capacity, void *scratch_dev,
                        unsigned long long *n_runs_host_pinned, hipStream_t stream);
 
+// several solutions in three launches and one synchronisation (n <= 1 tasks must be left out by the caller)
+constexpr int kDecodeBatchMax = 48;
+struct DecodeTask {
+    const uint8_t *solution;
+    long long n;
+    long long tile_begin;  // first tile of this task in the launches (decode_tiles(n) tiles each)
+    int64_t *run_begin;
+    int64_t *run_end;
+    unsigned long long capacity;
+};
+struct DecodeBatch {
+    DecodeTask tasks[kDecodeBatchMax];
+    int n_tasks;
+    int pad;
+};
+long long decode_tiles(size_t n);
+size_t decode_batch_scratch_bytes(long long total_tiles, int n_tasks);
+// totals_host_pinned: 2 * n_tasks values (runs begun, runs ended -- equal) after the synchronisation
+int launch_decode_runs_batch(const DecodeBatch &batch, long long total_tiles, void *scratch_dev,
+                             unsigned long long *totals_host_pinned, hipStream_t stream);
+
 // ---- objective.hip --------------------------------------------------------------------------
 size_t objective_scratch_bytes(size_t n);
 int launch_objective(const uint8_t *solution_dev, const double *scores_dev,

@@ -78,8 +78,9 @@ def _solve_group(chroms: Sequence[ChromWork], scores: list) -> list:
     targets = [int(np.floor(c.n * c.budget)) for c in chroms]  # rocco/dp.py:197
     solved = _dp.calibrate_batch_device(scores, [c.gamma for c in chroms], targets)
     out = []
-    for c, s_t, (penalty, sol_t, value, count, info) in zip(chroms, scores, solved):
-        begin_t, end_t = _rocco.decode_runs_device(sol_t, capacity=max(1024, c.n // 64))
+    runs = _rocco.decode_runs_batch_device([sol_t for (_p, sol_t, _v, _c, _i) in solved],
+                                           capacities=[max(1024, c.n // 64) for c in chroms])
+    for c, s_t, (penalty, sol_t, value, count, info), (begin_t, end_t) in zip(chroms, scores, solved, runs):
         out.append({
             "name": c.name, "n": c.n, "selected_count": count, "selection_penalty": penalty,
             "penalized_objective": value, "path": info["path"], "info": info,
@@ -103,7 +104,8 @@ def _group_chunks(order: List[int], n_groups: int) -> List[List[int]]:
     return [c for c in out if c]
 
 
-def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, groups: Optional[int] = None):
+def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, groups: Optional[int] = None,
+               median_timing: Optional[list] = None):
     """Score, solve and decode every chromosome of this rank.
 
     Returns a list of dicts (in the order of `chroms`): name, n, selected_count, selection_penalty,
@@ -115,6 +117,9 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
     stream, longest chromosomes first, and every group starts calibrating (launch-latency-bound rounds on its own
     stream and host thread) as soon as ITS chromosomes are scored, while the later groups' medians are still
     running.  Count-path scoring (latency-bound chain kernels) runs inside the groups.
+
+    `median_timing`: a list that receives one (start event, end event, algorithmic bytes) per median launch,
+    recorded on the stream the launch goes to (for bench.py's roofline block).
     """
     import torch
 
@@ -128,7 +133,15 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
     def score_all(members: Sequence[ChromWork]) -> list:
         # the medians of a group in one launch (count-path chromosomes are scored inside their group)
         med = [c for c in members if c.scoring != "wls"]
+        if median_timing is not None and med:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(device))
         got = dict(zip((id(c) for c in med), _rocco.score_central_tendency_chrom_batch_device([c.matrix_t for c in med])))
+        if median_timing is not None and med:
+            ev1.record(torch.cuda.current_stream(device))
+            # K elements read + 8 bytes written per locus
+            nbytes = sum((c.matrix_t.element_size() * int(c.matrix_t.shape[0]) + 8) * c.n for c in med)
+            median_timing.append((ev0, ev1, nbytes))
         for c in med:
             c._effect_mean = got[id(c)]  # rocco/rocco.py:995-997: the bigWig branch uses the scores themselves
         return [got.get(id(c)) for c in members]

@@ -248,6 +248,45 @@ def decode_runs_device(solution_t, capacity: Optional[int] = None):
         cap = int(n_runs.value)
 
 
+def decode_runs_batch_device(solutions, capacities=None):
+    """`decode_runs_device` for several uint8 CUDA solution tensors in three launches and one synchronisation
+    (rocco_hip_decode_runs_batch); returns a list of (begin, end) tensor pairs."""
+    import torch
+
+    solutions = [s.contiguous() for s in solutions]
+    count = len(solutions)
+    if count == 0:
+        return []
+    if any(s.dtype != torch.uint8 for s in solutions):
+        return [decode_runs_device(s) for s in solutions]
+    dev = solutions[0].device
+    ns = [int(s.shape[0]) for s in solutions]
+    caps = [int(c) for c in capacities] if capacities is not None else [max(1024, n // 64) for n in ns]
+    solver = _native.solver_for(dev.index)
+    lib = _native.load()
+    out = [None] * count
+    todo = list(range(count))
+    while todo:
+        begins = [torch.empty(caps[i], dtype=torch.int64, device=dev) for i in todo]
+        ends = [torch.empty(caps[i], dtype=torch.int64, device=dev) for i in todo]
+        k = len(todo)
+        n_runs = (ctypes.c_size_t * k)()
+        _native.check(lib.rocco_hip_decode_runs_batch(
+            solver.handle, k, (ctypes.c_void_p * k)(*[solutions[i].data_ptr() for i in todo]),
+            (ctypes.c_size_t * k)(*[ns[i] for i in todo]), (ctypes.c_void_p * k)(*[b.data_ptr() for b in begins]),
+            (ctypes.c_void_p * k)(*[e.data_ptr() for e in ends]), (ctypes.c_size_t * k)(*[caps[i] for i in todo]),
+            n_runs, _dp._stream_ptr(solutions[0])), "rocco_hip_decode_runs_batch")
+        again = []
+        for slot, i in enumerate(todo):
+            if n_runs[slot] <= caps[i]:
+                out[i] = (begins[slot][: n_runs[slot]], ends[slot][: n_runs[slot]])
+            else:
+                caps[i] = int(n_runs[slot])
+                again.append(i)
+        todo = again
+    return out
+
+
 def chrom_solution_records(chromosome, intervals, solution, check_gaps_intervals=True,
                            min_length_bp=None) -> List[Record]:
     """The merged records chrom_solution_to_bed writes (rocco/rocco.py:165-190), as a list."""

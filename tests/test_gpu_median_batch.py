@@ -32,3 +32,24 @@ def test_batch_with_mixed_shapes_falls_back(gpu):
     outs = score_central_tendency_chrom_batch_device([torch.from_numpy(m).to(gpu) for m in mats])
     for m, o in zip(mats, outs):
         assert np.array_equal(o.cpu().numpy(), np.median(m, axis=0))
+
+
+def test_decode_batch_equals_single_decodes(gpu):
+    """rocco_hip_decode_runs_batch: the runs of several solutions in three launches are those of one decode each
+    (including a capacity that is too small at first, an empty and a one-locus solution)."""
+    import torch
+    from rocco_amd.rocco import decode_runs_batch_device, decode_runs_device
+
+    rng = np.random.default_rng(3)
+    sols = []
+    for n in (1, 2, 15, 16, 17, 4095, 4096, 4097, 100003, 0):
+        z = (rng.random(n) < 0.3).astype(np.uint8)
+        sols.append(torch.from_numpy(z).to(gpu))
+    sols = [s for s in sols if s.numel() > 0]
+    got = decode_runs_batch_device(sols, capacities=[4] * len(sols))
+    for s, (b, e) in zip(sols, got):
+        wb, we = decode_runs_device(s)
+        assert torch.equal(b, wb) and torch.equal(e, we)
+        z = s.cpu().numpy()[:-1].astype(np.int8)  # the last locus is never emitted (rocco/rocco.py:180)
+        d = np.diff(np.concatenate([[0], z, [0]]))
+        assert np.array_equal(b.cpu().numpy(), np.flatnonzero(d == 1)) and np.array_equal(e.cpu().numpy(), np.flatnonzero(d == -1))
