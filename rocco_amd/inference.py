@@ -6,7 +6,10 @@ device replacement of the reference's ``rocco._baseline.crossfit_whittaker_basel
 ``_estimate_local_background_matrix`` mirrors rocco/inference.py:185-229 around it -- and the centred-WLS
 scores (row a4): ``score_centered_wls`` replaces ``rocco._wls.score_centered_wls`` (rocco/_wls.c over
 rocco/native/wls_backend.c:744-947), ``_score_centered_wls_matrix`` mirrors rocco/inference.py:231-299.
-Results are the reference's bit for bit.  There is no CPU fallback: without the library or a GPU these raise.
+Every track equals the reference's bit for bit from the log-scaled matrix on.  The log scale itself (log2 of
+count + 1) follows NumPy's to the last place or the one next to it: NumPy's own log2 is not correctly rounded and
+differs between its SVML and libm builds, so no fixed algorithm reproduces it on
+every host.  There is no CPU fallback: without the library or a GPU these raise.
 """
 from __future__ import annotations
 
@@ -19,25 +22,24 @@ from . import dp as _dp
 
 
 def _resolve_local_baseline_window(n_loci: int, target_window: int = 101) -> int:
-    """rocco/inference.py:49-62: odd window <= n_loci, 0 when fewer than 25 loci."""
-    n_loci = int(n_loci)
-    if n_loci < 25:
+    """Window of the local baseline (rocco/inference.py:50-62): the requested size, at least 3, made odd and
+    fitted into the track; no baseline (0) for tracks shorter than 25 loci."""
+    n = int(n_loci)
+    if n < 25:
         return 0
-    window = int(max(3, target_window))
-    if window > n_loci:
-        window = n_loci
-    if (window % 2) == 0:
-        window = window - 1 if window == n_loci else window + 1
-    return int(max(0, window))
+    w = min(max(3, int(target_window)), n)
+    if w % 2:
+        return w
+    return w + 1 if w < n else w - 1  # even: the next odd size, unless the track ends there
+
+
+_BLOCK_TO_BANDWIDTH = 0.15915494  # the reference's constant, digit for digit (rocco/inference.py:75)
 
 
 def _consenrich_whittaker_lambda(block_size: int) -> float:
-    """rocco/inference.py:65-76: smoothing block size -> Whittaker penalty."""
-    block = int(max(3, block_size))
-    if (block % 2) == 0:
-        block += 1
-    w_hat = float(block) * 0.15915494
-    return float(7.0 * (w_hat**4))
+    """Whittaker penalty of a smoothing block (rocco/inference.py:65-76): 7 (odd block size x 0.15915494)^4."""
+    odd_block = max(3, int(block_size)) | 1
+    return 7.0 * (float(odd_block) * _BLOCK_TO_BANDWIDTH) ** 4
 
 
 def crossfit_whittaker_baseline_device(values_t, penalty_lambda: float, out_t=None):

@@ -367,22 +367,20 @@ def narrowpeak_summit_offsets_device(intervals_t, effect_mean_t, peak_start_t, p
 
 
 def _cpy_narrowpeak_summit_track(chrom: str, intervals, effect_mean) -> Optional[str]:
-    """rocco/rocco.py:809-835: the per-chromosome summit track (starts, centres, float32 mean) as a temporary
-    .npz file, or None when there is no usable locus."""
+    """The per-chromosome summit track `_write_narrowpeak_summit_offsets` reads back (rocco/rocco.py:809-835): an
+    .npz with the left edge and the centre of every locus that has a right neighbour, and the float32 effect mean
+    there.  Returns the path of a temporary file the caller owns, or None when no locus qualifies."""
     import tempfile
 
-    intervals_ = np.asarray(intervals, dtype=np.int64)
-    effect_mean_ = np.asarray(effect_mean, dtype=np.float32)
-    usable = int(min(max(intervals_.shape[0] - 1, 0), effect_mean_.shape[0]))
-    if usable <= 0:
+    edges = np.asarray(intervals).astype(np.int64, copy=False)
+    track = np.asarray(effect_mean).astype(np.float32, copy=False)
+    n_bins = min(edges.shape[0] - 1, track.shape[0])  # a locus needs its right edge to have a centre
+    if n_bins < 1:
         return None
-    starts = intervals_[:usable]
-    centers = (intervals_[:usable].astype(np.int64) + intervals_[1:usable + 1].astype(np.int64)) // 2
-    fd, summit_track_file = tempfile.mkstemp(prefix=f"rocco_summit_track_{chrom}_", suffix=".npz")
-    os.close(fd)
-    np.savez(summit_track_file, starts=starts.astype(np.int64, copy=False),
-             centers=centers.astype(np.int64, copy=False), mean=effect_mean_[:usable].astype(np.float32, copy=False))
-    return summit_track_file
+    left, right = edges[:n_bins], edges[1:n_bins + 1]
+    with tempfile.NamedTemporaryFile(prefix=f"rocco_summit_track_{chrom}_", suffix=".npz", delete=False) as handle:
+        np.savez(handle, starts=left, centers=(left + right) // 2, mean=track[:n_bins])
+    return handle.name
 
 
 def _write_narrowpeak_summit_offsets(peak_file: str, chrom_cache: dict, output_file: str) -> str:

@@ -1,0 +1,68 @@
+"""GPU: `_score_centered_wls_matrix` and `_consenrich_crossfit_whittaker_baseline` on a handful of hand-built
+situations; expected outputs written by the reference's own functions (tests/golden/make_golden_count_path_cases.py).
+Every track must equal the reference's bit for bit; the properties asserted on top are this repository's reading of
+what those situations are about."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "count_path_cases.npz")
+TRACKS = ("mean", "raw_variance", "prior_variance", "moderated_variance", "standard_error", "z_scores")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _run(gold, name):
+    from rocco_amd.inference import _score_centered_wls_matrix
+
+    lb, df, win, floor = gold[f"{name}_kwargs"]
+    scores, details = _score_centered_wls_matrix(gold[f"{name}_centered"], lower_bound_z=float(lb), prior_df=float(df),
+                                                 spatial_window=int(win), precision_floor_ratio=float(floor))
+    assert scores.tobytes() == gold[f"{name}_scores"].tobytes(), name
+    for key in TRACKS:
+        assert np.asarray(details[key], dtype=np.float64).tobytes() == gold[f"{name}_{key}"].tobytes(), (name, key)
+    return scores, details
+
+
+def test_all_tied_values_score_minus_the_bound(gpu, gold):
+    scores, details = _run(gold, "zeros")
+    assert not details["mean"].any() and not details["z_scores"].any()
+    assert np.all(scores == -1.0) and details["standard_error"].min() > 0.0
+
+
+def test_noisy_stretch_of_one_track_is_downweighted(gpu, gold):
+    _, details = _run(gold, "noisy_pair")
+    lo, hi = (int(v) for v in gold["noisy_pair_region"])
+    tracks = gold["noisy_pair_centered"]
+    truth = tracks[0]
+    err_wls = np.abs(details["mean"][lo:hi] - truth[lo:hi]).mean()
+    err_plain = np.abs(tracks.mean(axis=0)[lo:hi] - truth[lo:hi]).mean()
+    assert err_wls < err_plain  # the weighted mean leans on the quiet track there
+    assert details["standard_error"][lo:hi].mean() > details["standard_error"][:lo - 50].mean()
+
+
+def test_precision_floor_never_lowers_the_standard_error(gpu, gold):
+    s0, d0 = _run(gold, "trio_no_floor")
+    s1, d1 = _run(gold, "trio_floor")
+    assert np.isclose(d1["precision_floor_ratio"], 0.3) and d0["precision_floor_ratio"] == 0.0
+    assert np.all(d1["standard_error"] >= d0["standard_error"]) and np.all(s1 <= s0)
+
+
+def test_baseline_follows_the_hump_not_the_spike(gpu, gold):
+    from rocco_amd.inference import _consenrich_crossfit_whittaker_baseline
+
+    signal, hump = gold["baseline_signal"], gold["baseline_hump"]
+    base = _consenrich_crossfit_whittaker_baseline(signal, block_size=int(gold["baseline_block"][0]))
+    assert base.tobytes() == gold["baseline_expected"].tobytes()
+    flank, top = 50, 75
+    assert base[flank] > 0.5 * hump[flank] and (signal - base)[top] > 3.0 * max((signal - base)[flank], 1e-6)
+    short = _consenrich_crossfit_whittaker_baseline(np.full(20, 3.0))  # fewer than 25 loci: zeros
+    assert short.tobytes() == gold["baseline_short_expected"].tobytes() and not short.any()
+    with pytest.raises(ValueError):
+        _consenrich_crossfit_whittaker_baseline(np.ones((2, 40)))
