@@ -312,6 +312,25 @@ int rocco_hip_multiply_f64(rocco_hip_solver *solver, const double *a_dev, const 
 int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *matrix_dev, const double *row_dev,
                                         size_t K, size_t n, double *out_dev, void *stream);
 
+/* ---- score-track budget estimate: the n-long pieces (rocco/inference.py:1151-1421, 446-501; rocco/rocco.py:751-789) ----
+ * rocco_hip_sort_f64: ascending sorted copy of a float64 vector (-0.0 before +0.0).  Every np.median / MAD / median
+ *   of the positive scores of the estimate is an order statistic of it.
+ * rocco_hip_sorted_probe_f64: values at up to 8 ranks of a sorted vector, and for up to 8 thresholds t how many
+ *   elements x have (x - shift) <= t and (x - shift) < t (binary search: x - shift is monotone in x).
+ * rocco_hip_autocovariance_sums_f64: sums_out[k] = sum_i (x_i - mean)(x_{i+k} - mean), k = 0..max_lag (<= 1023), summed
+ *   in a fixed order.  (The reference takes them from an FFT: agreement to ~1e-13 relative, not bitwise.)
+ * rocco_hip_negative_part_f64: out = scores - clip(scores, 0, None) (the residual template of the direct-score null).
+ * rocco_hip_soft_counts_f64: out = clip(scores - center, 0, None) / scale (the series whose autocorrelation time is taken). */
+int rocco_hip_sort_f64(rocco_hip_solver *solver, const double *x_dev, size_t n, double *sorted_out_dev, void *stream);
+int rocco_hip_sorted_probe_f64(rocco_hip_solver *solver, const double *sorted_dev, size_t n, const long long *ranks,
+                               size_t n_ranks, double *values_out, double shift, const double *thresholds,
+                               size_t n_thresholds, long long *counts_le_out, long long *counts_lt_out, void *stream);
+int rocco_hip_autocovariance_sums_f64(rocco_hip_solver *solver, const double *x_dev, size_t n, double mean, int max_lag,
+                                      double *sums_out, void *stream);
+int rocco_hip_negative_part_f64(rocco_hip_solver *solver, const double *scores_dev, double *out_dev, size_t n, void *stream);
+int rocco_hip_soft_counts_f64(rocco_hip_solver *solver, const double *scores_dev, double center, double scale, double *out_dev,
+                              size_t n, void *stream);
+
 /* bigWig dense fill: the NumPy statements of get_bigwig_chrom_scores after the file has been read
  * (rocco/readtracks.py:141-186) for one track's intervals in ascending order (as pyBigWig returns them).
  * *flags_out: bit 0 non-finite value (147-150), bit 1 non-positive width (153-156), bit 2 variable width (158-161),

@@ -11,6 +11,10 @@ from .dp import (  # noqa: F401
     solve_chrom_exact,
     solve_penalized_chain,
 )
+from .budget import (  # noqa: F401  (rocco/inference.py:1312-1421, 1593-1737)
+    estimate_budget_nonnull_fraction_from_score_track,
+    estimate_empirical_bayes_budgets,
+)
 from .inference import crossfit_whittaker_baseline  # noqa: F401  (rocco/_baseline.c:16-104)
 from .inference import score_centered_wls  # noqa: F401  (rocco/_wls.c)
 from .inference import score_loci_wls  # noqa: F401  (rocco/inference.py:302-379)

@@ -121,6 +121,15 @@ PROTOTYPES = [
     ("rocco_hip_objective_value_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
       ctypes.c_size_t, c_double_p, ctypes.c_void_p]),
+    ("rocco_hip_sort_f64", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_sorted_probe_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, c_ll_p, ctypes.c_size_t, c_double_p, ctypes.c_double, c_double_p,
+      ctypes.c_size_t, c_ll_p, c_ll_p, ctypes.c_void_p]),
+    ("rocco_hip_autocovariance_sums_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_int, c_double_p, ctypes.c_void_p]),
+    ("rocco_hip_negative_part_f64", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("rocco_hip_soft_counts_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("rocco_hip_decode_runs_batch", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), c_size_p, ctypes.POINTER(ctypes.c_void_p),
       ctypes.POINTER(ctypes.c_void_p), c_size_p, c_size_p, ctypes.c_void_p]),

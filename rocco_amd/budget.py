@@ -1,0 +1,508 @@
+"""Budget and switch-cost estimation around the solve, for score tracks held in HBM.
+
+What stands where in the reference:
+
+    estimate_budget_nonnull_fraction_from_score_track   rocco/inference.py:1312-1421 (+ the direct-score null, 1151-1309)
+    _estimate_effective_sample_size                     rocco/inference.py:446-501
+    estimate_empirical_bayes_budgets                    rocco/inference.py:1593-1737 (+ 1488-1590)
+    _resolve_chrom_gamma                                rocco/rocco.py:751-789
+    _resolve_budgets                                    rocco/rocco.py:1113-1143
+    the bigWig branch of _build_chrom_cache             rocco/rocco.py:977-1008, 1049-1097
+
+Split: every n-long step runs on the device -- the order statistics (np.median of the residual template, the MAD of
+its mirrored non-positive part, the median of the positive scores) are read off ONE radix sort of the vector, the
+means are summed in NumPy's own order (npsum.hip: equal to np.mean bit for bit), the per-draw product and its four
+statistics are the kernels of the count-path null, the autocovariances are summed in a fixed order
+(budget_stats.hip).  The dependent multipliers of the bootstrap draws come from NumPy's generator and SciPy's
+fftconvolve on the host, draw by draw as the reference makes them (their streams cannot be reproduced elsewhere;
+SURVEY.md section 8 (f)), and the scalar logic (Welford updates, the stopping rule, Geyer's truncation, the beta-binomial
+fit through SciPy) is host code.  Given the same multipliers every statistic equals the reference's bit for bit except
+the autocorrelation time, which the reference takes from an FFT (agreement ~1e-13; tests/golden/make_golden_budget.py).
+"""
+from __future__ import annotations
+
+import ctypes
+import logging
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+from . import dp as _dp
+
+logger = logging.getLogger(__name__)
+
+_MAD_TO_SIGMA = 1.4826  # rocco/inference.py:37
+
+
+# --------------------------------------------------------------------------------------------------------------
+# device helpers
+# --------------------------------------------------------------------------------------------------------------
+
+def _as_score_tensor(score_track):
+    import torch
+
+    if _dp._is_tensor(score_track):
+        t = score_track
+        if not t.is_cuda:
+            t = t.to(f"cuda:{_dp._device_index()}")
+        return t.to(torch.float64).contiguous()
+    arr = np.asarray(score_track, dtype=np.float64)
+    if arr.ndim != 1:
+        raise ValueError("`score_track` must be one-dimensional")
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(f"cuda:{_dp._device_index()}")
+
+
+def _lib_solver_stream(t):
+    return _native.load(), _native.solver_for(t.device.index), _dp._stream_ptr(t)
+
+
+def sort_device(x_t):
+    """Ascending sorted copy of a one-dimensional float64 CUDA tensor (rocco_hip_sort_f64)."""
+    import torch
+
+    out = torch.empty_like(x_t)
+    lib, solver, stream = _lib_solver_stream(x_t)
+    _native.check(lib.rocco_hip_sort_f64(solver.handle, x_t.data_ptr(), int(x_t.shape[0]), out.data_ptr(), stream),
+                  "rocco_hip_sort_f64")
+    return out
+
+
+def sorted_probe(sorted_t, ranks=(), thresholds=(), shift: float = 0.0):
+    """Values at `ranks` of a sorted tensor; for each threshold t the counts of (x - shift) <= t and < t."""
+    lib, solver, stream = _lib_solver_stream(sorted_t)
+    nr, nt = len(ranks), len(thresholds)
+    r = (ctypes.c_longlong * max(1, nr))(*[int(v) for v in ranks])
+    vals = (ctypes.c_double * max(1, nr))()
+    th = (ctypes.c_double * max(1, nt))(*[float(v) for v in thresholds])
+    le = (ctypes.c_longlong * max(1, nt))()
+    lt = (ctypes.c_longlong * max(1, nt))()
+    _native.check(lib.rocco_hip_sorted_probe_f64(solver.handle, sorted_t.data_ptr(), int(sorted_t.shape[0]), r, nr, vals,
+                                                 float(shift), th, nt, le, lt, stream), "rocco_hip_sorted_probe_f64")
+    return [float(v) for v in vals[:nr]], [int(v) for v in le[:nt]], [int(v) for v in lt[:nt]]
+
+
+def _median_of_sorted_range(sorted_t, first: int, count: int) -> float:
+    """np.median of sorted_t[first : first + count] (count >= 1): the middle value or the mean of the two middle ones."""
+    lo, hi = first + (count - 1) // 2, first + count // 2
+    (a, b), _, _ = sorted_probe(sorted_t, ranks=(lo, hi))
+    return a if lo == hi else (a + b) / 2.0
+
+
+def _draw_stats(scores_t, center: float, soft_scale: float, threshold: float) -> Tuple[float, float, float, float]:
+    """np.mean(pos), np.mean(pos / soft_scale), np.mean(pos > 0), np.mean(scores > threshold), pos = clip(scores - center, 0)."""
+    lib, solver, stream = _lib_solver_stream(scores_t)
+    out = (ctypes.c_double * 4)()
+    _native.check(lib.rocco_hip_budget_null_draw_stats_f64(solver.handle, scores_t.data_ptr(), int(scores_t.shape[0]),
+                                                           float(center), float(soft_scale), float(threshold), out, stream),
+                  "rocco_hip_budget_null_draw_stats_f64")
+    return float(out[0]), float(out[1]), float(out[2]), float(out[3])
+
+
+def _numpy_mean(x_t) -> float:
+    from .inference import numpy_sum_device
+
+    return numpy_sum_device(x_t) / float(x_t.shape[0])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# scalar rules of the estimate (host)
+# --------------------------------------------------------------------------------------------------------------
+
+def _resolve_budget_ess_max_lag(n_loci: int, dependence_lag_hint: Optional[int] = None) -> int:
+    """Lag cap of the autocorrelation sum (rocco/inference.py:504-517): four times the dependence scale (101 loci
+    unless hinted), at least 16, below the track length."""
+    n = max(1, int(n_loci))
+    scale = min(n, 101) if dependence_lag_hint is None else max(1, min(n, int(dependence_lag_hint)))
+    return int(min(n - 1, max(16, 4 * scale)))
+
+
+def _resolve_budget_bootstrap_bandwidth(n_loci: int, dependence_lag_hint: Optional[int] = None) -> int:
+    """Bandwidth of the dependent multipliers (rocco/inference.py:520-531): the hint, else n^(1/3), at least 8."""
+    n = max(1, int(n_loci))
+    if n <= 1:
+        return 1
+    wanted = round(n ** (1.0 / 3.0)) if dependence_lag_hint is None else int(dependence_lag_hint)
+    return int(min(n - 1, max(8, wanted)))
+
+
+def _build_budget_bootstrap_kernel(bandwidth: int) -> np.ndarray:
+    """Bartlett weights on -b..b, scaled to unit sum of squares (rocco/inference.py:534-543)."""
+    b = max(1, int(bandwidth))
+    taps = np.maximum(1.0 - np.abs(np.arange(-b, b + 1, dtype=np.float64)) / float(b + 1), 0.0)
+    taps /= np.sqrt(np.sum(taps * taps))
+    return taps
+
+
+def _generate_dependent_wild_weights(n_loci: int, kernel: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+    """One draw of the multiplier process (rocco/inference.py:546-575): smoothed standard normals, centred and scaled
+    to unit variance -- on the host, with the reference's own generator calls in the reference's own order (what makes a
+    draw reproducible is the generator's stream, which no other implementation shares)."""
+    from scipy import signal
+
+    n = max(1, int(n_loci))
+    if n == 1:
+        return np.ones(1, dtype=np.float64)
+    taps = np.asarray(kernel, dtype=np.float64)
+    w = np.asarray(signal.fftconvolve(rng.standard_normal(n + taps.size - 1), taps, mode="valid"), dtype=np.float64)
+    w -= float(np.mean(w))
+    spread = float(np.std(w))
+    if np.isfinite(spread) and spread > 1.0e-8:
+        return w / spread
+    signs = rng.choice(np.array([-1.0, 1.0]), size=n)  # degenerate smoothing: Rademacher signs instead
+    signs -= float(np.mean(signs))
+    return signs / max(float(np.std(signs)), 1.0e-6)
+
+
+class _Running:
+    """Welford mean / sum of squared deviations (rocco/inference.py:578-590)."""
+
+    def __init__(self):
+        self.count, self.mean, self.m2 = 0, 0.0, 0.0
+
+    def add(self, value: float) -> None:
+        self.count += 1
+        delta = float(value) - self.mean
+        self.mean += delta / float(self.count)
+        self.m2 += delta * (float(value) - self.mean)
+
+    def sd(self) -> float:
+        return float(np.sqrt(max(self.m2 / float(max(self.count - 1, 1)), 0.0)))
+
+    def stderr(self) -> float:
+        return float(np.sqrt(max(self.m2 / float(max(self.count - 1, 1)), 0.0) / float(max(self.count, 1))))
+
+
+def _stable_enough(run: _Running, min_draws: int, abs_tol: float, rel_tol: float) -> bool:
+    """Stopping rule of the draws (rocco/inference.py:593-606)."""
+    if run.count < max(2, int(min_draws)):
+        return False
+    return run.stderr() <= max(abs_tol, rel_tol * max(abs(run.mean), 1.0e-6))
+
+
+def _estimate_effective_sample_size_device(values_t, max_lag: int) -> Tuple[float, float, int]:
+    """n / tau_int with Geyer's positive-pair truncation (rocco/inference.py:446-501); autocovariances on the device."""
+    n = int(values_t.shape[0])
+    if n < 4:
+        return float(max(1, n)), 1.0, 0
+    mean = _numpy_mean(values_t)
+    lag_cap = int(min(max(2, int(max_lag)), n - 1))
+    lib, solver, stream = _lib_solver_stream(values_t)
+    sums = (ctypes.c_double * (lag_cap + 1))()
+    _native.check(lib.rocco_hip_autocovariance_sums_f64(solver.handle, values_t.data_ptr(), n, float(mean), lag_cap, sums, stream),
+                  "rocco_hip_autocovariance_sums_f64")
+    acov = np.array(sums[:lag_cap + 1], dtype=np.float64)
+    var0 = acov[0] / float(n)  # np.mean(centered * centered)
+    if not np.isfinite(var0) or var0 <= 1.0e-12:
+        return float(n), 1.0, 0
+    acov /= np.arange(n, n - lag_cap - 1, -1, dtype=np.float64)
+    if not np.isfinite(acov[0]) or acov[0] <= 1.0e-12:
+        return float(n), 1.0, 0
+    acf = np.clip(acov[1:] / acov[0], -1.0, 1.0)
+    tau, used = 1.0, 0
+    for k in range(0, acf.size, 2):
+        pair = float(acf[k]) + (float(acf[k + 1]) if k + 1 < acf.size else 0.0)
+        if not np.isfinite(pair) or pair <= 0.0:
+            break
+        tau += 2.0 * pair
+        used = int(min(lag_cap, k + 2))
+    return float(np.clip(n / max(tau, 1.0), 1.0, n)), float(tau), int(used)
+
+
+def _estimate_effective_sample_size(values, max_lag: int) -> Tuple[float, float, int]:
+    """Same call as the reference's (host array in, three numbers out)."""
+    arr = np.asarray(values, dtype=np.float64)
+    if arr.ndim != 1:
+        raise ValueError("`values` must be one-dimensional")
+    if arr.size < 4:
+        return float(max(1, arr.size)), 1.0, 0
+    return _estimate_effective_sample_size_device(_as_score_tensor(arr), max_lag)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the estimate
+# --------------------------------------------------------------------------------------------------------------
+
+def estimate_budget_nonnull_fraction_from_score_track(score_track, dependence_lag_hint: Optional[int] = None,
+                                                      num_null_draws: int = 25, random_seed: int = 0,
+                                                      progress_label: Optional[str] = None, num_processes: int = 1,
+                                                      return_details: bool = False, min_null_draws: Optional[int] = None,
+                                                      stability_abs_tol: float = 5.0e-3, stability_rel_tol: float = 5.0e-2):
+    """Conservative enriched fraction of a score track (rocco/inference.py:1312-1421): tail occupancy of the observed
+    scores above the null's threshold minus that of dependent-wild-bootstrap draws of the one-sided residual track.
+    `score_track`: NumPy array or float64 CUDA tensor.  Same return value and details keys as the reference."""
+    import torch
+
+    _ = int(max(1, num_processes))
+    s_t = _as_score_tensor(score_track)
+    if s_t.dim() != 1:
+        raise ValueError("`score_track` must be one-dimensional")
+    n = int(s_t.shape[0])
+    if n == 0:
+        raise ValueError("`score_track` must contain at least one locus")
+    lib, solver, stream = _lib_solver_stream(s_t)
+
+    # ---- the null's reference: residual = score - max(score, 0); centre = its median; scale from the mirrored
+    # non-positive side (rocco/inference.py:1170-1188).  One sort serves every order statistic.
+    template_t = torch.empty_like(s_t)
+    _native.check(lib.rocco_hip_negative_part_f64(solver.handle, s_t.data_ptr(), template_t.data_ptr(), n, stream),
+                  "rocco_hip_negative_part_f64")
+    sorted_template = sort_device(template_t)
+    null_center = _median_of_sorted_range(sorted_template, 0, n)
+    # residuals (template - centre) <= 0 are the first `m` of the sorted template (x - c is monotone in x)
+    _, (m,), (n_below,) = sorted_probe(sorted_template, thresholds=(0.0,), shift=null_center)
+    if m == 0:  # cannot happen (the median has at least one element at or below it); kept for the reference's branch
+        raise ValueError("Direct-score budget null fit produced non-finite values")
+    # magnitudes = -(template - centre) of those, ascending = the sorted residuals read backwards; the mirrored sample
+    # (-mag, +mag) has median 0 and absolute deviations (mag, mag): its median is the mean of two magnitudes
+    k_lo, k_hi = (m - 1) // 2, m // 2
+    (r_lo, r_hi), _, _ = sorted_probe(sorted_template, ranks=(m - 1 - k_lo, m - 1 - k_hi))
+    mad = ((-(r_lo - null_center)) + (-(r_hi - null_center))) / 2.0
+    null_scale = float(max(mad * _MAD_TO_SIGMA, 1.0e-6))
+    if not np.isfinite(null_center) or not np.isfinite(null_scale):
+        raise ValueError("Direct-score budget null fit produced non-finite values")
+    soft_scale = float(max(null_scale, 1.0e-6))
+    null_threshold = float(null_center + 2.0 * null_scale)
+
+    # ---- the draws (rocco/inference.py:1190-1262) ----
+    bandwidth = _resolve_budget_bootstrap_bandwidth(n, dependence_lag_hint)
+    taps = _build_budget_bootstrap_kernel(bandwidth)
+    max_draws = int(max(1, num_null_draws))
+    min_draws = int(min(max_draws, max(4, 8 if min_null_draws is None else min_null_draws)))
+    mass, units, fraction, tail = _Running(), _Running(), _Running(), _Running()
+    rng = np.random.default_rng(int(random_seed))
+    product_t = torch.empty_like(s_t)
+    weights_dev = torch.empty_like(s_t)
+    for _draw in range(max_draws):
+        weights_dev.copy_(torch.from_numpy(_generate_dependent_wild_weights(n, taps, rng)))
+        _native.check(lib.rocco_hip_multiply_f64(solver.handle, template_t.data_ptr(), weights_dev.data_ptr(),
+                                                 product_t.data_ptr(), n, stream), "rocco_hip_multiply_f64")
+        d_mass, d_units, d_fraction, d_tail = _draw_stats(product_t, null_center, soft_scale, null_threshold)
+        mass.add(d_mass)
+        units.add(d_units)
+        fraction.add(d_fraction)
+        tail.add(d_tail)
+        if _stable_enough(units, min_draws, stability_abs_tol, stability_rel_tol):
+            break
+    draws_used = units.count
+
+    # ---- observed side and the effective sample size (rocco/inference.py:1340-1366) ----
+    obs_mass, obs_units, obs_pos_fraction, obs_tail = _draw_stats(s_t, null_center, soft_scale, null_threshold)
+    sorted_scores = sort_device(s_t)
+    _, _, (n_neg,) = sorted_probe(sorted_scores, thresholds=(0.0,), shift=null_center)  # residual < 0
+    obs_neg_fraction = float(n_neg) / float(n)
+    soft_t = torch.empty_like(s_t)
+    _native.check(lib.rocco_hip_soft_counts_f64(solver.handle, s_t.data_ptr(), float(null_center), soft_scale, soft_t.data_ptr(),
+                                                n, stream), "rocco_hip_soft_counts_f64")
+    ess_max_lag = _resolve_budget_ess_max_lag(n, dependence_lag_hint)
+    effective_total, tau_int, ess_lags_used = _estimate_effective_sample_size_device(soft_t, ess_max_lag)
+    nonnull_fraction = float(np.clip(obs_tail - tail.mean, 0.0, 1.0))
+    if not (np.isfinite(nonnull_fraction) and np.isfinite(effective_total) and np.isfinite(tau_int)):
+        raise ValueError("Direct-score budget initialization produced non-finite values")
+    # positive consensus = clip(scores, 0): its mean / max (rocco/inference.py:1305-1306)
+    pos_mean, _u, _f, _t = _draw_stats(s_t, 0.0, 1.0, 0.0)
+    (top,), _, _ = sorted_probe(sorted_scores, ranks=(n - 1,))
+    details: Dict[str, Any] = {
+        "observed_positive_fraction": float(obs_pos_fraction),
+        "observed_negative_fraction": float(obs_neg_fraction),
+        "null_positive_fraction": float(fraction.mean),
+        "observed_excess_mass": float(obs_mass),
+        "null_excess_mass": float(mass.mean),
+        "observed_excess_units": float(obs_units),
+        "null_excess_units": float(units.mean),
+        "null_excess_units_sd": float(units.sd()),
+        "null_excess_units_stderr": float(units.stderr()),
+        "null_threshold": float(null_threshold),
+        "observed_tail_occupancy": float(obs_tail),
+        "null_tail_occupancy": float(tail.mean),
+        "null_tail_occupancy_sd": float(tail.sd()),
+        "null_tail_occupancy_stderr": float(tail.stderr()),
+        "null_center": float(null_center),
+        "null_scale": float(null_scale),
+        "nonnull_fraction": float(nonnull_fraction),
+        "effective_count": float(nonnull_fraction * effective_total),
+        "effective_total_count": float(effective_total),
+        "autocorrelation_time": float(tau_int),
+        "ess_max_lag": float(ess_max_lag),
+        "ess_lags_used": float(ess_lags_used),
+        "num_loci": float(n),
+        "negative_support_size": float(m),
+        "negative_fraction": float(m / max(n, 1)),
+        "num_null_draws": float(draws_used),
+        "max_null_draws": float(max_draws),
+        "adaptive_stop": bool(draws_used < max_draws),
+        "wild_bandwidth": float(bandwidth),
+        "wild_process": "bartlett_multiplier",
+        "null_method": "dependent_wild_score_bootstrap",
+        "null_reference_mean_positive_consensus": float(pos_mean),
+        "null_reference_max_positive_consensus": float(max(top, 0.0)),
+    }
+    if return_details:
+        return nonnull_fraction, details
+    return nonnull_fraction
+
+
+# --------------------------------------------------------------------------------------------------------------
+# switch cost (rocco/rocco.py:751-789)
+# --------------------------------------------------------------------------------------------------------------
+
+def _resolve_chrom_gamma(chrom: str, args: dict, chrom_scores, budget_rate_meta: dict):
+    """A fixed `--gamma`, or 0.5 x ceil(autocorrelation time) x median of the positive scores clipped to [0.5, 10];
+    same return value (gamma, metadata or None) as the reference."""
+    if args["gamma"] is not None:
+        fixed = float(args["gamma"])
+        if not np.isfinite(fixed) or fixed < 0.0:
+            raise ValueError("`--gamma` must be finite and non-negative")
+        return fixed, None
+    s_t = _as_score_tensor(chrom_scores)
+    n = int(s_t.shape[0])
+    positive_count, positive_median = 0, 1.0
+    if n > 0:
+        ordered = sort_device(s_t)
+        _, (not_positive,), _ = sorted_probe(ordered, thresholds=(0.0,))  # scores <= 0 come first
+        positive_count = n - not_positive
+        if positive_count > 0:
+            positive_median = _median_of_sorted_range(ordered, not_positive, positive_count)
+    tau = max(1.0, float(budget_rate_meta.get("autocorrelation_time", 1.0)))
+    run_length = int(np.ceil(tau))
+    raw = 0.5 * float(run_length) * float(positive_median)
+    gamma = float(np.clip(raw, 0.5, 10.0))
+    meta = {"method": "auto_score_autocorr", "autocorrelation_time": float(tau), "characteristic_run_length": int(run_length),
+            "positive_score_median": float(positive_median), "positive_score_count": int(positive_count),
+            "gamma_raw": float(raw), "gamma_clipped": float(gamma), "gamma_clip_min": 0.5, "gamma_clip_max": 10.0}
+    logger.info("%s auto gamma estimate: %s", chrom, meta)
+    return gamma, meta
+
+
+# --------------------------------------------------------------------------------------------------------------
+# empirical-Bayes pooling across chromosomes (rocco/inference.py:1488-1737) -- scalar host code over <= 24 pairs
+# --------------------------------------------------------------------------------------------------------------
+
+def fit_beta_prior_mle(successes, totals, init_center: float = 0.05, init_strength: float = 10.0) -> Tuple[float, float]:
+    """Beta prior of the per-chromosome rates by beta-binomial maximum likelihood (rocco/inference.py:1488-1562)."""
+    from scipy import optimize, special
+
+    x = np.asarray(successes, dtype=np.float64)
+    t = np.asarray(totals, dtype=np.float64)
+    if x.shape != t.shape:
+        raise ValueError("`successes` and `totals` must have the same shape")
+    if x.size == 0:
+        return 1.0, 1.0
+    center = min(max(float(init_center), 1.0e-6), 1.0 - 1.0e-6)
+    pooled, seen_var, floor_var = _rate_dispersion(x, t)
+    if seen_var <= floor_var + 1.0e-12:  # no dispersion beyond the binomial: a (practically) degenerate prior at the pooled rate
+        strength = float(max(1.0e12, 100.0 * np.max(t)))
+        return pooled * strength, (1.0 - pooled) * strength
+
+    def negative_log_likelihood(theta):
+        a, b = float(np.exp(theta[0])), float(np.exp(theta[1]))
+        return float(-np.sum(special.betaln(x + a, t - x + b) - special.betaln(a, b)))
+
+    start = np.log(np.array([center * float(init_strength), (1.0 - center) * float(init_strength)], dtype=np.float64))
+    fit = optimize.minimize(negative_log_likelihood, start, method="L-BFGS-B")
+    if not fit.success:
+        logger.warning("Falling back to a weak beta prior while fitting EB budgets: %s", fit.message)
+        return center * float(init_strength), (1.0 - center) * float(init_strength)
+    return float(np.exp(fit.x[0])), float(np.exp(fit.x[1]))
+
+
+def _rate_dispersion(x: np.ndarray, t: np.ndarray) -> Tuple[float, float, float]:
+    """Pooled rate, the variance of the raw rates across chromosomes, and its binomial floor."""
+    rates = x / np.maximum(t, 1.0)
+    pooled = float(np.clip(np.sum(x) / max(np.sum(t), 1.0), 1.0e-6, 1.0 - 1.0e-6))
+    seen = float(np.var(rates, ddof=1)) if rates.size > 1 else 0.0
+    floor = float(pooled * (1.0 - pooled) * np.mean(1.0 / np.maximum(t, 1.0)))
+    return pooled, seen, floor
+
+
+def _posterior_budget(x: float, t: float, a: float, b: float, quantile: float, lo: float, hi: float) -> float:
+    """Quantile of the Beta(x + a, t - x + b) posterior, clipped to the budget range (rocco/inference.py:1565-1590)."""
+    from scipy import stats
+
+    q = float(np.clip(quantile, 1.0e-6, 1.0 - 1.0e-6))
+    value = float(stats.beta.ppf(q, float(max(1.0e-12, x + a)), float(max(1.0e-12, (t - x) + b))))
+    return float(np.clip(value, lo, hi))
+
+
+def estimate_empirical_bayes_budgets(chrom_candidate_counts: Dict[str, float], chrom_total_counts: Dict[str, float],
+                                     min_budget: float = 1.0e-4, max_budget: float = 0.5, init_center: float = 0.05,
+                                     init_strength: float = 10.0, posterior_quantile: float = 0.01):
+    """Per-chromosome budgets shrunk towards a genome-wide beta prior (rocco/inference.py:1593-1737); same return value
+    (budgets, metadata) and metadata keys as the reference."""
+    chroms = list(chrom_candidate_counts)
+    if chroms != list(chrom_total_counts):
+        raise ValueError("`chrom_candidate_counts` and `chrom_total_counts` must share keys in the same order")
+    x = np.array([chrom_candidate_counts[c] for c in chroms], dtype=np.float64)
+    t = np.array([chrom_total_counts[c] for c in chroms], dtype=np.float64)
+    pooled, seen_var, floor_var = _rate_dispersion(x, t)
+    q = float(posterior_quantile)
+    if not (0.0 < q < 1.0):
+        raise ValueError("`posterior_quantile` must lie strictly between 0 and 1")
+    at_floor = bool(seen_var <= floor_var + 1.0e-12)
+    if len(chroms) <= 1:  # nothing to pool: the default prior
+        a, b = float(init_center) * float(init_strength), (1.0 - float(init_center)) * float(init_strength)
+        method, genome_wide, strength = "single_chrom_default", float(init_center), float(init_strength)
+        dispersion, flag = float(1.0 / (1.0 + a + b)), False
+    elif len(chroms) <= 3:  # too few chromosomes to fit a dispersion: a weak prior at the pooled rate
+        a, b = float(pooled) * float(init_strength), (1.0 - float(pooled)) * float(init_strength)
+        method, genome_wide, strength = "weak_pooled_prior", float(pooled), float(a + b)
+        dispersion, flag = float(max(0.0, 1.0 / (1.0 + strength))), at_floor
+    else:
+        a, b = fit_beta_prior_mle(x, t, init_center=init_center, init_strength=init_strength)
+        method, genome_wide, strength = "beta_binomial_mle", float(a / (a + b)), float(a + b)
+        dispersion, flag = float(max(0.0, 1.0 / (1.0 + strength))), at_floor
+    budgets = {c: _posterior_budget(float(x[i]), float(t[i]), a, b, q, min_budget, max_budget) for i, c in enumerate(chroms)}
+    meta = {"alpha": float(a), "beta": float(b), "genome_wide_budget": float(genome_wide), "prior_strength": float(strength),
+            "prior_dispersion": float(dispersion), "min_prior_dispersion": 0.0, "observed_raw_budget_var": float(seen_var),
+            "theoretical_min_raw_budget_var": float(floor_var), "prior_dispersion_at_floor": bool(flag),
+            "posterior_summary": "beta_quantile", "posterior_quantile": float(q), "prior_fit_method": method}
+    return budgets, meta
+
+
+def _resolve_budgets(chrom_cache: dict, args: dict):
+    """Budgets of every chromosome of the cache (rocco/rocco.py:1113-1143): the empirical-Bayes estimates, rescaled to
+    a requested genome-wide `--budget`, times `--scale_chrom_budgets`, clipped to [0.005, 0.1]."""
+    counts = {c: chrom_cache[c]["budget_count_hat"] for c in chrom_cache}
+    totals = {c: chrom_cache[c]["total_count"] for c in chrom_cache}
+    budgets, meta = estimate_empirical_bayes_budgets(counts, totals, posterior_quantile=args["budget_posterior_quantile"])
+    rescale = 1.0
+    if args["budget"] is not None and meta["genome_wide_budget"] > 0:
+        rescale = float(args["budget"]) / meta["genome_wide_budget"]
+    scale = float(args["scale_chrom_budgets"])
+    budgets = {c: min(max(budgets[c] * rescale * scale, 0.005), 0.1) for c in budgets}
+    logger.info("Empirical-Bayes budget prior: %s", meta)
+    return budgets, meta
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the bigWig branch of _build_chrom_cache (rocco/rocco.py:977-1008, 1049-1097) for matrices held in HBM
+# --------------------------------------------------------------------------------------------------------------
+
+def build_chrom_cache_from_tracks(chrom_tracks: Dict[str, Tuple[Any, Any]], args: dict) -> dict:
+    """`chrom_tracks[chrom] = (intervals, matrix)` with `matrix` a [K, n] NumPy array or CUDA tensor of signal tracks.
+    Returns the reference's cache entries (scores as float64 CUDA tensors): scores, gamma, gamma_meta,
+    budget_count_hat, budget_fraction_hat, budget_rate_meta, total_count, num_loci, intervals."""
+    import torch
+
+    from . import rocco as _rocco
+
+    cache = {}
+    for chrom, (intervals, matrix) in chrom_tracks.items():
+        m_t = matrix if _dp._is_tensor(matrix) else torch.from_numpy(np.ascontiguousarray(matrix)).to(f"cuda:{_dp._device_index()}")
+        if not bool(torch.isfinite(m_t).all()):
+            raise ValueError(f"{chrom} matrix contains non-finite values")
+        scores_t = _rocco.score_central_tendency_chrom_device(m_t)
+        if not bool(torch.isfinite(scores_t).all()):
+            raise ValueError(f"{chrom} direct scores contain non-finite values")
+        fraction, rate_meta = estimate_budget_nonnull_fraction_from_score_track(
+            scores_t, num_null_draws=args["budget_null_draws"], return_details=True)
+        if not np.isfinite(fraction):
+            raise ValueError(f"{chrom} budget estimate is not finite")
+        n = int(scores_t.shape[0])
+        total = float(np.clip(rate_meta.get("effective_total_count", n), 1.0, n))
+        count = float(np.clip(fraction * total, 0.0, total))
+        gamma, gamma_meta = _resolve_chrom_gamma(chrom, args, scores_t, rate_meta)
+        cache[chrom] = {"intervals": intervals, "scores": scores_t, "gamma": gamma, "gamma_meta": gamma_meta,
+                        "budget_count_hat": count, "budget_fraction_hat": float(fraction), "budget_rate_meta": rate_meta,
+                        "total_count": total, "num_loci": n}
+    return cache

@@ -326,6 +326,97 @@ int rocco_hip_objective_value_f64(rocco_hip_solver *solver, const uint8_t *solut
     return rc;
 }
 
+int rocco_hip_sort_f64(rocco_hip_solver *solver, const double *x_dev, size_t n, double *sorted_out_dev, void *stream)
+{
+    if (solver == nullptr || (n > 0 && (x_dev == nullptr || sorted_out_dev == nullptr)) || n >= ((size_t)1 << 31)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    const int rc = solver->dev_misc.reserve(sort_f64_scratch_bytes(n));
+    if (rc != ROCCO_HIP_OK) return rc;
+    return launch_sort_f64(x_dev, n, sorted_out_dev, solver->dev_misc.ptr, (hipStream_t)stream);
+}
+
+int rocco_hip_sorted_probe_f64(rocco_hip_solver *solver, const double *sorted_dev, size_t n, const long long *ranks,
+                               size_t n_ranks, double *values_out, double shift, const double *thresholds,
+                               size_t n_thresholds, long long *counts_le_out, long long *counts_lt_out, void *stream)
+{
+    if (solver == nullptr || sorted_dev == nullptr || n == 0 || n_ranks > 8 || n_thresholds > 8 ||
+        (n_ranks > 0 && (ranks == nullptr || values_out == nullptr)) ||
+        (n_thresholds > 0 && (thresholds == nullptr || counts_le_out == nullptr || counts_lt_out == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    SortedProbe p;
+    p.n_ranks = (int)n_ranks;
+    p.n_thresholds = (int)n_thresholds;
+    p.shift = shift;
+    for (size_t i = 0; i < 8; ++i) {
+        p.ranks[i] = (i < n_ranks) ? ranks[i] : 0;
+        p.thresholds[i] = (i < n_thresholds) ? thresholds[i] : 0.0;
+    }
+    int rc = solver->dev_results.reserve(8 * sizeof(double) + 16 * sizeof(long long) + 64);
+    if (rc != ROCCO_HIP_OK) return rc;
+    rc = solver->host_back.reserve(8 * sizeof(double) + 16 * sizeof(long long) + 64);
+    if (rc != ROCCO_HIP_OK) return rc;
+    double *d_vals = (double *)solver->dev_results.ptr;
+    long long *d_cnts = (long long *)((char *)solver->dev_results.ptr + 64);
+    rc = launch_sorted_probe(sorted_dev, n, p, d_vals, d_cnts, (hipStream_t)stream);
+    if (rc != ROCCO_HIP_OK) return rc;
+    ROCCO_HIP_TRY(hipMemcpyAsync(solver->host_back.ptr, solver->dev_results.ptr, 64 + 16 * sizeof(long long), hipMemcpyDeviceToHost,
+                                 (hipStream_t)stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    const double *hv = (const double *)solver->host_back.ptr;
+    const long long *hc = (const long long *)((const char *)solver->host_back.ptr + 64);
+    for (size_t i = 0; i < n_ranks; ++i) values_out[i] = hv[i];
+    for (size_t i = 0; i < n_thresholds; ++i) {
+        counts_le_out[i] = hc[2 * i];
+        counts_lt_out[i] = hc[2 * i + 1];
+    }
+    return ROCCO_HIP_OK;
+}
+
+int rocco_hip_autocovariance_sums_f64(rocco_hip_solver *solver, const double *x_dev, size_t n, double mean, int max_lag,
+                                      double *sums_out, void *stream)
+{
+    if (solver == nullptr || x_dev == nullptr || n == 0 || sums_out == nullptr || max_lag < 0 || max_lag > 1023) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc = solver->dev_misc.reserve(autocov_scratch_bytes(n, max_lag));
+    if (rc != ROCCO_HIP_OK) return rc;
+    rc = solver->dev_results.reserve(1024 * sizeof(double));
+    if (rc != ROCCO_HIP_OK) return rc;
+    rc = solver->host_back.reserve(1024 * sizeof(double));
+    if (rc != ROCCO_HIP_OK) return rc;
+    rc = launch_autocov(x_dev, n, mean, max_lag, (double *)solver->dev_results.ptr, solver->dev_misc.ptr, (hipStream_t)stream);
+    if (rc != ROCCO_HIP_OK) return rc;
+    ROCCO_HIP_TRY(hipMemcpyAsync(solver->host_back.ptr, solver->dev_results.ptr, (size_t)(max_lag + 1) * sizeof(double),
+                                 hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    std::memcpy(sums_out, solver->host_back.ptr, (size_t)(max_lag + 1) * sizeof(double));
+    return ROCCO_HIP_OK;
+}
+
+int rocco_hip_negative_part_f64(rocco_hip_solver *solver, const double *scores_dev, double *out_dev, size_t n, void *stream)
+{
+    if (solver == nullptr || (n > 0 && (scores_dev == nullptr || out_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_negative_part(scores_dev, out_dev, n, (hipStream_t)stream);
+}
+
+int rocco_hip_soft_counts_f64(rocco_hip_solver *solver, const double *scores_dev, double center, double scale, double *out_dev,
+                              size_t n, void *stream)
+{
+    if (solver == nullptr || (n > 0 && (scores_dev == nullptr || out_dev == nullptr)) || !(scale > 0.0)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_soft_counts(scores_dev, center, scale, out_dev, n, (hipStream_t)stream);
+}
+
 int rocco_hip_decode_runs_batch(rocco_hip_solver *solver, size_t count, const uint8_t *const *solutions_dev, const size_t *n,
                                 int64_t *const *run_begin_dev, int64_t *const *run_end_dev, const size_t *capacities,
                                 size_t *n_runs_out, void *stream)

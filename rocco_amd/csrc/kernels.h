@@ -154,6 +154,25 @@ int launch_bigwig_dense_fill(const int64_t *starts_dev, const int64_t *ends_dev,
                              int64_t *first_start_out, int64_t *step_out, size_t *n_full_out, int *flags_out,
                              void *scratch_dev, hipStream_t stream);
 
+// ---- budget_stats.hip ----------------------------------------------------------------------
+struct SortedProbe {
+    long long ranks[8];
+    double thresholds[8];
+    double shift;  // thresholds are compared with (x - shift)
+    int n_ranks, n_thresholds;
+};
+size_t sort_f64_scratch_bytes(size_t n);
+int launch_sort_f64(const double *x_dev, size_t n, double *sorted_out_dev, void *scratch_dev, hipStream_t stream);
+// values_out_dev: n_ranks doubles; counts_out_dev: 2 * n_thresholds (count of (x - shift) <= t, then < t)
+int launch_sorted_probe(const double *sorted_dev, size_t n, const SortedProbe &probe, double *values_out_dev,
+                        long long *counts_out_dev, hipStream_t stream);
+size_t autocov_scratch_bytes(size_t n, int max_lag);
+// sums_out_dev[k] = sum_i (x_i - mean)(x_{i+k} - mean), k = 0..max_lag (<= 1023), in a fixed order
+int launch_autocov(const double *x_dev, size_t n, double mean, int max_lag, double *sums_out_dev, void *scratch_dev,
+                   hipStream_t stream);
+int launch_negative_part(const double *scores_dev, double *out_dev, size_t n, hipStream_t stream);
+int launch_soft_counts(const double *scores_dev, double center, double scale, double *out_dev, size_t n, hipStream_t stream);
+
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
                  hipStream_t stream);

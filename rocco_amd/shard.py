@@ -32,6 +32,34 @@ def makespan(sizes: Sequence[int], owned: List[List[int]]) -> int:
     return max((sum(int(sizes[i]) for i in part) for part in owned), default=0)
 
 
+def gather_budget_counts(local: Dict[int, Tuple[float, float]], n_units: int, device=None, group=None) -> Dict[int, Tuple[float, float]]:
+    """The one cross-chromosome exchange BEFORE the solve (rocco/rocco.py:1117-1127 read every chromosome's
+    `budget_count_hat` and `total_count` to pool the budgets): `local` maps the units this rank owns to that pair;
+    returns the pairs of every unit, identical on every rank, so that each rank runs the same host-side
+    empirical-Bayes fit (rocco_amd/budget.py) and keeps the budgets of its own units.  One all_gather of a
+    [n_units, 3] float64 tensor (flag, count, total) per rank: 24 x 24 bytes on a genome."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dict(local)
+    world = dist.get_world_size(group)
+    dev = device if device is not None else "cpu"
+    mine = torch.zeros((n_units, 3), dtype=torch.float64, device=dev)
+    for u, (count, total) in local.items():
+        mine[u, 0], mine[u, 1], mine[u, 2] = 1.0, float(count), float(total)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    merged: Dict[int, Tuple[float, float]] = {}
+    for part in parts:
+        arr = part.cpu().numpy()
+        for u in np.flatnonzero(arr[:, 0] > 0.5):
+            if int(u) in merged:
+                raise ValueError(f"unit {int(u)} is owned by more than one rank")
+            merged[int(u)] = (float(arr[u, 1]), float(arr[u, 2]))
+    return merged
+
+
 def gather_intervals(local: Dict[int, np.ndarray], device=None, group=None) -> Dict[int, np.ndarray]:
     """Gather per-unit interval arrays to every rank.
 

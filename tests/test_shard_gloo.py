@@ -41,3 +41,51 @@ def test_gather_intervals_two_ranks(tmp_path):
                 continue
             want = np.stack([np.arange(m) * 100 + u, np.arange(m) * 100 + u + 50], axis=1)
             assert np.array_equal(g[str(u)], want)
+
+
+def _budget_worker(rank, world, port, out_dir):
+    import json
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rocco_amd import budget, shard
+
+    sizes = [50, 40, 30, 20, 10, 5]
+    counts = [3.0, 40.0, 11.0, 26.5, 0.0, 88.0]
+    totals = [1000.0, 1500.0, 800.0, 1200.0, 600.0, 2000.0]
+    owned = shard.lpt_partition(sizes, world)
+    local = {u: (counts[u], totals[u]) for u in owned[rank]}
+    merged = shard.gather_budget_counts(local, len(sizes))
+    # every rank pools the same pairs in the same (global) order and keeps its own chromosomes' budgets
+    order = sorted(merged)
+    budgets, meta = budget.estimate_empirical_bayes_budgets({f"u{u}": merged[u][0] for u in order},
+                                                            {f"u{u}": merged[u][1] for u in order})
+    with open(os.path.join(out_dir, f"budget{rank}.json"), "w") as fh:
+        json.dump({"merged": {str(u): merged[u] for u in order}, "budgets": budgets, "alpha": meta["alpha"],
+                   "owned": owned[rank]}, fh)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_budget_counts_exchange_two_ranks(tmp_path):
+    """SURVEY.md section 8(e), exchange 1: all-gather of (budget_count_hat, total_count) per chromosome, then the same
+    host-side empirical-Bayes fit on every rank."""
+    import json
+
+    import torch.multiprocessing as mp
+
+    from rocco_amd import budget
+
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_budget_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [json.load(open(tmp_path / f"budget{r}.json")) for r in range(2)]
+    counts = [3.0, 40.0, 11.0, 26.5, 0.0, 88.0]
+    totals = [1000.0, 1500.0, 800.0, 1200.0, 600.0, 2000.0]
+    want, meta = budget.estimate_empirical_bayes_budgets({f"u{u}": counts[u] for u in range(6)}, {f"u{u}": totals[u] for u in range(6)})
+    assert sorted(got[0]["owned"] + got[1]["owned"]) == list(range(6))
+    for g in got:
+        assert g["merged"] == {str(u): [counts[u], totals[u]] for u in range(6)}
+        assert g["budgets"] == want and g["alpha"] == meta["alpha"]  # identical on every rank, equal to the one-process fit
