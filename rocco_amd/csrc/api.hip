@@ -557,7 +557,7 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
     }
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
     int rc;
-    if ((rc = solver->dev_misc.reserve(wls_scratch_bytes(K, n))) != ROCCO_HIP_OK) {
+    if ((rc = solver->dev_misc.reserve(wls_scratch_bytes(K, n, spatial_window))) != ROCCO_HIP_OK) {
         return rc;
     }
     return launch_score_centered_wls(centered_dev, K, n, lower_bound_z, prior_df, min_effect, use_min_effect,

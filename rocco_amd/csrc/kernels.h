@@ -112,7 +112,7 @@ int launch_crossfit_whittaker(const double *matrix_dev, size_t rows, size_t cols
 // scratch: at least wls_scratch_bytes(K, n) bytes; synchronises the stream before returning
 int wls_spatial_window(size_t n, int requested);
 int wls_max_window();
-size_t wls_scratch_bytes(size_t K, size_t n);
+size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window = 0);
 int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, double lower_bound_z, double prior_df,
                               double min_effect, int use_min_effect, int spatial_window,
                               double precision_floor_ratio, double *mean_dev, double *raw_var_dev,

@@ -191,6 +191,84 @@ __global__ __launch_bounds__(kLanes + kHelpers) void wls_rolling_kernel(const do
     }
 }
 
+// ---- any window (above the LDS-tiled kernel's 63 loci): the same three chains straight from global memory, one
+// wavefront per row, then the variances elementwise.  Slower (every step waits for its own loads) but the
+// reference takes any window (wls_backend.c:610-742), so this must too.
+__global__ __launch_bounds__(kLanes) void wls_rolling_general_sums_kernel(const double *__restrict__ matrix, long long n, int window,
+                                                                         double *__restrict__ sums)
+{
+    const int lane = threadIdx.x;
+    if (lane >= 3) {
+        return;
+    }
+    const double *__restrict__ row = matrix + (long long)blockIdx.x * n;
+    const long long max_start = n - window;
+    double *__restrict__ S = sums + ((long long)blockIdx.x * 3 + lane) * (max_start + 1);
+    const int off = (lane == 2) ? (window - 1) : window;
+    auto term = [&](long long i) -> double {
+        // past the row's end: zeros (those sums are never used)
+        const double v = (i < n) ? row[i] : 0.0;
+        if (lane == 0) {
+            return v;
+        }
+        if (lane == 1) {
+            return v * v;
+        }
+        const double nx = (i + 1 < n) ? row[i + 1] : 0.0;
+        return v * nx;
+    };
+    double sum = 0.0;
+    for (int i = 0; i < off; ++i) {  // wls_backend.c:652-661
+        sum += term(i);
+    }
+    for (long long t = 0; t <= max_start; ++t) {
+        S[t] = sum;
+        sum = (sum - term(t)) + term(t + off);  // wls_backend.c:711-722
+    }
+}
+
+__global__ __launch_bounds__(256) void wls_rolling_general_variance_kernel(const double *__restrict__ matrix, long long n, int window,
+                                                                          const double *__restrict__ sums, double *__restrict__ vas)
+{
+    const long long max_start = n - window;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > max_start) {
+        return;
+    }
+    const long long r = blockIdx.y;
+    const double *__restrict__ row = matrix + r * n;
+    const double *__restrict__ S = sums + r * 3 * (max_start + 1);
+    const double wd = (double)window, pair_count = (double)(window - 1);
+    const double sy = S[t], ssq = S[(max_start + 1) + t], slag = S[2 * (max_start + 1) + t];
+    const double leaving = row[t], entering = row[t + window - 1];
+    const double sum_x_seq = sy - entering, sum_y_seq = sy - leaving;
+    const double mean_all = sy / wd;
+    double g0n = ssq - (wd * mean_all * mean_all);
+    if (g0n < 0.0) {
+        g0n = 0.0;
+    }
+    const double g1n = slag - (mean_all * sum_x_seq) - (mean_all * sum_y_seq) + (pair_count * mean_all * mean_all);
+    const double lambda_eff = 1.0 / (wd + 1.0);
+    const double scale_floor = 1.0e-4 * (g0n + 1.0);
+    const double denom = (g0n * (1.0 + lambda_eff)) + scale_floor;
+    const double eps = 1.0e-12 * (g0n + 1.0);
+    double beta1 = 0.0;
+    if (denom > eps) {
+        beta1 = g1n / denom;
+    }
+    if (beta1 > 0.99) {
+        beta1 = 0.99;
+    } else if (beta1 < 0.0) {
+        beta1 = 0.0;
+    }
+    const double gamma0 = g0n / wd;
+    double omb = 1.0 - (beta1 * beta1);
+    if (omb < 0.0) {
+        omb = 0.0;
+    }
+    vas[r * (max_start + 1) + t] = fmax(gamma0 * omb, 0.0);
+}
+
 __device__ __forceinline__ double obs_variance_at(const double *__restrict__ vas_row, long long i, long long half,
                                                   long long max_start)
 {
@@ -614,9 +692,11 @@ size_t sort_temp_bytes(size_t n)
     return align_up(std::max(a, std::max(b, c)), 256);
 }
 
-size_t wls_scratch_bytes(size_t K, size_t n)
+size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window)
 {
-    return align_up(K * n * 8, 256) + 6 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256) + 2 * align_up(n, 256) +
+    // windows above the tiled kernel's limit keep the three running sums of every row in memory
+    const size_t general = (wls_spatial_window(n, spatial_window) > kMaxWindow) ? align_up(3 * K * n * 8, 256) : 0;
+    return general + align_up(K * n * 8, 256) + 6 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256) + 2 * align_up(n, 256) +
            align_up(4 * n * 8, 256) + sort_temp_bytes(n) + 4096;
 }
 
@@ -636,10 +716,6 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     if (window_out != nullptr) {
         *window_out = window;
     }
-    if (window > kMaxWindow) {
-        set_last_error("rocco_hip_score_centered_wls_f64: spatial windows above 63 loci are not supported");
-        return ROCCO_HIP_EINVAL;
-    }
     const long long nn = (long long)n;
     char *sc = (char *)scratch_dev;
     size_t off = 0;
@@ -656,6 +732,7 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     double *sums = (double *)carve(4 * n * 8);
     TrendFit *fit = (TrendFit *)carve(sizeof(TrendFit));
     int *bad = (int *)carve(256);
+    double *general_sums = (window > kMaxWindow) ? (double *)carve(3 * K * n * 8) : nullptr;
     void *tmp = sc + off;
     const size_t tmp_bytes = sort_temp_bytes(n);
     ROCCO_HIP_TRY(hipMemsetAsync(sums, 0, 4 * n * 8, stream));
@@ -667,9 +744,16 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     } else {
         const long long half = window / 2, max_start = nn - window;
         const size_t vas_stride = (size_t)(max_start + 1);
-        hipLaunchKernelGGL(wls_rolling_kernel, dim3((unsigned)K), dim3(kLanes + kHelpers), 0, stream, centered_dev, nn, window, vas);
+        if (window <= kMaxWindow) {
+            hipLaunchKernelGGL(wls_rolling_kernel, dim3((unsigned)K), dim3(kLanes + kHelpers), 0, stream, centered_dev, nn, window, vas);
+        } else {
+            hipLaunchKernelGGL(wls_rolling_general_sums_kernel, dim3((unsigned)K), dim3(kLanes), 0, stream, centered_dev, nn, window,
+                               general_sums);
+            hipLaunchKernelGGL(wls_rolling_general_variance_kernel, dim3((unsigned)((max_start + 256) / 256), (unsigned)K), dim3(256), 0,
+                               stream, centered_dev, nn, window, general_sums, vas);
+        }
         const int bins = trend_bins(n);
-        if (bins > kMaxBins) {
+        if (bins > kMaxBins) {  // (floor(1 + log2(n + 1)) <= 64 for every n < 2^63: unreachable, kept as a guard)
             set_last_error("rocco_hip_score_centered_wls_f64: more than 64 trend bins");
             return ROCCO_HIP_EINVAL;
         }

@@ -71,8 +71,21 @@ def test_argument_errors(gpu):
     bad[1, 7] = np.nan
     with pytest.raises(ValueError):
         score_centered_wls(bad)
-    with pytest.raises(ValueError):
-        score_centered_wls(np.ones((2, 1000)), spatial_window=101)
+
+
+@pytest.mark.parametrize("K,n,window", [(2, 1000, 65), (3, 1000, 101), (1, 64, 64), (4, 5000, 1001), (2, 300, 10**6), (3, 70001, 255)])
+def test_windows_above_the_tiled_kernel_limit(gpu, oracle, K, n, window):
+    """The reference takes any spatial window (wls_backend.c:610-742, resolved at 232-260); above 63 loci the
+    rolling sums run straight from memory (slower) with the same results."""
+    from rocco_amd.inference import score_centered_wls
+
+    rng = np.random.default_rng(n + window)
+    m = np.round(rng.normal(0.0, 1.0, size=(K, n)) * np.exp(rng.normal(0.0, 0.5, size=(1, n))), 3)
+    got, dfw = stack(score_centered_wls(m, spatial_window=window))
+    want, dfw_o = stack(oracle.score_centered_wls(m, spatial_window=window))
+    for t, label in enumerate(ORDER):
+        assert got[t].tobytes() == want[t].tobytes(), (K, n, window, label)
+    assert np.array_equal(dfw, dfw_o) and dfw[1] >= 63
 
 
 def test_wrapper_details(gpu, oracle):
