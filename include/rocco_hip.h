@@ -76,6 +76,17 @@ int rocco_hip_score_order_statistic(rocco_hip_solver *solver, const void *matrix
 int rocco_hip_score_mean(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K, size_t n,
                          size_t row_stride, double *scores_dev, void *stream);
 
+/* method="tmean" (rocco/rocco.py:273-297): per column the values outside [q_lo, q_hi] (the order statistics of ranks
+ * rank_lo <= rank_hi: np.quantile(..., method="nearest") at tprop and 1 - tprop) are dropped and the rest averaged, summed as
+ * SciPy 1.15's stats.tmean sums them (dropped values as 0.0, NumPy's pairwise order over the K entries): bit for bit. */
+int rocco_hip_score_trimmed_mean(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K, size_t n,
+                                 size_t row_stride, int rank_lo, int rank_hi, double *scores_dev, void *stream);
+
+/* np.power(scores, power) (rocco/rocco.py:255, 304): exact for power 2 (NumPy squares); any other exponent through the
+ * device's pow -- NumPy's own pow differs between its SVML and libm builds in the last place, so no algorithm matches
+ * it on every host (power 1, the driver's value, never comes here). */
+int rocco_hip_power_f64(rocco_hip_solver *solver, const double *x_dev, double power, double *out_dev, size_t n, void *stream);
+
 /* ---- chain solve at a fixed selection penalty ----------------------------------------------
  * Replaces rocco/_chain_dp.c:9-213 `solve_penalized_chain` (Python wrapper rocco/dp.py:49-86).
  * `switch_costs_dev` has n-1 entries, or is NULL to use the scalar `gamma` at every boundary

@@ -85,6 +85,11 @@ PROTOTYPES = [
     ("rocco_hip_solver_create", ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     ("rocco_hip_solver_destroy", None, [ctypes.c_void_p]),
     ("rocco_hip_solver_set", ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong]),
+    ("rocco_hip_score_trimmed_mean", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+      ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_power_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("rocco_hip_score_median_batch", ctypes.c_int,
      [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_size_t, c_size_p, c_size_p,
       ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_void_p]),

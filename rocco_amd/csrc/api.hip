@@ -187,6 +187,26 @@ int rocco_hip_score_order_statistic(rocco_hip_solver *solver, const void *matrix
     return launch_order_statistic(matrix_dev, dtype, K, n, row_stride, rank, scores_dev, (hipStream_t)stream);
 }
 
+int rocco_hip_score_trimmed_mean(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K, size_t n,
+                                 size_t row_stride, int rank_lo, int rank_hi, double *scores_dev, void *stream)
+{
+    if (solver == nullptr || matrix_dev == nullptr || scores_dev == nullptr || K == 0 || row_stride < n ||
+        (dtype != 0 && dtype != 1) || rank_lo < 0 || rank_hi < rank_lo || rank_hi >= (int)K) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_trimmed_mean(matrix_dev, dtype, K, n, row_stride, rank_lo, rank_hi, scores_dev, (hipStream_t)stream);
+}
+
+int rocco_hip_power_f64(rocco_hip_solver *solver, const double *x_dev, double power, double *out_dev, size_t n, void *stream)
+{
+    if (solver == nullptr || (n > 0 && (x_dev == nullptr || out_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_power(x_dev, power, out_dev, n, (hipStream_t)stream);
+}
+
 int rocco_hip_score_mean(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K, size_t n,
                          size_t row_stride, double *scores_dev, void *stream)
 {

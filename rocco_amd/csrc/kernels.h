@@ -48,6 +48,9 @@ int launch_order_statistic(const void *matrix_dev, int dtype, size_t K, size_t n
                            double *scores_dev, hipStream_t stream);
 int launch_column_mean(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, double *scores_dev,
                        hipStream_t stream);
+int launch_trimmed_mean(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, int rank_lo, int rank_hi,
+                        double *scores_dev, hipStream_t stream);
+int launch_power(const double *x_dev, double p, double *out_dev, size_t n, hipStream_t stream);
 
 // ---- decode.hip -----------------------------------------------------------------------------
 // scratch: at least decode_scratch_bytes(n) bytes

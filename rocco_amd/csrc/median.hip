@@ -131,6 +131,77 @@ __global__ __launch_bounds__(256) void median_batch_kernel(MedianBatch batch)
     median_column<T, KP, EXACT>((const T *)task.matrix, batch.K, task.n, task.stride, task.out, j);
 }
 
+// 100 < K <= 200: two sorted halves.  The column (padded to 200 entries with -inf / +inf in equal numbers, one extra
+// +inf for odd K, which leaves the middle order statistics where they are) is split into its first 100 entries and
+// the rest; each half is sorted completely by the 100-input network (registers), the first one parked in LDS; the two
+// middle entries of the union of two sorted 100-sequences are  max_i min(a_i, b_{99-i})  and  min_i max(a_i, b_{99-i}).
+// About 4 800 min / max per locus against 2 K^2 compares of the rank-counting kernel.
+constexpr int kHalf = 100;
+
+template <typename T>
+__global__ __launch_bounds__(64) void median_split_kernel(const T *__restrict__ m, int K, long long n, long long stride,
+                                                          double *__restrict__ out)
+{
+    __shared__ double first[kHalf][64];
+    const long long j = (long long)xcd_contiguous_block() * blockDim.x + threadIdx.x;
+    if (j >= n) {
+        return;
+    }
+    const double inf = std::numeric_limits<double>::infinity();
+    const int pad = 2 * kHalf - K;
+    const int n_lo = pad / 2;  // -inf entries (the other pad entries are +inf)
+    double v[kHalf];
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k) {  // rows 0..99 (K > 100)
+        v[k] = (double)m[(long long)k * stride + j];
+        sum += v[k];
+    }
+    bool has_nan = false;
+    if (is_nan_bits(sum)) {
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) {
+            const bool bad = is_nan_bits(v[k]);
+            has_nan |= bad;
+            v[k] = bad ? inf : v[k];
+        }
+    }
+    select_middle<kHalf>(v);  // every output is used below: a complete sort
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k) {
+        first[k][threadIdx.x] = v[k];
+    }
+    sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k) {  // rows 100..K-1, then the padding
+        const int row = kHalf + k;
+        if (row < K) {
+            v[k] = (double)m[(long long)row * stride + j];
+            sum += v[k];
+        } else {
+            v[k] = (row - K < n_lo) ? -inf : inf;
+        }
+    }
+    if (is_nan_bits(sum)) {
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) {
+            const bool bad = (kHalf + k < K) && is_nan_bits(v[k]);
+            has_nan |= bad;
+            v[k] = bad ? inf : v[k];
+        }
+    }
+    select_middle<kHalf>(v);
+    double lower = -inf, upper = inf;
+#pragma unroll
+    for (int i = 0; i < kHalf; ++i) {
+        const double a = first[i][threadIdx.x], b = v[kHalf - 1 - i];
+        lower = fmax(lower, fmin(a, b));
+        upper = fmin(upper, fmax(a, b));
+    }
+    const double r = (K & 1) ? lower : (lower + upper) / 2.0;
+    out[j] = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : r;
+}
+
 // K == 1: copy (rocco.py:254-255; power == 1.0 is the identity)
 template <typename T>
 __global__ __launch_bounds__(256) void copy_row_kernel(const T *__restrict__ m, long long n,
@@ -225,6 +296,101 @@ __global__ __launch_bounds__(256) void column_mean_kernel(const T *__restrict__ 
     out[j] = acc / (double)K;
 }
 
+// stats.tmean(column, limits=(lo, hi), inclusive=(True, True)) of SciPy 1.15 (rocco/rocco.py:273-297): values outside
+// [lo, hi] are replaced by 0.0, np.sum adds the K entries of the (strided) column in NumPy's pairwise order -- fewer
+// than 8 one after the other, up to 128 with eight interleaved accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+// and the remainder appended, longer ranges split at n/2 rounded down to a multiple of 8 -- and the sum is divided by
+// the number of values kept.  lo / hi are order statistics of the column (np.quantile(..., method="nearest") at tprop
+// and 1 - tprop: their ranks come from the host, by NumPy's own rounding rule).
+template <typename T>
+__device__ double trimmed_pairwise(const T *__restrict__ col, long long stride, int n, double lo, double hi)
+{
+    auto kept = [&](int k) -> double {
+        const double v = (double)col[(long long)k * stride];
+        return (v < lo || v > hi) ? 0.0 : v;
+    };
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) {
+            res += kept(i);
+        }
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int q = 0; q < 8; ++q) {
+            r[q] = kept(q);
+        }
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) {
+            for (int q = 0; q < 8; ++q) {
+                r[q] += kept(i + q);
+            }
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) {
+            res += kept(i);
+        }
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return trimmed_pairwise(col, stride, n2, lo, hi) + trimmed_pairwise(col + (long long)n2 * stride, stride, n - n2, lo, hi);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trimmed_mean_kernel(const T *__restrict__ m, int K, long long n, long long stride,
+                                                          int rank_lo, int rank_hi, double *__restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) {
+        return;
+    }
+    // the two limits by rank counting (as order_statistic_kernel)
+    double lo = 0.0, hi = 0.0;
+    bool has_nan = false;
+    for (int a = 0; a < K; ++a) {
+        const double x = (double)m[(long long)a * stride + j];
+        if (is_nan_bits(x)) {
+            has_nan = true;
+            continue;
+        }
+        int less = 0, equal = 0;
+        for (int b = 0; b < K; ++b) {
+            const double y = (double)m[(long long)b * stride + j];
+            less += (y < x);
+            equal += (y == x);
+        }
+        if (rank_lo >= less && rank_lo < less + equal) {
+            lo = x;
+        }
+        if (rank_hi >= less && rank_hi < less + equal) {
+            hi = x;
+        }
+    }
+    if (has_nan) {  // NaN limits keep every value, and the NaN in the sum makes the mean NaN
+        out[j] = __longlong_as_double(0x7FF8000000000000LL);
+        return;
+    }
+    double count = 0.0;
+    for (int a = 0; a < K; ++a) {
+        const double v = (double)m[(long long)a * stride + j];
+        count += (v < lo || v > hi) ? 0.0 : 1.0;
+    }
+    out[j] = trimmed_pairwise(m + j, stride, K, lo, hi) / count;
+}
+
+// np.power(x, p) of rocco/rocco.py:255,304: NumPy's loop squares for p == 2 (exact); every other exponent goes to its
+// pow, which differs between NumPy's SVML and libm builds in the last place -- the device's pow stands in for it.
+__global__ __launch_bounds__(256) void power_kernel(const double *__restrict__ x, double p, double *__restrict__ out, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double v = x[i];
+        out[i] = (p == 2.0) ? (v * v) : pow(v, p);
+    }
+}
+
 template <typename T, int KP>
 void launch_kp(const T *m, int K, long long n, long long stride, double *out, hipStream_t stream)
 {
@@ -279,6 +445,8 @@ int dispatch(const T *m, size_t K, size_t n, size_t stride, double *out, hipStre
         launch_kp<T, 80>(m, (int)K, nn, st, out, stream);
     } else if (K <= 100) {
         launch_kp<T, 100>(m, (int)K, nn, st, out, stream);
+    } else if (K <= 2 * (size_t)kHalf) {
+        hipLaunchKernelGGL((median_split_kernel<T>), dim3((unsigned)((nn + 63) / 64)), dim3(64), 0, stream, m, (int)K, nn, st, out);
     } else {
         hipLaunchKernelGGL((median_rank_kernel<T>), dim3((unsigned)blocks), dim3(threads), 0, stream,
                            m, (int)K, nn, st, out);
@@ -388,6 +556,33 @@ int launch_order_statistic(const void *matrix_dev, int dtype, size_t K, size_t n
                            (long long)n, (long long)row_stride, rank, scores_dev);
     }
     ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_trimmed_mean(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, int rank_lo, int rank_hi,
+                        double *scores_dev, hipStream_t stream)
+{
+    if (n == 0) {
+        return ROCCO_HIP_OK;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == 0) {
+        hipLaunchKernelGGL(trimmed_mean_kernel<double>, grid, block, 0, stream, (const double *)matrix_dev, (int)K, (long long)n,
+                           (long long)row_stride, rank_lo, rank_hi, scores_dev);
+    } else {
+        hipLaunchKernelGGL(trimmed_mean_kernel<float>, grid, block, 0, stream, (const float *)matrix_dev, (int)K, (long long)n,
+                           (long long)row_stride, rank_lo, rank_hi, scores_dev);
+    }
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_power(const double *x_dev, double p, double *out_dev, size_t n, hipStream_t stream)
+{
+    if (n > 0) {
+        hipLaunchKernelGGL(power_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x_dev, p, out_dev, (long long)n);
+        ROCCO_HIP_TRY(hipGetLastError());
+    }
     return ROCCO_HIP_OK;
 }
 

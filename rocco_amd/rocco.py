@@ -105,9 +105,10 @@ def combine_chrom_results(chrom_bed_files: list, output_file: str, name_features
 # scoring
 # --------------------------------------------------------------------------------------------
 
-def score_central_tendency_chrom_device(matrix_t, out_t=None, method: str = "median", rank: int = 0):
+def score_central_tendency_chrom_device(matrix_t, out_t=None, method: str = "median", rank: int = 0, rank_hi: int = 0):
     """Column-wise median of a [K, n] float64/float32 CUDA tensor -> float64 CUDA tensor [n]
-    (``method="rank"``: the order statistic `rank`; ``method="mean"``: the column mean)."""
+    (``method="rank"``: the order statistic `rank`; ``method="mean"``: the column mean; ``method="tmean"``: the mean
+    of the values between the order statistics `rank` and `rank_hi`)."""
     import torch
 
     if matrix_t.ndim != 2:
@@ -132,6 +133,10 @@ def score_central_tendency_chrom_device(matrix_t, out_t=None, method: str = "med
     elif method == "mean":
         _native.check(lib.rocco_hip_score_mean(solver.handle, matrix_t.data_ptr(), dtype, K, n, max(row_stride, n),
                                                out_t.data_ptr(), stream), "rocco_hip_score_mean")
+    elif method == "tmean":
+        _native.check(lib.rocco_hip_score_trimmed_mean(solver.handle, matrix_t.data_ptr(), dtype, K, n, max(row_stride, n),
+                                                       int(rank), int(rank_hi), out_t.data_ptr(), stream),
+                      "rocco_hip_score_trimmed_mean")
     else:
         _native.check(lib.rocco_hip_score_median(solver.handle, matrix_t.data_ptr(), dtype, K, n, max(row_stride, n),
                                                  out_t.data_ptr(), stream), "rocco_hip_score_median")
@@ -175,9 +180,10 @@ def score_central_tendency_chrom(chrom_matrix, method="quantile", quantile=0.50,
     r"""Return a column-wise location summary across samples (rocco/rocco.py:243-304).
 
     The median branch -- the only one the reference's driver reaches (rocco/rocco.py:983-991) -- runs the
-    selection-network kernel; the nearest-rank quantile and the mean run simple kernels.  The trimmed mean (its
-    summation order is SciPy's masked-array business) and `power` != 1 (libm `pow`) are not reproduced and raise
-    NotImplementedError.
+    selection-network kernel; the nearest-rank quantile, the mean and the trimmed mean (summed the way SciPy 1.15's
+    stats.tmean sums) run simple kernels, all bit-exact against NumPy / SciPy.  `power`: 1 (the driver's value) is the
+    identity and 2 a square, as in NumPy; any other exponent goes through the device's pow (NumPy's own pow is not the
+    same function on every host, see include/rocco_hip.h).
     """
     import torch
 
@@ -194,7 +200,7 @@ def score_central_tendency_chrom(chrom_matrix, method="quantile", quantile=0.50,
             raise ValueError("`chrom_matrix` must be a 2D array.")
         matrix_t = torch.from_numpy(np.ascontiguousarray(arr)).to(f"cuda:{_dp._device_index()}")
     method_ = str(method).strip().lower().replace("-", "").replace("_", "")
-    kernel, rank = "median", 0
+    kernel, rank, rank_hi = "median", 0, 0
     if matrix_t.shape[0] > 1:
         if method_ == "quantile":
             if not 0.0 <= quantile <= 1.0:
@@ -207,16 +213,25 @@ def score_central_tendency_chrom(chrom_matrix, method="quantile", quantile=0.50,
         elif method_ == "mean":
             kernel = "mean"
         elif method_ == "tmean":
-            raise NotImplementedError("method 'tmean' is not on the accelerated path")
+            # the sorted positions np.quantile(..., method="nearest") picks at tprop and 1 - tprop (rocco/rocco.py:275-286)
+            K = int(matrix_t.shape[0])
+            ramp = np.arange(K, dtype=float)
+            kernel = "tmean"
+            rank = int(np.quantile(ramp, tprop, method="nearest"))
+            rank_hi = int(np.quantile(ramp, 1.0 - tprop, method="nearest"))
+            if rank > rank_hi:
+                raise ValueError("No array values within given limits")  # what SciPy's tmean raises for an empty range
         else:
             raise ValueError(f"Central tendency method not recognized: {method}")
-    if power != 1.0:
-        raise NotImplementedError("`power` != 1.0 is not on the accelerated path")
     if not matrix_t.is_cuda:
         matrix_t = matrix_t.to(f"cuda:{_dp._device_index()}")
     if kernel != "median" and matrix_t.dtype != torch.float64:
         matrix_t = matrix_t.to(torch.float64)  # np.asarray(chrom_matrix, dtype=float), rocco/rocco.py:251
-    out = score_central_tendency_chrom_device(matrix_t, method=kernel, rank=rank)
+    out = score_central_tendency_chrom_device(matrix_t, method=kernel, rank=rank, rank_hi=rank_hi)
+    if power != 1.0:  # np.power(central_tendency, power), rocco/rocco.py:255, 304
+        solver = _native.solver_for(out.device.index)
+        _native.check(_native.load().rocco_hip_power_f64(solver.handle, out.data_ptr(), float(power), out.data_ptr(),
+                                                         int(out.shape[0]), _dp._stream_ptr(out)), "rocco_hip_power_f64")
     return out.cpu().numpy()
 
 

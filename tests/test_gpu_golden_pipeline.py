@@ -59,10 +59,8 @@ def test_median_expectation_and_validation(gpu, gold):
         score_central_tendency_chrom(np.zeros(4))
     with pytest.raises(ValueError):
         score_central_tendency_chrom(np.zeros((3, 4)), method="no-such-method")
-    with pytest.raises(NotImplementedError):
-        score_central_tendency_chrom(np.zeros((3, 4)), method="tmean")
-    with pytest.raises(NotImplementedError):
-        score_central_tendency_chrom(np.zeros((3, 4)), power=2.0)
+    assert score_central_tendency_chrom(np.zeros((3, 4)), method="tmean").tolist() == [0.0] * 4
+    assert score_central_tendency_chrom(np.full((3, 4), 3.0), power=2.0).tolist() == [9.0] * 4
     one = np.arange(5.0)[None, :]
     assert np.array_equal(score_central_tendency_chrom(one), one[0])
 
@@ -86,7 +84,32 @@ def test_quantile_and_mean_branches_equal_numpy(gpu, K):
         assert got.tobytes() == want.tobytes(), K
 
 
-@pytest.mark.parametrize("K", [2, 3, 4, 5, 7, 8, 9, 10, 11, 16, 17, 25, 33, 50, 51, 64, 77, 100, 101, 130])
+@pytest.mark.parametrize("K", [2, 3, 7, 8, 9, 33, 100, 129, 137, 300])
+def test_trimmed_mean_and_power_branches(gpu, K):
+    """rocco/rocco.py:273-297 (per column: stats.tmean between the nearest-rank quantiles at tprop and 1 - tprop) bit
+    for bit against SciPy itself; `power` (255, 304): 2 is a square as in NumPy, other exponents to the last places."""
+    from scipy import stats
+
+    from rocco_amd import score_central_tendency_chrom
+
+    rng = np.random.default_rng(K)
+    n = 3001
+    m = np.round(rng.gamma(1.0, 0.3, size=(K, n)), 2)  # plenty of ties at the limits
+    m[:, 4] = 0.5
+    for tprop in (0.05, 0.2, 0.0, 0.5):
+        lo = np.quantile(m, tprop, axis=0, method="nearest")
+        hi = np.quantile(m, 1.0 - tprop, axis=0, method="nearest")
+        want = np.array([stats.tmean(m[:, i], limits=(lo[i], hi[i]), inclusive=(True, True)) for i in range(n)])
+        got = score_central_tendency_chrom(m, method="tmean", tprop=tprop)
+        assert got.tobytes() == want.tobytes(), (K, tprop)
+    med = np.median(m, axis=0)
+    assert score_central_tendency_chrom(m, power=2.0).tobytes() == np.power(med, 2.0).tobytes()
+    assert np.allclose(score_central_tendency_chrom(m, power=0.5), np.power(med, 0.5), rtol=1e-14, atol=0.0)
+    one = np.round(rng.gamma(1.0, 0.3, size=(1, 50)), 3)
+    assert score_central_tendency_chrom(one, power=2.0).tobytes() == np.power(one[0], 2.0).tobytes()
+
+
+@pytest.mark.parametrize("K", [2, 3, 4, 5, 7, 8, 9, 10, 11, 16, 17, 25, 33, 50, 51, 64, 77, 100, 101, 128, 130, 151, 160, 199, 200, 201, 256])
 def test_median_kernel_all_sizes(gpu, K):
     import torch
     from rocco_amd.rocco import score_central_tendency_chrom_device
@@ -98,6 +121,10 @@ def test_median_kernel_all_sizes(gpu, K):
     m[0, 7] = np.inf
     if K > 2:
         m[1, 9] = np.nan
+    if K > 110:  # the second half of the two-half kernel (rows 100 ...): NaN, +-inf, ties
+        m[105, 11] = np.nan
+        m[103, 13] = -np.inf
+        m[100:, 15] = m[0, 15]
     got = score_central_tendency_chrom_device(torch.from_numpy(m).to(gpu)).cpu().numpy()
     want = np.median(m, axis=0)
     assert np.array_equal(got, want, equal_nan=True)
