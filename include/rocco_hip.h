@@ -262,6 +262,13 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
  * may alias counts_dev; row_offsets_out_dev (K doubles, may be NULL) receives the medians.  apply_log2 == 0
  * takes the matrix as already log-scaled (only the pilot offset is removed; bit-exact).  Non-finite
  * input -> EINVAL (the reference raises ValueError). */
+/* out = log2(max(values, 0) + pseudocount) elementwise (`_log_scale_wls_matrix`, rocco/inference.py:40-47), CORRECTLY
+ * ROUNDED.  The reference calls np.log2, which is an AVX-512 SVML routine or libm's log2 depending on the host; neither
+ * is correctly rounded (in this image ~0.03 % of integer counts are one ulp off) and they differ from each other, so
+ * the correctly rounded value is the host-independent target.  ROCCO_HIP_EINVAL for a non-finite value. */
+int rocco_hip_log_scale_f64(rocco_hip_solver *solver, const double *values_dev, size_t count, double pseudocount, double *out_dev,
+                            void *stream);
+
 int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *counts_dev, size_t K, size_t n,
                                         double pseudocount, int apply_log2, double *centered_out_dev,
                                         double *row_offsets_out_dev, void *stream);

@@ -586,6 +586,28 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
                                      (hipStream_t)stream);
 }
 
+int rocco_hip_log_scale_f64(rocco_hip_solver *solver, const double *values_dev, size_t count, double pseudocount, double *out_dev,
+                            void *stream)
+{
+    if (solver == nullptr || (count > 0 && (values_dev == nullptr || out_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc = solver->dev_results.reserve(256);
+    if (rc != ROCCO_HIP_OK) return rc;
+    int *bad = (int *)solver->dev_results.ptr;
+    ROCCO_HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), (hipStream_t)stream));
+    if ((rc = launch_log_scale(values_dev, out_dev, count, pseudocount, bad, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
+    int bad_host = 0;
+    ROCCO_HIP_TRY(hipMemcpyAsync(&bad_host, bad, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (bad_host != 0) {
+        set_last_error("`chrom_matrix` contains non-finite values");
+        return ROCCO_HIP_EINVAL;
+    }
+    return ROCCO_HIP_OK;
+}
+
 int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *counts_dev, size_t K, size_t n,
                                         double pseudocount, int apply_log2, double *centered_out_dev,
                                         double *row_offsets_out_dev, void *stream)

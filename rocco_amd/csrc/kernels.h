@@ -127,6 +127,8 @@ size_t log_scale_scratch_bytes(size_t K, size_t n);
 int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount, int apply_log,
                                  double *centered_out_dev, double *row_offsets_out_dev, void *scratch_dev,
                                  hipStream_t stream);
+// out = log2(max(in, 0) + pseudocount), correctly rounded; *bad_dev |= 1 if a value is not finite
+int launch_log_scale(const double *in_dev, double *out_dev, size_t count, double pseudocount, int *bad_dev, hipStream_t stream);
 int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream);
 
 // ---- summit.hip -----------------------------------------------------------------------------

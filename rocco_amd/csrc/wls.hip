@@ -13,6 +13,7 @@
 //     segmented sort of each bin's variances; pooling (262-339) and knots run in one thread per row;
 //   * rows are accumulated into the per-locus precision sums in row order (858-910), one launch per row.
 #include "kernels.h"
+#include "log2_cr.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -597,7 +598,14 @@ __global__ __launch_bounds__(256) void log_scale_kernel(const double *__restrict
     if (!isfinite(v)) {
         atomicOr(bad, 1);
     }
-    out[i] = apply_log ? log2(fmax(v, 0.0) + pseudocount) : v;  // np.log2(np.clip(matrix, 0.0, None) + pseudocount)
+    // np.log2(np.clip(matrix, 0.0, None) + pseudocount): correctly rounded (log2_cr.h; NumPy's own log2 is one ulp off
+    // that in ~0.03 % of counts, differently on its SVML and libm builds)
+    if (apply_log) {
+        const double t = fmax(v, 0.0) + pseudocount;
+        out[i] = (t > 0.0 && t < INFINITY) ? log2_correctly_rounded(t) : log2(t);
+    } else {
+        out[i] = v;
+    }
 }
 
 // order-preserving key of a double (negative values: all bits flipped, others: sign bit set)
@@ -833,6 +841,17 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
         set_last_error("`chrom_matrix` contains non-finite values");
         return ROCCO_HIP_EINVAL;
     }
+    return ROCCO_HIP_OK;
+}
+
+int launch_log_scale(const double *in_dev, double *out_dev, size_t count, double pseudocount, int *bad_dev, hipStream_t stream)
+{
+    if (count == 0) {
+        return ROCCO_HIP_OK;
+    }
+    hipLaunchKernelGGL(log_scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, in_dev, out_dev,
+                       (long long)count, pseudocount, 1, bad_dev);
+    ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }
 

@@ -179,6 +179,21 @@ def _score_centered_wls_matrix(centered_matrix, lower_bound_z: float = 1.0, prio
     return scores, details
 
 
+def log_scale_device(values_t, pseudocount: float = 1.0):
+    """log2(max(values, 0) + pseudocount) of a float64 CUDA tensor, correctly rounded (rocco_hip_log_scale_f64): the
+    device form of `_log_scale_wls_matrix` (rocco/inference.py:40-47)."""
+    import torch
+
+    if values_t.dtype != torch.float64 or not values_t.is_cuda or not values_t.is_contiguous():
+        raise ValueError("values_t must be a contiguous float64 CUDA tensor")
+    out_t = torch.empty_like(values_t)
+    solver = _native.solver_for(values_t.device.index)
+    _native.check(_native.load().rocco_hip_log_scale_f64(solver.handle, values_t.data_ptr(), int(values_t.numel()),
+                                                         float(pseudocount), out_t.data_ptr(), _dp._stream_ptr(values_t)),
+                  "rocco_hip_log_scale_f64")
+    return out_t
+
+
 def log_scale_center_rows_device(counts_t, pseudocount: float = 1.0, out_t=None, apply_log2: bool = True):
     """rocco/inference.py:40-47 + 330-331 on the device: log2(max(counts, 0) + pseudocount) with every row's
     median subtracted (``apply_log2=False``: the matrix is already log-scaled).  Returns (centred tensor

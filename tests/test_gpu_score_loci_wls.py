@@ -1,11 +1,14 @@
 """GPU: the count-path scoring glue `score_loci_wls` (rocco/inference.py:302-379).
 
-Everything downstream of the logarithm equals the reference bit for bit, so counts of the form 2^k - 1
-(log2(count + 1) is exact on any platform) must reproduce the oracle's composition exactly.  On general counts
-the device's log2 may differ from NumPy's in the last place (NumPy's own log2 differs between its SVML and
-libm builds): tolerance 4 ulp on the log scale, 1e-6 relative on the tracks."""
+Everything downstream of the logarithm equals the reference bit for bit, and the logarithm itself is correctly
+rounded on the device (tests/test_gpu_log2.py).  So: counts of the form 2^k - 1 (log2(count + 1) exact on any platform)
+reproduce the oracle's composition exactly; general counts reproduce it exactly when the oracle is handed the correctly
+rounded log matrix; and against NumPy's own log2 -- what the reference calls, not correctly rounded and not the same
+on every host -- the log scale is within one ulp, equal in all but a fraction of a per cent of the entries."""
 import numpy as np
 import pytest
+
+from log2_truth import log2_correctly_rounded
 
 pytestmark = pytest.mark.gpu
 TRACKS = ("mean", "raw_variance", "prior_variance", "moderated_variance", "standard_error", "z_scores",
@@ -62,29 +65,33 @@ def test_log_scale_and_pilot_offset(gpu):
         counts[0, :: 3] = 0.0
         counts[1] = -counts[1]
         c_t, off_t = log_scale_center_rows_device(torch.from_numpy(counts).cuda())
-        log_ref = np.log2(np.clip(counts, 0.0, None) + 1.0)
+        log_ref = log2_correctly_rounded(np.clip(counts, 0.0, None) + 1.0)
         med = np.median(log_ref, axis=1)
-        assert np.allclose(off_t.cpu().numpy(), med, rtol=0, atol=4 * np.spacing(np.abs(med).max() + 1.0))
-        recon = c_t.cpu().numpy() + off_t.cpu().numpy()[:, None]
-        assert np.all(np.abs(recon - log_ref) <= 4 * np.spacing(np.maximum(np.abs(log_ref), np.abs(med)[:, None]) + 1.0))
+        assert np.array_equal(off_t.cpu().numpy(), med)
+        assert np.array_equal(c_t.cpu().numpy(), log_ref - med[:, None])
+        host = np.log2(np.clip(counts, 0.0, None) + 1.0)  # this host's NumPy: one ulp at most, rarely
+        assert np.all(np.abs(host - log_ref) <= np.spacing(np.abs(log_ref))) and (host != log_ref).mean() < 2.0e-3
     with pytest.raises(ValueError):
         log_scale_center_rows_device(torch.tensor([[1.0, float("inf")]], dtype=torch.float64).cuda())
 
 
-def test_general_counts_within_tolerance(gpu, oracle):
+@pytest.mark.parametrize("kind", ["fractional", "integer"])
+def test_general_counts_bit_for_bit_given_the_correctly_rounded_log(gpu, oracle, kind):
     from rocco_amd.inference import score_loci_wls
 
     rng = np.random.default_rng(9)
     K, n = 6, 50000
     counts = rng.gamma(0.8, 6.0, size=(K, n)) * (1.0 + 4.0 * (rng.random(n) < 0.03))[None, :]
+    if kind == "integer":
+        counts = np.floor(counts * 3.0)
     got, gd = score_loci_wls(counts, return_details=True)
-    want, wd = oracle.score_loci_wls(counts)
-    # tolerance: 1e-6 relative to the track's scale (a last-place change of one log value may move one pair across
-    # a trend-bin border; the tracks are continuous in everything else)
-    for key in ("mean", "raw_variance", "prior_variance", "moderated_variance", "standard_error"):
-        scale = np.abs(wd[key]).max()
-        assert np.abs(gd[key] - wd[key]).max() <= 1e-6 * scale, key
-    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+    want, wd = oracle.score_loci_wls(counts, log_matrix=log2_correctly_rounded(np.clip(counts, 0.0, None) + 1.0))
+    assert got.tobytes() == want.tobytes()
+    for key in TRACKS:
+        assert np.asarray(gd[key]).tobytes() == np.asarray(wd[key]).tobytes(), key
+    # with this host's NumPy log2 in the oracle instead: the same to the last places
+    host, hd = oracle.score_loci_wls(counts)
+    assert np.abs(got - host).max() <= 1e-9 * np.abs(host).max()
 
 
 def test_golden_vectors_of_the_reference_function(gpu):
@@ -102,6 +109,9 @@ def test_golden_vectors_of_the_reference_function(gpu):
         runs = [(gold[f"{name}_log"], "log2p1")]
         if "_pow2_" in name:
             runs.append((gold[f"{name}_counts"], "counts"))
+        # the log scale NumPy produced on the generating host against the correctly rounded one: one ulp at most
+        cr = log2_correctly_rounded(np.clip(gold[f"{name}_counts"], 0.0, None) + 1.0)
+        assert np.all(np.abs(cr - gold[f"{name}_log"]) <= np.spacing(np.abs(cr))), name
         for matrix, scale in runs:
             scores, details = score_loci_wls(matrix, return_details=True, input_scale=scale, **kw)
             assert scores.tobytes() == gold[f"{name}_scores"].tobytes(), (name, scale)
