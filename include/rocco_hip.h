@@ -349,6 +349,20 @@ int rocco_hip_negative_part_f64(rocco_hip_solver *solver, const double *scores_d
 int rocco_hip_soft_counts_f64(rocco_hip_solver *solver, const double *scores_dev, double center, double scale, double *out_dev,
                               size_t n, void *stream);
 
+/* ---- post-hoc peak scoring: the per-peak arithmetic (rocco/scores.py:180-194, 128-141, 560-583) ----
+ * rocco_hip_peak_signal_stat_f64: counts_dev is [n_peaks][n_samples] (scaled counts, row-major), lengths_dev the peak
+ *   lengths; stat_out[p] = np.percentile(log2(max(counts[p] * row_scale / max(int(length), 1) + pc, pc)), percentile)
+ *   (`_peak_signal_stat`; the logarithm correctly rounded, see rocco_hip_log_scale_f64; NaN in a row gives NaN).
+ * rocco_hip_ecdf_survival_f64: bin_dev[p] selects the sorted null values null_values_dev[null_offsets_dev[b] ..
+ *   null_offsets_dev[b + 1]); pvals_out[p] = (size - searchsorted_left(null, stat[p]) + 1) / (size + 1) (`EmpiricalNull.survival`).
+ * rocco_hip_bh_adjust_f64: Benjamini-Hochberg adjusted p-values as scipy.stats.false_discovery_control(ps, method="bh")
+ *   computes them for m > 1 (p * (m / rank), running minimum from the largest rank down, clip to [0, 1]). */
+int rocco_hip_peak_signal_stat_f64(rocco_hip_solver *solver, const double *counts_dev, const double *lengths_dev, size_t n_peaks,
+                                   size_t n_samples, double row_scale, double pc, double percentile, double *stat_out_dev, void *stream);
+int rocco_hip_ecdf_survival_f64(rocco_hip_solver *solver, const double *stat_dev, const int *bin_dev, const double *null_values_dev,
+                                const long long *null_offsets_dev, size_t n_peaks, double *pvals_out_dev, void *stream);
+int rocco_hip_bh_adjust_f64(rocco_hip_solver *solver, const double *pvals_dev, size_t m, double *qvals_out_dev, void *stream);
+
 /* bigWig dense fill: the NumPy statements of get_bigwig_chrom_scores after the file has been read
  * (rocco/readtracks.py:141-186) for one track's intervals in ascending order (as pyBigWig returns them).
  * *flags_out: bit 0 non-finite value (147-150), bit 1 non-positive width (153-156), bit 2 variable width (158-161),

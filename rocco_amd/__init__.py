@@ -18,6 +18,7 @@ from .budget import (  # noqa: F401  (rocco/inference.py:1312-1421, 1593-1737)
 from .inference import crossfit_whittaker_baseline  # noqa: F401  (rocco/_baseline.c:16-104)
 from .inference import score_centered_wls  # noqa: F401  (rocco/_wls.c)
 from .inference import score_loci_wls  # noqa: F401  (rocco/inference.py:302-379)
+from .scores import EmpiricalNull, score_peak_counts  # noqa: F401  (rocco/scores.py:120-149, 560-625)
 from .readtracks import assemble_chrom_matrix, bigwig_dense_fill  # noqa: F401  (rocco/readtracks.py:141-186, 614-633)
 from .rocco import (  # noqa: F401
     chrom_solution_to_bed,

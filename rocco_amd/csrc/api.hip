@@ -346,6 +346,42 @@ int rocco_hip_objective_value_f64(rocco_hip_solver *solver, const uint8_t *solut
     return rc;
 }
 
+int rocco_hip_peak_signal_stat_f64(rocco_hip_solver *solver, const double *counts_dev, const double *lengths_dev, size_t n_peaks,
+                                   size_t n_samples, double row_scale, double pc, double percentile, double *stat_out_dev, void *stream)
+{
+    if (solver == nullptr || n_samples == 0 || n_samples > 4096 || !(percentile >= 0.0 && percentile <= 100.0) ||
+        (n_peaks > 0 && (counts_dev == nullptr || lengths_dev == nullptr || stat_out_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    const int rc = solver->dev_misc.reserve(n_peaks * n_samples * sizeof(double) + 256);
+    if (rc != ROCCO_HIP_OK) return rc;
+    return launch_peak_signal(counts_dev, lengths_dev, n_peaks, n_samples, row_scale, pc, percentile, stat_out_dev, solver->dev_misc.ptr,
+                              (hipStream_t)stream);
+}
+
+int rocco_hip_ecdf_survival_f64(rocco_hip_solver *solver, const double *stat_dev, const int *bin_dev, const double *null_values_dev,
+                                const long long *null_offsets_dev, size_t n_peaks, double *pvals_out_dev, void *stream)
+{
+    if (solver == nullptr || (n_peaks > 0 && (stat_dev == nullptr || bin_dev == nullptr || null_values_dev == nullptr ||
+                                              null_offsets_dev == nullptr || pvals_out_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return launch_ecdf_survival(stat_dev, bin_dev, null_values_dev, null_offsets_dev, n_peaks, pvals_out_dev, (hipStream_t)stream);
+}
+
+int rocco_hip_bh_adjust_f64(rocco_hip_solver *solver, const double *pvals_dev, size_t m, double *qvals_out_dev, void *stream)
+{
+    if (solver == nullptr || m >= ((size_t)1 << 31) || (m > 0 && (pvals_dev == nullptr || qvals_out_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    const int rc = solver->dev_misc.reserve(bh_scratch_bytes(m));
+    if (rc != ROCCO_HIP_OK) return rc;
+    return launch_bh_adjust(pvals_dev, m, qvals_out_dev, solver->dev_misc.ptr, (hipStream_t)stream);
+}
+
 int rocco_hip_sort_f64(rocco_hip_solver *solver, const double *x_dev, size_t n, double *sorted_out_dev, void *stream)
 {
     if (solver == nullptr || (n > 0 && (x_dev == nullptr || sorted_out_dev == nullptr)) || n >= ((size_t)1 << 31)) {

@@ -178,6 +178,15 @@ int launch_autocov(const double *x_dev, size_t n, double mean, int max_lag, doub
 int launch_negative_part(const double *scores_dev, double *out_dev, size_t n, hipStream_t stream);
 int launch_soft_counts(const double *scores_dev, double center, double scale, double *out_dev, size_t n, hipStream_t stream);
 
+// ---- peakscore.hip -------------------------------------------------------------------------
+// scratch_dev: P * K doubles
+int launch_peak_signal(const double *counts_dev, const double *lengths_dev, size_t P, size_t K, double row_scale, double pc,
+                       double percentile, double *out_dev, void *scratch_dev, hipStream_t stream);
+int launch_ecdf_survival(const double *stat_dev, const int *bin_dev, const double *null_values_dev, const long long *null_offsets_dev,
+                         size_t P, double *out_dev, hipStream_t stream);
+size_t bh_scratch_bytes(size_t m);
+int launch_bh_adjust(const double *pvals_dev, size_t m, double *qvals_out_dev, void *scratch_dev, hipStream_t stream);
+
 // ---- synth.hip ------------------------------------------------------------------------------
 int launch_synth(void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, uint64_t seed,
                  hipStream_t stream);
