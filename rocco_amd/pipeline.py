@@ -25,6 +25,9 @@ from . import shard as _shard
 # calibrate side by side -- one host thread, HIP stream and solver handle (scratch buffers) per group; the
 # native call releases the GIL -- and fill each other's gaps.  Results do not depend on the grouping.
 SOLVE_GROUPS = int(os.environ.get("ROCCO_SOLVE_GROUPS", "3"))
+# 1: score every chromosome of the rank in ONE launch before any group starts solving (the median kernel then runs at
+# its full bandwidth); 0: score group after group so that the first groups solve while the later ones are scored
+SCORE_FIRST = int(os.environ.get("ROCCO_SCORE_FIRST", "0"))
 _pool: Optional[concurrent.futures.ThreadPoolExecutor] = None
 _group_state: Dict[Tuple[int, int], tuple] = {}  # (device, group) -> (Solver, torch.cuda.Stream)
 _group_lock = threading.Lock()  # the groups' solver handles are per process: one grouped solve at a time
@@ -172,11 +175,19 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
                 if _pool is None:
                     _pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-solve")
                 futures = []
-                for g, idx in enumerate(members):
-                    scores = score_all([chroms[i] for i in idx])
+                if SCORE_FIRST:
+                    every = score_all([chroms[i] for i in order])
+                    by_index = dict(zip(order, every))
                     scored = torch.cuda.Event()
                     scored.record(caller_stream)
-                    futures.append(_pool.submit(work, g, idx, scores, scored))
+                    for g, idx in enumerate(members):
+                        futures.append(_pool.submit(work, g, idx, [by_index[i] for i in idx], scored))
+                else:
+                    for g, idx in enumerate(members):
+                        scores = score_all([chroms[i] for i in idx])
+                        scored = torch.cuda.Event()
+                        scored.record(caller_stream)
+                        futures.append(_pool.submit(work, g, idx, scores, scored))
                 # every group is waited for (the solver handles are shared) before any failure is reported
                 first_error = None
                 for f in futures:
