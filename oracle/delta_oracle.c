@@ -97,12 +97,24 @@ typedef struct {
     double nlam;    /* clean: rn_u(-lambda)                       */
 } chunk_mode;
 
+/* Smallest exponent a hazard chunk may price its roundings with: the reference forms (value + s) before it
+ * subtracts lambda (rocco/_chain_dp.c:120,125,127-128), so its intermediates leave the stay-off value P0 by up to
+ * c + (c + |s - lambda|) + |s| <= 2 cmax + 2 sabs + |lambda|, whatever P0 is (P0 = 0 at the head of a chromosome). */
+int oracle_hazard_floor(double cmax, double sabs, double lambda)
+{
+    return ilogb(2.0 * cmax + 2.0 * sabs + fabs(lambda) + 2.0);
+}
+
 static chunk_mode make_mode(int code, int force_hazard, int e_global, int qexp, double lambda,
-                            double gamma_raw, int has_cost_vector)
+                            double gamma_raw, int has_cost_vector, double cmax, double sabs)
 {
     chunk_mode m;
-    const int e = (code == ORACLE_MAP_NONE) ? e_global : (code & 0x7F) - ORACLE_MAP_BIAS;
+    int e = (code == ORACLE_MAP_NONE) ? e_global : (code & 0x7F) - ORACLE_MAP_BIAS;
     int hazard = force_hazard || (code == ORACLE_MAP_NONE) || (code & 0x80);
+    if (code != ORACLE_MAP_NONE && (code & 0x80)) {
+        const int e_floor = oracle_hazard_floor(cmax, sabs, lambda);
+        e = (e > e_floor) ? e : e_floor;
+    }
     const double q = ldexp(1.0, qexp);
     if (!hazard && e - 52 < qexp) {
         hazard = 1; /* reference grid finer than the arithmetic grid */
@@ -167,11 +179,11 @@ int oracle_delta_chain_f64(const double *scores, const double *switch_costs, dou
     long long last_clear = -1;
     long long uncertain = 0, effect = 0, max_run = 0;
     int overflow = 0;
-    chunk_mode mode = make_mode(ORACLE_MAP_NONE, 0, e_global, qexp, lam, gamma, vec);
+    chunk_mode mode = make_mode(ORACLE_MAP_NONE, 0, e_global, qexp, lam, gamma, vec, cmax, sabs);
 
     for (size_t j = 0; j < n; ++j) {
         if (j % ORACLE_CHUNK == 0) {
-            mode = make_mode(emap ? emap[j / ORACLE_CHUNK] : ORACLE_MAP_NONE, 0, e_global, qexp, lam, gamma, vec);
+            mode = make_mode(emap ? emap[j / ORACLE_CHUNK] : ORACLE_MAP_NONE, 0, e_global, qexp, lam, gamma, vec, cmax, sabs);
         }
         double a, w;
         const double c_raw_prev = (j == 0) ? 0.0 : (vec ? switch_costs[j - 1] : gamma);
@@ -254,17 +266,17 @@ int oracle_delta_window_f64(const double *scores, const double *switch_costs, do
     long long last_clear = -1, max_run = 0, n_diff = 0;
     int adjacent = 1, overflow = 0;
     chunk_mode mode[2];
-    mode[0] = make_mode(ORACLE_MAP_NONE, 0, e_global, qexp, lam[0], gamma, vec);
+    mode[0] = make_mode(ORACLE_MAP_NONE, 0, e_global, qexp, lam[0], gamma, vec, cmax, sabs);
     mode[1] = mode[0];
 
     for (size_t j = 0; j < n; ++j) {
         if (j % ORACLE_CHUNK == 0) {
             const int code = emap ? emap[j / ORACLE_CHUNK] : ORACLE_MAP_NONE;
-            mode[0] = make_mode(code, 0, e_global, qexp, lam[0], gamma, vec);
-            mode[1] = make_mode(code, 0, e_global, qexp, lam[1], gamma, vec);
+            mode[0] = make_mode(code, 0, e_global, qexp, lam[0], gamma, vec, cmax, sabs);
+            mode[1] = make_mode(code, 0, e_global, qexp, lam[1], gamma, vec, cmax, sabs);
             if (mode[0].clean != mode[1].clean) { /* one penalty ties on this grid: both hazard */
-                mode[0] = make_mode(code, 1, e_global, qexp, lam[0], gamma, vec);
-                mode[1] = make_mode(code, 1, e_global, qexp, lam[1], gamma, vec);
+                mode[0] = make_mode(code, 1, e_global, qexp, lam[0], gamma, vec, cmax, sabs);
+                mode[1] = make_mode(code, 1, e_global, qexp, lam[1], gamma, vec, cmax, sabs);
             }
         }
         double wmax = 0.0;

@@ -56,6 +56,7 @@ struct LeanLevel {
     const int *orig = nullptr;
     long long m = 0;
     double base = -INFINITY;
+    double sep = 0.0;       // score of the level's separator loci
     bool has_eval = false;  // pts / child_len / bits / tile_off describe the latest evaluation on this level
     std::vector<double> pts;
     std::vector<long long> child_len;
@@ -596,18 +597,33 @@ public:
         return lean_eligible(problem) && (long long)((probs[problem].n + kLeanTile - 1) / kLeanTile) >= kPilotMinTiles;
     }
 
-    int bound_points(size_t problem, int default_points) const override
+    int bound_points(size_t problem, int default_points, double base_hint) const override
     {
         if (!lean_eligible(problem)) {
             return default_points;
         }
         long long m = (long long)probs[problem].n;
         bool deep = false;
-        if (lean_ready_ && problem < lean_.size() && lean_[problem].levels.size() > 1) {
-            m = lean_[problem].levels.back().m;
-            deep = true;
+        if (lean_ready_ && problem < lean_.size() && !lean_[problem].levels.empty()) {
+            const LeanLevel &lv = lean_[problem].levels.back();
+            if (lean_[problem].levels.size() > 1) {
+                m = lv.m;
+                deep = true;
+            }
+            // the next round compacts at `base_hint` first if that halves the level: it then runs on the child
+            if (lv.has_eval && base_hint == base_hint) {
+                for (size_t i = 0; i < lv.pts.size(); ++i) {
+                    if (lv.pts[i] == base_hint && lv.child_len[i] >= 1 && 2 * lv.child_len[i] <= lv.m) {
+                        m = lv.child_len[i];
+                        deep = true;
+                    }
+                }
+            }
         }
-        int pts = (m > 8000000) ? 3 : ((m > 2000000) ? 4 : ((m > 256000) ? 8 : ((m > 32000) ? 16 : 32)));
+        // a round on a small level costs its launch latency whatever it evaluates (one tile and 8 penalties per
+        // workgroup: up to 256 of them run at once), a pass over a long one its evaluations
+        static const long long small = std::getenv("ROCCO_HIP_POINTS_SMALL") ? std::atoll(std::getenv("ROCCO_HIP_POINTS_SMALL")) : 256000;
+        int pts = (m > 8000000) ? 3 : ((m > 2000000) ? 4 : ((m > 4 * small) ? 8 : ((m > 2 * small) ? 16 : ((m > small) ? 32 : 64))));
         if (!deep) {
             pts = std::min(pts, 8);
         }
@@ -753,6 +769,7 @@ public:
                         child.orig = co;
                         child.m = cl;
                         child.base = lv.pts[(size_t)best];
+                        child.sep = ct.sep;
                         child.pool_mark = mark;
                         ls.levels.push_back(child);
                     } else {
@@ -931,26 +948,10 @@ public:
                 const long long cl = res[r.result_begin].child_len;
                 const bool fits = r.out_s != nullptr && cl >= 1 && cl <= r.capacity && !(error & 2u);
                 // worth it only when the compacted problem is much smaller than the caller's
-                if (fits && 10 * cl <= 6 * (long long)p.n) {
-                    uint8_t *sol = (uint8_t *)lean_alloc(ls, (size_t)cl);
-                    if (sol != nullptr) {
-                        p.orig_scores = p.scores;
-                        p.orig_n = p.n;
-                        p.orig_solution = p.solution;
-                        p.compacted = true;
-                        p.scores = r.out_s;
-                        p.n = (size_t)cl;
-                        p.solution = sol;
-                        p.lean_orig = r.out_orig;
-                        p.emap = nullptr;
-                        p.frz_valid = false;
-                        p.smin = std::min(p.smin, r.sep);
-                        p.sabs = std::max(p.sabs, std::fabs(r.sep));
-                        p.qexp = grid_exponent(std::max(p.cmax, 0.0), p.smin, p.smax);
-                        r.comp->done = true;
-                        r.comp->n_new = (size_t)cl;
-                        r.comp->score_floor = r.sep;
-                    }
+                if (fits && 10 * cl <= 6 * (long long)p.n && adopt_level(r.problem, r.out_s, r.out_orig, cl, r.sep)) {
+                    r.comp->done = true;
+                    r.comp->n_new = (size_t)cl;
+                    r.comp->score_floor = r.sep;
                 }
                 if (!r.comp->done && std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
                     std::fprintf(stderr, "[lean] problem %zu: final compaction declined (child %lld of %zu)\n", r.problem, cl, p.n);
@@ -962,6 +963,61 @@ public:
     }
 
     int lean_result_count_ = 0;
+
+    // switch a problem over to one of its compacted levels
+    bool adopt_level(size_t problem, const double *level_s, const int *level_orig, long long m, double sep)
+    {
+        DevProblem &p = probs[problem];
+        LeanState &ls = lean_[problem];
+        uint8_t *sol = (uint8_t *)lean_alloc(ls, (size_t)m);
+        if (sol == nullptr) {
+            return false;
+        }
+        p.orig_scores = p.scores;
+        p.orig_n = p.n;
+        p.orig_solution = p.solution;
+        p.compacted = true;
+        p.scores = level_s;
+        p.n = (size_t)m;
+        p.solution = sol;
+        p.lean_orig = level_orig;
+        p.emap = nullptr;
+        p.frz_valid = false;
+        p.smin = std::min(p.smin, sep);
+        p.sabs = std::max(p.sabs, std::fabs(sep));
+        p.qexp = grid_exponent(std::max(p.cmax, 0.0), p.smin, p.smax);
+        return true;
+    }
+
+    // the deepest level built at or below the requested penalty serves as the compacted problem: no device work
+    bool compact_now(CompactRequest &req) override
+    {
+        req.done = false;
+        if (!lean_ready_ || !lean_eligible(req.problem) || req.problem >= lean_.size()) {
+            return false;
+        }
+        LeanState &ls = lean_[req.problem];
+        for (size_t k = ls.levels.size(); k-- > 1;) {
+            const LeanLevel &lv = ls.levels[k];
+            if (lv.base <= req.lambda_base) {
+                if (10 * lv.m > 6 * (long long)probs[req.problem].n) {
+                    return false;  // not worth it: let the regular request evaluate and compact at the penalty itself
+                }
+                if (!adopt_level(req.problem, lv.s, lv.orig, lv.m, lv.sep)) {
+                    return false;
+                }
+                req.done = true;
+                req.n_new = (size_t)lv.m;
+                req.score_floor = lv.sep;
+                if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                    std::fprintf(stderr, "[lean] problem %zu: level %zu (m=%lld, base %.17g) adopted for penalties >= %.17g\n",
+                                 req.problem, k, lv.m, lv.base, req.lambda_base);
+                }
+                return true;
+            }
+        }
+        return false;
+    }
 
     int compact(std::vector<CompactRequest> &reqs) override
     {
@@ -1010,6 +1066,12 @@ public:
                   std::vector<SpineRequest> &spines) override
     {
         int rc;
+        const double tr0 = now_us();
+        struct Total {
+            double &acc;
+            double t0;
+            ~Total() { acc += now_us() - t0; }
+        } total{t_round_, tr0};
         if ((rc = lean_submit(compacts, probes)) != ROCCO_HIP_OK) return rc;
         std::vector<RoundTask> tasks;
         if ((rc = add_map_tasks(maps, tasks)) != ROCCO_HIP_OK) return rc;
@@ -1018,12 +1080,17 @@ public:
         add_window_tasks(windows, tasks);
         if ((rc = add_spine_tasks(spines, tasks)) != ROCCO_HIP_OK) return rc;
         if (tasks.empty()) {
+            const double ts0 = now_us();
             ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+            t_wait_ += now_us() - ts0;
         } else if ((rc = run_round(tasks)) != ROCCO_HIP_OK) {
             return rc;
         }
+        const double tc0 = now_us();
         if ((rc = lean_consume()) != ROCCO_HIP_OK) return rc;
         adopt_maps(maps);
+        t_consume_ += now_us() - tc0;
+        ++rounds_all;
         return ROCCO_HIP_OK;
     }
 
@@ -1079,7 +1146,8 @@ public:
 private:
 
 public:
-    double t_prep_ = 0.0, t_launch_ = 0.0, t_wait_ = 0.0, t_consume_ = 0.0;
+    double t_prep_ = 0.0, t_launch_ = 0.0, t_wait_ = 0.0, t_consume_ = 0.0, t_round_ = 0.0;
+    int rounds_all = 0;
     static double now_us()
     {
         return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -1835,9 +1903,12 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
     if ((rc = ev.scatter_all()) != ROCCO_HIP_OK) return rc;
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));
-    if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
-        std::fprintf(stderr, "[host] solve %.0f us: %d rounds, prep %.0f launch %.0f wait %.0f us (rest: search logic, other calls)\n",
-                     HipEvaluator::now_us() - t_solve0, ev.rounds, ev.t_prep_, ev.t_launch_, ev.t_wait_);
+    if (std::getenv("ROCCO_HIP_DEBUG") != nullptr || std::getenv("ROCCO_HIP_TIMING") != nullptr) {
+        const double total = HipEvaluator::now_us() - t_solve0;
+        std::fprintf(stderr, "[host] solve %.0f us: %d rounds (%d with rounding-model kernels): in the rounds %.0f us = waiting for the device %.0f "
+                             "+ reading results %.0f + preparing and submitting %.0f; search logic and the rest %.0f us\n",
+                     total, ev.rounds_all, ev.rounds, ev.t_round_, ev.t_wait_, ev.t_consume_,
+                     ev.t_round_ - ev.t_wait_ - ev.t_consume_, total - ev.t_round_);
     }
     for (size_t t = 0; t < n_tasks; ++t) {
         results[t].selection_penalty = res[t].selection_penalty;

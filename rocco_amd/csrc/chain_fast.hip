@@ -85,8 +85,13 @@ __device__ __forceinline__ Mode make_mode(int code, bool force_hazard, int e_glo
 {
     Mode m;
     const bool none = (code == kMapNone);
-    const int e = none ? e_global : ((code & 0x7F) - kMapBias);
+    int e = none ? e_global : ((code & 0x7F) - kMapBias);
     bool hazard = force_hazard || none || ((code & 0x80) != 0);
+    if (!none && (code & 0x80) != 0) {
+        // a hazard chunk's intermediates (value + s, before lambda comes off) leave the stay-off value by up to
+        // 2 cmax + 2 sabs + |lambda| whatever that value is: oracle_hazard_floor
+        e = max(e, ilogb(2.0 * task.cmax + 2.0 * task.sabs + fabs(lambda) + 2.0));
+    }
     if (!hazard && e - 52 < task.qexp) {
         hazard = true;
     }

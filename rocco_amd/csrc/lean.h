@@ -23,7 +23,7 @@ constexpr int kLeanChunk = 32;                                // loci per lane
 constexpr int kLeanThreads = 256;                             // lanes per workgroup
 constexpr int kLeanTile = kLeanChunk * kLeanThreads;          // 8192 loci per workgroup
 constexpr int kLeanBatch = 8;                                 // penalties one workgroup carries in registers
-constexpr int kLeanMaxPoints = 32;                            // penalties per task and round
+constexpr int kLeanMaxPoints = 64;                            // penalties per task and round
 
 // per (tile, penalty): what the finish kernel needs to close the backward fill and to place the tile's
 // loci in a compacted array

@@ -220,6 +220,15 @@ void replay_with_critical(const ChainProblem &p, State &s, double critical)
     }
 }
 
+// How far the reference's intermediates can sit from its stay-off value (the distance a clean chunk of the binade
+// map keeps from every power of two): c + |s - lambda| for the state-1 value, plus |s| because the reference adds the
+// score before it subtracts the penalty (rocco/_chain_dp.c:120,125,127-128).
+double model_reach(const ChainProblem &p, double lambda_lo, double lambda_hi)
+{
+    const double sabs = std::max(std::fabs(p.score_min), std::fabs(p.score_max));
+    return p.cost_max + (std::max(p.score_max, lambda_hi) - std::min(p.score_min, lambda_lo)) + sabs + 2.0;
+}
+
 // Decide which binade map to build for the current bracket: one valid for the whole bracket when
 // the running values cannot move much inside it, otherwise a point map at the next midpoint.
 void plan_map(const ChainProblem &p, State &s, bool force_bracket)
@@ -227,7 +236,7 @@ void plan_map(const ChainProblem &p, State &s, bool force_bracket)
     const double lo = eff_lower(s);
     const double hi = force_bracket ? s.upper : eff_upper(s);  // (forced: for the final window)
     const double width = hi - lo;
-    const double reach = p.cost_max + (p.score_max - p.score_min) + 2.0;
+    const double reach = model_reach(p, p.score_min, p.score_max);
     const double drift = 2.0 * width * (double)s.lower_count;
     if (force_bracket || drift <= 4.0 * reach) {
         s.req_ref = (lo + hi) / 2.0;
@@ -408,7 +417,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 r.bound = true;
                 r.pilot = true;
                 const int qexp = bound_grid_exponent(p);
-                const int pts = std::max(2, std::min(32, opt.pilot_points));
+                const int pts = std::max(2, std::min(64, opt.pilot_points));
                 for (int k = 1; k <= pts; ++k) {
                     const double x = snap_to_grid(s.pg + (s.pl - s.pg) * (double)k / (double)(pts + 1), qexp);
                     if (x > s.pg && x < s.pl && (r.lambdas.empty() || x > r.lambdas.back())) {
@@ -432,7 +441,8 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 // (two per round are cheapest per bit), a small one by its fixed launch + sync cost
                 const int points_default = (round_loci > 30.0e6) ? opt.search_points
                                                                  : ((round_loci > 12.0e6) ? opt.search_points + 1 : opt.search_points + 3);
-                const int points = std::max(1, std::min(32, ev.bound_points(b, points_default)));
+                const double base_hint = s.G_real ? (s.G + s.eps) : std::nan("");
+                const int points = std::max(1, std::min(64, ev.bound_points(b, points_default, base_hint)));
                 std::vector<double> fr;
                 for (int k = 1; k <= points; ++k) {
                     fr.push_back((double)k / (double)(points + 1));
@@ -502,9 +512,20 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 CompactRequest r;
                 r.problem = b;
                 r.lambda_base = s.G - s.eps;
-                compacts.push_back(r);
-                compact_owner.push_back(b);
-                continue;
+                if (!ev.compact_now(r)) {
+                    compacts.push_back(r);
+                    compact_owner.push_back(b);
+                    continue;
+                }
+                // the evaluator already held a compacted copy built at or below that penalty: go on at once
+                s.want_compact = false;
+                if (r.done) {
+                    s.compacted = true;
+                    ChainProblem &pm = problems[b];
+                    pm.n = r.n_new;
+                    pm.score_min = std::min(pm.score_min, r.score_floor);
+                    s.lower_count = std::min(s.lower_count, (long long)pm.n);
+                }
             }
             advance_analytic(p, s);
             if (s.phase == State::kBisect && s.iters_left <= 0) {
@@ -602,7 +623,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     const bool point_ok = s.point_pending && s.map_lo == mid && s.map_hi == mid;
                     // a map built for a much wider bracket carries a larger hazard margin than needed:
                     // rebuild it once that margin would shrink materially
-                    const double reach = p.cost_max + (p.score_max - p.score_min) + 2.0;
+                    const double reach = model_reach(p, p.score_min, p.score_max);
                     const double margin_now = reach + 2.0 * width * (double)s.lower_count + 2.0;
                     const bool stale = inside && (s.map_hi - s.map_lo) > 16.0 * width &&
                                        margin_now < opt.map_rebuild_ratio * s.map_margin;
@@ -885,7 +906,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     } else if (!is_point_here) {
                         // retry this midpoint alone with a map built exactly at it
                         s.req_ref = s.req_lo = s.req_hi = mid;
-                        s.req_margin = p.cost_max + (p.score_max - p.score_min) + 4.0;
+                        s.req_margin = model_reach(p, p.score_min, p.score_max) + 2.0;
                         s.point_pending = true;
                         s.phase = State::kNeedMap;
                         s.after_map = State::kBisect;
@@ -936,7 +957,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     s.phase = State::kDone;
                 } else if (!s.has_map) {
                     s.req_ref = s.req_lo = s.req_hi = 0.0;  // map at the penalty being solved
-                    s.req_margin = p.cost_max + (p.score_max - p.score_min) + 4.0;
+                    s.req_margin = model_reach(p, p.score_min, p.score_max) + 2.0;
                     s.phase = State::kNeedMap;
                     s.after_map = State::kAll;
                 } else if (opt.use_spine) {
@@ -1098,7 +1119,7 @@ int solve_fixed_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
                 m.problem = b;
                 m.lambda_ref = lambdas[b];
                 const ChainProblem &p = problems[b];
-                m.margin = p.cost_max + (std::max(p.score_max, lambdas[b]) - std::min(p.score_min, lambdas[b])) + 4.0;
+                m.margin = model_reach(p, lambdas[b], lambdas[b]) + 2.0;
                 maps.push_back(m);
             }
             WindowRequest r;

@@ -167,6 +167,13 @@ public:
         (void)reqs;
         return 0;
     }
+    // A compaction that needs no device work (the evaluator already holds a suitable compacted copy): done at once,
+    // so that the problem can go on within the same search iteration.  Default: not available.
+    virtual bool compact_now(CompactRequest &req)
+    {
+        (void)req;
+        return false;
+    }
     // One search iteration including compactions (which touch no other request of the iteration).
     virtual int round_all(std::vector<CompactRequest> &compacts, std::vector<MapRequest> &maps,
                           std::vector<WindowRequest> &surveys, std::vector<ProbeRequest> &probes,
@@ -186,9 +193,12 @@ public:
     }
     // Evaluations per threshold-search round of this problem (an evaluator whose exact-arithmetic
     // counts are cheap may ask for more than the default).
-    virtual int bound_points(size_t problem, int default_points) const
+    // `base_hint`: the largest evaluated penalty known to select more than the target (NaN: none yet) -- where the
+    // evaluator would compact before the next round.
+    virtual int bound_points(size_t problem, int default_points, double base_hint) const
     {
         (void)problem;
+        (void)base_hint;
         return default_points;
     }
     // Fraction of a problem's loci that rounds inside the surveyed bracket still evaluate.
@@ -246,8 +256,8 @@ struct SearchOptions {
     bool force_exact = false;
     bool use_spine = true;  // finish undecided endgames through the exact spine (else the exact kernel)
     bool use_compaction = true;  // after the threshold search: continue on the loci that can still be selected
-    int pilot_rounds = 3;        // sampled estimates that place the first certified evaluations (0: none)
-    int pilot_points = 16;
+    int pilot_rounds = 2;        // sampled estimates that place the first certified evaluations (0: none)
+    int pilot_points = 32;
 };
 
 // Calibrate every problem of the batch; solutions are left in the evaluator's solution buffers.

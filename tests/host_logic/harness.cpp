@@ -4,6 +4,7 @@
 // librocco_hip.so) against an Evaluator backed by the CPU oracle (oracle/liboracle.so), so the
 // certification / replay logic can be checked against the reference without a GPU.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <vector>
@@ -23,6 +24,7 @@ struct HostProblem {
     size_t n;
     int qexp;
     double cmax, sabs;
+    double smin0 = 0.0, smax0 = 0.0;  // the caller's score range
     uint8_t *solution;
     std::vector<uint8_t> emap;  // empty = no map
     // compaction (CompactRequest): the arrays above then point into these
@@ -49,6 +51,15 @@ public:
     long long compact_calls = 0;
     int compact_tile = 0;  // > 0: keep trailing COPY runs of every tile of this many loci (what the device kernels do)
     bool allow_compact = true;
+    double compact_slack = 0.0;  // compact at lambda_base - slack (the device side may hold a copy built lower)
+    bool compact_at_once = false;  // serve compactions through compact_now()
+    int round_points = 0;          // > 0: penalties per bound round (what the device side asks for on small levels)
+    int bound_points(size_t problem, int default_points, double base_hint) const override
+    {
+        (void)problem;
+        (void)base_hint;
+        return round_points > 0 ? round_points : default_points;
+    }
     double pilot_noise = -1.0;  // >= 0: answer pilot requests with counts off by up to this relative error
     long long pilot_calls = 0;
 
@@ -63,10 +74,22 @@ public:
     // without a map, i.e. what a bound evaluation computes), optionally widened by the trailing COPY runs of
     // every tile; then the compacted arrays: runs of that set, separated by one locus that no penalty >=
     // lambda_base can select.
+    bool compact_now(CompactRequest &req) override
+    {
+        if (!compact_at_once) {
+            return false;
+        }
+        std::vector<CompactRequest> one{req};
+        compact(one);
+        req = one[0];
+        return true;
+    }
+
     int compact(std::vector<CompactRequest> &reqs) override
     {
         ++compact_calls;
         for (CompactRequest &r : reqs) {
+            const double lambda_base = r.lambda_base - compact_slack;
             HostProblem &p = hp[r.problem];
             if (p.costs != nullptr || p.compacted) {
                 continue;
@@ -81,7 +104,7 @@ public:
             std::vector<uint8_t> cls(n), act(n);
             double d = 0.0;
             for (size_t j = 0; j < n; ++j) {
-                const double a = rq(p.scores[j] - r.lambda_base);
+                const double a = rq(p.scores[j] - lambda_base);
                 d = (j == 0) ? a : std::fmin(std::fmax(d, -c), c) + a;
                 if (j + 1 < n) {
                     cls[j] = (d > c) ? 2 : ((d <= -c) ? 0 : 1);
@@ -128,11 +151,9 @@ public:
             p.n = p.c_scores.size();
             p.solution = p.c_solution.data();
             p.emap.clear();
-            double smin = p.scores[0], smax = p.scores[0];
-            for (size_t i = 1; i < p.n; ++i) {
-                smin = std::fmin(smin, p.scores[i]);
-                smax = std::fmax(smax, p.scores[i]);
-            }
+            // grid and magnitude as the product keeps them (rocco_amd/csrc/budget.hip: adopt_level): the caller's score
+            // range widened by the separator, never the narrower range of the compacted copy
+            double smin = std::fmin(p.smin0, sep), smax = p.smax0;
             p.qexp = grid_exponent(p.cmax, smin, smax);
             p.sabs = std::fmax(std::fabs(smin), std::fabs(smax));
             p.compacted = true;
@@ -186,6 +207,12 @@ public:
                 r.results[i].uncertain = r.bound ? 0 : st.uncertain;
                 r.results[i].effect = r.bound ? 0 : (st.overflow ? (long long)p.n + 1 : st.effect);
                 r.results[i].max_run = st.max_run;
+                if (std::getenv("ROCCO_HOSTLOGIC_TRACE") != nullptr) {
+                    std::fprintf(stderr, "[probe] n=%zu %s lambda=%.17g count=%lld uncertain=%lld effect=%lld\n", p.n,
+                                 r.bound ? "bound" : (r.pilot ? "pilot" : "model"), r.lambdas[i],
+                                 (long long)r.results[i].count, (long long)r.results[i].uncertain,
+                                 (long long)r.results[i].effect);
+                }
             }
         }
         return 0;
@@ -207,6 +234,10 @@ public:
             r.result.diff_adjacent = st.diff_adjacent != 0;
             r.result.overflow = st.overflow != 0;
             r.result.max_run = st.max_run;
+            if (std::getenv("ROCCO_HOSTLOGIC_TRACE") != nullptr) {
+                std::fprintf(stderr, "[window] n=%zu [%.17g, %.17g] counts %lld %lld n_diff=%lld overflow=%d\n", p.n, r.lambda_lo,
+                             r.lambda_hi, (long long)st.count_lo, (long long)st.count_hi, (long long)st.n_diff, (int)st.overflow);
+            }
             r.result.diffs.clear();
             for (long long i = 0; i < st.n_diff && i < 16; ++i) {
                 WindowDiff d;
@@ -322,12 +353,16 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     if (const char *e = std::getenv("ROCCO_HOSTLOGIC_COMPACT")) ev.allow_compact = std::atoi(e) != 0;
     if (const char *e = std::getenv("ROCCO_HOSTLOGIC_TILE")) ev.compact_tile = std::atoi(e);
     if (const char *e = std::getenv("ROCCO_HOSTLOGIC_PILOT")) ev.pilot_noise = std::atof(e);
+    if (const char *e = std::getenv("ROCCO_HOSTLOGIC_SLACK")) ev.compact_slack = std::atof(e);
+    if (const char *e = std::getenv("ROCCO_HOSTLOGIC_NOW")) ev.compact_at_once = std::atoi(e) != 0;
     HostProblem h;
     h.scores = scores;
     h.costs = costs;
     h.gamma = gamma;
     h.n = n;
     h.qexp = grid_exponent(cmax, smin, smax);
+    h.smin0 = smin;
+    h.smax0 = smax;
     h.cmax = cmax;
     h.sabs = std::fmax(std::fabs(smin), std::fabs(smax));
     h.solution = solution;
@@ -354,6 +389,9 @@ int hostlogic_calibrate(const double *scores, const double *costs, double gamma,
     opt.spec_depth = spec_depth;
     opt.force_exact = force_exact != 0;
     if (const char *e = std::getenv("ROCCO_HIP_BOUNDS")) opt.use_bounds = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ROCCO_HOSTLOGIC_PILOT_ROUNDS")) opt.pilot_rounds = std::atoi(e);
+    if (const char *e = std::getenv("ROCCO_HOSTLOGIC_PILOT_POINTS")) opt.pilot_points = std::atoi(e);
+    if (const char *e = std::getenv("ROCCO_HOSTLOGIC_POINTS")) ev.round_points = std::atoi(e);
     std::vector<CalibrationResult> res;
     const int rc = calibrate_batch(ev, {p}, opt, res);
     if (rc != 0) return rc;
@@ -403,6 +441,8 @@ int hostlogic_solve_fixed(const double *scores, const double *costs, double gamm
     h.gamma = gamma;
     h.n = n;
     h.qexp = grid_exponent(cmax, lo, hi);
+    h.smin0 = smin;
+    h.smax0 = smax;
     h.cmax = cmax;
     h.sabs = std::fmax(std::fabs(smin), std::fabs(smax));
     h.solution = solution;

@@ -109,6 +109,23 @@ def test_budget_solve_vs_oracle(gpu, oracle, n, budget, gamma):
     assert np.isclose(det["penalized_objective"], o_det["penalized_objective"], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("offset,n,gamma,budget", [
+    (1.0e3, 40000, 1.0, 0.05), (3.0e4, 300000, 0.5, 0.1), (-1.0e6, 3000, 3.0, 0.05), (1.0e9, 100, 1.0, 0.3),
+    (1.0e3, 1200000, 1.0, 0.02),
+])
+def test_scores_far_from_zero(gpu, oracle, offset, n, gamma, budget):
+    """Scores whose magnitude dwarfs their spread (the reference adds the score before it subtracts the penalty,
+    rocco/_chain_dp.c:120,125,127-128, so it rounds at the magnitude of the score): bit-exact all the same."""
+    from rocco_amd import dp
+
+    rng = np.random.default_rng([n, int(abs(offset)) % 1000])
+    s = offset + rng.gamma(1.0, 1.0, n)
+    target = int(np.floor(n * budget))
+    ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, gamma), target)
+    got = dp.calibrate_selection_penalty(s, gamma, target)
+    assert got[0] == ref[0] and got[3] == ref[3] and np.array_equal(got[1], ref[1])
+
+
 def test_errors_like_reference(gpu):
     from rocco_amd import solve_chrom_exact, solve_penalized_chain
 

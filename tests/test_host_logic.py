@@ -79,6 +79,38 @@ def test_edge_cases_match_oracle(oracle):
     assert np.array_equal(sol, ref[1]) and cnt == ref[3]
 
 
+@pytest.mark.parametrize("offset,n,gamma,budget", [
+    (1.0e3, 40000, 1.0, 0.05), (1.0e3, 3000, 1.0, 0.1), (3.0e4, 40000, 0.5, 0.1), (-1.0e6, 3000, 3.0, 0.05),
+    (1.0e9, 100, 1.0, 0.3),
+])
+def test_scores_far_from_zero(oracle, offset, n, gamma, budget):
+    """Scores whose magnitude dwarfs their spread: the reference adds the score BEFORE it subtracts the penalty
+    (rocco/_chain_dp.c:120,125,127-128), so its roundings happen at the magnitude of the score, which the rounding
+    model has to price whatever the running value is."""
+    for seed in range(4):
+        rng = np.random.default_rng([seed, n])
+        s = offset + rng.gamma(1.0, 1.0, n)
+        target = int(np.floor(n * budget))
+        ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, gamma), target)
+        pen, sol, val, cnt, info = hl.calibrate(s, gamma, target)
+        assert pen == ref[0] and cnt == ref[3] and np.array_equal(sol, ref[1]), (seed, info)
+
+
+def test_single_large_peak_at_the_end(oracle):
+    """Target 0 on scores of magnitude 1e6: the penalty that stops selecting the last locus is decided by one
+    rounding at that magnitude (a case the compacted copy of the chromosome once got wrong in the harness)."""
+    bad = 0
+    for it in range(300):
+        rng = np.random.default_rng(it)
+        n = int(rng.choice([5, 7, 12]))
+        s = rng.normal(0, 1e6, n)
+        gamma = float(rng.choice([0.5, 1.0, 3.0, 10.0, float(abs(rng.normal()) * 2)]))
+        ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, gamma), 0)
+        pen, sol, val, cnt, info = hl.calibrate(s, gamma, 0, spec_depth=1 + it % 3)
+        bad += not (pen == ref[0] and cnt == ref[3] and np.array_equal(sol, ref[1]))
+    assert bad == 0
+
+
 def test_integer_scores_many_ties(oracle):
     """Integer data makes exact value ties the rule; whichever path is taken the answer is the
     reference's (count tie-break of rocco/_chain_dp.c:133-179)."""

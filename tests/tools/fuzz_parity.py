@@ -14,7 +14,7 @@ while time.time() < t_end:
     rng = np.random.default_rng(seed0 * 100000 + it)
     n = int(rng.choice([1, 2, 3, 5, 31, 32, 33, 100, 1000, 8191, 8192, 8193, 20000, 70000, 300000, 1200000], p=None))
     n = max(1, n + int(rng.integers(-3, 4))) if n > 10 else n
-    kind = rng.choice(["normal", "int", "round5", "heavy", "const", "sparse", "tiny", "huge"])
+    kind = rng.choice(["normal", "int", "round5", "heavy", "const", "sparse", "tiny", "huge", "offset"])
     if kind == "normal": s = rng.normal(0.2, 1.0, n)
     elif kind == "int": s = rng.integers(-3, 6, n).astype(float)
     elif kind == "round5": s = np.round(rng.gamma(1.0, 0.3, n), 5)
@@ -22,6 +22,7 @@ while time.time() < t_end:
     elif kind == "const": s = np.full(n, float(rng.normal()))
     elif kind == "sparse": s = np.where(rng.random(n) < 0.02, rng.gamma(6.0, 1.0, n), 0.0)
     elif kind == "tiny": s = rng.normal(0, 1e-9, n)
+    elif kind == "offset": s = float(rng.choice([1e3, 3e4, -1e6, 1e9])) + rng.gamma(1.0, 1.0, n)
     else: s = rng.normal(0, 1e6, n)
     gamma = float(rng.choice([0.0, 0.5, 1.0, 3.0, 10.0, float(abs(rng.normal()) * 2)]))
     use_vec = n > 1 and rng.random() < 0.25
