@@ -67,6 +67,15 @@ int rocco_hip_score_median_batch(rocco_hip_solver *solver, const void *const *ma
                                  const size_t *n, const size_t *row_strides, double *const *scores_dev, size_t count,
                                  void *stream);
 
+/* ... and, reduced inside the same launch, what the budgeted solve first asks of every score array
+ * (rocco/dp.py:110-111 np.min / np.max; the sum of absolute values bounds its running values):
+ * stats_dev[3 i .. 3 i + 3) = min, max, sum |.| of scores_dev[i] (device memory; min / max skip NaN scores, the sum
+ * carries them).  Every n[i] must be positive.  Copy them to the host and hand them to
+ * rocco_hip_solve_budget_batch_stats_f64: the scores are then not read a second time. */
+int rocco_hip_score_median_batch_stats(rocco_hip_solver *solver, const void *const *matrices_dev, int dtype, size_t K,
+                                       const size_t *n, const size_t *row_strides, double *const *scores_dev,
+                                       size_t count, double *stats_dev, void *stream);
+
 /* The other branches of score_central_tendency_chrom (not reached from the reference's driver): the nearest-rank
  * quantile of rocco.py:267-272 -- `rank` (0-based position in the sorted column) is computed by the caller with
  * NumPy's own rule, np.quantile(np.arange(K), q, method="nearest") -- and the column mean of rocco.py:298-299
@@ -132,6 +141,14 @@ typedef struct {
 int rocco_hip_solve_budget_batch_f64(rocco_hip_solver *solver, size_t n_tasks,
                                      const rocco_hip_budget_task *tasks,
                                      rocco_hip_budget_result *results, void *stream);
+
+/* The same with the score statistics the solve starts from -- np.min(scores), np.max(scores) (rocco/dp.py:110-111)
+ * and sum |scores| (bounds the running values) -- handed in by the caller: score_stats_host[3 t .. 3 t + 3) in HOST
+ * memory, exactly as rocco_hip_score_median_batch_stats produced them for these very arrays (NULL: computed here,
+ * as above; ignored for a batch with cost vectors).  Saves one pass over every score array and one device round. */
+int rocco_hip_solve_budget_batch_stats_f64(rocco_hip_solver *solver, size_t n_tasks,
+                                           const rocco_hip_budget_task *tasks, const double *score_stats_host,
+                                           rocco_hip_budget_result *results, void *stream);
 
 /* ---- delta-form evaluation (the parallel kernels behind the two solves above) ----------------
  * Count-only evaluation of the chain at several penalties in one pass over the scores, with the

@@ -93,6 +93,9 @@ PROTOTYPES = [
     ("rocco_hip_score_median_batch", ctypes.c_int,
      [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_size_t, c_size_p, c_size_p,
       ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_void_p]),
+    ("rocco_hip_score_median_batch_stats", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_size_t, c_size_p, c_size_p,
+      ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     ("rocco_hip_score_median", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
       ctypes.c_void_p, ctypes.c_void_p]),
@@ -107,6 +110,9 @@ PROTOTYPES = [
       ctypes.c_double, ctypes.c_void_p, c_double_p, c_ll_p, c_int_p, ctypes.c_void_p]),
     ("rocco_hip_solve_budget_batch_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(BudgetTask), ctypes.POINTER(BudgetResult),
+      ctypes.c_void_p]),
+    ("rocco_hip_solve_budget_batch_stats_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(BudgetTask), ctypes.c_void_p, ctypes.POINTER(BudgetResult),
       ctypes.c_void_p]),
     ("rocco_hip_delta_probe_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p,

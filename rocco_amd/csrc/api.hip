@@ -165,6 +165,30 @@ int rocco_hip_score_median_batch(rocco_hip_solver *solver, const void *const *ma
     return launch_median_batch(matrices_dev, dtype, K, n, row_strides, scores_dev, count, (hipStream_t)stream);
 }
 
+int rocco_hip_score_median_batch_stats(rocco_hip_solver *solver, const void *const *matrices_dev, int dtype, size_t K,
+                                       const size_t *n, const size_t *row_strides, double *const *scores_dev, size_t count,
+                                       double *stats_dev, void *stream)
+{
+    if (stats_dev == nullptr) {
+        return rocco_hip_score_median_batch(solver, matrices_dev, dtype, K, n, row_strides, scores_dev, count, stream);
+    }
+    if (solver == nullptr || K == 0 || (dtype != 0 && dtype != 1) ||
+        (count > 0 && (matrices_dev == nullptr || n == nullptr || row_strides == nullptr || scores_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    for (size_t i = 0; i < count; ++i) {
+        if (n[i] == 0 || matrices_dev[i] == nullptr || scores_dev[i] == nullptr || row_strides[i] < n[i]) {
+            return ROCCO_HIP_EINVAL;  // (statistics of an empty score array do not exist)
+        }
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    const size_t blocks = median_partials_count(n, count);
+    int rc;
+    if ((rc = solver->dev_median_partials.reserve(3 * blocks * sizeof(double) + 256)) != ROCCO_HIP_OK) return rc;
+    return launch_median_batch(matrices_dev, dtype, K, n, row_strides, scores_dev, count, (hipStream_t)stream, stats_dev,
+                               (double *)solver->dev_median_partials.ptr);
+}
+
 int rocco_hip_score_median(rocco_hip_solver *solver, const void *matrix_dev, int dtype, size_t K,
                            size_t n, size_t row_stride, double *scores_dev, void *stream)
 {
@@ -247,6 +271,25 @@ int rocco_hip_solve_budget_batch_f64(rocco_hip_solver *solver, size_t n_tasks,
     }
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
     return solve_budget_batch(solver, n_tasks, tasks, results, (hipStream_t)stream);
+}
+
+int rocco_hip_solve_budget_batch_stats_f64(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip_budget_task *tasks,
+                                           const double *score_stats_host, rocco_hip_budget_result *results, void *stream)
+{
+    if (solver == nullptr || (n_tasks > 0 && (tasks == nullptr || results == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    for (size_t t = 0; t < n_tasks; ++t) {
+        if (tasks[t].scores_dev == nullptr || tasks[t].n == 0 || tasks[t].n >= ((size_t)1 << 31) ||
+            tasks[t].solution_dev == nullptr || tasks[t].max_iter < 0) {
+            return ROCCO_HIP_EINVAL;
+        }
+        if (score_stats_host != nullptr && !(score_stats_host[3 * t] <= score_stats_host[3 * t + 1])) {
+            return ROCCO_HIP_EINVAL;  // min <= max (also refuses NaN)
+        }
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return solve_budget_batch(solver, n_tasks, tasks, results, (hipStream_t)stream, score_stats_host);
 }
 
 int rocco_hip_delta_probe_f64(rocco_hip_solver *solver, const double *scores_dev,

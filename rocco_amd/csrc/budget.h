@@ -10,8 +10,10 @@ int solve_fixed_penalty(rocco_hip_solver *solver, const double *scores_dev,
                         uint8_t *solution_dev, double *value_out, long long *count_out, int *path_out,
                         hipStream_t stream);
 
+// `score_stats_host` (optional): [n_tasks][3] = min, max, sum |.| of every task's scores, already known to the caller
+// (rocco_hip_score_median_batch_stats): the statistics pass over the scores is skipped for a batch without cost vectors.
 int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip_budget_task *tasks,
-                       rocco_hip_budget_result *results, hipStream_t stream);
+                       rocco_hip_budget_result *results, hipStream_t stream, const double *score_stats_host = nullptr);
 
 }  // namespace rocco
 

@@ -1608,12 +1608,26 @@ private:
 };
 
 // Fill ChainProblem / DevProblem statistics from one stats pass.
-int prepare(HipEvaluator &ev, std::vector<ChainProblem> &problems, const std::vector<double> *fixed_lambdas)
+int prepare(HipEvaluator &ev, std::vector<ChainProblem> &problems, const std::vector<double> *fixed_lambdas,
+            const double *score_stats_host = nullptr)
 {
     std::vector<double> stats;
-    const int rc = ev.compute_stats(stats);
-    if (rc != ROCCO_HIP_OK) {
-        return rc;
+    bool given = (score_stats_host != nullptr);
+    for (size_t b = 0; given && b < problems.size(); ++b) {
+        given = (ev.probs[b].costs == nullptr || ev.probs[b].n <= 1);  // cost vectors need their own extremes
+    }
+    if (given) {
+        stats.assign(5 * problems.size(), 0.0);
+        for (size_t b = 0; b < problems.size(); ++b) {
+            stats[5 * b + 0] = score_stats_host[3 * b + 0];
+            stats[5 * b + 1] = score_stats_host[3 * b + 1];
+            stats[5 * b + 4] = score_stats_host[3 * b + 2];
+        }
+    } else {
+        const int rc = ev.compute_stats(stats);
+        if (rc != ROCCO_HIP_OK) {
+            return rc;
+        }
     }
     for (size_t b = 0; b < problems.size(); ++b) {
         ChainProblem &p = problems[b];
@@ -1862,7 +1876,7 @@ int delta_window(rocco_hip_solver *solver, const double *scores_dev, const doubl
 }
 
 int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip_budget_task *tasks,
-                       rocco_hip_budget_result *results, hipStream_t stream)
+                       rocco_hip_budget_result *results, hipStream_t stream, const double *score_stats_host)
 {
     HipEvaluator ev(solver, stream);
     std::vector<ChainProblem> problems(n_tasks);
@@ -1881,7 +1895,7 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
         problems[t].max_iter = tasks[t].max_iter;
     }
     int rc;
-    if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    if ((rc = prepare(ev, problems, nullptr, score_stats_host)) != ROCCO_HIP_OK) return rc;
     SearchOptions opt;
     opt.force_exact = solver->force_exact != 0;
     opt.spec_depth = solver->spec_depth;

@@ -55,6 +55,7 @@ struct rocco_hip_solver {
     rocco::DeviceBuffer dev_results;  // per-launch counters / values
     rocco::DeviceBuffer dev_bits;     // exact-path decision bits
     rocco::DeviceBuffer dev_misc;     // decode / reduction scratch
+    rocco::DeviceBuffer dev_median_partials;  // per-workgroup score statistics of a median launch
     rocco::DeviceBuffer dev_solution; // solution scratch when the caller wants counts only
     rocco::DeviceBuffer dev_maps;     // per-chunk binade maps of the problems being solved
     rocco::DeviceBuffer dev_frozen;   // per-block frozen summaries of the problems being solved

@@ -35,14 +35,20 @@ struct MedianTask {
     long long stride;
     unsigned block_begin;
     unsigned pad;
+    double *partials;  // [wavefront of this task][3] = min, max, sum |.| of its scores (nullptr: not wanted)
 };
 struct MedianBatch {
     MedianTask tasks[kMedianBatchMax];
     int n_tasks;
     int K;
 };
+// `stats_dev` (optional): [count][3] = min, max and sum of absolute values of every score array (what the budgeted
+// solve otherwise reads the scores once more for), reduced from per-workgroup partials kept in `partials_dev`
+// (3 doubles per 64 loci of every matrix; median_partials_count() tells how many wavefronts that is).
+size_t median_partials_count(const size_t *n, size_t count);
 int launch_median_batch(const void *const *matrices_dev, int dtype, size_t K, const size_t *n, const size_t *row_strides,
-                        double *const *scores_dev, size_t count, hipStream_t stream);
+                        double *const *scores_dev, size_t count, hipStream_t stream, double *stats_dev = nullptr,
+                        double *partials_dev = nullptr);
 
 int launch_order_statistic(const void *matrix_dev, int dtype, size_t K, size_t n, size_t row_stride, int rank,
                            double *scores_dev, hipStream_t stream);

@@ -65,11 +65,11 @@ __device__ __forceinline__ unsigned xcd_contiguous_block()
 
 // EXACT: K == KP is known at compile time (no padding, unpredicated loads).
 template <typename T, int KP, bool EXACT>
-__device__ __forceinline__ void median_column(const T *__restrict__ m, int K_runtime, long long n, long long stride,
-                                              double *__restrict__ out, long long j)
+__device__ __forceinline__ double median_column(const T *__restrict__ m, int K_runtime, long long n, long long stride,
+                                                double *__restrict__ out, long long j)
 {
     if (j >= n) {
-        return;
+        return 0.0;
     }
     const int K = EXACT ? KP : K_runtime;
     const int pad = KP - K;
@@ -104,7 +104,9 @@ __device__ __forceinline__ void median_column(const T *__restrict__ m, int K_run
     } else {
         r = (v[KP / 2 - 1] + v[KP / 2]) / 2.0;
     }
-    out[j] = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : r;
+    r = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : r;
+    out[j] = r;
+    return r;
 }
 
 template <typename T, int KP, bool EXACT>
@@ -128,7 +130,126 @@ __global__ __launch_bounds__(256) void median_batch_kernel(MedianBatch batch)
     }
     const MedianTask &task = batch.tasks[ti];
     const long long j = (long long)(logical - task.block_begin) * blockDim.x + threadIdx.x;
-    median_column<T, KP, EXACT>((const T *)task.matrix, batch.K, task.n, task.stride, task.out, j);
+    const double r = median_column<T, KP, EXACT>((const T *)task.matrix, batch.K, task.n, task.stride, task.out, j);
+    if (task.partials != nullptr) {
+        // min / max / sum |.| of this WAVEFRONT's scores (fmin / fmax skip NaN as the solve's own statistics pass
+        // does, the sum carries it): the budgeted solve starts from these instead of reading the scores again.
+        // No barrier: a workgroup-wide reduction would hold every wavefront of the workgroup until its slowest.
+        const bool valid = j < task.n;
+        const bool nan = valid && is_nan_bits(r);
+        const double inf = std::numeric_limits<double>::infinity();
+        double mn = (valid && !nan) ? r : inf, mx = (valid && !nan) ? r : -inf, ab = (valid && !nan) ? fabs(r) : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fmin(mn, __shfl_xor(mn, off));
+            mx = fmax(mx, __shfl_xor(mx, off));
+            ab += __shfl_xor(ab, off);
+        }
+        const bool any_nan = __ballot(nan) != 0ull;
+        if ((threadIdx.x & 63) == 0) {
+            double *p = task.partials + 3LL * (4LL * (logical - task.block_begin) + (threadIdx.x >> 6));
+            p[0] = mn;
+            p[1] = mx;
+            p[2] = any_nan ? __longlong_as_double(0x7FF8000000000000LL) : ab;
+        }
+    }
+}
+
+// Per-wavefront partials -> [min, max, sum |.|] of every score array, in two steps: kStatsSlices workgroups per array
+// reduce a slice each (a single workgroup would crawl through megabytes of partials), one more folds the slices.
+constexpr int kStatsSlices = 64;
+struct MedianStatsTask {
+    const double *partials;
+    long long n_partials;
+};
+struct MedianStatsBatch {
+    MedianStatsTask tasks[kMedianBatchMax];
+};
+
+__device__ __forceinline__ void stats_block_reduce(double mn, double mx, double ab, bool nan, double *__restrict__ out)
+{
+    __shared__ double red[4][3];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, off));
+        mx = fmax(mx, __shfl_xor(mx, off));
+        ab += __shfl_xor(ab, off);
+    }
+    const bool any_nan = __syncthreads_or(nan ? 1 : 0) != 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave][0] = mn;
+        red[wave][1] = mx;
+        red[wave][2] = ab;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0]));
+        out[1] = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
+        const double sum = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+        out[2] = any_nan ? __longlong_as_double(0x7FF8000000000000LL) : sum;
+    }
+}
+
+// grid (kStatsSlices, tasks): slice s of task t -> slices[(t * kStatsSlices + s) * 3]
+__global__ __launch_bounds__(256) void median_stats_slice_kernel(MedianStatsBatch batch, double *__restrict__ slices)
+{
+    const MedianStatsTask task = batch.tasks[blockIdx.y];
+    const long long per = (task.n_partials + kStatsSlices - 1) / kStatsSlices;
+    const long long lo = per * blockIdx.x, hi = min(task.n_partials, lo + per);
+    const double inf = std::numeric_limits<double>::infinity();
+    double mn = inf, mx = -inf, ab = 0.0;
+    bool nan = false;
+    for (long long b = lo + threadIdx.x; b < hi; b += 256) {
+        mn = fmin(mn, task.partials[3 * b + 0]);
+        mx = fmax(mx, task.partials[3 * b + 1]);
+        const double a = task.partials[3 * b + 2];
+        const bool bad = is_nan_bits(a);
+        nan |= bad;
+        ab += bad ? 0.0 : a;
+    }
+    stats_block_reduce(mn, mx, ab, nan, slices + 3LL * ((long long)blockIdx.y * kStatsSlices + blockIdx.x));
+}
+
+// one workgroup per task: its slices -> out[task * 3]
+__global__ __launch_bounds__(256) void median_stats_final_kernel(const double *__restrict__ slices, double *__restrict__ out)
+{
+    const double inf = std::numeric_limits<double>::infinity();
+    double mn = inf, mx = -inf, ab = 0.0;
+    bool nan = false;
+    if (threadIdx.x < kStatsSlices) {
+        const double *p = slices + 3LL * ((long long)blockIdx.x * kStatsSlices + threadIdx.x);
+        mn = p[0];
+        mx = p[1];
+        nan = is_nan_bits(p[2]);
+        ab = nan ? 0.0 : p[2];
+    }
+    stats_block_reduce(mn, mx, ab, nan, out + 3LL * blockIdx.x);
+}
+
+// the same statistics from a score array itself (element types / K the network kernel does not take)
+__global__ __launch_bounds__(256) void score_stats_partial_kernel(const double *__restrict__ scores, long long n,
+                                                                  double *__restrict__ partials)
+{
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = j < n;
+    const double r = valid ? scores[j] : 0.0;
+    const bool nan = valid && is_nan_bits(r);
+    const double inf = std::numeric_limits<double>::infinity();
+    double mn = (valid && !nan) ? r : inf, mx = (valid && !nan) ? r : -inf, ab = (valid && !nan) ? fabs(r) : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, off));
+        mx = fmax(mx, __shfl_xor(mx, off));
+        ab += __shfl_xor(ab, off);
+    }
+    const bool any_nan = __ballot(nan) != 0ull;
+    if ((threadIdx.x & 63) == 0) {
+        double *p = partials + 3LL * (4LL * blockIdx.x + (threadIdx.x >> 6));
+        p[0] = mn;
+        p[1] = mx;
+        p[2] = any_nan ? __longlong_as_double(0x7FF8000000000000LL) : ab;
+    }
 }
 
 // 100 < K <= 200: two sorted halves.  The column (padded to 200 entries with -inf / +inf in equal numbers, one extra
@@ -492,24 +613,48 @@ bool dispatch_batch(const MedianBatch &batch, unsigned blocks, hipStream_t strea
 
 }  // namespace
 
-int launch_median_batch(const void *const *matrices_dev, int dtype, size_t K, const size_t *n, const size_t *row_strides,
-                        double *const *scores_dev, size_t count, hipStream_t stream)
+size_t median_partials_count(const size_t *n, size_t count)
 {
+    size_t blocks = 0;
+    for (size_t i = 0; i < count; ++i) {
+        blocks += 4 * ((n[i] + 255) / 256);  // one partial per wavefront
+    }
+    return blocks + (size_t)kMedianBatchMax * 64;  // + the slices of the second reduction step (kStatsSlices per task)
+}
+
+int launch_median_batch(const void *const *matrices_dev, int dtype, size_t K, const size_t *n, const size_t *row_strides,
+                        double *const *scores_dev, size_t count, hipStream_t stream, double *stats_dev, double *partials_dev)
+{
+    const bool want_stats = (stats_dev != nullptr && partials_dev != nullptr);
+    size_t partials_total = 0;
+    for (size_t i = 0; i < count; ++i) {
+        partials_total += 4 * ((n[i] + 255) / 256);
+    }
     size_t at = 0;
+    size_t partial_at = 0;  // workgroups (of 256 loci) before the current matrix
     while (at < count) {
         MedianBatch batch;
+        MedianStatsBatch finals;
+        int final_index[kMedianBatchMax];
         batch.K = (int)K;
         batch.n_tasks = 0;
         unsigned blocks = 0;
+        const size_t first = at;
         while (at < count && batch.n_tasks < kMedianBatchMax) {
             if (n[at] > 0) {
+                const size_t nb = (n[at] + 255) / 256;
+                finals.tasks[batch.n_tasks].partials = want_stats ? partials_dev + 3 * partial_at : nullptr;
+                finals.tasks[batch.n_tasks].n_partials = (long long)(4 * nb);
+                final_index[batch.n_tasks] = (int)at;
                 MedianTask &t = batch.tasks[batch.n_tasks++];
                 t.matrix = matrices_dev[at];
                 t.out = scores_dev[at];
                 t.n = (long long)n[at];
                 t.stride = (long long)row_strides[at];
                 t.block_begin = blocks;
-                blocks += (unsigned)((n[at] + 255) / 256);
+                t.partials = want_stats ? partials_dev + 3 * partial_at : nullptr;
+                blocks += (unsigned)nb;
+                partial_at += 4 * nb;
             }
             ++at;
         }
@@ -517,13 +662,39 @@ int launch_median_batch(const void *const *matrices_dev, int dtype, size_t K, co
             continue;
         }
         const bool done = (dtype == 0) ? dispatch_batch<double>(batch, blocks, stream) : dispatch_batch<float>(batch, blocks, stream);
-        if (!done) {  // K outside the network sizes: one launch per matrix
+        if (!done) {  // K outside the network sizes: one launch per matrix, statistics from the scores
             for (int i = 0; i < batch.n_tasks; ++i) {
                 const int rc = launch_median(batch.tasks[i].matrix, dtype, K, (size_t)batch.tasks[i].n,
                                              (size_t)batch.tasks[i].stride, batch.tasks[i].out, stream);
                 if (rc != ROCCO_HIP_OK) return rc;
+                if (want_stats) {
+                    hipLaunchKernelGGL(score_stats_partial_kernel, dim3((unsigned)(finals.tasks[i].n_partials / 4)), dim3(256), 0, stream,
+                                       (const double *)batch.tasks[i].out, batch.tasks[i].n, batch.tasks[i].partials);
+                }
             }
         }
+        if (want_stats) {
+            // results of this launch's matrices are contiguous in stats_dev only if no empty matrix lies between
+            // them: reduce every run of consecutive indices with one launch
+            int i = 0;
+            while (i < batch.n_tasks) {
+                int k = i + 1;
+                while (k < batch.n_tasks && final_index[k] == final_index[k - 1] + 1) {
+                    ++k;
+                }
+                MedianStatsBatch part;
+                for (int q = i; q < k; ++q) {
+                    part.tasks[q - i] = finals.tasks[q];
+                }
+                // (the slices live behind the partials: 3 * kStatsSlices doubles per task of one launch)
+                double *slices = partials_dev + 3 * partials_total;
+                hipLaunchKernelGGL(median_stats_slice_kernel, dim3(kStatsSlices, (unsigned)(k - i)), dim3(256), 0, stream, part, slices);
+                hipLaunchKernelGGL(median_stats_final_kernel, dim3((unsigned)(k - i)), dim3(256), 0, stream, (const double *)slices,
+                                   stats_dev + 3 * (size_t)final_index[i]);
+                i = k;
+            }
+        }
+        (void)first;
         ROCCO_HIP_TRY(hipGetLastError());
     }
     return ROCCO_HIP_OK;

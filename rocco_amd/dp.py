@@ -246,8 +246,12 @@ def calibrate_selection_penalty_device(scores_t, switch_costs, target_count: int
     return calibrate_batch_device([scores_t], [switch_costs], [target_count], max_iter=max_iter)[0]
 
 
-def calibrate_batch_device(scores_list, switch_costs_list, target_counts, max_iter: int = 60):
-    """One device launch sequence for several chromosomes (rocco_hip_solve_budget_batch_f64)."""
+def calibrate_batch_device(scores_list, switch_costs_list, target_counts, max_iter: int = 60, score_stats=None):
+    """One device launch sequence for several chromosomes (rocco_hip_solve_budget_batch_f64).
+
+    `score_stats`: optional [k, 3] float64 HOST array (NumPy, or a CPU tensor whose copy from the device has
+    completed) of np.min, np.max and sum |.| of every score array as score_central_tendency_chrom_batch_device
+    (with_stats=True) produced them: the solve then skips its own pass over the scores."""
     torch = _torch()
     lib = _native.load()
     k = len(scores_list)
@@ -275,9 +279,17 @@ def calibrate_batch_device(scores_list, switch_costs_list, target_counts, max_it
         tasks[i].max_iter = int(max_iter)
         tasks[i].solution_dev = sol_t.data_ptr()
     solver = _native.solver_for(device.index)
-    _native.check(lib.rocco_hip_solve_budget_batch_f64(solver.handle, k, tasks, results,
-                                                       _stream_ptr(scores_list[0])),
-                  "rocco_hip_solve_budget_batch_f64")
+    if score_stats is not None:
+        stats_h = np.ascontiguousarray(score_stats.numpy() if _is_tensor(score_stats) else score_stats, dtype=np.float64)
+        if stats_h.shape != (k, 3):
+            raise ValueError("`score_stats` must have shape [len(scores_list), 3]")
+        _native.check(lib.rocco_hip_solve_budget_batch_stats_f64(solver.handle, k, tasks, stats_h.ctypes.data, results,
+                                                                 _stream_ptr(scores_list[0])),
+                      "rocco_hip_solve_budget_batch_stats_f64")
+    else:
+        _native.check(lib.rocco_hip_solve_budget_batch_f64(solver.handle, k, tasks, results,
+                                                           _stream_ptr(scores_list[0])),
+                      "rocco_hip_solve_budget_batch_f64")
     out = []
     for i in range(k):
         r = results[i]

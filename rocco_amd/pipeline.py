@@ -28,6 +28,10 @@ SOLVE_GROUPS = int(os.environ.get("ROCCO_SOLVE_GROUPS", "3"))
 # 1: score every chromosome of the rank in ONE launch before any group starts solving (the median kernel then runs at
 # its full bandwidth); 0: score group after group so that the first groups solve while the later ones are scored
 SCORE_FIRST = int(os.environ.get("ROCCO_SCORE_FIRST", "0"))
+# 1: the median launch also reduces min / max / sum |.| of its scores, which the calibration starts from, instead of
+# the calibration's own pass over the scores.  Measured on the whole genome: the reduction at
+# the end of every wavefront of the bandwidth-bound kernel costs what the separate pass costs -- off by default.
+MEDIAN_STATS = bool(int(os.environ.get("ROCCO_MEDIAN_STATS", "0")))
 _pool: Optional[concurrent.futures.ThreadPoolExecutor] = None
 _group_state: Dict[Tuple[int, int], tuple] = {}  # (device, group) -> (Solver, torch.cuda.Stream)
 _group_lock = threading.Lock()  # the groups' solver handles are per process: one grouped solve at a time
@@ -73,13 +77,15 @@ def _score_wls(c: ChromWork):
     return s_t
 
 
-def _solve_group(chroms: Sequence[ChromWork], scores: list) -> list:
+def _solve_group(chroms: Sequence[ChromWork], scores: list, score_stats=None) -> list:
     """Calibrate and decode the given chromosomes on the calling thread's current stream / solver; count-path
     chromosomes (scores[i] is None) are scored here first, so that the groups' chain kernels -- one latency-bound
     wavefront per row and parity -- run side by side as well."""
+    if any(s is None for s in scores):
+        score_stats = None
     scores = [s if s is not None else _score_wls(c) for c, s in zip(chroms, scores)]
     targets = [int(np.floor(c.n * c.budget)) for c in chroms]  # rocco/dp.py:197
-    solved = _dp.calibrate_batch_device(scores, [c.gamma for c in chroms], targets)
+    solved = _dp.calibrate_batch_device(scores, [c.gamma for c in chroms], targets, score_stats=score_stats)
     out = []
     runs = _rocco.decode_runs_batch_device([sol_t for (_p, sol_t, _v, _c, _i) in solved],
                                            capacities=[max(1024, c.n // 64) for c in chroms])
@@ -133,35 +139,52 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
     n_groups = max(1, min(int(groups if groups is not None else SOLVE_GROUPS), len(chroms)))
     out: List[Optional[dict]] = [None] * len(chroms)
 
-    def score_all(members: Sequence[ChromWork]) -> list:
-        # the medians of a group in one launch (count-path chromosomes are scored inside their group)
+    def score_all(members: Sequence[ChromWork]):
+        # the medians of a group in one launch (count-path chromosomes are scored inside their group), together
+        # with the statistics the calibration starts from (min, max, sum |.| of every score array: reduced in the
+        # same launch and copied to pinned host memory behind it -- valid once the caller has waited for the stream)
         med = [c for c in members if c.scoring != "wls"]
         if median_timing is not None and med:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(torch.cuda.current_stream(device))
-        got = dict(zip((id(c) for c in med), _rocco.score_central_tendency_chrom_batch_device([c.matrix_t for c in med])))
+        outs, stats_d = [], None
+        if med and MEDIAN_STATS:
+            outs, stats_d = _rocco.score_central_tendency_chrom_batch_device([c.matrix_t for c in med], with_stats=True)
+        elif med:
+            outs = _rocco.score_central_tendency_chrom_batch_device([c.matrix_t for c in med])
+        got = dict(zip((id(c) for c in med), outs))
         if median_timing is not None and med:
             ev1.record(torch.cuda.current_stream(device))
             # K elements read + 8 bytes written per locus
             nbytes = sum((c.matrix_t.element_size() * int(c.matrix_t.shape[0]) + 8) * c.n for c in med)
             median_timing.append((ev0, ev1, nbytes))
+        stats_h = None
+        if stats_d is not None and len(med) == len(members):
+            stats_h = torch.empty((len(med), 3), dtype=torch.float64, pin_memory=True)
+            stats_h.copy_(stats_d, non_blocking=True)
         for c in med:
             c._effect_mean = got[id(c)]  # rocco/rocco.py:995-997: the bigWig branch uses the scores themselves
-        return [got.get(id(c)) for c in members]
+        return [got.get(id(c)) for c in members], stats_h
 
     if n_groups == 1:
-        out = _solve_group(chroms, score_all(chroms))
+        scores, stats_h = score_all(chroms)
+        if stats_h is not None:
+            torch.cuda.current_stream(device).synchronize()
+        out = _solve_group(chroms, scores, stats_h)
     else:
         order = sorted(range(len(chroms)), key=lambda i: -chroms[i].n)
         members = _group_chunks(order, n_groups)
         with torch.cuda.device(device):
             caller_stream = torch.cuda.current_stream(device)
 
-            def work(group: int, idx: List[int], scores: list, scored):
+            def work(group: int, idx: List[int], scores: list, scored, stats_h=None):
                 solver, stream = _group_resources(device.index, group)
                 with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
-                    stream.wait_event(scored)
-                    res = _solve_group([chroms[i] for i in idx], scores)
+                    if stats_h is not None:
+                        scored.synchronize()  # the statistics are read on the host
+                    else:
+                        stream.wait_event(scored)
+                    res = _solve_group([chroms[i] for i in idx], scores, stats_h)
                     stream.synchronize()
                 # the results were allocated on the group's stream and are handed to the caller's
                 for r in res:
@@ -176,18 +199,20 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
                     _pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-solve")
                 futures = []
                 if SCORE_FIRST:
-                    every = score_all([chroms[i] for i in order])
+                    every, stats_all = score_all([chroms[i] for i in order])
                     by_index = dict(zip(order, every))
+                    row = {i: k for k, i in enumerate(order)}
                     scored = torch.cuda.Event()
                     scored.record(caller_stream)
                     for g, idx in enumerate(members):
-                        futures.append(_pool.submit(work, g, idx, [by_index[i] for i in idx], scored))
+                        stats_g = stats_all[[row[i] for i in idx]] if stats_all is not None else None
+                        futures.append(_pool.submit(work, g, idx, [by_index[i] for i in idx], scored, stats_g))
                 else:
                     for g, idx in enumerate(members):
-                        scores = score_all([chroms[i] for i in idx])
+                        scores, stats_h = score_all([chroms[i] for i in idx])
                         scored = torch.cuda.Event()
                         scored.record(caller_stream)
-                        futures.append(_pool.submit(work, g, idx, scores, scored))
+                        futures.append(_pool.submit(work, g, idx, scores, scored, stats_h))
                 # every group is waited for (the solver handles are shared) before any failure is reported
                 first_error = None
                 for f in futures:

@@ -143,10 +143,14 @@ def score_central_tendency_chrom_device(matrix_t, out_t=None, method: str = "med
     return out_t
 
 
-def score_central_tendency_chrom_batch_device(matrices):
+def score_central_tendency_chrom_batch_device(matrices, with_stats: bool = False):
     """Column medians of several [K, n_i] CUDA tensors of one K and dtype in ONE launch
     (rocco_hip_score_median_batch); returns the float64 score tensors.  Falls back to one launch each when the
-    matrices differ in K or dtype."""
+    matrices differ in K or dtype.
+
+    `with_stats`: returns ``(scores, stats)`` where `stats` is a [count, 3] float64 CUDA tensor of np.min, np.max and
+    sum |.| of every score array, reduced inside the same launch (None when the launch could not be batched):
+    what dp.calibrate_batch_device otherwise reads every score once more for."""
     import ctypes
 
     import torch
@@ -159,8 +163,10 @@ def score_central_tendency_chrom_batch_device(matrices):
             raise ValueError("`chrom_matrix` must be a 2D array.")
     same = all(m.dtype == matrices[0].dtype and m.shape[0] == matrices[0].shape[0] and m.stride(1) == 1
                and m.device == matrices[0].device for m in matrices)
-    if not same or matrices[0].dtype not in (torch.float64, torch.float32) or int(matrices[0].shape[0]) < 2:
-        return [score_central_tendency_chrom_device(m) for m in matrices]
+    if (not same or matrices[0].dtype not in (torch.float64, torch.float32) or int(matrices[0].shape[0]) < 2
+            or (with_stats and any(int(m.shape[1]) == 0 for m in matrices))):
+        outs = [score_central_tendency_chrom_device(m) for m in matrices]
+        return (outs, None) if with_stats else outs
     K = int(matrices[0].shape[0])
     count = len(matrices)
     outs = [torch.empty(int(m.shape[1]), dtype=torch.float64, device=m.device) for m in matrices]
@@ -170,6 +176,12 @@ def score_central_tendency_chrom_batch_device(matrices):
     strides = (ctypes.c_size_t * count)(*[max(int(m.stride(0)), int(m.shape[1])) for m in matrices])
     solver = _native.solver_for(matrices[0].device.index)
     dtype = 0 if matrices[0].dtype == torch.float64 else 1
+    if with_stats:
+        stats = torch.empty((count, 3), dtype=torch.float64, device=matrices[0].device)
+        _native.check(_native.load().rocco_hip_score_median_batch_stats(solver.handle, ptrs, dtype, K, ns, strides, optrs,
+                                                                        count, stats.data_ptr(), _dp._stream_ptr(matrices[0])),
+                      "rocco_hip_score_median_batch_stats")
+        return outs, stats
     _native.check(_native.load().rocco_hip_score_median_batch(solver.handle, ptrs, dtype, K, ns, strides, optrs, count,
                                                               _dp._stream_ptr(matrices[0])),
                   "rocco_hip_score_median_batch")

@@ -1,0 +1,83 @@
+"""The score statistics reduced inside the median launch (rocco_hip_score_median_batch_stats) and the budgeted solve
+that starts from them (rocco_hip_solve_budget_batch_stats_f64): the same numbers NumPy gives on the scores, and the
+same solve as without them."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("K,dtype", [(100, "float64"), (7, "float32"), (100, "float32"), (150, "float64"), (256, "float64")])
+def test_stats_match_numpy(gpu, K, dtype):
+    import torch
+
+    from rocco_amd import rocco as rr
+
+    rng = np.random.default_rng(K)
+    ns = [1, 255, 256, 257, 5000, 70001]
+    mats_h = [np.round(rng.gamma(1.0, 0.4, size=(K, n)), 4).astype(dtype) - 0.3 for n in ns]
+    mats = [torch.from_numpy(m).cuda() for m in mats_h]
+    scores, stats = rr.score_central_tendency_chrom_batch_device(mats, with_stats=True)
+    assert stats is not None and tuple(stats.shape) == (len(ns), 3)
+    stats_h = stats.cpu().numpy()
+    for m, s_t, row in zip(mats_h, scores, stats_h):
+        s = np.median(m.astype(np.float64), axis=0)
+        assert np.array_equal(s_t.cpu().numpy(), s)
+        assert row[0] == s.min() and row[1] == s.max()
+        assert abs(row[2] - np.abs(s).sum()) <= 1e-12 * max(1.0, np.abs(s).sum())
+
+
+def test_nan_columns_are_skipped_by_min_max_and_poison_the_sum(gpu):
+    import torch
+
+    from rocco_amd import rocco as rr
+
+    rng = np.random.default_rng(3)
+    m = rng.normal(size=(100, 1000))
+    m[17, 400] = np.nan
+    scores, stats = rr.score_central_tendency_chrom_batch_device([torch.from_numpy(m).cuda()], with_stats=True)
+    s = scores[0].cpu().numpy()
+    row = stats.cpu().numpy()[0]
+    assert np.isnan(s[400]) and np.isnan(row[2])
+    assert row[0] == np.nanmin(s) and row[1] == np.nanmax(s)
+
+
+def test_solve_from_given_statistics_is_the_same_solve(gpu, oracle):
+    import torch
+
+    from rocco_amd import dp
+    from rocco_amd import rocco as rr
+
+    rng = np.random.default_rng(11)
+    ns = [300000, 40000, 9000]
+    mats = [torch.from_numpy(np.round(rng.gamma(1.0, 0.3, size=(20, n)), 5)).cuda() for n in ns]
+    scores, stats = rr.score_central_tendency_chrom_batch_device(mats, with_stats=True)
+    targets = [int(np.floor(n * 0.03)) for n in ns]
+    plain = dp.calibrate_batch_device(scores, [1.0] * 3, targets)
+    given = dp.calibrate_batch_device(scores, [1.0] * 3, targets, score_stats=stats.cpu())
+    for s_t, target, a, b in zip(scores, targets, plain, given):
+        assert a[0] == b[0] and a[3] == b[3], (a[0], b[0], a[3], b[3])
+        assert torch.equal(a[1], b[1])
+        assert a[2] == b[2], (a[2], b[2])
+        s = s_t.cpu().numpy()
+        ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 1.0), target)
+        assert b[0] == ref[0] and b[3] == ref[3] and np.array_equal(b[1].cpu().numpy(), ref[1])
+    with pytest.raises(ValueError):
+        dp.calibrate_batch_device(scores, [1.0] * 3, targets, score_stats=np.zeros((2, 3)))
+
+
+def test_pipeline_with_and_without_fused_statistics(gpu, monkeypatch):
+    import torch
+
+    from rocco_amd import pipeline, synth
+
+    works = [pipeline.ChromWork(f"c{i}", synth.hash_matrix_device(12, n, 77 + i, device=torch.device("cuda:0")), 0.03, 1.0)
+             for i, n in enumerate([120000, 50000, 20000, 3000])]
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(pipeline, "MEDIAN_STATS", flag)
+        for groups in (1, 2):
+            res = pipeline.solve_rank(works, groups=groups)
+            outs[(flag, groups)] = [(r["selection_penalty"], r["selected_count"], r["begin"].cpu().numpy().tolist()) for r in res]
+    first = outs[(True, 1)]
+    assert all(v == first for v in outs.values())
