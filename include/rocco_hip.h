@@ -195,6 +195,16 @@ int rocco_hip_delta_window_f64(rocco_hip_solver *solver, const double *scores_de
                                const uint8_t *emap_dev, double lambda_lo, double lambda_hi,
                                uint8_t *solution_dev, rocco_hip_window_stats *stats_out, void *stream);
 
+/* The counts rocco_hip_delta_probe_f64 gives -- what rocco/_chain_dp.c returns as best_count at each penalty, through
+ * the rounding model of oracle/delta_oracle.c -- from the lean kernel that carries several penalties per workgroup
+ * (lean.hip: lean_model_kernel; what the budgeted solve runs on its compacted problems).  It certifies more
+ * conservatively than the full kernels: open_out[i] != 0 says counts_out[i] is NOT certified equal to the reference's
+ * (the solve repeats such a penalty with the full kernels); open_out[i] == 0 says it is.  Needs a binade map
+ * (rocco_hip_delta_build_map_f64); scalar switch cost only; n >= 2. */
+int rocco_hip_delta_model_lean_f64(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n,
+                                   const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,
+                                   long long *counts_out, long long *open_out, void *stream);
+
 /* Count-only evaluation in exact arithmetic on the problem's grid q (the "bound" evaluation of DESIGN.md
  * section 4.4: no rounding model; shifted by -/+ eps it brackets what rocco/_chain_dp.c returns as
  * best_count), in `n_rounds` rounds of up to 32 penalties each (round r holds round_sizes[r] of them).  A round

@@ -114,6 +114,9 @@ PROTOTYPES = [
     ("rocco_hip_solve_budget_batch_stats_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(BudgetTask), ctypes.c_void_p, ctypes.POINTER(BudgetResult),
       ctypes.c_void_p]),
+    ("rocco_hip_delta_model_lean_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p, c_double_p, ctypes.c_size_t,
+      c_ll_p, c_ll_p, ctypes.c_void_p]),
     ("rocco_hip_delta_probe_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p,
       c_double_p, ctypes.c_size_t, ctypes.POINTER(ProbeStats), ctypes.c_void_p]),

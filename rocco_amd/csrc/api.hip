@@ -292,6 +292,18 @@ int rocco_hip_solve_budget_batch_stats_f64(rocco_hip_solver *solver, size_t n_ta
     return solve_budget_batch(solver, n_tasks, tasks, results, (hipStream_t)stream, score_stats_host);
 }
 
+int rocco_hip_delta_model_lean_f64(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n,
+                                   const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas, long long *counts_out,
+                                   long long *open_out, void *stream)
+{
+    if (solver == nullptr || scores_dev == nullptr || emap_dev == nullptr || n < 2 || n >= ((size_t)1 << 31) ||
+        (n_lambdas > 0 && (lambdas == nullptr || counts_out == nullptr || open_out == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return delta_model_lean(solver, scores_dev, gamma, n, emap_dev, lambdas, n_lambdas, counts_out, open_out, (hipStream_t)stream);
+}
+
 int rocco_hip_delta_probe_f64(rocco_hip_solver *solver, const double *scores_dev,
                               const double *switch_costs_dev, double gamma, size_t n,
                               const uint8_t *emap_dev, const double *lambdas, size_t n_lambdas,

@@ -39,4 +39,9 @@ int delta_window(rocco_hip_solver *solver, const double *scores_dev, const doubl
                  double gamma, size_t n, const uint8_t *emap_dev, double lambda_lo, double lambda_hi,
                  uint8_t *solution_dev, rocco_hip_window_stats *stats_out, hipStream_t stream);
 
+// Test entry of the lean rounding-model evaluation (lean_model_kernel) on any array with a binade map: counts and,
+// per penalty, whether the count is NOT certified (the product then asks the full kernels).
+int delta_model_lean(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n, const uint8_t *emap_dev,
+                     const double *lambdas, size_t n_lambdas, long long *counts_out, long long *open_out, hipStream_t stream);
+
 }  // namespace rocco

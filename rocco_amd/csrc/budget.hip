@@ -47,6 +47,8 @@ struct DevProblem {
     size_t orig_n = 0;
     uint8_t *orig_solution = nullptr;
     const int *lean_orig = nullptr;  // original locus of every compacted locus (-1: separator)
+    int map_version = 0;             // bumped whenever `emap` is (re)built
+    int wcap_version = -1;           // map version the tolerance cap of the lean model kernel was computed for
 };
 
 // Levels of one problem (lean.h): level 0 = the caller's array; every deeper level holds the loci selected
@@ -77,6 +79,7 @@ struct LeanReq {
     ProbeRequest *probe = nullptr;
     CompactRequest *comp = nullptr;  // final compaction at lambdas[0]
     bool pilot = false;              // estimates from a sample of the tiles of level 0
+    bool model = false;              // rounding-model counts on the compacted problem (lean_model_kernel)
     double pilot_scale = 1.0;
     int result_begin = 0;
     // final compaction
@@ -170,7 +173,8 @@ public:
         } else if ((rc = run_round(tasks)) != ROCCO_HIP_OK) {
             return rc;
         }
-        return lean_consume();
+        if ((rc = lean_consume()) != ROCCO_HIP_OK) return rc;
+        return model_fallback();
     }
 
     void add_window_tasks(std::vector<WindowRequest> &reqs, std::vector<RoundTask> &tasks)
@@ -301,6 +305,7 @@ public:
     {
         for (MapRequest &r : reqs) {
             probs[r.problem].emap = map_ptrs_[r.problem];
+            ++probs[r.problem].map_version;
         }
     }
 
@@ -590,6 +595,19 @@ public:
 
     bool can_compact(size_t problem) const override { return lean_eligible(problem); }
 
+    // rounding-model probes of a compacted problem with a map in place go through lean_model_kernel
+    bool model_eligible(size_t problem) const
+    {
+        static const bool enabled = std::getenv("ROCCO_HIP_LEAN_MODEL") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_MODEL")) != 0;
+        const DevProblem &p = probs[problem];
+        return enabled && !force_full_ && solver_->lean != 0 && lean_ready_ && ((p.compacted && p.lean_orig != nullptr) || model_any_) &&
+               p.costs == nullptr && p.emap != nullptr && p.n >= 2;
+    }
+    bool force_full_ = false;  // (set while penalties the model kernel could not certify are repeated by the full kernels)
+    bool model_any_ = false;   // test entry: any problem with a map, and the flags are reported instead of settled
+
+    int probe_depth(size_t problem) const override { return model_eligible(problem) ? 5 : 0; }
+
     static constexpr long long kPilotMinTiles = 128;
 
     bool can_pilot(size_t problem) const override
@@ -643,8 +661,13 @@ public:
             lean_[b].pool_end = total;
             lean_[b].pool_at = lean_[b].pool_begin;
         }
-        const int rc = solver_->dev_lean_pool.reserve(total + 256);
+        int rc = solver_->dev_lean_pool.reserve(total + 256);
         if (rc != ROCCO_HIP_OK) return rc;
+        // per problem: the tolerance cap of the rounding-model evaluation and the counters it is summed from (zero
+        // between uses: lean_wcap_sum_kernel clears what it read)
+        const size_t wcap_bytes = align_up(probs.size() * sizeof(double), 256) + probs.size() * 256 * sizeof(unsigned);
+        if ((rc = solver_->dev_lean_wcap.reserve(wcap_bytes + 256)) != ROCCO_HIP_OK) return rc;
+        ROCCO_HIP_TRY(hipMemsetAsync(solver_->dev_lean_wcap.ptr, 0, wcap_bytes, stream_));
         lean_ready_ = true;
         return ROCCO_HIP_OK;
     }
@@ -674,7 +697,9 @@ public:
         if ((rc = lean_prepare()) != ROCCO_HIP_OK) return rc;
         ++lean_rounds;
         std::vector<LeanCompactTask> pre, post;
-        std::vector<LeanTask> tasks;
+        std::vector<LeanTask> tasks, model_tasks;
+        std::vector<LeanWcapTask> wcap_tasks;
+        int model_units = 0, wcap_blocks = 0;
         std::vector<double> points;
         std::vector<size_t> post_req;
         int units = 0, recs = 0, results = 0, pre_blocks = 0, post_blocks = 0;
@@ -682,6 +707,58 @@ public:
         for (LeanReq &r : reqs) {
             DevProblem &p = probs[r.problem];
             LeanState &ls = lean_[r.problem];
+            if (r.model) {
+                // the compacted problem itself, chunk modes from its binade map; its own launch (other kernel)
+                double *wcap = (double *)solver_->dev_lean_wcap.ptr + r.problem;
+                if (p.wcap_version != p.map_version) {
+                    LeanWcapTask wt;
+                    wt.emap = p.emap;
+                    wt.s = p.scores;
+                    wt.m = (long long)p.n;
+                    wt.qexp = p.qexp;
+                    wt.e_floor = std::ilogb(2.0 * p.cmax + 2.0 * p.sabs + (p.sabs + 2.0) + 2.0);  // (|penalty| <= sabs + 2)
+                    wt.counters = (unsigned *)((char *)solver_->dev_lean_wcap.ptr + align_up(probs.size() * sizeof(double), 256)) + 256 * r.problem;
+                    wt.wcap = wcap;
+                    wt.block_begin = wcap_blocks;
+                    wt.pad = 0;
+                    wcap_blocks += (int)((p.n + kLeanTile - 1) / kLeanTile);
+                    wcap_tasks.push_back(wt);
+                    p.wcap_version = p.map_version;
+                }
+                const int np = (int)r.lambdas.size();
+                const int nt = (int)((p.n + kLeanTile - 1) / kLeanTile);
+                LeanTask t;
+                t.s = p.scores;
+                t.m = (long long)p.n;
+                t.c_raw = p.gamma;
+                t.magic = std::ldexp(1.5, 52 + p.qexp);
+                t.big = std::ldexp(1.0, 50 + p.qexp);
+                t.n_tiles = nt;
+                t.n_points = np;
+                t.n_groups = (np + kLeanModelBatch - 1) / kLeanModelBatch;
+                t.unit_begin = model_units;
+                t.point_begin = (int)points.size();
+                t.rec_begin = recs;
+                t.bits_begin = 0;
+                t.off_begin = 0;
+                t.result_begin = results;
+                t.tile_stride = 1;
+                t.independent = 0;
+                t.store = 0;
+                t.emap = p.emap;
+                t.wcap = wcap;
+                t.cmax = p.cmax;
+                t.sabs = p.sabs;
+                t.qexp = p.qexp;
+                t.pad = 0;
+                r.result_begin = results;
+                model_units += nt * t.n_groups;
+                recs += nt * np;
+                results += np;
+                points.insert(points.end(), r.lambdas.begin(), r.lambdas.end());
+                model_tasks.push_back(t);
+                continue;
+            }
             if (ls.levels.empty()) {
                 LeanLevel l0;
                 l0.s = p.scores;
@@ -718,6 +795,11 @@ public:
                 t.result_begin = results;
                 t.tile_stride = stride;
                 t.independent = 1;
+                t.store = 0;
+                t.emap = nullptr;
+                t.wcap = nullptr;
+                t.cmax = t.sabs = 0.0;
+                t.qexp = p.qexp;
                 t.pad = 0;
                 r.result_begin = results;
                 units += nt * t.n_groups;
@@ -809,6 +891,11 @@ public:
             t.result_begin = results;
             t.tile_stride = 1;
             t.independent = 0;
+            t.store = 1;
+            t.emap = nullptr;
+            t.wcap = nullptr;
+            t.cmax = t.sabs = 0.0;
+            t.qexp = p.qexp;
             t.pad = 0;
             r.result_begin = results;
             units += nt * t.n_groups;
@@ -844,14 +931,17 @@ public:
                 }
             }
         }
-        lean_units += units;
+        lean_units += units + model_units;
+        const int n_bound_tasks = (int)tasks.size();
+        tasks.insert(tasks.end(), model_tasks.begin(), model_tasks.end());
 
-        // descriptors: [pre][tasks][points][post]
+        // descriptors: [pre][tasks (bound, then rounding-model)][points][post]
         const size_t b_pre = align_up(pre.size() * sizeof(LeanCompactTask), 256);
         const size_t b_tasks = align_up(tasks.size() * sizeof(LeanTask), 256);
         const size_t b_points = align_up(points.size() * sizeof(double), 256);
         const size_t b_post = align_up(post.size() * sizeof(LeanCompactTask), 256);
-        const size_t desc = b_pre + b_tasks + b_points + b_post;
+        const size_t b_wcap = align_up(wcap_tasks.size() * sizeof(LeanWcapTask), 256);
+        const size_t desc = b_pre + b_tasks + b_points + b_post + b_wcap;
         if ((rc = solver_->dev_lean_desc.reserve(desc + 256)) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_lean_stage.reserve(desc + 256)) != ROCCO_HIP_OK) return rc;
         char *h = (char *)solver_->host_lean_stage.ptr;
@@ -860,7 +950,12 @@ public:
         std::memcpy(h + b_pre, tasks.data(), tasks.size() * sizeof(LeanTask));
         std::memcpy(h + b_pre + b_tasks, points.data(), points.size() * sizeof(double));
         if (!post.empty()) std::memcpy(h + b_pre + b_tasks + b_points, post.data(), post.size() * sizeof(LeanCompactTask));
+        if (!wcap_tasks.empty()) std::memcpy(h + b_pre + b_tasks + b_points + b_post, wcap_tasks.data(), wcap_tasks.size() * sizeof(LeanWcapTask));
         ROCCO_HIP_TRY(hipMemcpyAsync(d, h, desc, hipMemcpyHostToDevice, stream_));
+        if (!wcap_tasks.empty()) {
+            if ((rc = launch_lean_wcap((const LeanWcapTask *)(d + b_pre + b_tasks + b_points + b_post), (int)wcap_tasks.size(), wcap_blocks,
+                                       stream_)) != ROCCO_HIP_OK) return rc;
+        }
 
         // round scratch: [ticket | granules] (all-ones), [records], [results | error] (zero)
         const size_t b_look = align_up(256 + (size_t)recs * 4 * sizeof(unsigned long long), 256);
@@ -877,7 +972,7 @@ public:
         }
         LeanLaunch L;
         L.tasks = (const LeanTask *)(d + b_pre);
-        L.n_tasks = (int)tasks.size();
+        L.n_tasks = n_bound_tasks;
         L.n_units = units;
         L.points = (const double *)(d + b_pre + b_tasks);
         L.ticket = (unsigned *)sc;
@@ -888,6 +983,15 @@ public:
         L.results = (LeanResult *)(sc + b_look + b_recs);
         L.error = error;
         if ((rc = launch_lean_eval(L, stream_)) != ROCCO_HIP_OK) return rc;
+        if (!model_tasks.empty()) {
+            LeanLaunch M = L;
+            M.tasks = L.tasks + n_bound_tasks;
+            M.n_tasks = (int)model_tasks.size();
+            M.n_units = model_units;
+            M.ticket = (unsigned *)sc + 2;
+            if ((rc = launch_lean_model(M, stream_)) != ROCCO_HIP_OK) return rc;
+        }
+        L.n_tasks = (int)tasks.size();  // the finish launch closes every task's fill
         if ((rc = launch_lean_finish(L, results, stream_)) != ROCCO_HIP_OK) return rc;
         if (!post.empty()) {
             if ((rc = launch_lean_compact((const LeanCompactTask *)(d + b_pre + b_tasks + b_points), (int)post.size(), post_blocks,
@@ -898,8 +1002,8 @@ public:
         lean_result_count_ = results;
         lean_inflight_ = reqs;
         if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
-            std::fprintf(stderr, "[lean round %d] %zu tasks, %d workgroups, %zu compactions before, %zu after\n", lean_rounds,
-                         tasks.size(), units, pre.size(), post.size());
+            std::fprintf(stderr, "[lean round %d] %zu tasks (%zu rounding-model), %d + %d workgroups, %zu compactions before, %zu after\n",
+                         lean_rounds, tasks.size(), model_tasks.size(), units, model_units, pre.size(), post.size());
         }
         return ROCCO_HIP_OK;
     }
@@ -922,6 +1026,30 @@ public:
                 r.probe->results.assign(r.lambdas.size(), ProbeResult());
                 for (size_t i = 0; i < r.lambdas.size(); ++i) {
                     r.probe->results[i].count = (long long)std::llround((double)res[r.result_begin + (int)i].count * r.pilot_scale);
+                }
+                continue;
+            }
+            if (r.model) {
+                r.probe->results.assign(r.lambdas.size(), ProbeResult());
+                size_t open = 0;
+                long long why = 0;
+                for (size_t i = 0; i < r.lambdas.size(); ++i) {
+                    const LeanResult &lr = res[r.result_begin + (int)i];
+                    r.probe->results[i].count = lr.count;
+                    why |= lr.flags;
+                    if (lr.flags != 0) {
+                        // not certified here: the full kernels decide (model_fallback)
+                        r.probe->results[i].uncertain = lr.flags;  // (reason mask, see lean_model_kernel)
+                        r.probe->results[i].effect = (long long)p.n + 1;
+                        model_open_.emplace_back(r.probe, i);
+                        ++open;
+                    }
+                }
+                lean_model_points += (long long)r.lambdas.size();
+                lean_model_open += (long long)open;
+                if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                    std::fprintf(stderr, "[lean model] problem %zu (n=%zu): %zu penalties, first %.17g -> count %lld, %zu not certified (reasons %lld)\n",
+                                 r.problem, p.n, r.lambdas.size(), r.lambdas[0], res[r.result_begin].count, open, why);
                 }
                 continue;
             }
@@ -963,6 +1091,48 @@ public:
     }
 
     int lean_result_count_ = 0;
+    std::vector<std::pair<ProbeRequest *, size_t>> model_open_;  // penalties the model kernel left open
+    long long lean_model_points = 0, lean_model_open = 0;
+
+    // penalties the lean model kernel could not certify: once more through the full kernels (rare)
+    int model_fallback()
+    {
+        if (model_open_.empty() || model_any_) {
+            model_open_.clear();
+            return ROCCO_HIP_OK;
+        }
+        std::vector<ProbeRequest> again;
+        std::vector<std::vector<std::pair<ProbeRequest *, size_t>>> back;
+        for (const auto &o : model_open_) {
+            size_t k = 0;
+            while (k < again.size() && back[k][0].first != o.first) {
+                ++k;
+            }
+            if (k == again.size()) {
+                ProbeRequest q;
+                q.problem = o.first->problem;
+                again.push_back(q);
+                back.emplace_back();
+            }
+            again[k].lambdas.push_back(o.first->lambdas[o.second]);
+            back[k].push_back(o);
+        }
+        model_open_.clear();
+        force_full_ = true;
+        std::vector<RoundTask> tasks;
+        add_probe_tasks(again, tasks);
+        const int rc = run_round(tasks);
+        force_full_ = false;
+        if (rc != ROCCO_HIP_OK) {
+            return rc;
+        }
+        for (size_t k = 0; k < again.size(); ++k) {
+            for (size_t i = 0; i < back[k].size(); ++i) {
+                back[k][i].first->results[back[k][i].second] = again[k].results[i];
+            }
+        }
+        return ROCCO_HIP_OK;
+    }
 
     // switch a problem over to one of its compacted levels
     bool adopt_level(size_t problem, const double *level_s, const int *level_orig, long long m, double sep)
@@ -1044,12 +1214,13 @@ public:
             reqs.push_back(r);
         }
         for (ProbeRequest &q : probes) {
-            if (q.bound && !q.lambdas.empty() && q.lambdas.size() <= (size_t)kLeanMaxPoints && lean_eligible(q.problem)) {
+            if (lean_takes(*this, q)) {
                 LeanReq r;
                 r.problem = q.problem;
                 r.lambdas = q.lambdas;
                 r.probe = &q;
-                r.pilot = q.pilot && can_pilot(q.problem);
+                r.model = !q.bound;
+                r.pilot = q.bound && q.pilot && can_pilot(q.problem);
                 reqs.push_back(r);
             }
         }
@@ -1058,7 +1229,10 @@ public:
 
     static bool lean_takes(const HipEvaluator &ev, const ProbeRequest &q)
     {
-        return q.bound && !q.lambdas.empty() && q.lambdas.size() <= (size_t)kLeanMaxPoints && ev.lean_eligible(q.problem);
+        if (q.lambdas.empty() || q.lambdas.size() > (size_t)kLeanMaxPoints) {
+            return false;
+        }
+        return q.bound ? ev.lean_eligible(q.problem) : (!q.pilot && ev.model_eligible(q.problem));
     }
 
     int round_all(std::vector<CompactRequest> &compacts, std::vector<MapRequest> &maps, std::vector<WindowRequest> &surveys,
@@ -1088,6 +1262,7 @@ public:
         }
         const double tc0 = now_us();
         if ((rc = lean_consume()) != ROCCO_HIP_OK) return rc;
+        if ((rc = model_fallback()) != ROCCO_HIP_OK) return rc;
         adopt_maps(maps);
         t_consume_ += now_us() - tc0;
         ++rounds_all;
@@ -1783,6 +1958,43 @@ int delta_probe(rocco_hip_solver *solver, const double *scores_dev, const double
     return ROCCO_HIP_OK;
 }
 
+int delta_model_lean(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n, const uint8_t *emap_dev,
+                     const double *lambdas, size_t n_lambdas, long long *counts_out, long long *open_out, hipStream_t stream)
+{
+    HipEvaluator ev(solver, stream);
+    DevProblem d;
+    d.scores = scores_dev;
+    d.costs = nullptr;
+    d.gamma = gamma;
+    d.n = n;
+    ev.probs.push_back(d);
+    std::vector<ChainProblem> problems(1);
+    problems[0].n = n;
+    problems[0].gamma = gamma;
+    int rc;
+    if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    ev.probs[0].emap = const_cast<uint8_t *>(emap_dev);
+    ev.probs[0].map_version = 1;
+    if ((rc = ev.lean_prepare()) != ROCCO_HIP_OK) return rc;
+    ev.model_any_ = true;
+    if (!ev.model_eligible(0)) {
+        set_last_error("rocco_hip_delta_model_lean_f64: the lean evaluation is switched off for this solver");
+        return ROCCO_HIP_EINVAL;
+    }
+    for (size_t at = 0; at < n_lambdas; at += (size_t)kLeanMaxPoints) {
+        std::vector<ProbeRequest> reqs(1);
+        reqs[0].problem = 0;
+        const size_t k = std::min((size_t)kLeanMaxPoints, n_lambdas - at);
+        reqs[0].lambdas.assign(lambdas + at, lambdas + at + k);
+        if ((rc = ev.probe(reqs)) != ROCCO_HIP_OK) return rc;
+        for (size_t i = 0; i < k; ++i) {
+            counts_out[at + i] = reqs[0].results[i].count;
+            open_out[at + i] = reqs[0].results[i].uncertain;
+        }
+    }
+    return ROCCO_HIP_OK;
+}
+
 int delta_bound_rounds(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n,
                        const double *lambdas, const int *round_sizes, int n_rounds, double *lambdas_used_out,
                        long long *counts_out, long long *level_len_out, hipStream_t stream)
@@ -1913,6 +2125,11 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_COMPACT")) opt.use_compaction = std::atoi(e) != 0;
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_ROUNDS")) opt.pilot_rounds = std::atoi(e);
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_POINTS")) opt.pilot_points = std::atoi(e);
+    struct LeanOverride {  // ROCCO_HIP_LEAN overrides the solver's setting for this call only
+        rocco_hip_solver *solver;
+        int saved;
+        ~LeanOverride() { solver->lean = saved; }
+    } lean_override{solver, solver->lean};
     if (const char *e = std::getenv("ROCCO_HIP_LEAN")) solver->lean = std::atoi(e) != 0;
     if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
     if ((rc = ev.scatter_all()) != ROCCO_HIP_OK) return rc;

@@ -65,6 +65,7 @@ struct rocco_hip_solver {
     rocco::DeviceBuffer dev_lean_pool;   // compacted levels of the problems being solved (lean.hip)
     rocco::DeviceBuffer dev_lean_round;  // per-round scratch of the lean evaluation
     rocco::DeviceBuffer dev_lean_desc;   // its descriptors
+    rocco::DeviceBuffer dev_lean_wcap;   // per problem: tolerance cap of the rounding-model evaluation
     rocco::PinnedBuffer host_lean_stage; // ... their pinned staging
     rocco::PinnedBuffer host_lean_back;  // ... and the readback of its results
     rocco::PinnedBuffer host_stage;   // pinned staging for uploads

@@ -32,7 +32,8 @@ struct LeanTileRec {
     unsigned tail;   // loci at the tile's end that copy that value
     unsigned cells;  // loci + separators the tile contributes to a compaction (the tile's last run end excluded)
     unsigned flags;  // bit 0: every locus of the tile copies; bit 1: value leaving to the left (if not bit 0);
-                     // bit 2: first locus kept; bit 3: last locus kept
+                     // bit 2: first locus kept; bit 3: last locus kept; bit 4 (model tasks): a class of the tile is
+                     // not certified
 };
 
 struct LeanTask {
@@ -52,12 +53,20 @@ struct LeanTask {
     int result_begin;     // offset of the task's results: [point]
     int tile_stride;      // 1; a pilot task evaluates every tile_stride-th tile of the array ...
     int independent;      // ... each as a chain of its own (estimates from a sample; nothing is stored)
+    int store;            // 1: keep the kept-locus words and tile offsets of every penalty (compaction candidates)
+    // rounding-model tasks (lean_model_kernel): the reference's own arithmetic per chunk of 32 loci, as
+    // oracle/delta_oracle.c defines it from the binade map; penalties are arbitrary doubles
+    const uint8_t *emap;  // binade code of every chunk (nullptr: a bound task)
+    const double *wcap;   // upper bound on the tolerance any locus can inherit (sum of the hazard chunks' weights)
+    double cmax, sabs;    // largest switch cost, largest |score| (floor of the hazard chunks' exponent)
+    int qexp;
     int pad;
 };
 
 struct LeanResult {
     long long count;      // selected loci
     long long child_len;  // length of the level a compaction at this penalty would produce
+    long long flags;      // model tasks: nonzero = the count is not certified equal to the reference's
 };
 
 struct LeanLaunch {
@@ -90,6 +99,25 @@ struct LeanCompactTask {
 };
 
 int launch_lean_eval(const LeanLaunch &L, hipStream_t stream);
+// the same for rounding-model tasks (kLeanModelBatch penalties per workgroup)
+constexpr int kLeanModelBatch = 4;
+int launch_lean_model(const LeanLaunch &L, hipStream_t stream);
+// wcap[0] = sum over the hazard chunks of `emap` of 32 * (4 hb + q), + u for every score of a clean chunk that rounds
+// as an exact tie, + the largest hazard base (9 hb + 2 q), with the hazard exponent floored at e_floor (that of the
+// largest penalty magnitude to come): what a locus can inherit at most.  `counters`: 256 words, zero before the
+// launch and again after it.
+struct LeanWcapTask {
+    const uint8_t *emap;
+    const double *s;
+    long long m;
+    int qexp;
+    int e_floor;
+    unsigned *counters;
+    double *wcap;
+    int block_begin;  // first workgroup of this task (one per 8192 loci)
+    int pad;
+};
+int launch_lean_wcap(const LeanWcapTask *tasks_dev, int n_tasks, int n_blocks, hipStream_t stream);
 int launch_lean_finish(const LeanLaunch &L, int n_pairs, hipStream_t stream);
 int launch_lean_compact(const LeanCompactTask *tasks_dev, int n_tasks, int n_blocks, unsigned *error_dev, hipStream_t stream);
 // every compacted problem of a batch in two launches: zero the callers' solution buffers, then scatter

@@ -86,6 +86,7 @@ __device__ __forceinline__ double granule_wait(const unsigned long long *p, unsi
 }
 
 // ---- tile staging: rn_q(score) into LDS --------------------------------------------------------
+template <bool RAW>
 __device__ __forceinline__ void stage_tile(const double *__restrict__ s, long long m, long long base, double magic,
                                            double *lds)
 {
@@ -103,8 +104,8 @@ __device__ __forceinline__ void stage_tile(const double *__restrict__ s, long lo
         for (int r = 0; r < 16; ++r) {
             const int e = 2 * (r * kLeanThreads + t);
             double2 w;
-            w.x = (v[r].x + magic) - magic;
-            w.y = (v[r].y + magic) - magic;
+            w.x = RAW ? v[r].x : (v[r].x + magic) - magic;
+            w.y = RAW ? v[r].y : (v[r].y + magic) - magic;
             *reinterpret_cast<double2 *>(lds + (e >> 5) * kStride + (e & 31)) = w;
         }
     } else {
@@ -115,8 +116,10 @@ __device__ __forceinline__ void stage_tile(const double *__restrict__ s, long lo
             double2 v = make_double2(0.0, 0.0);
             if (j < m) v.x = s[j];
             if (j + 1 < m) v.y = s[j + 1];
-            v.x = (v.x + magic) - magic;
-            v.y = (v.y + magic) - magic;
+            if (!RAW) {
+                v.x = (v.x + magic) - magic;
+                v.y = (v.y + magic) - magic;
+            }
             *reinterpret_cast<double2 *>(lds + (e >> 5) * kStride + (e & 31)) = v;
         }
     }
@@ -130,6 +133,7 @@ struct Scratch {
     unsigned char wave_pass[4][kLeanBatch], wave_v[4][kLeanBatch];
     unsigned first_word[4][kLeanBatch];  // kept-locus word of every wavefront's first lane
     unsigned last_word[kLeanBatch];      // ... and of the tile's last lane
+    unsigned uncertain[kLeanBatch];      // model tasks: a class of the tile is not certified
     int ticket;
     int pad[3];
 };
@@ -228,6 +232,210 @@ __device__ __forceinline__ void chunk_classes(const double *__restrict__ row, co
     }
 }
 
+
+// ---- rounding-model tasks: the reference's own arithmetic, chunk by chunk (oracle/delta_oracle.c) --------------
+// A lane owns one chunk of 32 loci and therefore one arithmetic mode per penalty:
+//   clean  (the chunk's running values stay inside one binade, grid u = 2^(e-52)):  a = rn_u(s) + rn_u(-lambda),
+//          c = rn_u(gamma), no tolerance unless rn_u(s) is an exact half-way tie;
+//   hazard (binade edge nearby, or a tie in rn_u(-lambda) / rn_u(gamma), or u < q):  a = rn_q(s - lambda), c = rn_q(gamma),
+//          every step adds weight 4 hb + q to the tolerance, 9 hb + 2 q on top, hb = 2^(e+2-53).
+// A class is certified when its distance from the decision boundary exceeds the tolerance accumulated since the last
+// clear clamp (|delta| - c > 2^-16: reference and model clamp to the same bound there, whatever came before).  This
+// kernel certifies conservatively -- a wavefront's first lane inherits `wcap`, the sum of ALL hazard weights of the
+// array, and a tie flags the whole tile -- and reports per penalty whether every class was certified; a penalty
+// that is not goes through the full kernels of chain_fast.hip.
+constexpr double kModelGuard = 0x1p-16;  // == ORACLE_GUARD
+constexpr int kModelMapBias = 64;        // == ORACLE_MAP_BIAS
+
+template <int PB>
+struct LaneModel {
+    double magic_u, half_u, magic_q;
+    double nlam[PB];  // rn_u(-lambda)
+    double c[PB];     // cost on the lane's grid
+    double w[PB];     // weight per step (0: clean)
+    double base[PB];  // hazard: 9 hb + 2 q
+    bool hz[PB];
+    bool tie[PB];     // hazard only because -lambda or gamma rounds as a tie on u: not covered by `wcap`, never certified
+};
+
+template <int PB>
+__device__ __forceinline__ void lane_model(const LeanTask &task, int code, const double (&x)[PB], LaneModel<PB> &lm)
+{
+    int e = (code & 0x7F) - kModelMapBias;
+    const bool code_hz = (code & 0x80) != 0;
+    const double q = ldexp(1.0, task.qexp);
+    lm.magic_q = task.magic;
+    // (the floor of a hazard chunk's exponent depends on |lambda|: take the largest of this workgroup's penalties)
+    double lam_abs = 0.0;
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        lam_abs = fmax(lam_abs, fabs(x[p]));
+    }
+    if (code_hz) {
+        e = max(e, ilogb(2.0 * task.cmax + 2.0 * task.sabs + lam_abs + 2.0));
+    }
+    lm.magic_u = ldexp(1.5, e);
+    lm.half_u = ldexp(1.0, e - 53);
+    const double hb = ldexp(1.0, e + 2 - 53);
+    const double cu = (task.c_raw + lm.magic_u) - lm.magic_u;
+    const double cq = (task.c_raw + lm.magic_q) - lm.magic_q;
+    const bool gamma_tie = fabs(task.c_raw - cu) == lm.half_u;
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        lm.nlam[p] = (-x[p] + lm.magic_u) - lm.magic_u;
+        const bool coded = code_hz || (e - 52 < task.qexp);
+        const bool hz = coded || (fabs(-x[p] - lm.nlam[p]) == lm.half_u) || gamma_tie;
+        lm.hz[p] = hz;
+        lm.tie[p] = hz && !coded;
+        lm.c[p] = hz ? cq : cu;
+        lm.w[p] = hz ? (4.0 * hb + q) : 0.0;
+        lm.base[p] = hz ? (9.0 * hb + 2.0 * q) : 0.0;
+    }
+}
+
+template <int PB>
+__device__ __forceinline__ void chunk_function_model(const double *__restrict__ row, const double (&x)[PB],
+                                                     const LaneModel<PB> &lm, bool first_unclamped, double big, Fn (&f)[PB])
+{
+    double lo[PB], hi[PB], fa[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        fa[p] = 0.0;
+        lo[p] = -big;
+        hi[p] = big;
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < kLeanChunk; i0 += 8) {
+        double rs[8];
+#pragma unroll
+        for (int ii = 0; ii < 8; ii += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(row + i0 + ii);
+            rs[ii] = v.x;
+            rs[ii + 1] = v.y;
+        }
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const double su = (rs[ii] + lm.magic_u) - lm.magic_u;
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const double ah = ((rs[ii] - x[p]) + lm.magic_q) - lm.magic_q;
+                const double a = lm.hz[p] ? ah : (su + lm.nlam[p]);
+                const double cc = (first_unclamped && i0 + ii == 0) ? big : lm.c[p];
+                fa[p] += a;
+                lo[p] = fmin(fmax(lo[p], -cc), cc) + a;
+                hi[p] = fmin(fmax(hi[p], -cc), cc) + a;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        f[p].a = fa[p];
+        f[p].lo = lo[p];
+        f[p].hi = hi[p];
+    }
+}
+
+// what a lane reports about its tolerances: see eval_body
+template <int PB>
+struct LaneTolerance {
+    bool clear[PB];          // the lane holds a clear clamp
+    double tail[PB];         // weight after its last clear clamp (its whole weight if it has none)
+    double slack_all[PB];    // min over the loci up to the first clear clamp of (margin - local tolerance)
+    double slack_pos[PB];    // ... over those of them whose local tolerance is positive
+    double tau_pre[PB];      // largest local tolerance among them
+    unsigned bad[PB];        // 1: a class after the first clear clamp is not certified;
+                             // 32: the lane is hazard because of a tie of -lambda / gamma; 64: tolerance beyond the guard
+};
+
+template <int PB, bool EDGE>
+__device__ __forceinline__ void chunk_classes_model(const double *__restrict__ row, const double (&x)[PB],
+                                                    const LaneModel<PB> &lm, bool first_unclamped, double big,
+                                                    const double (&din)[PB], int valid, int last, unsigned (&one)[PB],
+                                                    unsigned (&nz)[PB], LaneTolerance<PB> &tol)
+{
+    double d[PB], wacc[PB];
+    bool pre[PB];
+    const double inf = __longlong_as_double(0x7FF0000000000000LL);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        one[p] = 0u;
+        nz[p] = 0u;
+        d[p] = din[p];
+        wacc[p] = 0.0;
+        pre[p] = true;
+        tol.slack_all[p] = inf;
+        tol.slack_pos[p] = inf;
+        tol.tau_pre[p] = 0.0;
+        tol.bad[p] = 0u;
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < kLeanChunk; i0 += 8) {
+        double rs[8];
+#pragma unroll
+        for (int ii = 0; ii < 8; ii += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(row + i0 + ii);
+            rs[ii] = v.x;
+            rs[ii + 1] = v.y;
+        }
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const int i = i0 + ii;
+            const double su = (rs[ii] + lm.magic_u) - lm.magic_u;
+            const bool exists = !EDGE || i < valid;
+            const bool su_tie = exists && (fabs(rs[ii] - su) == lm.half_u);
+            const bool terminal = EDGE && (i == last);
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const double ah = ((rs[ii] - x[p]) + lm.magic_q) - lm.magic_q;
+                const double a = lm.hz[p] ? ah : (su + lm.nlam[p]);
+                const double c = lm.c[p];
+                const double cc = (first_unclamped && i == 0) ? big : c;
+                d[p] = fmin(fmax(d[p], -cc), cc) + a;
+                double t1 = c - d[p];
+                double t2 = -c - d[p];
+                if (EDGE) {
+                    if (terminal) {
+                        t1 = 0.0 - d[p];
+                        t2 = t1;
+                    }
+                    if (i >= valid) {
+                        t1 = 0.0;
+                        t2 = 0.0;
+                    }
+                }
+                one[p] = __builtin_amdgcn_alignbit(one[p], (unsigned)__double2hiint(t1), 31);
+                nz[p] = __builtin_amdgcn_alignbit(nz[p], (unsigned)__double2hiint(t2), 31);
+                // tolerance of this class (a clean step whose rn_u(s) is an exact half-way tie weighs u)
+                const double over = fabs(d[p]) - c;                          // > 0: beyond a clamp bound
+                const double margin = terminal ? fabs(d[p]) : fabs(over);   // distance from the decision boundary
+                if (exists) {
+                    wacc[p] += lm.hz[p] ? lm.w[p] : (su_tie ? 2.0 * lm.half_u : 0.0);
+                    const double tau = wacc[p] + lm.base[p];
+                    if (pre[p]) {
+                        const double slack = margin - tau;
+                        tol.slack_all[p] = fmin(tol.slack_all[p], slack);
+                        tol.slack_pos[p] = (tau > 0.0) ? fmin(tol.slack_pos[p], slack) : tol.slack_pos[p];
+                        tol.tau_pre[p] = fmax(tol.tau_pre[p], tau);
+                    } else {
+                        tol.bad[p] |= (tau > kModelGuard) ? 64u : 0u;
+                        tol.bad[p] |= (tau > 0.0 && !(margin > tau)) ? 1u : 0u;
+                    }
+                    if (!terminal && over > kModelGuard) {
+                        wacc[p] = 0.0;
+                        pre[p] = false;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        tol.clear[p] = !pre[p];
+        tol.tail[p] = wacc[p];
+        tol.bad[p] |= (lm.tie[p] && valid > 0) ? 32u : 0u;
+    }
+}
+
 constexpr int kZeroBytes = 16384;  // per workgroup of the zero launch
 
 __global__ __launch_bounds__(256) void lean_zero_batch_kernel(const LeanScatterTask *__restrict__ tasks, int n_tasks)
@@ -270,7 +478,7 @@ __global__ __launch_bounds__(256) void lean_scatter_batch_kernel(const LeanScatt
     }
 }
 
-template <int PB>
+template <int PB, bool MODEL>
 __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &task, int tile, int p0, int np, double *lds,
                                           Scratch *sc)
 {
@@ -288,12 +496,23 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
     }
     const long long j0 = base + (long long)t * kLeanChunk;
     // the chain's first locus takes its input unclamped (pilot tasks: every tile is a chain of its own)
-    const double c_first = (j0 == 0 || (indep && t == 0)) ? big : c;
+    const bool first_unclamped = (j0 == 0 || (indep && t == 0));
+    const double c_first = first_unclamped ? big : c;
     const double *row = lds + t * kStride;
+    LaneModel<PB> lm;
+    if (MODEL) {
+        const long long chunk = j0 / kLeanChunk;
+        const long long last_chunk = (task.m - 1) / kLeanChunk;
+        lane_model<PB>(task, (int)task.emap[min(chunk, last_chunk)], x, lm);
+    }
 
     // ---- 2. chunk functions, composed across the workgroup ----
     Fn f[PB];
-    chunk_function<PB>(row, x, c, c_first, big, f);
+    if (MODEL) {
+        chunk_function_model<PB>(row, x, lm, first_unclamped, big, f);
+    } else {
+        chunk_function<PB>(row, x, c, c_first, big, f);
+    }
     Fn inc[PB];  // inclusive within the wavefront
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
@@ -379,7 +598,57 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
     const int valid = (int)max(0LL, min((long long)kLeanChunk, task.m - j0));
     const int last = (task.m - 1 >= j0 && task.m - 1 < j0 + kLeanChunk) ? (int)(task.m - 1 - j0) : -1;
     unsigned one[PB], nz[PB];
-    if (edge_tile) {
+    if (MODEL) {
+        LaneTolerance<PB> tol;
+        if (edge_tile) {
+            chunk_classes_model<PB, true>(row, x, lm, first_unclamped, big, din, valid, last, one, nz, tol);
+        } else {
+            chunk_classes_model<PB, false>(row, x, lm, first_unclamped, big, din, valid, last, one, nz, tol);
+        }
+        // tolerance a lane inherits: scan of (clear, tail) over the wavefront; its first lane takes the cap (nothing
+        // at the very start of the chain)
+        const double wcap = *task.wcap;
+        const double wave_in = (base == 0 && wave == 0) ? 0.0 : wcap;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            bool cl = tol.clear[p];
+            double tl = tol.tail[p];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int pc = __shfl_up((int)cl, off);
+                const double pt = __shfl_up(tl, off);
+                if (lane >= off) {
+                    tl = cl ? tl : pt + tl;
+                    cl = cl || (pc != 0);
+                }
+            }
+            int ec = __shfl_up((int)cl, 1);
+            double et = __shfl_up(tl, 1);
+            if (lane == 0) {
+                ec = 0;
+                et = 0.0;
+            }
+            const double w_in = ec ? et : wave_in + et;
+            // why a class is not certified (reported for diagnosis): 1 a class behind the lane's first clear clamp or
+            // a tie, 2 tolerance beyond the guard, 4 / 8 a class before the first clear clamp within the inherited
+            // tolerance (without / with local weights).  Lanes past the array's end hold no locus: their minima are
+            // +inf and they never report.
+            unsigned why = tol.bad[p];
+            why |= (w_in + tol.tau_pre[p] > kModelGuard) ? 2u : 0u;
+            why |= (w_in > 0.0 && !(tol.slack_all[p] > w_in)) ? 4u : 0u;
+            why |= !(tol.slack_pos[p] > w_in) ? 8u : 0u;
+            if (p >= np) {
+                why = 0u;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                why |= __shfl_xor(why, off);
+            }
+            if (why != 0u && lane == 0) {
+                atomicOr(&sc->uncertain[p], why);
+            }
+        }
+    } else if (edge_tile) {
         chunk_classes<PB, true>(row, x, c, c_first, din, valid, last, one, nz);
     } else {
         chunk_classes<PB, false>(row, x, c, c_first, din, valid, last, one, nz);
@@ -471,7 +740,7 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
             atomicAdd(&sc->red[p][1], tl);
             atomicAdd(&sc->red[p][2], ce);
         }
-        if (p < np && !indep) {
+        if (p < np && task.store != 0) {
             L.bits[task.bits_begin + ((long long)(p0 + p) * task.n_tiles + tile) * kLeanThreads + t] = zw[p];
         }
     }
@@ -492,7 +761,8 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
         r.tail = sc->red[p][1];
         r.cells = sc->red[p][2];
         const unsigned firstw = sc->first_word[0][p];
-        r.flags = (all_pass ? 1u : 0u) | (v << 1) | ((firstw >> 31) << 2) | ((sc->last_word[p] & 1u) << 3);
+        r.flags = (all_pass ? 1u : 0u) | (v << 1) | ((firstw >> 31) << 2) | ((sc->last_word[p] & 1u) << 3) |
+                  (MODEL ? (sc->uncertain[p] << 4) : 0u);
         L.recs[(long long)task.rec_begin + (long long)(p0 + p) * task.n_tiles + tile] = r;
     }
 }
@@ -518,11 +788,20 @@ __global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pai
     // backward: fill value entering every tile from the right
     unsigned carry = 0u;  // beyond the chain's end (the last locus never copies)
     unsigned long long total = 0ull;
+    unsigned uncertain = 0u;
     for (int hi = nt; hi > 0; hi -= 64) {
         const int k = hi - 64 + lane;  // lanes ascend with the tiles
         LeanTileRec r = {0u, 0u, 0u, 1u};
         if (k >= 0) {
             r = recs[k];
+        }
+        {
+            unsigned why = (k >= 0) ? (r.flags >> 4) : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                why |= __shfl_xor(why, off);
+            }
+            uncertain |= why;
         }
         const bool pass = (r.flags & 1u) != 0u;
         const bool v = (r.flags & 2u) != 0u;
@@ -563,7 +842,7 @@ __global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pai
                 incl += u;
             }
         }
-        if (k < nt && task.independent == 0) {
+        if (k < nt && task.store != 0) {
             off_out[k] = (unsigned)(running + incl - cells);
         }
         running += __shfl(incl, 63);
@@ -572,6 +851,7 @@ __global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pai
         LeanResult res;
         res.count = (long long)total;
         res.child_len = (long long)running;
+        res.flags = (long long)uncertain;
         L.results[task.result_begin + p] = res;
     }
 }
@@ -702,17 +982,149 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_eval_kernel(LeanLaunch L
     const int tile = unit / task.n_groups, group = unit % task.n_groups;
     const int p0 = group * kLeanBatch;
     const int np = min(kLeanBatch, task.n_points - p0);
-    stage_tile(task.s, task.m, (long long)tile * task.tile_stride * kLeanTile, task.magic, lds);
+    stage_tile<false>(task.s, task.m, (long long)tile * task.tile_stride * kLeanTile, task.magic, lds);
     // penalties of this workgroup, in registers: 1, 2, 4 or 8 interleaved chains per lane
     if (np > 4) {
-        eval_body<8>(L, task, tile, p0, np, lds, sc);
+        eval_body<8, false>(L, task, tile, p0, np, lds, sc);
     } else if (np > 2) {
-        eval_body<4>(L, task, tile, p0, np, lds, sc);
+        eval_body<4, false>(L, task, tile, p0, np, lds, sc);
     } else if (np > 1) {
-        eval_body<2>(L, task, tile, p0, np, lds, sc);
+        eval_body<2, false>(L, task, tile, p0, np, lds, sc);
     } else {
-        eval_body<1>(L, task, tile, p0, np, lds, sc);
+        eval_body<1, false>(L, task, tile, p0, np, lds, sc);
     }
+}
+
+// rounding-model tasks: raw scores in LDS, up to kLeanModelBatch penalties per workgroup
+__global__ __launch_bounds__(kLeanThreads, 2) void lean_model_kernel(LeanLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *lds = smem;
+    Scratch *sc = reinterpret_cast<Scratch *>(smem + kTileLds);
+    const int t = threadIdx.x;
+    if (t == 0) {
+        sc->ticket = (int)(atomicAdd(L.ticket, 1u) + 1u);
+    }
+    if (t < kLeanBatch * 4) {
+        (&sc->red[0][0])[t] = 0u;
+    }
+    if (t < kLeanBatch) {
+        sc->uncertain[t] = 0u;
+    }
+    __syncthreads();
+    const int ticket = sc->ticket;
+    if (ticket >= L.n_units) {
+        return;
+    }
+    int ti = 0;
+    while (ti + 1 < L.n_tasks && L.tasks[ti + 1].unit_begin <= ticket) {
+        ++ti;
+    }
+    const LeanTask task = L.tasks[ti];
+    const int unit = ticket - task.unit_begin;
+    const int tile = unit / task.n_groups, group = unit % task.n_groups;
+    const int p0 = group * kLeanModelBatch;
+    const int np = min(kLeanModelBatch, task.n_points - p0);
+    stage_tile<true>(task.s, task.m, (long long)tile * kLeanTile, task.magic, lds);
+    if (np > 2) {
+        eval_body<4, true>(L, task, tile, p0, np, lds, sc);
+    } else if (np > 1) {
+        eval_body<2, true>(L, task, tile, p0, np, lds, sc);
+    } else {
+        eval_body<1, true>(L, task, tile, p0, np, lds, sc);
+    }
+}
+
+// What a locus can inherit at most (see lean_model_kernel): the weights of every hazard chunk's steps and of every
+// exact half-way tie rn_u(s) in a clean chunk, plus the largest hazard base.  Counted per exponent (integers: no
+// order dependence) by one workgroup per tile, summed by one thread per task, which also clears the counters.
+__global__ __launch_bounds__(kLeanThreads) void lean_wcap_count_kernel(const LeanWcapTask *__restrict__ tasks, int n_tasks)
+{
+    __shared__ unsigned steps[128], ties[128];
+    __shared__ double magic_u[kLeanThreads], half_u[kLeanThreads];  // per chunk of the tile (0: hazard, no tie test)
+    int ti = 0;
+    while (ti + 1 < n_tasks && tasks[ti + 1].block_begin <= (int)blockIdx.x) {
+        ++ti;
+    }
+    const LeanWcapTask task = tasks[ti];
+    const int t = threadIdx.x;
+    if (t < 128) {
+        steps[t] = 0u;
+        ties[t] = 0u;
+    }
+    __syncthreads();
+    const long long base = (long long)((int)blockIdx.x - task.block_begin) * kLeanTile;
+    const long long n_chunks = (task.m + kLeanChunk - 1) / kLeanChunk;
+    const long long chunk = base / kLeanChunk + t;
+    int my_bin = 0;
+    magic_u[t] = 0.0;
+    half_u[t] = 0.0;
+    if (chunk < n_chunks) {
+        const int code = task.emap[chunk];
+        int e = (code & 0x7F) - kModelMapBias;
+        const bool code_hz = (code & 0x80) != 0;
+        if (code_hz) {
+            e = max(e, task.e_floor);
+        }
+        my_bin = min(max(e + kModelMapBias, 0), 127);
+        if (code_hz || e - 52 < task.qexp) {
+            atomicAdd(&steps[my_bin], (unsigned)kLeanChunk);
+        } else {
+            magic_u[t] = ldexp(1.5, e);
+            half_u[t] = ldexp(1.0, e - 53);
+        }
+    }
+    __syncthreads();
+    // coalesced pass over the tile's scores: element r * 256 + t lies in chunk (r * 256 + t) / 32 of the tile
+#pragma unroll 4
+    for (int r = 0; r < kLeanChunk; ++r) {
+        const int el = r * kLeanThreads + t;
+        const long long j = base + el;
+        const int c = el / kLeanChunk;
+        if (j < task.m && half_u[c] != 0.0) {
+            const double x = task.s[j];
+            const double su = (x + magic_u[c]) - magic_u[c];
+            if (fabs(x - su) == half_u[c]) {
+                // (the chunk's bin: recomputed from its grid)
+                atomicAdd(&ties[min(max(ilogb(half_u[c]) + 53 + kModelMapBias, 0), 127)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (t < 128) {
+        if (steps[t] != 0u) {
+            atomicAdd(&task.counters[t], steps[t]);
+        }
+        if (ties[t] != 0u) {
+            atomicAdd(&task.counters[128 + t], ties[t]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void lean_wcap_sum_kernel(const LeanWcapTask *__restrict__ tasks, int n_tasks)
+{
+    const int ti = blockIdx.x * 64 + threadIdx.x;
+    if (ti >= n_tasks) {
+        return;
+    }
+    const LeanWcapTask task = tasks[ti];
+    const double q = ldexp(1.0, task.qexp);
+    double sum = 0.0, base = 0.0;
+    for (int b = 0; b < 128; ++b) {
+        const int e = b - kModelMapBias;
+        const unsigned st = task.counters[b], tn = task.counters[128 + b];
+        if (st != 0u) {
+            const double hb = ldexp(1.0, e + 2 - 53);
+            sum += (double)st * (4.0 * hb + q);
+            base = 9.0 * hb + 2.0 * q;  // exponents ascend: the largest base stays
+        }
+        if (tn != 0u) {
+            sum += (double)tn * ldexp(1.0, e - 52);
+        }
+        task.counters[b] = 0u;
+        task.counters[128 + b] = 0u;
+    }
+    task.wcap[0] = sum + base;
 }
 
 int launch_eval_all(const LeanLaunch &L, hipStream_t stream)
@@ -739,6 +1151,34 @@ int launch_lean_eval(const LeanLaunch &L, hipStream_t stream)
     if (rc != ROCCO_HIP_OK) {
         return rc;
     }
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_model(const LeanLaunch &L, hipStream_t stream)
+{
+    if (L.n_units <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    static bool configured = false;
+    const size_t lds = (size_t)kTileLds * sizeof(double) + sizeof(Scratch);
+    if (!configured) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lean_model_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(lean_model_kernel, dim3((unsigned)L.n_units), dim3(kLeanThreads), lds, stream, L);
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_wcap(const LeanWcapTask *tasks_dev, int n_tasks, int n_blocks, hipStream_t stream)
+{
+    if (n_tasks <= 0 || n_blocks <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    hipLaunchKernelGGL(lean_wcap_count_kernel, dim3((unsigned)n_blocks), dim3(kLeanThreads), 0, stream, tasks_dev, n_tasks);
+    hipLaunchKernelGGL(lean_wcap_sum_kernel, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, stream, tasks_dev, n_tasks);
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }

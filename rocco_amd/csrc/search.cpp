@@ -106,6 +106,13 @@ struct State {
     int tree_depth = 0;
     std::vector<double> tree;
     std::vector<int> tree_slot;  // index into the request's penalty list, or -1 if decided analytically
+    // probe rounds: the reference's bisection tree below (lower, upper), grown only where the outcome is open
+    struct TreeNode {
+        double mid;
+        int slot;    // index into the request's penalty list, or -1: outcome known without device work
+        int le, gt;  // next node after "count <= target" / "count > target" (-1: the round ends there)
+    };
+    std::vector<TreeNode> nodes;
 };
 
 // Outcome of the reference at `lambda` known without device work: analytic, or outside the certified
@@ -124,6 +131,49 @@ bool known_count(const ChainProblem &p, const State &s, double lambda, long long
         return true;
     }
     return false;
+}
+
+// The reference's next bisection steps as a tree: a step whose outcome is known (analytically or from the certified
+// thresholds) costs nothing and has one successor; an open one is evaluated and has two.  `open_depth` open steps per
+// path at most, `max_steps` steps in all (the iterations the reference has left).
+void build_open_tree(const ChainProblem &p, const State &s, int open_depth, int max_steps, std::vector<State::TreeNode> &nodes,
+                     std::vector<double> &lambdas)
+{
+    struct Item {
+        double lo, hi;
+        int open, steps, parent;
+        bool gt;
+    };
+    nodes.clear();
+    std::vector<Item> queue;
+    queue.push_back({s.lower, s.upper, 0, 0, -1, false});
+    for (size_t at = 0; at < queue.size() && nodes.size() < 8192; ++at) {
+        const Item it = queue[at];
+        if (it.steps >= max_steps || it.open >= open_depth) {
+            continue;
+        }
+        const double mid = (it.lo + it.hi) / 2.0;  // rocco/dp.py:143
+        long long c = 0;
+        const bool known = known_count(p, s, mid, &c);
+        State::TreeNode node;
+        node.mid = mid;
+        node.slot = known ? -1 : (int)lambdas.size();
+        node.le = node.gt = -1;
+        const int idx = (int)nodes.size();
+        nodes.push_back(node);
+        if (!known) {
+            lambdas.push_back(mid);
+        }
+        if (it.parent >= 0) {
+            (it.gt ? nodes[(size_t)it.parent].gt : nodes[(size_t)it.parent].le) = idx;
+        }
+        if (!known || c > s.target) {
+            queue.push_back({mid, it.hi, it.open + (known ? 0 : 1), it.steps + 1, idx, true});
+        }
+        if (!known || c <= s.target) {
+            queue.push_back({it.lo, mid, it.open + (known ? 0 : 1), it.steps + 1, idx, false});
+        }
+    }
 }
 
 // Lowest penalty the device can still be asked about: below the certified threshold G every outcome is
@@ -393,6 +443,16 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
             while (deep > opt.spec_depth && blocks * (double)((1 << deep) - 1) > 1600.0) {
                 --deep;
             }
+            // (an evaluator with cheap probes says how deep it wants them)
+            int wanted = 64;
+            for (size_t b = 0; b < B; ++b) {
+                if (st[b].phase != State::kDone && !st[b].use_exact) {
+                    wanted = std::min(wanted, ev.probe_depth(b));
+                }
+            }
+            if (wanted > 0 && wanted < 64) {
+                deep = std::max(deep, wanted);
+            }
         }
         const int spec_depth =
             all_compacted ? deep :
@@ -642,6 +702,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     }
                 }
                 if (!s.use_exact && s.has_map && !s.point_pending && s.map_lo < s.map_hi && s.upper_count >= 0 &&
+                    ev.probe_depth(b) == 0 &&  // (settled blocks only pay off for the evaluators that can skip them)
                     (s.survey_width < 0.0 || s.survey_width > 16.0 * (eff_upper(s) - eff_lower(s)))) {
                     // the map covers the whole bracket: when few loci can still change inside it, let the
                     // evaluator find the settled parts so that later rounds skip them
@@ -660,8 +721,8 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 if (!s.use_exact && s.has_map && s.point_pending) {
                     s.tree_depth = std::min(1, s.iters_left);
                 }
-                build_tree(s.lower, s.upper, s.tree_depth, s.tree);
                 if (s.use_exact) {
+                    build_tree(s.lower, s.upper, s.tree_depth, s.tree);
                     ExactRequest r;
                     r.problem = b;
                     r.lambdas = s.tree;
@@ -670,14 +731,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 } else {
                     ProbeRequest r;
                     r.problem = b;
-                    s.tree_slot.assign(s.tree.size(), -1);
-                    long long unused = 0;
-                    for (size_t i = 0; i < s.tree.size(); ++i) {
-                        if (!known_count(p, s, s.tree[i], &unused)) {
-                            s.tree_slot[i] = (int)r.lambdas.size();
-                            r.lambdas.push_back(s.tree[i]);
-                        }
-                    }
+                    build_open_tree(p, s, s.tree_depth, s.iters_left, s.nodes, r.lambdas);
                     probes.push_back(r);
                     probe_owner.push_back(b);
                 }
@@ -884,20 +938,21 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 }
                 continue;
             }
-            // kBisect: walk the evaluated levels while the outcomes are certain
-            size_t i = 0;
-            for (int level = 0; level < s.tree_depth; ++level) {
+            // kBisect: walk the tree while the outcomes are certain
+            int i = s.nodes.empty() ? -1 : 0;
+            while (i >= 0) {
+                const State::TreeNode node = s.nodes[(size_t)i];
                 Outcome o;
                 long long analytic = 0;
-                if (s.tree_slot[i] < 0) {
-                    known_count(p, s, s.tree[i], &analytic);
+                if (node.slot < 0) {
+                    known_count(p, s, node.mid, &analytic);
                     o = (analytic > s.target) ? Outcome::kGreater : Outcome::kLessEqual;
                 } else {
-                    o = classify(r.results[(size_t)s.tree_slot[i]], s.target);
+                    o = classify(r.results[(size_t)node.slot], s.target);
                 }
                 if (o == Outcome::kUncertain) {
                     // the uncertain node is the midpoint of the current bracket
-                    const double mid = s.tree[i];
+                    const double mid = node.mid;
                     const bool is_point_here = s.has_map && s.map_lo == mid && s.map_hi == mid;
                     const bool covers = s.has_map && s.map_lo <= eff_lower(s) && s.upper <= s.map_hi;
                     if (!s.has_map) {
@@ -924,19 +979,17 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 ++s.out.evaluations;
                 --s.iters_left;
                 if (o == Outcome::kGreater) {
-                    s.lower = s.tree[i];
-                    if (s.tree_slot[i] >= 0) {
-                        s.lower_count = r.results[(size_t)s.tree_slot[i]].count +
-                                        r.results[(size_t)s.tree_slot[i]].effect;
+                    s.lower = node.mid;
+                    if (node.slot >= 0) {
+                        s.lower_count = r.results[(size_t)node.slot].count + r.results[(size_t)node.slot].effect;
                     }
-                    i = 2 * i + 2;
+                    i = node.gt;
                 } else {
-                    s.upper = s.tree[i];
-                    if (s.tree_slot[i] >= 0) {
-                        s.upper_count = std::max(0LL, r.results[(size_t)s.tree_slot[i]].count -
-                                                          r.results[(size_t)s.tree_slot[i]].effect);
+                    s.upper = node.mid;
+                    if (node.slot >= 0) {
+                        s.upper_count = std::max(0LL, r.results[(size_t)node.slot].count - r.results[(size_t)node.slot].effect);
                     }
-                    i = 2 * i + 1;
+                    i = node.le;
                 }
             }
         }

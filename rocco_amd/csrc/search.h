@@ -167,6 +167,13 @@ public:
         (void)reqs;
         return 0;
     }
+    // Levels of the bisection tree a probe round of this problem should speculate (0: no preference): an evaluator
+    // whose probes cost little per penalty asks for deep trees.
+    virtual int probe_depth(size_t problem) const
+    {
+        (void)problem;
+        return 0;
+    }
     // A compaction that needs no device work (the evaluator already holds a suitable compacted copy): done at once,
     // so that the problem can go on within the same search iteration.  Default: not available.
     virtual bool compact_now(CompactRequest &req)

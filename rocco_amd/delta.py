@@ -42,6 +42,20 @@ def delta_probe_device(scores_t, switch_costs, lambdas: Sequence[float], emap_t=
              "max_run": int(s.max_run)} for s in stats[:len(lambdas)]]
 
 
+def delta_model_lean_device(scores_t, gamma: float, lambdas: Sequence[float], emap_t):
+    """Rounding-model counts from the lean kernel (rocco_hip_delta_model_lean_f64): per penalty (count, open) where
+    open != 0 means the count is not certified equal to the reference's."""
+    n = int(scores_t.shape[0])
+    lam = (ctypes.c_double * max(1, len(lambdas)))(*[float(x) for x in lambdas])
+    counts = (ctypes.c_longlong * max(1, len(lambdas)))()
+    opens = (ctypes.c_longlong * max(1, len(lambdas)))()
+    solver = _native.solver_for(scores_t.device.index)
+    _native.check(_native.load().rocco_hip_delta_model_lean_f64(
+        solver.handle, scores_t.data_ptr(), float(gamma), n, emap_t.data_ptr(), lam, len(lambdas), counts, opens,
+        _dp._stream_ptr(scores_t)), "rocco_hip_delta_model_lean_f64")
+    return [(int(counts[i]), int(opens[i])) for i in range(len(lambdas))]
+
+
 def delta_bound_rounds_device(scores_t, gamma: float, rounds: Sequence[Sequence[float]]):
     """Exact-arithmetic counts (rocco_hip_delta_bound_rounds_f64) for rounds of penalties; returns per round
     (penalties as evaluated, counts, loci of the array the round ran on)."""
