@@ -769,7 +769,8 @@ public:
             if (r.pilot) {
                 // every stride-th tile of the caller's array, each as a chain of its own; nothing is kept
                 const long long all_tiles = (long long)((p.n + kLeanTile - 1) / kLeanTile);
-                const int stride = (int)std::max(4LL, all_tiles / 16);  // about 16 tiles per chromosome
+                static const long long pilot_tiles = std::getenv("ROCCO_HIP_PILOT_TILES") ? std::max(2, std::atoi(std::getenv("ROCCO_HIP_PILOT_TILES"))) : 16;
+                const int stride = (int)std::max(4LL, all_tiles / pilot_tiles);  // about 16 tiles per chromosome
                 const int nt = (int)((all_tiles + stride - 1) / stride);
                 long long sampled = 0;
                 for (int k = 0; k < nt; ++k) {

@@ -112,6 +112,7 @@ def _pairwise_constant(value: float, m: int) -> float:
     return rec(int(m))
 
 
+@functools.lru_cache(maxsize=4096)
 def sum_constant_like_numpy(value: float, length: int) -> float:
     """np.sum(np.full(length, value)) bit-for-bit (rocco/dp.py:110-111 uses np.sum(switch_costs)
     on the constant vector of rocco/dp.py:37-46).  np.add.reduce walks the array in chunks of the

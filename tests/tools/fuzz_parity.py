@@ -34,13 +34,16 @@ while time.time() < t_end:
             target = int(np.floor(n * budget))
             g = dp.calibrate_selection_penalty(s, costs, target)
             o = po.calibrate_selection_penalty(s, o_costs, target)
-            ok = g[0] == o[0] and np.array_equal(g[1], o[1]) and g[3] == o[3] and abs(g[2] - o[2]) <= 1e-9 * max(1.0, abs(o[2]))
+            # (the value is a difference of sums of magnitude count * (|s| + |penalty|): both sides round there)
+            tol = 1e-9 * max(1.0, abs(o[2])) + 8.0 * 2.0 ** -52 * max(1, o[3]) * (float(np.max(np.abs(s))) + abs(o[0]))
+            ok = g[0] == o[0] and np.array_equal(g[1], o[1]) and g[3] == o[3] and abs(g[2] - o[2]) <= tol
             mode = "budget"
         else:
             lam = float(rng.choice([0.0, float(np.median(s)), float(rng.normal()), float(np.max(s)) + 1.0, float(np.min(s)) - 1.0]))
             g = dp.solve_penalized_chain(s, costs, lam)
             o = po.solve_penalized_chain(s, o_costs, lam)
-            ok = np.array_equal(g[0], o[0]) and g[2] == o[2] and abs(g[1] - o[1]) <= 1e-9 * max(1.0, abs(o[1]))
+            tol = 1e-9 * max(1.0, abs(o[1])) + 8.0 * 2.0 ** -52 * max(1, o[2]) * (float(np.max(np.abs(s))) + abs(lam))
+            ok = np.array_equal(g[0], o[0]) and g[2] == o[2] and abs(g[1] - o[1]) <= tol
             mode = "fixed"
     except Exception as exc:  # an error on one side only is a mismatch
         ok, mode = False, f"exception {type(exc).__name__}: {exc}"
