@@ -76,10 +76,16 @@ __device__ __forceinline__ double median_column(const T *__restrict__ m, int K_r
     const int n_lo = pad / 2;  // -inf entries; the remaining pad entries are +inf
     double v[KP];
     double sum = 0.0;  // NaN in the column <=> NaN sum (or +inf and -inf together: checked below)
+    // every load unconditional (a load under a per-row condition is waited for before the next is issued): slots past
+    // the matrix re-read its last row (a cache hit) and are replaced by the padding afterwards
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int row = EXACT ? k : min(k, K - 1);
+        v[k] = (double)m[(long long)row * stride + j];
+    }
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         if (EXACT || k < K) {
-            v[k] = (double)m[(long long)k * stride + j];
             sum += v[k];
         } else {
             v[k] = (k - K < n_lo) ? -std::numeric_limits<double>::infinity()
@@ -293,11 +299,17 @@ __global__ __launch_bounds__(64) void median_split_kernel(const T *__restrict__ 
         first[k][threadIdx.x] = v[k];
     }
     sum = 0.0;
+    // rows 100..K-1, then the padding.  Every load is unconditional (a load under a per-row condition is waited for
+    // before the next is issued): rows past the matrix re-read its last row (a cache hit) and are replaced afterwards.
 #pragma unroll
-    for (int k = 0; k < kHalf; ++k) {  // rows 100..K-1, then the padding
+    for (int k = 0; k < kHalf; ++k) {
+        const int row = min(kHalf + k, K - 1);
+        v[k] = (double)m[(long long)row * stride + j];
+    }
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k) {
         const int row = kHalf + k;
         if (row < K) {
-            v[k] = (double)m[(long long)row * stride + j];
             sum += v[k];
         } else {
             v[k] = (row - K < n_lo) ? -inf : inf;
@@ -320,6 +332,117 @@ __global__ __launch_bounds__(64) void median_split_kernel(const T *__restrict__ 
         upper = fmin(upper, fmax(a, b));
     }
     const double r = (K & 1) ? lower : (lower + upper) / 2.0;
+    out[j] = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : r;
+}
+
+// 200 < K <= 300: P sorted parts of L entries (4 x 64 or 3 x 100) parked in LDS, one wavefront per workgroup, each lane
+// its own column; then a P-way merge with the parts' heads in registers up to the lower middle rank (P L / 2 steps of
+// P - 1 compares and ONE LDS read): the element taken last and the smallest remaining head are the middle pair.
+// (A first version searched the ranks by nested binary searches: P^2 log^2 L dependent LDS reads, 5x slower.)
+template <typename T, int L, int P>
+__global__ __launch_bounds__(64) void median_parts_kernel(const T *__restrict__ m, int K, long long n, long long stride,
+                                                          double *__restrict__ out)
+{
+    extern __shared__ double parts[];  // [P][L][64]
+    const long long j = (long long)xcd_contiguous_block() * blockDim.x + threadIdx.x;
+    if (j >= n) {
+        return;
+    }
+    const int lane = threadIdx.x;
+    const double inf = std::numeric_limits<double>::infinity();
+    const int pad = P * L - K;
+    const int n_lo = pad / 2;  // -inf entries in front of the last part's padding; the rest +inf
+    bool has_nan = false;
+#pragma unroll 1
+    for (int p = 0; p < P; ++p) {
+        double v[L];
+        double sum = 0.0;
+        if ((p + 1) * L <= K) {
+            // a whole part of real rows: unconditional loads, all in flight together (a load under a per-row condition
+            // is waited for before the next one is issued)
+            const T *__restrict__ src = m + (long long)(p * L) * stride + j;
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                v[k] = (double)src[(long long)k * stride];
+            }
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                sum += v[k];
+            }
+        } else {
+            // the part that holds the padding: rows past the matrix re-read its last row and are replaced afterwards
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                const int row = min(p * L + k, K - 1);
+                v[k] = (double)m[(long long)row * stride + j];
+            }
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                const int row = p * L + k;
+                if (row < K) {
+                    sum += v[k];
+                } else {
+                    v[k] = (row - K < n_lo) ? -inf : inf;
+                }
+            }
+        }
+        if (is_nan_bits(sum)) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                const bool bad = (p * L + k < K) && is_nan_bits(v[k]);
+                has_nan |= bad;
+                v[k] = bad ? inf : v[k];
+            }
+        }
+        select_middle<L>(v);  // every output is stored: a complete sort
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            parts[((size_t)p * L + k) * 64 + lane] = v[k];
+        }
+    }
+    // (each lane reads only what it wrote: no barrier)
+    // P-way merge up to the lower middle rank: the heads of the parts in registers, one LDS read per step
+    const int total = P * L;
+    const int k1 = total / 2;  // 1-based rank of the lower middle element of the padded column
+    int idx[P];
+    double head[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        idx[p] = 0;
+        head[p] = parts[((size_t)p * L) * 64 + lane];
+    }
+    double first = -inf;
+#pragma unroll 2
+    for (int step = 0; step < k1; ++step) {
+        double mn = head[0];
+        int w = 0;
+#pragma unroll
+        for (int p = 1; p < P; ++p) {
+            const bool less = head[p] < mn;
+            mn = less ? head[p] : mn;
+            w = less ? p : w;
+        }
+        first = mn;
+        int iw = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            idx[p] += (p == w) ? 1 : 0;
+            iw = (p == w) ? idx[p] : iw;
+        }
+        const double nv = (iw < L) ? parts[((size_t)w * L + min(iw, L - 1)) * 64 + lane] : inf;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            head[p] = (p == w) ? nv : head[p];
+        }
+    }
+    double second = head[0];
+#pragma unroll
+    for (int p = 1; p < P; ++p) {
+        second = fmin(second, head[p]);
+    }
+    // padded length is even; the padding keeps the middle pair where the K-column has it (odd K: one extra +inf, and
+    // the lower middle element is the median)
+    const double r = (K & 1) ? first : (first + second) / 2.0;
     out[j] = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : r;
 }
 
@@ -568,6 +691,24 @@ int dispatch(const T *m, size_t K, size_t n, size_t stride, double *out, hipStre
         launch_kp<T, 100>(m, (int)K, nn, st, out, stream);
     } else if (K <= 2 * (size_t)kHalf) {
         hipLaunchKernelGGL((median_split_kernel<T>), dim3((unsigned)((nn + 63) / 64)), dim3(64), 0, stream, m, (int)K, nn, st, out);
+    } else if (K <= 256) {
+        static bool configured = false;
+        const size_t lds = (size_t)4 * 64 * 64 * sizeof(double);
+        if (!configured) {
+            ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(median_parts_kernel<T, 64, 4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured = true;
+        }
+        hipLaunchKernelGGL((median_parts_kernel<T, 64, 4>), dim3((unsigned)((nn + 63) / 64)), dim3(64), lds, stream, m, (int)K, nn, st, out);
+    } else if (K <= 300) {
+        static bool configured = false;
+        const size_t lds = (size_t)3 * 100 * 64 * sizeof(double);
+        if (!configured) {
+            ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(median_parts_kernel<T, 100, 3>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured = true;
+        }
+        hipLaunchKernelGGL((median_parts_kernel<T, 100, 3>), dim3((unsigned)((nn + 63) / 64)), dim3(64), lds, stream, m, (int)K, nn, st, out);
     } else {
         hipLaunchKernelGGL((median_rank_kernel<T>), dim3((unsigned)blocks), dim3(threads), 0, stream,
                            m, (int)K, nn, st, out);

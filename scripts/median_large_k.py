@@ -5,7 +5,7 @@ import torch
 from rocco_amd import synth, rocco as rr
 dev = torch.device("cuda:0")
 n = 4979129
-for K in (100, 128, 160, 200, 256):
+for K in (33, 64, 90, 100, 128, 160, 200, 256, 300):
     m = synth.hash_matrix_device(K, n, 7, device=dev)
     out = torch.empty(n, dtype=torch.float64, device=dev)
     for _ in range(2):
