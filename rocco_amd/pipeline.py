@@ -21,10 +21,15 @@ from . import rocco as _rocco
 from . import shard as _shard
 
 # The calibration is a sequence of short device passes separated by host decisions: latency-bound once the
-# active set has shrunk.  Chromosomes are independent, so a rank's chromosomes are split into groups that
+# active set has shrunk.  Chromosomes are independent, so a rank's chromosomes CAN be split into groups that
 # calibrate side by side -- one host thread, HIP stream and solver handle (scratch buffers) per group; the
-# native call releases the GIL -- and fill each other's gaps.  Results do not depend on the grouping.
-SOLVE_GROUPS = int(os.environ.get("ROCCO_SOLVE_GROUPS", "3"))
+# native call releases the GIL -- and fill each other's gaps, each group solving while the next is scored.  Results do
+# not depend on the grouping.  Default 1 (no groups: every median in one launch at the kernel's full bandwidth, then one
+# batch): with the calibration of round 2 (about 12 rounds instead of 25, most of them on 2 % of the loci) the two
+# phases overlapped add up to the same time on the whole genome (12.39 against 12.44 ms, five alternating pairs) and
+# to MORE on the shards a rank owns at N = 2 / 4 / 8 (7.06 / 3.92 / 2.51 ms against 7.25 / 4.35 / 2.65 with three
+# groups; scripts/groups_ab.sh, scripts/groups_ab_shard.sh): the kernels compete for the same wavefront slots.
+SOLVE_GROUPS = int(os.environ.get("ROCCO_SOLVE_GROUPS", "1"))
 # 1: score every chromosome of the rank in ONE launch before any group starts solving (the median kernel then runs at
 # its full bandwidth); 0: score group after group so that the first groups solve while the later ones are scored
 SCORE_FIRST = int(os.environ.get("ROCCO_SCORE_FIRST", "0"))
@@ -122,7 +127,8 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
     the solution and the score tensors.  `groups` (default ROCCO_SOLVE_GROUPS): how many groups of chromosomes
     calibrate side by side (see SOLVE_GROUPS above).
 
-    Scoring and solving overlap: the medians (bandwidth-bound) are issued group after group on the caller's
+    With one group (the default) every median of the rank is one launch and the calibration one batch behind it.  With
+    more, scoring and solving overlap: the medians (bandwidth-bound) are issued group after group on the caller's
     stream, longest chromosomes first, and every group starts calibrating (launch-latency-bound rounds on its own
     stream and host thread) as soon as ITS chromosomes are scored, while the later groups' medians are still
     running.  Count-path scoring (latency-bound chain kernels) runs inside the groups.

@@ -189,6 +189,19 @@ def test_pipeline_three_chromosomes_vs_oracle(gpu, oracle):
         works.append(pipeline.ChromWork(name, synth.hash_matrix_device(K, n, seed), budget, gamma, step=50))
         hosts.append(synth.hash_matrix(K, n, seed))
     results = pipeline.solve_rank(works)
+    # grouped solves (scoring of a group overlapped with the solve of the one before; score-first ordering) and the
+    # ungrouped default return the same things
+    for groups, score_first in ((2, 0), (3, 0), (3, 1)):
+        old = pipeline.SCORE_FIRST
+        pipeline.SCORE_FIRST = score_first
+        try:
+            again = pipeline.solve_rank(works, groups=groups)
+        finally:
+            pipeline.SCORE_FIRST = old
+        for a, b in zip(results, again):
+            assert a["selection_penalty"] == b["selection_penalty"] and a["selected_count"] == b["selected_count"]
+            assert np.array_equal(a["solution"].cpu().numpy(), b["solution"].cpu().numpy())
+            assert np.array_equal(a["begin"].cpu().numpy(), b["begin"].cpu().numpy())
     for w, m, r in zip(works, hosts, results):
         s = np.median(m, axis=0)
         o_sol, o_obj, o_det = oracle.solve_chrom_exact(s, budget=w.budget, gamma=w.gamma, return_details=True)
