@@ -958,16 +958,32 @@ public:
                                        stream_)) != ROCCO_HIP_OK) return rc;
         }
 
-        // round scratch: [ticket | granules] (all-ones), [records], [results | error] (zero)
+        // Round scratch.  Tickets, the error word and the hand-off granules live in a buffer of their own that every
+        // round leaves as it found it (lean_finish_kernel restores what the round used: tickets and granules all-ones,
+        // error zero), so no fill is issued per round; it is initialised when it grows or after a failed round.  The
+        // records are plain scratch.  Results and the error word are written straight into pinned host memory by the
+        // finish kernel.
+        static const bool self_reset = std::getenv("ROCCO_HIP_LEAN_FILLS") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_FILLS")) == 0;
         const size_t b_look = align_up(256 + (size_t)recs * 4 * sizeof(unsigned long long), 256);
         const size_t b_recs = align_up((size_t)recs * sizeof(LeanTileRec), 256);
         const size_t b_res = align_up((size_t)results * sizeof(LeanResult) + 64, 256);
-        if ((rc = solver_->dev_lean_round.reserve(b_look + b_recs + b_res)) != ROCCO_HIP_OK) return rc;
+        {
+            const void *old_ptr = solver_->dev_lean_look.ptr;
+            const size_t old_bytes = solver_->dev_lean_look.bytes;
+            if ((rc = solver_->dev_lean_look.reserve(b_look)) != ROCCO_HIP_OK) return rc;
+            if (!self_reset || solver_->lean_look_dirty != 0 || solver_->dev_lean_look.ptr != old_ptr || solver_->dev_lean_look.bytes != old_bytes) {
+                ROCCO_HIP_TRY(hipMemsetAsync(solver_->dev_lean_look.ptr, 0xFF, solver_->dev_lean_look.bytes, stream_));
+                ROCCO_HIP_TRY(hipMemsetAsync((char *)solver_->dev_lean_look.ptr + 128, 0, 4, stream_));
+                solver_->lean_look_dirty = 0;
+            }
+        }
+        if ((rc = solver_->dev_lean_round.reserve(b_recs + 256)) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_lean_back.reserve(b_res)) != ROCCO_HIP_OK) return rc;
-        char *sc = (char *)solver_->dev_lean_round.ptr;
-        ROCCO_HIP_TRY(hipMemsetAsync(sc, 0xFF, b_look, stream_));
-        ROCCO_HIP_TRY(hipMemsetAsync(sc + b_look + b_recs, 0, b_res, stream_));
-        unsigned *error = (unsigned *)(sc + b_look + b_recs + (size_t)results * sizeof(LeanResult));
+        char *look = (char *)solver_->dev_lean_look.ptr;
+        unsigned *error = (unsigned *)(look + 128);
+        LeanResult *results_host = (LeanResult *)solver_->host_lean_back.ptr;
+        unsigned *error_host = (unsigned *)((char *)solver_->host_lean_back.ptr + (size_t)results * sizeof(LeanResult));
+        *error_host = 0u;
         if (!pre.empty()) {
             if ((rc = launch_lean_compact((const LeanCompactTask *)d, (int)pre.size(), pre_blocks, error, stream_)) != ROCCO_HIP_OK) return rc;
         }
@@ -976,30 +992,34 @@ public:
         L.n_tasks = n_bound_tasks;
         L.n_units = units;
         L.points = (const double *)(d + b_pre + b_tasks);
-        L.ticket = (unsigned *)sc;
-        L.look = (unsigned long long *)(sc + 256);
-        L.recs = (LeanTileRec *)(sc + b_look);
+        L.ticket = (unsigned *)look;
+        L.look = (unsigned long long *)(look + 256);
+        L.recs = (LeanTileRec *)solver_->dev_lean_round.ptr;
         L.bits = (unsigned *)solver_->dev_lean_pool.ptr;
         L.tile_off = (unsigned *)solver_->dev_lean_pool.ptr;
-        L.results = (LeanResult *)(sc + b_look + b_recs);
+        L.results = results_host;
         L.error = error;
+        L.error_out = error_host;
+        L.self_reset = 1;
+        L.pad = 0;
         if ((rc = launch_lean_eval(L, stream_)) != ROCCO_HIP_OK) return rc;
         if (!model_tasks.empty()) {
             LeanLaunch M = L;
             M.tasks = L.tasks + n_bound_tasks;
             M.n_tasks = (int)model_tasks.size();
             M.n_units = model_units;
-            M.ticket = (unsigned *)sc + 2;
+            M.ticket = (unsigned *)look + 2;
             if ((rc = launch_lean_model(M, stream_)) != ROCCO_HIP_OK) return rc;
         }
         L.n_tasks = (int)tasks.size();  // the finish launch closes every task's fill
         if ((rc = launch_lean_finish(L, results, stream_)) != ROCCO_HIP_OK) return rc;
         if (!post.empty()) {
+            // (rare since levels are adopted: a final compaction behind the finish kernel reports through a copy)
             if ((rc = launch_lean_compact((const LeanCompactTask *)(d + b_pre + b_tasks + b_points), (int)post.size(), post_blocks,
                                           error, stream_)) != ROCCO_HIP_OK) return rc;
+            ROCCO_HIP_TRY(hipMemcpyAsync(error_host, error, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+            ROCCO_HIP_TRY(hipMemsetAsync(error, 0, sizeof(unsigned), stream_));
         }
-        ROCCO_HIP_TRY(hipMemcpyAsync(solver_->host_lean_back.ptr, sc + b_look + b_recs, (size_t)results * sizeof(LeanResult) + 8,
-                                     hipMemcpyDeviceToHost, stream_));
         lean_result_count_ = results;
         lean_inflight_ = reqs;
         if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
@@ -1017,6 +1037,7 @@ public:
         const LeanResult *res = (const LeanResult *)solver_->host_lean_back.ptr;
         const unsigned error = *(const unsigned *)((const char *)solver_->host_lean_back.ptr + (size_t)lean_result_count_ * sizeof(LeanResult));
         if (error & 1u) {
+            solver_->lean_look_dirty = 1;  // tiles that gave up left granules behind
             set_last_error("lean evaluation: a tile waited for its predecessor beyond the spin limit");
             return ROCCO_HIP_EHIP;
         }

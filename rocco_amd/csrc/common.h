@@ -63,7 +63,9 @@ struct rocco_hip_solver {
     double factor_lambda = 0.0;       // ... its penalty
     size_t factor_cap = 0;            // ... and length (0: none)
     rocco::DeviceBuffer dev_lean_pool;   // compacted levels of the problems being solved (lean.hip)
-    rocco::DeviceBuffer dev_lean_round;  // per-round scratch of the lean evaluation
+    rocco::DeviceBuffer dev_lean_round;  // per-round scratch of the lean evaluation (tile records)
+    rocco::DeviceBuffer dev_lean_look;   // its tickets, error word and hand-off granules (restored by every round)
+    int lean_look_dirty = 1;             // ... unless a round failed: then the next one initialises it again
     rocco::DeviceBuffer dev_lean_desc;   // its descriptors
     rocco::DeviceBuffer dev_lean_wcap;   // per problem: tolerance cap of the rounding-model evaluation
     rocco::PinnedBuffer host_lean_stage; // ... their pinned staging

@@ -79,8 +79,11 @@ struct LeanLaunch {
     LeanTileRec *recs;
     unsigned *bits;
     unsigned *tile_off;
-    LeanResult *results;
-    unsigned *error;            // set when a bounded wait gave up
+    LeanResult *results;        // (may be pinned host memory: written once per task and penalty by the finish kernel)
+    unsigned *error;            // device word, zero before the launch; set when a bounded wait gave up
+    unsigned *error_out;        // where the finish kernel copies it for the host (next to the results), or nullptr
+    int self_reset;             // the finish kernel restores tickets, granules and the error word for the next round
+    int pad;
 };
 
 // compaction of one task at one of its evaluated penalties

@@ -854,6 +854,22 @@ __global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pai
         res.flags = (long long)uncertain;
         L.results[task.result_begin + p] = res;
     }
+    if (L.self_reset != 0) {
+        // leave the round's scratch as the next round expects it: granules and tickets all-ones, error word zero
+        unsigned long long *mine = L.look + ((long long)task.rec_begin + (long long)p * nt) * 4;
+        for (int k = lane; k < 4 * nt; k += 64) {
+            mine[k] = kSentinel;
+        }
+        if (pair == 0 && lane == 0) {
+            const unsigned e = __hip_atomic_load(L.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (L.error_out != nullptr) {
+                *L.error_out = e;
+            }
+            *L.error = 0u;
+            L.ticket[0] = 0xFFFFFFFFu;
+            L.ticket[2] = 0xFFFFFFFFu;
+        }
+    }
 }
 
 __global__ __launch_bounds__(kLeanThreads) void lean_compact_kernel(const LeanCompactTask *tasks, int n_tasks,
