@@ -665,7 +665,7 @@ public:
         if (rc != ROCCO_HIP_OK) return rc;
         // per problem: the tolerance cap of the rounding-model evaluation and the counters it is summed from (zero
         // between uses: lean_wcap_sum_kernel clears what it read)
-        const size_t wcap_bytes = align_up(probs.size() * sizeof(double), 256) + probs.size() * 256 * sizeof(unsigned);
+        const size_t wcap_bytes = align_up(probs.size() * sizeof(double), 256) + probs.size() * 512 * sizeof(unsigned);
         if ((rc = solver_->dev_lean_wcap.reserve(wcap_bytes + 256)) != ROCCO_HIP_OK) return rc;
         ROCCO_HIP_TRY(hipMemsetAsync(solver_->dev_lean_wcap.ptr, 0, wcap_bytes, stream_));
         lean_ready_ = true;
@@ -717,7 +717,8 @@ public:
                     wt.m = (long long)p.n;
                     wt.qexp = p.qexp;
                     wt.e_floor = std::ilogb(2.0 * p.cmax + 2.0 * p.sabs + (p.sabs + 2.0) + 2.0);  // (|penalty| <= sabs + 2)
-                    wt.counters = (unsigned *)((char *)solver_->dev_lean_wcap.ptr + align_up(probs.size() * sizeof(double), 256)) + 256 * r.problem;
+                    wt.counters = (unsigned *)((char *)solver_->dev_lean_wcap.ptr + align_up(probs.size() * sizeof(double), 256)) + 512 * r.problem;
+                    wt.clean_chunks = wt.counters + 384;
                     wt.wcap = wcap;
                     wt.block_begin = wcap_blocks;
                     wt.pad = 0;
@@ -747,6 +748,7 @@ public:
                 t.store = 0;
                 t.emap = p.emap;
                 t.wcap = wcap;
+                t.clean_chunks = (const unsigned *)((char *)solver_->dev_lean_wcap.ptr + align_up(probs.size() * sizeof(double), 256)) + 512 * r.problem + 384;
                 t.cmax = p.cmax;
                 t.sabs = p.sabs;
                 t.qexp = p.qexp;
@@ -799,6 +801,7 @@ public:
                 t.store = 0;
                 t.emap = nullptr;
                 t.wcap = nullptr;
+                t.clean_chunks = nullptr;
                 t.cmax = t.sabs = 0.0;
                 t.qexp = p.qexp;
                 t.pad = 0;
@@ -895,6 +898,7 @@ public:
             t.store = 1;
             t.emap = nullptr;
             t.wcap = nullptr;
+            t.clean_chunks = nullptr;
             t.cmax = t.sabs = 0.0;
             t.qexp = p.qexp;
             t.pad = 0;

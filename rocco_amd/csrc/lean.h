@@ -58,6 +58,7 @@ struct LeanTask {
     // oracle/delta_oracle.c defines it from the binade map; penalties are arbitrary doubles
     const uint8_t *emap;  // binade code of every chunk (nullptr: a bound task)
     const double *wcap;   // upper bound on the tolerance any locus can inherit (sum of the hazard chunks' weights)
+    const unsigned *clean_chunks;  // [128] clean chunks per binade code exponent (a penalty tying on that grid turns them hazard)
     double cmax, sabs;    // largest switch cost, largest |score| (floor of the hazard chunks' exponent)
     int qexp;
     int pad;
@@ -107,8 +108,8 @@ constexpr int kLeanModelBatch = 4;
 int launch_lean_model(const LeanLaunch &L, hipStream_t stream);
 // wcap[0] = sum over the hazard chunks of `emap` of 32 * (4 hb + q), + u for every score of a clean chunk that rounds
 // as an exact tie, + the largest hazard base (9 hb + 2 q), with the hazard exponent floored at e_floor (that of the
-// largest penalty magnitude to come): what a locus can inherit at most.  `counters`: 256 words, zero before the
-// launch and again after it.
+// largest penalty magnitude to come): what a locus can inherit at most.  `counters`: 384 words, zero before the
+// launch and again after it; `clean_chunks`: 128 words out, the clean chunks per exponent.
 struct LeanWcapTask {
     const uint8_t *emap;
     const double *s;
@@ -116,6 +117,7 @@ struct LeanWcapTask {
     int qexp;
     int e_floor;
     unsigned *counters;
+    unsigned *clean_chunks;
     double *wcap;
     int block_begin;  // first workgroup of this task (one per 8192 loci)
     int pad;

@@ -247,6 +247,23 @@ __device__ __forceinline__ void chunk_classes(const double *__restrict__ row, co
 constexpr double kModelGuard = 0x1p-16;  // == ORACLE_GUARD
 constexpr int kModelMapBias = 64;        // == ORACLE_MAP_BIAS
 
+// the exponent e whose grid u = 2^(e-52) has x exactly half-way between two of its points: the lowest set bit of x is
+// 2^(e-53).  (x == 0: none, returns a value outside every map code.)
+__device__ __forceinline__ int tie_exponent(double x)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x) & 0x7FFFFFFFFFFFFFFFull;
+    if (bits == 0ull) {
+        return 1 << 20;
+    }
+    const int ex = (int)(bits >> 52);
+    const unsigned long long frac = bits & 0xFFFFFFFFFFFFFull;
+    if (ex == 0) {  // subnormal: value = frac * 2^-1074
+        return -1074 + __builtin_ctzll(frac) + 53;
+    }
+    const unsigned long long sig = frac | (1ull << 52);  // value = sig * 2^(ex - 1075)
+    return (ex - 1075) + __builtin_ctzll(sig) + 53;
+}
+
 template <int PB>
 struct LaneModel {
     double magic_u, half_u, magic_q;
@@ -432,7 +449,7 @@ __device__ __forceinline__ void chunk_classes_model(const double *__restrict__ r
     for (int p = 0; p < PB; ++p) {
         tol.clear[p] = !pre[p];
         tol.tail[p] = wacc[p];
-        tol.bad[p] |= (lm.tie[p] && valid > 0) ? 32u : 0u;
+        (void)valid;
     }
 }
 
@@ -608,9 +625,26 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
         // tolerance a lane inherits: scan of (clear, tail) over the wavefront; its first lane takes the cap (nothing
         // at the very start of the chain)
         const double wcap = *task.wcap;
-        const double wave_in = (base == 0 && wave == 0) ? 0.0 : wcap;
+        // -gamma or -lambda may round as an exact tie on ONE grid u = 2^(e-52) (the one whose half step is the lowest
+        // set bit of the number): the clean chunks of that exponent then run in hazard mode (lane_model) and their steps
+        // weigh like any hazard step -- added to what a wavefront's first lane must assume
+        const double q_step = ldexp(1.0, task.qexp);
+        const int e_gamma = tie_exponent(task.c_raw);
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
+            double extra = 0.0;
+            const int e_lam = tie_exponent(x[p]);
+            if (e_lam + kModelMapBias >= 0 && e_lam + kModelMapBias < 128) {
+                const unsigned chunks = task.clean_chunks[e_lam + kModelMapBias];
+                const double hb = ldexp(1.0, e_lam + 2 - 53);
+                extra += (chunks != 0u) ? (double)chunks * (double)kLeanChunk * (4.0 * hb + q_step) + 9.0 * hb + 2.0 * q_step : 0.0;
+            }
+            if (e_gamma != e_lam && e_gamma + kModelMapBias >= 0 && e_gamma + kModelMapBias < 128) {
+                const unsigned chunks = task.clean_chunks[e_gamma + kModelMapBias];
+                const double hb = ldexp(1.0, e_gamma + 2 - 53);
+                extra += (chunks != 0u) ? (double)chunks * (double)kLeanChunk * (4.0 * hb + q_step) + 9.0 * hb + 2.0 * q_step : 0.0;
+            }
+            const double wave_in = (base == 0 && wave == 0) ? 0.0 : wcap + extra;
             bool cl = tol.clear[p];
             double tl = tol.tail[p];
 #pragma unroll
@@ -1056,7 +1090,7 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_model_kernel(LeanLaunch 
 // order dependence) by one workgroup per tile, summed by one thread per task, which also clears the counters.
 __global__ __launch_bounds__(kLeanThreads) void lean_wcap_count_kernel(const LeanWcapTask *__restrict__ tasks, int n_tasks)
 {
-    __shared__ unsigned steps[128], ties[128];
+    __shared__ unsigned steps[128], ties[128], clean[128];
     __shared__ double magic_u[kLeanThreads], half_u[kLeanThreads];  // per chunk of the tile (0: hazard, no tie test)
     int ti = 0;
     while (ti + 1 < n_tasks && tasks[ti + 1].block_begin <= (int)blockIdx.x) {
@@ -1067,6 +1101,7 @@ __global__ __launch_bounds__(kLeanThreads) void lean_wcap_count_kernel(const Lea
     if (t < 128) {
         steps[t] = 0u;
         ties[t] = 0u;
+        clean[t] = 0u;
     }
     __syncthreads();
     const long long base = (long long)((int)blockIdx.x - task.block_begin) * kLeanTile;
@@ -1088,6 +1123,7 @@ __global__ __launch_bounds__(kLeanThreads) void lean_wcap_count_kernel(const Lea
         } else {
             magic_u[t] = ldexp(1.5, e);
             half_u[t] = ldexp(1.0, e - 53);
+            atomicAdd(&clean[my_bin], 1u);
         }
     }
     __syncthreads();
@@ -1114,6 +1150,9 @@ __global__ __launch_bounds__(kLeanThreads) void lean_wcap_count_kernel(const Lea
         if (ties[t] != 0u) {
             atomicAdd(&task.counters[128 + t], ties[t]);
         }
+        if (clean[t] != 0u) {
+            atomicAdd(&task.counters[256 + t], clean[t]);
+        }
     }
 }
 
@@ -1137,8 +1176,10 @@ __global__ __launch_bounds__(64) void lean_wcap_sum_kernel(const LeanWcapTask *_
         if (tn != 0u) {
             sum += (double)tn * ldexp(1.0, e - 52);
         }
+        task.clean_chunks[b] = task.counters[256 + b];  // kept: a penalty that ties on this grid turns them hazard
         task.counters[b] = 0u;
         task.counters[128 + b] = 0u;
+        task.counters[256 + b] = 0u;
     }
     task.wcap[0] = sum + base;
 }
