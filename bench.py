@@ -225,7 +225,8 @@ def main():
         # intervals of every owned chromosome to the host in ONE transfer
         counts = [int(r["begin"].numel()) for r in res]
         if sum(counts):
-            flat = torch.cat([torch.stack([r["begin"], r["end"]], dim=1) for r in res if r["begin"].numel()]).cpu().numpy()
+            # (two concatenations and one interleave for the whole rank, not one small launch per chromosome)
+            flat = torch.stack([torch.cat([r["begin"] for r in res]), torch.cat([r["end"] for r in res])], dim=1).cpu().numpy()
         else:
             flat = np.zeros((0, 2), dtype=np.int64)
         local, at = {}, 0

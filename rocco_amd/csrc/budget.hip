@@ -598,7 +598,8 @@ public:
     // rounding-model probes of a compacted problem with a map in place go through lean_model_kernel
     bool model_eligible(size_t problem) const
     {
-        static const bool enabled = std::getenv("ROCCO_HIP_LEAN_MODEL") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_MODEL")) != 0;
+        const char *flag = std::getenv("ROCCO_HIP_LEAN_MODEL");  // (read per call: tests switch it within one process)
+        const bool enabled = flag == nullptr || std::atoi(flag) != 0;
         const DevProblem &p = probs[problem];
         return enabled && !force_full_ && solver_->lean != 0 && lean_ready_ && ((p.compacted && p.lean_orig != nullptr) || model_any_) &&
                p.costs == nullptr && p.emap != nullptr && p.n >= 2;
@@ -967,7 +968,8 @@ public:
         // error zero), so no fill is issued per round; it is initialised when it grows or after a failed round.  The
         // records are plain scratch.  Results and the error word are written straight into pinned host memory by the
         // finish kernel.
-        static const bool self_reset = std::getenv("ROCCO_HIP_LEAN_FILLS") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_FILLS")) == 0;
+        const char *fills = std::getenv("ROCCO_HIP_LEAN_FILLS");
+        const bool self_reset = fills == nullptr || std::atoi(fills) == 0;
         const size_t b_look = align_up(256 + (size_t)recs * 4 * sizeof(unsigned long long), 256);
         const size_t b_recs = align_up((size_t)recs * sizeof(LeanTileRec), 256);
         const size_t b_res = align_up((size_t)results * sizeof(LeanResult) + 64, 256);
@@ -1006,6 +1008,7 @@ public:
         L.error_out = error_host;
         L.self_reset = 1;
         L.pad = 0;
+        solver_->lean_look_dirty = 1;  // until the finish kernel that restores the scratch is in the stream
         if ((rc = launch_lean_eval(L, stream_)) != ROCCO_HIP_OK) return rc;
         if (!model_tasks.empty()) {
             LeanLaunch M = L;
@@ -1017,6 +1020,7 @@ public:
         }
         L.n_tasks = (int)tasks.size();  // the finish launch closes every task's fill
         if ((rc = launch_lean_finish(L, results, stream_)) != ROCCO_HIP_OK) return rc;
+        solver_->lean_look_dirty = 0;
         if (!post.empty()) {
             // (rare since levels are adopted: a final compaction behind the finish kernel reports through a copy)
             if ((rc = launch_lean_compact((const LeanCompactTask *)(d + b_pre + b_tasks + b_points), (int)post.size(), post_blocks,
