@@ -92,3 +92,26 @@ def test_calibration_with_and_without_compaction(gpu, oracle, seed, monkeypatch)
         assert pen == ref[0] and cnt == ref[3], (kind, n, gamma, budget, lean, compact, info)
         assert np.array_equal(sol_t.cpu().numpy(), ref[1]), (kind, n, lean, compact, info)
         assert abs(val - ref[2]) <= 1e-9 * max(1.0, abs(ref[2]))
+
+
+@pytest.mark.parametrize("model,fills", [("0", "0"), ("1", "1"), ("0", "1")])
+def test_lean_model_kernel_and_scratch_fills_switched(gpu, oracle, monkeypatch, model, fills):
+    """ROCCO_HIP_LEAN_MODEL=0 sends every rounding-model probe through the full kernels, ROCCO_HIP_LEAN_FILLS=1 fills
+    the lean rounds' scratch before every round instead of trusting the finish kernel to restore it: same results."""
+    import torch
+
+    from rocco_amd import dp, synth
+    from rocco_amd.rocco import score_central_tendency_chrom_device
+
+    ns = [700000, 150000, 42000]
+    scores = [score_central_tendency_chrom_device(synth.hash_matrix_device(8, n, seed=977 + i)) for i, n in enumerate(ns)]
+    targets = [int(np.floor(n * 0.02)) for n in ns]
+    base = dp.calibrate_batch_device(scores, [1.0] * 3, targets)
+    monkeypatch.setenv("ROCCO_HIP_LEAN_MODEL", model)
+    monkeypatch.setenv("ROCCO_HIP_LEAN_FILLS", fills)
+    other = dp.calibrate_batch_device(scores, [1.0] * 3, targets)
+    for s_t, target, a, b in zip(scores, targets, base, other):
+        assert a[0] == b[0] and a[3] == b[3] and torch.equal(a[1], b[1])
+        s = s_t.cpu().numpy()
+        ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 1.0), target)
+        assert b[0] == ref[0] and b[3] == ref[3] and np.array_equal(b[1].cpu().numpy(), ref[1])
