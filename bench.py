@@ -220,10 +220,25 @@ def main():
 
     median_events = []
 
+    units_of_mine = None  # (device tensor of this rank's unit indices, built once)
+
     def one_step(timing=None):
+        nonlocal units_of_mine
         res = pipeline.solve_rank(works, median_timing=timing)
-        # intervals of every owned chromosome to the host in ONE transfer
         counts = [int(r["begin"].numel()) for r in res]
+        if world > 1:
+            # rows (unit, start, end) stay on the device until every rank's have been gathered (RCCL), then ONE
+            # transfer to the host; under Gloo (CPU rehearsal of this path) they are moved to the CPU first
+            if units_of_mine is None:
+                units_of_mine = torch.tensor(mine, dtype=torch.int64, device=device)
+            if sum(counts):
+                units = torch.repeat_interleave(units_of_mine, torch.tensor(counts, dtype=torch.int64, device=device))
+                rows = torch.stack([units, torch.cat([r["begin"] for r in res]), torch.cat([r["end"] for r in res])], dim=1)
+            else:
+                rows = torch.zeros((0, 3), dtype=torch.int64, device=device)
+            merged = shard.gather_interval_rows(rows if backend == "nccl" else rows.cpu())
+            return res, merged
+        # intervals of every owned chromosome to the host in ONE transfer
         if sum(counts):
             # (two concatenations and one interleave for the whole rank, not one small launch per chromosome)
             flat = torch.stack([torch.cat([r["begin"] for r in res]), torch.cat([r["end"] for r in res])], dim=1).cpu().numpy()
@@ -233,8 +248,7 @@ def main():
         for idx, c in zip(mine, counts):
             local[idx] = flat[at:at + c]
             at += c
-        merged = shard.gather_intervals(local, device=device if backend == "nccl" else None) if world > 1 else local
-        return res, merged
+        return res, local
 
     def sync_all():
         torch.cuda.synchronize()

@@ -60,6 +60,41 @@ def gather_budget_counts(local: Dict[int, Tuple[float, float]], n_units: int, de
     return merged
 
 
+def gather_interval_rows(rows_t, group=None) -> Dict[int, np.ndarray]:
+    """The same gather from rows that are still on the device: `rows_t` is an int64 tensor [m, 3] of (unit, start, end),
+    on the GPU under RCCL (backend "nccl") or on the CPU under Gloo.  Two collectives (row counts, padded rows) and ONE
+    transfer to the host at the end -- the intervals are not brought to the host first and sent back for the exchange.
+    Returns unit -> [m_u, 2] arrays, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        arr = rows_t.cpu().numpy()
+    else:
+        world = dist.get_world_size(group)
+        count = torch.tensor([int(rows_t.shape[0])], dtype=torch.int64, device=rows_t.device)
+        counts = torch.zeros(world, dtype=torch.int64, device=rows_t.device)
+        dist.all_gather_into_tensor(counts, count, group=group)
+        sizes = [int(c) for c in counts.cpu().tolist()]
+        width = max(max(sizes), 1)
+        mine = torch.zeros((width, 3), dtype=torch.int64, device=rows_t.device)
+        if rows_t.shape[0]:
+            mine[: rows_t.shape[0]] = rows_t
+        parts = torch.empty((world * width, 3), dtype=torch.int64, device=rows_t.device)
+        dist.all_gather_into_tensor(parts, mine, group=group)
+        host = parts.cpu().numpy().reshape(world, width, 3)
+        arr = np.concatenate([host[r, : sizes[r]] for r in range(world)], axis=0) if sum(sizes) else np.zeros((0, 3), dtype=np.int64)
+    merged: Dict[int, np.ndarray] = {}
+    if arr.shape[0]:
+        order = np.argsort(arr[:, 0], kind="stable")
+        arr = arr[order]
+        units, first = np.unique(arr[:, 0], return_index=True)
+        bounds = list(first) + [arr.shape[0]]
+        for k, u in enumerate(units):
+            merged[int(u)] = arr[bounds[k]:bounds[k + 1], 1:]
+    return merged
+
+
 def gather_intervals(local: Dict[int, np.ndarray], device=None, group=None) -> Dict[int, np.ndarray]:
     """Gather per-unit interval arrays to every rank.
 

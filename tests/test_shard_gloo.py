@@ -22,6 +22,13 @@ def _worker(rank, world, port, out_dir):
         local[u] = np.stack([np.arange(m) * 100 + u, np.arange(m) * 100 + u + 50], axis=1).astype(np.int64)
     merged = shard.gather_intervals(local)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{str(k): v for k, v in merged.items()})
+    # the same exchange from rows that never left the "device" (here: CPU tensors under Gloo)
+    import torch
+
+    rows = [np.concatenate([np.full((a.shape[0], 1), u, dtype=np.int64), a], axis=1) for u, a in sorted(local.items()) if a.shape[0]]
+    rows_t = torch.from_numpy(np.concatenate(rows, axis=0) if rows else np.zeros((0, 3), dtype=np.int64))
+    again = shard.gather_interval_rows(rows_t)
+    assert sorted(again) == sorted(merged) and all(np.array_equal(again[u], merged[u]) for u in merged)
     dist.destroy_process_group()
 
 
