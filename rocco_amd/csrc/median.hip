@@ -335,15 +335,15 @@ __global__ __launch_bounds__(64) void median_split_kernel(const T *__restrict__ 
     out[j] = has_nan ? __longlong_as_double(0x7FF8000000000000LL) : r;
 }
 
-// 200 < K <= 300: P sorted parts of L entries (4 x 64 or 3 x 100) parked in LDS, one wavefront per workgroup, each lane
-// its own column; then a P-way merge with the parts' heads in registers up to the lower middle rank (P L / 2 steps of
+// 200 < K <= 1200: P sorted parts of L entries parked in LDS (4 x 64 or 3 x 100 for 64 columns per workgroup; 6 x 100 for
+// 32 and 12 x 100 for 16 -- the parts of a whole wavefront's columns would not fit), each lane its own column; then a P-way merge with the parts' heads in registers up to the lower middle rank (P L / 2 steps of
 // P - 1 compares and ONE LDS read): the element taken last and the smallest remaining head are the middle pair.
 // (A first version searched the ranks by nested binary searches: P^2 log^2 L dependent LDS reads, 5x slower.)
-template <typename T, int L, int P>
-__global__ __launch_bounds__(64) void median_parts_kernel(const T *__restrict__ m, int K, long long n, long long stride,
-                                                          double *__restrict__ out)
+template <typename T, int L, int P, int LANES>
+__global__ __launch_bounds__(LANES) void median_parts_kernel(const T *__restrict__ m, int K, long long n, long long stride,
+                                                             double *__restrict__ out)
 {
-    extern __shared__ double parts[];  // [P][L][64]
+    extern __shared__ double parts[];  // [P][L][LANES]
     const long long j = (long long)xcd_contiguous_block() * blockDim.x + threadIdx.x;
     if (j >= n) {
         return;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64) void median_parts_kernel(const T *__restrict__ 
         select_middle<L>(v);  // every output is stored: a complete sort
 #pragma unroll
         for (int k = 0; k < L; ++k) {
-            parts[((size_t)p * L + k) * 64 + lane] = v[k];
+            parts[((size_t)p * L + k) * LANES + lane] = v[k];
         }
     }
     // (each lane reads only what it wrote: no barrier)
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64) void median_parts_kernel(const T *__restrict__ 
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         idx[p] = 0;
-        head[p] = parts[((size_t)p * L) * 64 + lane];
+        head[p] = parts[((size_t)p * L) * LANES + lane];
     }
     double first = -inf;
 #pragma unroll 2
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64) void median_parts_kernel(const T *__restrict__ 
             idx[p] += (p == w) ? 1 : 0;
             iw = (p == w) ? idx[p] : iw;
         }
-        const double nv = (iw < L) ? parts[((size_t)w * L + min(iw, L - 1)) * 64 + lane] : inf;
+        const double nv = (iw < L) ? parts[((size_t)w * L + min(iw, L - 1)) * LANES + lane] : inf;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             head[p] = (p == w) ? nv : head[p];
@@ -649,9 +649,25 @@ void launch_kp(const T *m, int K, long long n, long long stride, double *out, hi
     }
 }
 
+template <typename T, int L, int P, int LANES>
+int launch_parts(const T *m, int K, long long n, long long stride, double *out, hipStream_t stream)
+{
+    static bool configured = false;
+    const size_t lds = (size_t)P * L * LANES * sizeof(double);
+    if (!configured) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(median_parts_kernel<T, L, P, LANES>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL((median_parts_kernel<T, L, P, LANES>), dim3((unsigned)((n + LANES - 1) / LANES)), dim3(LANES), lds, stream, m, K,
+                       n, stride, out);
+    return ROCCO_HIP_OK;
+}
+
 template <typename T>
 int dispatch(const T *m, size_t K, size_t n, size_t stride, double *out, hipStream_t stream)
 {
+    int rc = ROCCO_HIP_OK;
     const long long nn = (long long)n;
     const long long st = (long long)stride;
     const int threads = 256;
@@ -692,23 +708,14 @@ int dispatch(const T *m, size_t K, size_t n, size_t stride, double *out, hipStre
     } else if (K <= 2 * (size_t)kHalf) {
         hipLaunchKernelGGL((median_split_kernel<T>), dim3((unsigned)((nn + 63) / 64)), dim3(64), 0, stream, m, (int)K, nn, st, out);
     } else if (K <= 256) {
-        static bool configured = false;
-        const size_t lds = (size_t)4 * 64 * 64 * sizeof(double);
-        if (!configured) {
-            ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(median_parts_kernel<T, 64, 4>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = true;
-        }
-        hipLaunchKernelGGL((median_parts_kernel<T, 64, 4>), dim3((unsigned)((nn + 63) / 64)), dim3(64), lds, stream, m, (int)K, nn, st, out);
+        if ((rc = launch_parts<T, 64, 4, 64>(m, (int)K, nn, st, out, stream)) != ROCCO_HIP_OK) return rc;
     } else if (K <= 300) {
-        static bool configured = false;
-        const size_t lds = (size_t)3 * 100 * 64 * sizeof(double);
-        if (!configured) {
-            ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(median_parts_kernel<T, 100, 3>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = true;
-        }
-        hipLaunchKernelGGL((median_parts_kernel<T, 100, 3>), dim3((unsigned)((nn + 63) / 64)), dim3(64), lds, stream, m, (int)K, nn, st, out);
+        if ((rc = launch_parts<T, 100, 3, 64>(m, (int)K, nn, st, out, stream)) != ROCCO_HIP_OK) return rc;
+    } else if (K <= 600) {
+        // half a wavefront per workgroup (the parts of 64 columns would not fit the LDS): half the lanes idle
+        if ((rc = launch_parts<T, 100, 6, 32>(m, (int)K, nn, st, out, stream)) != ROCCO_HIP_OK) return rc;
+    } else if (K <= 1200) {
+        if ((rc = launch_parts<T, 100, 12, 16>(m, (int)K, nn, st, out, stream)) != ROCCO_HIP_OK) return rc;
     } else {
         hipLaunchKernelGGL((median_rank_kernel<T>), dim3((unsigned)blocks), dim3(threads), 0, stream,
                            m, (int)K, nn, st, out);

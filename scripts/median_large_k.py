@@ -5,7 +5,9 @@ import torch
 from rocco_amd import synth, rocco as rr
 dev = torch.device("cuda:0")
 n = 4979129
-for K in (33, 64, 90, 100, 128, 160, 200, 256, 300):
+n_large = 1000000  # (K > 300: a 1 M-locus matrix, 8 GB at K = 1000)
+for K in (33, 64, 90, 100, 128, 160, 200, 256, 300, 400, 600, 1000):
+    n = n if K <= 300 else n_large
     m = synth.hash_matrix_device(K, n, 7, device=dev)
     out = torch.empty(n, dtype=torch.float64, device=dev)
     for _ in range(2):

@@ -110,7 +110,7 @@ def test_trimmed_mean_and_power_branches(gpu, K):
 
 
 @pytest.mark.parametrize("K", [2, 3, 4, 5, 7, 8, 9, 10, 11, 16, 17, 25, 33, 50, 51, 64, 77, 100, 101, 128, 130, 151, 160, 199, 200, 201,
-                               202, 229, 255, 256, 257, 258, 299, 300, 301, 400])
+                               202, 229, 255, 256, 257, 258, 299, 300, 301, 400, 555, 600, 601, 1000, 1200, 1201])
 def test_median_kernel_all_sizes(gpu, K):
     import torch
     from rocco_amd.rocco import score_central_tendency_chrom_device
