@@ -61,6 +61,43 @@ def test_random_problems_match_oracle(oracle, seed):
     assert info["path"] == 2
 
 
+_DEVICE_SIDE_BEHAVIOURS = [
+    {"NOW": "1"},                                                      # a compacted copy already exists: adopted at once
+    {"NOW": "1", "SLACK": "1e-5", "TILE": "64"},                       # ... built at a lower penalty, tile borders kept
+    {"POINTS": "64", "PILOT": "0.05", "TILE": "8192"},                 # 64 penalties a round, a good pilot
+    {"POINTS": "7", "PILOT": "3.0", "PILOT_ROUNDS": "1", "PILOT_POINTS": "64"},  # a pilot that is wrong by 300 %
+    {"COMPACT": "0"},                                                  # no compaction at all
+]
+
+
+@pytest.mark.parametrize("behaviour", range(len(_DEVICE_SIDE_BEHAVIOURS)))
+def test_search_does_not_depend_on_what_the_device_side_does(oracle, monkeypatch, behaviour):
+    """The evaluator of the harness imitates what the HIP evaluator may do behind the search's back -- adopt an
+    existing compacted level (at once, built lower than asked, with tile borders kept), ask for few or many
+    penalties a round, feed it pilot estimates of any quality -- and the answer must stay the reference's."""
+    for key, value in _DEVICE_SIDE_BEHAVIOURS[behaviour].items():
+        monkeypatch.setenv("ROCCO_HOSTLOGIC_" + key, value)
+    kinds = ("round5", "int", "normal", "offset")
+    for it in range(24):
+        rng = np.random.default_rng([behaviour, it])
+        n = int(rng.choice([33, 1000, 8193, 30000]))
+        kind = kinds[it % len(kinds)]
+        if kind == "round5":
+            s = np.round(rng.gamma(1.0, 0.3, n), 5)
+            s[rng.integers(0, n, max(1, n // 50))] += rng.gamma(6.0, 1.0, max(1, n // 50))
+        elif kind == "int":
+            s = rng.integers(-3, 6, n).astype(float)
+        elif kind == "normal":
+            s = rng.normal(0.2, 1.0, n)
+        else:
+            s = 1.0e3 + rng.gamma(1.0, 1.0, n)
+        gamma = float(rng.choice([0.5, 1.0, 3.0]))
+        target = int(np.floor(n * float(rng.choice([0.01, 0.05, 0.2]))))
+        ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, gamma), target)
+        pen, sol, val, cnt, info = hl.calibrate(s, gamma, target, spec_depth=1 + it % 3)
+        assert pen == ref[0] and cnt == ref[3] and np.array_equal(sol, ref[1]), (kind, n, gamma, target, info)
+
+
 def test_edge_cases_match_oracle(oracle):
     rng = np.random.default_rng(0)
     s = np.round(rng.gamma(1.0, 0.3, size=200), 5)
