@@ -753,7 +753,7 @@ public:
                 t.cmax = p.cmax;
                 t.sabs = p.sabs;
                 t.qexp = p.qexp;
-                t.pad = 0;
+                t.batch = kLeanModelBatch;
                 r.result_begin = results;
                 model_units += nt * t.n_groups;
                 recs += nt * np;
@@ -805,7 +805,7 @@ public:
                 t.clean_chunks = nullptr;
                 t.cmax = t.sabs = 0.0;
                 t.qexp = p.qexp;
-                t.pad = 0;
+                t.batch = kLeanBatch;
                 r.result_begin = results;
                 units += nt * t.n_groups;
                 recs += nt * np;
@@ -902,7 +902,7 @@ public:
             t.clean_chunks = nullptr;
             t.cmax = t.sabs = 0.0;
             t.qexp = p.qexp;
-            t.pad = 0;
+            t.batch = kLeanBatch;
             r.result_begin = results;
             units += nt * t.n_groups;
             recs += nt * np;
@@ -936,6 +936,33 @@ public:
                     r.out_s = nullptr;
                 }
             }
+        }
+        // Penalties per workgroup: a workgroup's time grows with what it carries (about 6 us + 4 us per penalty), a
+        // round's with the number of waves of workgroups the device needs (512 at a time).  While the whole round fits
+        // at once, carry less per workgroup.
+        static const bool adapt = std::getenv("ROCCO_HIP_LEAN_BATCH") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_BATCH")) != 0;
+        auto rebatch = [](std::vector<LeanTask> &ts, int full, int &total_units) {
+            for (int b = 2; b < full; b *= 2) {
+                long long u = 0;
+                for (const LeanTask &t : ts) {
+                    u += (long long)t.n_tiles * ((t.n_points + b - 1) / b);
+                }
+                if (u <= 512) {
+                    int at = 0;
+                    for (LeanTask &t : ts) {
+                        t.batch = b;
+                        t.n_groups = (t.n_points + b - 1) / b;
+                        t.unit_begin = at;
+                        at += t.n_tiles * t.n_groups;
+                    }
+                    total_units = at;
+                    return;
+                }
+            }
+        };
+        if (adapt) {
+            rebatch(tasks, kLeanBatch, units);
+            rebatch(model_tasks, kLeanModelBatch, model_units);
         }
         lean_units += units + model_units;
         const int n_bound_tasks = (int)tasks.size();

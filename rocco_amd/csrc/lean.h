@@ -44,7 +44,7 @@ struct LeanTask {
     double big;           // 2^(50 + qexp)
     int n_tiles;
     int n_points;
-    int n_groups;         // workgroups per tile (each takes kLeanBatch penalties)
+    int n_groups;         // workgroups per tile (each takes `batch` penalties)
     int unit_begin;       // first ticket of this task (tickets are tile-major: tile * n_groups + group)
     int point_begin;      // offset of the task's penalties in the round's point list
     int rec_begin;        // offset of the task's records: [(point) * n_tiles + tile]
@@ -61,7 +61,8 @@ struct LeanTask {
     const unsigned *clean_chunks;  // [128] clean chunks per binade code exponent (a penalty tying on that grid turns them hazard)
     double cmax, sabs;    // largest switch cost, largest |score| (floor of the hazard chunks' exponent)
     int qexp;
-    int pad;
+    int batch;            // penalties per workgroup of this task (bound: 8, 4 or 2; rounding model: 4 or 2): fewer when the
+                          // whole round still fits the device at once -- a workgroup's time grows with what it carries
 };
 
 struct LeanResult {

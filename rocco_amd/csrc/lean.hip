@@ -1030,8 +1030,8 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_eval_kernel(LeanLaunch L
     const LeanTask task = L.tasks[ti];
     const int unit = ticket - task.unit_begin;
     const int tile = unit / task.n_groups, group = unit % task.n_groups;
-    const int p0 = group * kLeanBatch;
-    const int np = min(kLeanBatch, task.n_points - p0);
+    const int p0 = group * task.batch;
+    const int np = min(task.batch, task.n_points - p0);
     stage_tile<false>(task.s, task.m, (long long)tile * task.tile_stride * kLeanTile, task.magic, lds);
     // penalties of this workgroup, in registers: 1, 2, 4 or 8 interleaved chains per lane
     if (np > 4) {
@@ -1073,8 +1073,8 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_model_kernel(LeanLaunch 
     const LeanTask task = L.tasks[ti];
     const int unit = ticket - task.unit_begin;
     const int tile = unit / task.n_groups, group = unit % task.n_groups;
-    const int p0 = group * kLeanModelBatch;
-    const int np = min(kLeanModelBatch, task.n_points - p0);
+    const int p0 = group * task.batch;
+    const int np = min(task.batch, task.n_points - p0);
     stage_tile<true>(task.s, task.m, (long long)tile * kLeanTile, task.magic, lds);
     if (np > 2) {
         eval_body<4, true>(L, task, tile, p0, np, lds, sc);
