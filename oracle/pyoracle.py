@@ -568,3 +568,18 @@ def bigwig_dense_fill(starts, ends, vals, const_scale: float = 1.0, round_digits
     if const_scale >= 0:
         full_vals = full_vals * float(const_scale)
     return full_intervals.astype(int), np.round(full_vals, round_digits)
+
+
+# --------------------------------------------------------------------------------------------
+# budget / switch-cost estimation and the composed driver (oracle/budget_oracle.py), under this module's name
+# --------------------------------------------------------------------------------------------
+from budget_oracle import (  # noqa: E402,F401
+    build_chrom_cache,
+    effective_sample_size,
+    estimate_budget_nonnull_fraction_from_score_track,
+    estimate_budget_nonnull_fraction_from_wild_bootstrap_null,
+    estimate_empirical_bayes_budgets,
+    resolve_budgets,
+    resolve_chrom_gamma,
+    run_chromosomes,
+)

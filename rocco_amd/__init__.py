@@ -11,8 +11,11 @@ from .dp import (  # noqa: F401
     solve_chrom_exact,
     solve_penalized_chain,
 )
-from .budget import (  # noqa: F401  (rocco/inference.py:1312-1421, 1593-1737)
+from .budget import (  # noqa: F401  (rocco/inference.py:988-1148, 1312-1485, 1593-1737)
+    estimate_budget_nonnull_fraction_from_empirical_null,
+    estimate_budget_nonnull_fraction_from_resampled_null,
     estimate_budget_nonnull_fraction_from_score_track,
+    estimate_budget_nonnull_fraction_from_wild_bootstrap_null,
     estimate_empirical_bayes_budgets,
 )
 from .inference import crossfit_whittaker_baseline  # noqa: F401  (rocco/_baseline.c:16-104)

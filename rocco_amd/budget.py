@@ -42,6 +42,8 @@ _MAD_TO_SIGMA = 1.4826  # rocco/inference.py:37
 def _as_score_tensor(score_track):
     import torch
 
+    if _dp._resident_tensor(score_track) is not None:
+        score_track = _dp._resident_tensor(score_track)
     if _dp._is_tensor(score_track):
         t = score_track
         if not t.is_cuda:
@@ -340,6 +342,272 @@ def estimate_budget_nonnull_fraction_from_score_track(score_track, dependence_la
     if return_details:
         return nonnull_fraction, details
     return nonnull_fraction
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the count-matrix (BAM) branch: dependent wild residual bootstrap of the centred K x n matrix
+# (rocco/inference.py:719-985 and 988-1148; call-site rocco/rocco.py:1027-1048)
+# --------------------------------------------------------------------------------------------------------------
+
+def _as_centered_tensor(centered_matrix):
+    """[K, n] float64 CUDA tensor of a centred matrix (a float32 one -- `--low_memory` -- is widened as
+    np.asarray(..., dtype=np.float64) widens it, rocco/inference.py:750, 1041)."""
+    import torch
+
+    if _dp._resident_tensor(centered_matrix) is not None:
+        centered_matrix = _dp._resident_tensor(centered_matrix)
+    if _dp._is_tensor(centered_matrix):
+        t = centered_matrix
+        if not t.is_cuda:
+            t = t.to(f"cuda:{_dp._device_index()}")
+    else:
+        arr = np.asarray(centered_matrix)
+        if arr.dtype not in (np.float64, np.float32):
+            arr = np.asarray(arr, dtype=np.float64)
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(f"cuda:{_dp._device_index()}")
+    if t.dim() == 1:
+        t = t[None, :]
+    if t.dim() != 2:
+        raise ValueError("`centered_matrix` must be one- or two-dimensional")
+    return t.to(torch.float64).contiguous()
+
+
+def _null_reference_of(sorted_t) -> Tuple[float, float, int]:
+    """Centre, scale and support of a null's reference scores from their sorted copy (rocco/inference.py:776-787,
+    1176-1188): the median; 1.4826 x the median magnitude of the residuals at or below it (the mirrored sample
+    (-m, +m) has median 0 and absolute deviations (m, m)); the number of those residuals."""
+    n = int(sorted_t.shape[0])
+    center = _median_of_sorted_range(sorted_t, 0, n)
+    _, (m,), _ = sorted_probe(sorted_t, thresholds=(0.0,), shift=center)  # residuals (x - centre) <= 0 come first
+    if m == 0:  # the median always has an element at or below it; the reference's branch for it takes |residuals|
+        raise ValueError("Budget null fit produced non-finite values")
+    k_lo, k_hi = (m - 1) // 2, m // 2
+    (r_lo, r_hi), _, _ = sorted_probe(sorted_t, ranks=(m - 1 - k_lo, m - 1 - k_hi))
+    mad = ((-(r_lo - center)) + (-(r_hi - center))) / 2.0
+    return float(center), float(max(mad * _MAD_TO_SIGMA, 1.0e-6)), int(m)
+
+
+def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
+                                        precision_floor_ratio: float = 0.01, observed_scores=None,
+                                        dependence_lag_hint: Optional[int] = None, num_null_draws: int = 25,
+                                        random_seed: int = 0, progress_label: Optional[str] = None, num_processes: int = 1,
+                                        min_null_draws: Optional[int] = None, stability_abs_tol: float = 5.0e-3,
+                                        stability_rel_tol: float = 5.0e-2) -> Dict[str, Any]:
+    """Score null of one chromosome by the dependent wild residual bootstrap (rocco/inference.py:719-985).
+
+    Same arguments and the same dictionary as the reference's (`observed_scores` comes back as a float64 CUDA tensor).
+    On the device: the two WLS scorings of the fit (centred matrix, residual template), ONE sort of the null's reference
+    scores for its centre and scale, and per draw the K x n product with the multipliers, the WLS rescoring and the four
+    means in NumPy's order.  On the host: the multipliers -- draw d takes `default_rng(seed + 104729 (d + 1))` and makes
+    row after row with it, as rocco/inference.py:654-664 does -- and the running moments / stopping rule.  The
+    reference's worker pool (`num_processes`) only changes how many draws it finishes between two looks at the
+    stopping rule; that batching is kept, the draws themselves run one after another on the GPU."""
+    import sys
+
+    import torch
+
+    from . import inference as _inf
+
+    centered_t = _as_centered_tensor(centered_matrix)
+    K, n = int(centered_t.shape[0]), int(centered_t.shape[1])
+    if K == 0 or n == 0:
+        raise ValueError("`centered_matrix` must be non-empty")
+    floor_ratio = float(max(precision_floor_ratio, 0.0))
+    template_t, fitted_scores_t, positive_t = _inf.fit_budget_null_residual_template_device(
+        centered_t, lower_bound_z=lower_bound_z, prior_df=prior_df, min_effect=min_effect,
+        precision_floor_ratio=floor_ratio)
+    fit_tracks = torch.stack([fitted_scores_t, positive_t])
+    if not bool(torch.isfinite(fit_tracks).all()):
+        raise ValueError("EB scoring produced non-finite values")
+    if observed_scores is None:
+        observed_t = fitted_scores_t
+    else:
+        observed_t = _as_score_tensor(observed_scores)
+        if observed_t.dim() != 1 or int(observed_t.shape[0]) != n:
+            raise ValueError("`observed_scores` must have the same number of loci as `centered_matrix`")
+
+    reference_t = _inf.score_centered_wls_device(template_t, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df),
+                                                 min_effect=min_effect, spatial_window=31,
+                                                 precision_floor_ratio=floor_ratio)[0]
+    if not bool(torch.isfinite(reference_t).all()):
+        raise ValueError("EB scoring produced non-finite values")
+    null_center, null_scale, support = _null_reference_of(sort_device(reference_t))
+    if not np.isfinite(null_center) or not np.isfinite(null_scale):
+        raise ValueError("Budget null fit produced non-finite values")
+    soft_scale = float(max(null_scale, 1.0e-6))
+    null_threshold = float(null_center + (2.0 * null_scale))
+
+    bandwidth = _resolve_budget_bootstrap_bandwidth(n, dependence_lag_hint)
+    taps = _build_budget_bootstrap_kernel(bandwidth)
+    max_draws = int(max(1, num_null_draws))
+    min_draws = int(min(max_draws, max(4, 8 if min_null_draws is None else min_null_draws)))
+    look_every = int(max(1, min(max(1, int(num_processes)), max_draws)))  # the reference's pool batch
+    draw_min_effect = None if min_effect is None else float(max(min_effect, 0.0))
+    mass, units, fraction, tail = _Running(), _Running(), _Running(), _Running()
+    weights_t = torch.empty_like(template_t)
+    product_t = torch.empty_like(template_t)
+    staging = torch.empty((2, n), dtype=torch.float64).pin_memory()
+    copies = [torch.cuda.Event(), torch.cuda.Event()]
+    for first in range(0, max_draws, look_every):
+        for draw in range(first, min(max_draws, first + look_every)):
+            rng = np.random.default_rng(int(random_seed) + (104729 * (draw + 1)))
+            for row in range(K):  # the generator's stream runs through the rows in order; uploads overlap the next row
+                slot = row & 1
+                if row >= 2:
+                    copies[slot].synchronize()
+                staging[slot].numpy()[:] = _generate_dependent_wild_weights(n, taps, rng)
+                weights_t[row].copy_(staging[slot], non_blocking=True)
+                copies[slot].record()
+            d_mass, d_units, d_fraction, d_tail = _inf.compute_budget_null_draw_device(
+                template_t, weights_t, lower_bound_z, prior_df, draw_min_effect, floor_ratio, null_center, soft_scale,
+                null_threshold, work_t=product_t)
+            torch.cuda.current_stream().synchronize()
+            mass.add(d_mass)
+            units.add(d_units)
+            fraction.add(d_fraction)
+            tail.add(d_tail)
+            if progress_label:
+                sys.stderr.write(f"\r{progress_label}: {units.count}/{max_draws}")
+                sys.stderr.flush()
+        if _stable_enough(units, min_draws, stability_abs_tol, stability_rel_tol):
+            break
+    if progress_label:
+        sys.stderr.write("\n")
+        sys.stderr.flush()
+    draws_used = units.count
+    return {
+        "observed_scores": observed_t,
+        "null_center": float(null_center),
+        "null_scale": float(null_scale),
+        "null_positive_mass": float(mass.mean),
+        "null_positive_units": float(units.mean),
+        "null_positive_fraction": float(fraction.mean),
+        "null_positive_units_sd": float(units.sd()),
+        "null_positive_units_stderr": float(units.stderr()),
+        "null_threshold": float(null_threshold),
+        "null_tail_occupancy": float(tail.mean),
+        "null_tail_occupancy_sd": float(tail.sd()),
+        "null_tail_occupancy_stderr": float(tail.stderr()),
+        "negative_support_size": int(support),
+        "negative_fraction": float(support / max(n, 1)),
+        "num_null_draws": int(draws_used),
+        "max_null_draws": int(max_draws),
+        "adaptive_stop": bool(draws_used < max_draws),
+        "wild_bandwidth": int(bandwidth),
+        "wild_process": "bartlett_multiplier",
+        "null_method": "dependent_wild_residual_bootstrap",
+        "null_reference_mean_positive_consensus": float(_numpy_mean(positive_t)),
+        "null_reference_max_positive_consensus": float(positive_t.max().item()),
+    }
+
+
+def estimate_budget_nonnull_fraction_from_wild_bootstrap_null(centered_matrix, observed_scores=None, lower_bound_z: float = 1.0,
+                                                              prior_df: float = 5.0, min_effect=None,
+                                                              precision_floor_ratio: float = 0.01,
+                                                              dependence_lag_hint: Optional[int] = None,
+                                                              num_null_draws: int = 25, random_seed: int = 0,
+                                                              progress_label: Optional[str] = None, num_processes: int = 1,
+                                                              return_details: bool = False):
+    """Conservative enriched fraction of a chromosome from its centred K x n matrix (rocco/inference.py:988-1148): the
+    tail occupancy of the observed scores above the fitted null's threshold (centre + 2 scale) minus the average of the
+    same statistic over dependent-wild-bootstrap draws of the residual template, clipped to [0, 1].
+    `centered_matrix`: NumPy array or CUDA tensor (float64 or float32), [K, n] or [n]; `observed_scores`: NumPy array or
+    float64 CUDA tensor.  Same return value and details keys as the reference."""
+    import torch
+
+    centered_t = _as_centered_tensor(centered_matrix)
+    n = int(centered_t.shape[1])
+    if n <= 0:
+        raise ValueError("`centered_matrix` must contain at least one locus")
+    null = _estimate_wild_bootstrap_score_null(
+        centered_t, lower_bound_z=lower_bound_z, prior_df=prior_df, min_effect=min_effect,
+        precision_floor_ratio=precision_floor_ratio, observed_scores=observed_scores,
+        dependence_lag_hint=dependence_lag_hint, num_null_draws=num_null_draws, random_seed=random_seed,
+        progress_label=progress_label, num_processes=num_processes)
+    s_t = null["observed_scores"]
+    null_center, null_scale = float(null["null_center"]), float(null["null_scale"])
+    soft_scale = float(max(null_scale, 1.0e-6))
+    null_threshold = float(null["null_threshold"])
+    lib, solver, stream = _lib_solver_stream(s_t)
+    obs_mass, obs_units, obs_pos_fraction, obs_tail = _draw_stats(s_t, null_center, soft_scale, null_threshold)
+    _, _, (n_neg,) = sorted_probe(sort_device(s_t), thresholds=(0.0,), shift=null_center)  # residual < 0
+    obs_neg_fraction = float(n_neg) / float(n)
+    soft_t = torch.empty_like(s_t)
+    _native.check(lib.rocco_hip_soft_counts_f64(solver.handle, s_t.data_ptr(), float(null_center), soft_scale, soft_t.data_ptr(),
+                                                n, stream), "rocco_hip_soft_counts_f64")
+    ess_max_lag = _resolve_budget_ess_max_lag(n, dependence_lag_hint)
+    effective_total, tau_int, ess_lags_used = _estimate_effective_sample_size_device(soft_t, ess_max_lag)
+    nonnull_fraction = float(np.clip(obs_tail - float(null["null_tail_occupancy"]), 0.0, 1.0))
+    if not (np.isfinite(nonnull_fraction) and np.isfinite(effective_total) and np.isfinite(tau_int)):
+        raise ValueError("Budget initialization produced non-finite values")
+    details: Dict[str, Any] = {
+        "observed_positive_fraction": float(obs_pos_fraction),
+        "observed_negative_fraction": float(obs_neg_fraction),
+        "null_positive_fraction": float(null["null_positive_fraction"]),
+        "observed_excess_mass": float(obs_mass),
+        "null_excess_mass": float(null["null_positive_mass"]),
+        "observed_excess_units": float(obs_units),
+        "null_excess_units": float(null["null_positive_units"]),
+        "null_excess_units_sd": float(null["null_positive_units_sd"]),
+        "null_excess_units_stderr": float(null["null_positive_units_stderr"]),
+        "null_threshold": float(null_threshold),
+        "observed_tail_occupancy": float(obs_tail),
+        "null_tail_occupancy": float(null["null_tail_occupancy"]),
+        "null_tail_occupancy_sd": float(null["null_tail_occupancy_sd"]),
+        "null_tail_occupancy_stderr": float(null["null_tail_occupancy_stderr"]),
+        "null_center": float(null_center),
+        "null_scale": float(null_scale),
+        "nonnull_fraction": float(nonnull_fraction),
+        "effective_count": float(nonnull_fraction * effective_total),
+        "effective_total_count": float(effective_total),
+        "autocorrelation_time": float(tau_int),
+        "ess_max_lag": float(ess_max_lag),
+        "ess_lags_used": float(ess_lags_used),
+        "num_loci": float(n),
+        "negative_support_size": float(null["negative_support_size"]),
+        "negative_fraction": float(null["negative_fraction"]),
+        "num_null_draws": float(null["num_null_draws"]),
+        "max_null_draws": float(null["max_null_draws"]),
+        "adaptive_stop": bool(null["adaptive_stop"]),
+        "wild_bandwidth": float(null["wild_bandwidth"]),
+        "wild_process": str(null["wild_process"]),
+        "null_method": str(null["null_method"]),
+        "null_reference_mean_positive_consensus": float(null["null_reference_mean_positive_consensus"]),
+        "null_reference_max_positive_consensus": float(null["null_reference_max_positive_consensus"]),
+    }
+    if return_details:
+        return nonnull_fraction, details
+    return nonnull_fraction
+
+
+def estimate_budget_nonnull_fraction_from_empirical_null(centered_matrix, observed_scores=None, lower_bound_z: float = 1.0,
+                                                         prior_df: float = 5.0, min_effect=None,
+                                                         precision_floor_ratio: float = 0.01,
+                                                         dependence_lag_hint: Optional[int] = None, num_null_draws: int = 25,
+                                                         random_seed: int = 0, progress_label: Optional[str] = None,
+                                                         num_processes: int = 1, return_details: bool = False):
+    """The reference's older name of the estimator above (rocco/inference.py:1424-1452)."""
+    return estimate_budget_nonnull_fraction_from_wild_bootstrap_null(
+        centered_matrix, observed_scores=observed_scores, lower_bound_z=lower_bound_z, prior_df=prior_df,
+        min_effect=min_effect, precision_floor_ratio=precision_floor_ratio, dependence_lag_hint=dependence_lag_hint,
+        num_null_draws=num_null_draws, random_seed=random_seed, progress_label=progress_label,
+        num_processes=num_processes, return_details=return_details)
+
+
+def estimate_budget_nonnull_fraction_from_resampled_null(centered_matrix, observed_scores=None, lower_bound_z: float = 1.0,
+                                                         prior_df: float = 5.0, min_effect=None,
+                                                         precision_floor_ratio: float = 0.01, num_null_draws: int = 25,
+                                                         mean_block_length: Optional[int] = None,
+                                                         null_threshold_scale: float = 1.0, random_seed: int = 0,
+                                                         progress_label: Optional[str] = None, num_processes: int = 1,
+                                                         return_details: bool = False):
+    """Another older name (rocco/inference.py:1455-1485): `mean_block_length` is the dependence hint, the threshold
+    scale is ignored there too."""
+    return estimate_budget_nonnull_fraction_from_wild_bootstrap_null(
+        centered_matrix, observed_scores=observed_scores, lower_bound_z=lower_bound_z, prior_df=prior_df,
+        min_effect=min_effect, precision_floor_ratio=precision_floor_ratio, dependence_lag_hint=mean_block_length,
+        num_null_draws=num_null_draws, random_seed=random_seed, progress_label=progress_label,
+        num_processes=num_processes, return_details=return_details)
 
 
 # --------------------------------------------------------------------------------------------------------------

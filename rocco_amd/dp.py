@@ -53,9 +53,38 @@ def _is_tensor(x) -> bool:
     return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
 
 
+class ResidentArray(np.ndarray):
+    """A read-only host array that remembers the CUDA tensor it was copied from.
+
+    The reference's chromosome cache holds NumPy arrays (rocco/rocco.py:1087-1098) and everything downstream indexes,
+    prints and compares them as such; the solve wants the same numbers in HBM.  An entry made by `host_with_device`
+    serves both: NumPy sees an ordinary float64 array, `_to_device_f64` / the budget estimators take the tensor and
+    skip the upload.  Any array derived from it (a slice, a copy, arithmetic) is a plain ndarray again."""
+
+    device_tensor = None
+
+    def __array_finalize__(self, obj):
+        self.device_tensor = None  # only the array made by host_with_device itself keeps its twin
+
+
+def host_with_device(t) -> "ResidentArray":
+    """Host copy of a CUDA tensor as a `ResidentArray` (read-only: the tensor is the other half of the pair)."""
+    host = t.detach().cpu().numpy().view(ResidentArray)
+    host.device_tensor = t
+    host.flags.writeable = False
+    return host
+
+
+def _resident_tensor(x):
+    """The CUDA twin of a `ResidentArray`, else None."""
+    return getattr(x, "device_tensor", None) if isinstance(x, ResidentArray) else None
+
+
 def _to_device_f64(x, device=None, name="scores"):
     """1-D float64 contiguous CUDA tensor from NumPy / list / tensor input."""
     torch = _torch()
+    if _resident_tensor(x) is not None:
+        x = _resident_tensor(x)
     if _is_tensor(x):
         t = x
         if t.ndim != 1:

@@ -275,21 +275,41 @@ def score_loci_wls_device(counts_t, lower_bound_z: float = 1.0, prior_df: float 
 
 def score_loci_wls(chrom_matrix, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
                    precision_floor_ratio: float = 0.01, low_memory: bool = False, return_details: bool = False,
-                   input_scale: str = "counts"):
+                   input_scale: str = "counts", resident: bool = False):
     """rocco/inference.py:302-379 with the same signature, NumPy in and out (``input_scale``: see
-    ``score_loci_wls_device``)."""
+    ``score_loci_wls_device``).  ``chrom_matrix`` may also be a CUDA tensor.  ``resident=True`` (not in the
+    reference; what the chromosome cache asks for) leaves every track and the centred matrix in HBM and returns CUDA
+    tensors -- the centred matrix as float32 under ``low_memory``, as the reference stores it."""
     import torch
 
     _native.load()
-    matrix = np.ascontiguousarray(chrom_matrix, dtype=np.float64)
-    if matrix.ndim != 2:
-        raise ValueError("`chrom_matrix` must be two-dimensional")
-    if matrix.shape[0] == 0 or matrix.shape[1] == 0:
-        raise ValueError("`chrom_matrix` must be non-empty")
-    counts_t = _dp._to_device_f64(matrix.reshape(-1)).reshape(matrix.shape)
+    if _dp._is_tensor(chrom_matrix):
+        if chrom_matrix.ndim != 2:
+            raise ValueError("`chrom_matrix` must be two-dimensional")
+        if chrom_matrix.shape[0] == 0 or chrom_matrix.shape[1] == 0:
+            raise ValueError("`chrom_matrix` must be non-empty")
+        counts_t = chrom_matrix if chrom_matrix.is_cuda else chrom_matrix.to(f"cuda:{_dp._device_index()}")
+        owned = counts_t.dtype != torch.float64 or not counts_t.is_contiguous() or counts_t is not chrom_matrix
+        counts_t = counts_t.to(torch.float64).contiguous()
+        if not bool(torch.isfinite(counts_t).all()):
+            raise ValueError("`chrom_matrix` contains non-finite values")
+    else:
+        matrix = np.ascontiguousarray(chrom_matrix, dtype=np.float64)
+        if np.any(~np.isfinite(matrix)):
+            raise ValueError("`chrom_matrix` contains non-finite values")  # rocco/inference.py:45-46
+        if matrix.ndim != 2:
+            raise ValueError("`chrom_matrix` must be two-dimensional")
+        if matrix.shape[0] == 0 or matrix.shape[1] == 0:
+            raise ValueError("`chrom_matrix` must be non-empty")
+        counts_t = _dp._to_device_f64(matrix.reshape(-1)).reshape(matrix.shape)
+        owned = True
     scores_t, details_t = score_loci_wls_device(counts_t, lower_bound_z=lower_bound_z, prior_df=prior_df,
                                                 min_effect=min_effect, precision_floor_ratio=precision_floor_ratio,
-                                                overwrite_input=True, input_scale=input_scale)
+                                                overwrite_input=owned, input_scale=input_scale)
+    if resident:
+        if low_memory:
+            details_t["centered_matrix"] = details_t["centered_matrix"].to(torch.float32)
+        return (scores_t, details_t) if return_details else scores_t
     scores = scores_t.cpu().numpy()
     if not return_details:
         return scores

@@ -28,6 +28,10 @@ import numpy as np
 from . import _native
 from . import dp as _dp
 
+from .budget import (estimate_budget_nonnull_fraction_from_score_track,  # noqa: E402,F401  (looked up by name in
+                     estimate_budget_nonnull_fraction_from_wild_bootstrap_null)  # _build_chrom_cache, as rocco/rocco.py:23-31)
+from .inference import score_loci_wls  # noqa: E402,F401
+
 logger = logging.getLogger(__name__)
 
 Record = Tuple[str, int, int]
@@ -444,6 +448,211 @@ def _write_narrowpeak_summit_offsets(peak_file: str, chrom_cache: dict, output_f
         for (chrom, start, end), summit_offset in zip(records, offsets):
             handle.write(f"{chrom}_{start}_{end}\t{summit_offset}\n")
     return output_file
+
+
+# --------------------------------------------------------------------------------------------
+# chromosome cache: matrix -> scores, budget estimate, switch cost (rocco/rocco.py:933-1110)
+# --------------------------------------------------------------------------------------------
+
+def generate_chrom_matrix(chromosome, signal_inputs, *_args, **_kwargs):
+    """Where the reference decodes BAM / bigWig files into (locus starts, K x n matrix) per chromosome
+    (rocco/readtracks.py:521-633).  File decoding stays with the reference's readers (out of
+    scope); here `signal_inputs` is a mapping ``{chromosome: (intervals, matrix)}`` of matrices already in memory
+    (NumPy arrays or CUDA tensors) and a chromosome without an entry gives ``(None, None)`` as the reference's reader
+    does for one without data.  `_build_chrom_cache` looks this name up in the module at call time, so an integrator
+    (or a test, as the reference's own tests do) can put the real reader in its place."""
+    if not hasattr(signal_inputs, "get"):
+        raise RuntimeError("rocco_amd does not decode BAM / bigWig files: pass {chromosome: (intervals, matrix)} or "
+                           "replace rocco_amd.rocco.generate_chrom_matrix with the reference's reader")
+    entry = signal_inputs.get(chromosome)
+    return (None, None) if entry is None else (entry[0], entry[1])
+
+
+def _resolve_parallel_process_count(item_count: int, thread_limit: int) -> int:
+    """rocco/rocco.py:792-806: how many workers the reference would fork -- at most 4, the items, the cores.  Nothing
+    is forked here; the number only sets how many bootstrap draws pass between two looks at the stopping rule
+    (rocco/inference.py:804-805, 889-937), which decides how many draws a chromosome's budget estimate uses."""
+    import multiprocessing as mp
+
+    cores = max(1, os.cpu_count() or 1) if int(thread_limit) <= 0 else max(1, int(thread_limit))
+    if int(item_count) <= 1 or cores <= 1 or "fork" not in mp.get_all_start_methods():
+        return 1
+    return int(min(int(item_count), cores, 4))
+
+
+def _all_finite(values) -> bool:
+    import torch
+
+    if _dp._is_tensor(values):
+        return bool(torch.isfinite(values).all())
+    return bool(np.all(np.isfinite(values)))
+
+
+def _host_scores(values):
+    """The cache's score array: NumPy as in the reference, with its HBM twin attached when there is one."""
+    if _dp._is_tensor(values):
+        return _dp.host_with_device(values) if values.is_cuda else values.numpy()
+    return np.asarray(values, dtype=np.float64)
+
+
+def _matrix_to_device(chrom_matrix):
+    import torch
+
+    if _dp._is_tensor(chrom_matrix):
+        return chrom_matrix if chrom_matrix.is_cuda else chrom_matrix.to(f"cuda:{_dp._device_index()}")
+    arr = np.asarray(chrom_matrix)
+    if arr.dtype != np.float32:
+        arr = np.asarray(arr, dtype=np.float64)
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(f"cuda:{_dp._device_index()}")
+
+
+def _median_scores_resident(chrom_matrix, method="quantile", quantile=0.50, power=1.0):
+    """The cache's bigWig scoring call (rocco/rocco.py:983-991) with the result left in HBM."""
+    matrix_t = _matrix_to_device(chrom_matrix)
+    if matrix_t.ndim != 2:
+        raise ValueError("`chrom_matrix` must be a 2D array.")
+    if matrix_t.shape[0] == 1:
+        import torch
+
+        return matrix_t[0].to(torch.float64).contiguous()  # one track: the row itself (rocco/rocco.py:254-255)
+    return score_central_tendency_chrom_device(matrix_t)
+
+
+def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> dict:
+    """rocco/rocco.py:933-1110 for matrices in memory: per chromosome the scores (bigWig tracks: column median; count
+    matrices: the WLS score), the data-driven budget estimate with its metadata, the switch cost, and the narrowPeak
+    summit track when asked for.  Same keys as the reference's cache; "scores" is a NumPy array that keeps its copy in
+    HBM (`dp.ResidentArray`), so the solve does not upload it again.  `generate_chrom_matrix`, `score_loci_wls` and the
+    two budget estimators are taken from this module's namespace when called, as in the reference."""
+    from . import budget as _budget
+
+    this = globals()
+    chrom_cache = {}
+    low_memory = bool(args.get("low_memory", False))
+    budget_null_processes = 1 if low_memory else _resolve_parallel_process_count(int(args["budget_null_draws"]),
+                                                                                 int(args["threads"]))
+    null_processes = min(int(args["budget_null_draws"]), int(budget_null_processes))
+    for chrom_ in chroms_to_process:
+        logger.info("Generating chromosome matrix: %s", chrom_)
+        chrom_intervals, chrom_matrix = this["generate_chrom_matrix"](
+            chrom_, signal_inputs, args.get("chrom_sizes_file"), args.get("step"),
+            round_digits=args.get("round_digits"), effective_genome_size=args.get("effective_genome_size"),
+            norm_method=args.get("norm_method"), min_mapping_score=args.get("min_mapping_score"),
+            flag_include=args.get("flag_include"), flag_exclude=args.get("flag_exclude"),
+            extend_reads=args.get("extend_reads"), center_reads=args.get("center_reads"),
+            ignore_for_norm=args.get("ignore_for_norm"), scale_factor=args.get("scale_factor"),
+            num_processors=args.get("threads"), low_memory=low_memory)
+        if chrom_intervals is None or chrom_matrix is None:
+            logger.warning("Skipping chromosome %s... no data found.", chrom_)
+            continue
+        logger.info("Chromosome %s matrix: %s", chrom_, tuple(chrom_matrix.shape))
+        if not _all_finite(chrom_matrix):
+            raise ValueError(f"{chrom_} matrix contains non-finite values")
+        if args["input_track_type"] == "bigwig":
+            if chrom_matrix.shape[0] > 1:
+                logger.warning("Multiple bigwig tracks detected for %s: aggregated by the column-wise median, not WLS.", chrom_)
+            chrom_scores = _median_scores_resident(chrom_matrix, method="quantile", quantile=0.50, power=1.0)
+            if not _all_finite(chrom_scores):
+                raise ValueError(f"{chrom_} direct scores contain non-finite values")
+            score_details = {"mean": chrom_scores}
+            chrom_scores = _host_scores(chrom_scores)
+            budget_fraction_hat, budget_rate_meta = this["estimate_budget_nonnull_fraction_from_score_track"](
+                chrom_scores, num_null_draws=args["budget_null_draws"], progress_label=f"Budget null {chrom_}",
+                num_processes=null_processes, return_details=True)
+        else:
+            chrom_scores, score_details = this["score_loci_wls"](
+                _matrix_to_device(chrom_matrix), lower_bound_z=args["score_lower_bound_z"],
+                prior_df=args["score_prior_df"], min_effect=args.get("score_min_effect"),
+                precision_floor_ratio=args["score_precision_floor_ratio"], low_memory=low_memory, return_details=True,
+                resident=True)
+            if not _all_finite(chrom_scores):
+                raise ValueError(f"{chrom_} scores contain non-finite values")
+            centered_matrix = score_details.pop("centered_matrix")
+            if not _all_finite(centered_matrix):
+                raise ValueError(f"{chrom_} centered matrix contains non-finite values")
+            chrom_scores = _host_scores(chrom_scores)
+            budget_fraction_hat, budget_rate_meta = this["estimate_budget_nonnull_fraction_from_wild_bootstrap_null"](
+                centered_matrix, observed_scores=chrom_scores, lower_bound_z=args["score_lower_bound_z"],
+                prior_df=args["score_prior_df"], min_effect=args.get("score_min_effect"),
+                precision_floor_ratio=args["score_precision_floor_ratio"],
+                dependence_lag_hint=max(25, int(score_details.get("local_baseline_window", 101))),
+                num_null_draws=args["budget_null_draws"], progress_label=f"Budget null {chrom_}",
+                num_processes=null_processes, return_details=True)
+            del centered_matrix
+        del chrom_matrix
+        if not np.isfinite(budget_fraction_hat):
+            raise ValueError(f"{chrom_} budget estimate is not finite")
+        n_loci = int(chrom_scores.shape[0])
+        budget_total_count_hat = float(np.clip(budget_rate_meta.get("effective_total_count", n_loci), 1.0, n_loci))
+        budget_count_hat = float(np.clip(budget_fraction_hat * budget_total_count_hat, 0.0, budget_total_count_hat))
+        logger.info("%s raw budget estimate: %s", chrom_, budget_rate_meta)
+        chrom_gamma, gamma_meta = _budget._resolve_chrom_gamma(chrom_, args, chrom_scores, budget_rate_meta)
+        chrom_cache[chrom_] = {
+            "intervals": chrom_intervals,
+            "scores": chrom_scores,
+            "effect_mean": score_details.get("mean", chrom_scores),
+            "gamma": chrom_gamma,
+            "gamma_meta": gamma_meta,
+            "budget_count_hat": float(budget_count_hat),
+            "budget_fraction_hat": float(budget_fraction_hat),
+            "budget_rate_meta": budget_rate_meta,
+            "total_count": float(budget_total_count_hat),
+            "num_loci": n_loci,
+        }
+    if args.get("narrowPeak", False) and args["input_track_type"] == "bam":
+        for chrom_, chrom_data in chrom_cache.items():
+            effect = chrom_data["effect_mean"]
+            effect = effect.cpu().numpy() if _dp._is_tensor(effect) else np.asarray(effect, dtype=np.float64)
+            chrom_data["summit_track_file"] = _cpy_narrowpeak_summit_track(chrom_, chrom_data["intervals"], effect)
+    for chrom_data in chrom_cache.values():
+        chrom_data.pop("effect_mean", None)
+    return chrom_cache
+
+
+def _resolve_budgets(chrom_cache: dict, args: dict):
+    """rocco/rocco.py:1113-1143 (the pooling itself: rocco_amd/budget.py)."""
+    from . import budget as _budget
+
+    return _budget._resolve_budgets(chrom_cache, args)
+
+
+def _solve_cached_chromosomes(chrom_cache: dict, chrom_budgets: dict, args: dict, run_id: str) -> list:
+    """rocco/rocco.py:1146-1196 with the reference's arguments and return value (the per-chromosome BED files, in cache
+    order, written to the working directory): the chromosomes share the device passes of one calibration instead of a
+    pool of <= 4 forked workers."""
+    for chrom_, chrom_data in chrom_cache.items():
+        logger.info("%s: budget=%s gamma=%s", chrom_, round(float(chrom_budgets[chrom_]), 6),
+                    round(float(chrom_data["gamma"]), 6))
+    solved = solve_cached_chromosomes(chrom_cache, chrom_budgets, selection_penalty=args["selection_penalty"],
+                                      min_length_bp=args["min_length_bp"], run_id=run_id, write_files=True)
+    return [out for _chrom, _objective, _details, out in solved]
+
+
+def run_chromosomes(chroms_to_process: list, signal_inputs, args: dict, run_id: Optional[str] = None) -> str:
+    """What the reference's `main` does between its argument parsing and its narrowPeak step (rocco/rocco.py:1269-1300):
+    cache -> pooled budgets -> solve -> combined BED at `args["output"]`; the per-chromosome files are removed.  Returns
+    the path of the combined BED.  (`rocco_amd.pipeline.solve_rank` is the multi-GPU form with user-given budgets.)"""
+    import uuid
+
+    run_id = str(int(uuid.uuid4().hex[:5], base=16)) if run_id is None else str(run_id)
+    this = globals()
+    chrom_cache = this["_build_chrom_cache"](chroms_to_process, signal_inputs, args)
+    chrom_budgets, _ = this["_resolve_budgets"](chrom_cache, args)
+    tmp_chrom_bed_files = this["_solve_cached_chromosomes"](chrom_cache, chrom_budgets, args, run_id)
+    final_output = combine_chrom_results(tmp_chrom_bed_files, args["output"], name_features=False)
+    for tmp_file in tmp_chrom_bed_files:
+        try:
+            os.remove(tmp_file)
+        except OSError as exc:
+            logger.info("Could not remove chromosome-specific temp. file %s\n%s", tmp_file, exc)
+    for chrom_data in chrom_cache.values():  # rocco/rocco.py:875-887
+        summit_track_file = chrom_data.pop("summit_track_file", None)
+        if summit_track_file is not None:
+            try:
+                os.remove(summit_track_file)
+            except OSError as exc:
+                logger.info("Could not remove narrowPeak summit temp. file %s\n%s", summit_track_file, exc)
+    return final_output
 
 
 # --------------------------------------------------------------------------------------------
