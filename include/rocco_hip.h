@@ -271,8 +271,9 @@ int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, c
  * buffers: centered_dev is the row-major K x n matrix of baseline-subtracted tracks; the six outputs are
  * n doubles each; *df_out / *window_out (host, may be NULL) receive the degrees of freedom and the
  * spatial window used.  Same arguments and, on finite input, the same results bit for bit.  Differences:
- * non-finite values are rejected with EINVAL (the reference drops such pairs from the trend fit);
- * spatial windows above 63 loci are rejected with EINVAL (the reference's caller always passes 31).
+ * non-finite values are rejected with EINVAL (the reference drops such pairs from the trend fit).  Any spatial
+ * window is taken (up to 63 loci the rolling sums run on LDS tiles, above that straight from memory; the
+ * reference's caller always passes 31).
  * Returns 0, ROCCO_HIP_ENOMEM (the reference's -1), EINVAL (its -2) or EHIP. */
 int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *centered_dev, size_t K, size_t n,
                                      double lower_bound_z, double prior_df, double min_effect, int use_min_effect,
@@ -284,8 +285,9 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
  * Replaces the NumPy statements of rocco/inference.py:40-47 (`_log_scale_wls_matrix`) and 330-331 (pilot
  * offset): centered_out[k][i] = log2(max(counts[k][i], 0) + pseudocount) - median_i(log2(...)[k][:]).
  * The row medians are exact order statistics (np.median: mean of the two middle values for even n); the
- * logarithm is the device's, which may differ from NumPy's by one unit in the last place (NumPy's own
- * log2 differs between its SVML and libm builds), so this row is checked to a tolerance.  centered_out_dev
+ * logarithm is CORRECTLY ROUNDED (log2_cr.h; see rocco_hip_log_scale_f64 below).  NumPy's own log2 is an SVML
+ * routine or libm's, neither correctly rounded: it is one ulp off on ~0.03 % of integer counts, and what that does
+ * downstream is measured in tests/test_gpu_score_loci_wls.py and stated in INTEGRATION.md section 5.  centered_out_dev
  * may alias counts_dev; row_offsets_out_dev (K doubles, may be NULL) receives the medians.  apply_log2 == 0
  * takes the matrix as already log-scaled (only the pilot offset is removed; bit-exact).  Non-finite
  * input -> EINVAL (the reference raises ValueError). */
@@ -362,8 +364,8 @@ int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *
  *   of the positive scores of the estimate is an order statistic of it.
  * rocco_hip_sorted_probe_f64: values at up to 8 ranks of a sorted vector, and for up to 8 thresholds t how many
  *   elements x have (x - shift) <= t and (x - shift) < t (binary search: x - shift is monotone in x).
- * rocco_hip_autocovariance_sums_f64: sums_out[k] = sum_i (x_i - mean)(x_{i+k} - mean), k = 0..max_lag (<= 1023), summed
- *   in a fixed order.  (The reference takes them from an FFT: agreement to ~1e-13 relative, not bitwise.)
+ * rocco_hip_autocovariance_sums_f64: sums_out[k] = sum_i (x_i - mean)(x_{i+k} - mean), k = 0..max_lag (< n; any number of lags,
+ *   1024 per pair of launches), summed in a fixed order.  (The reference takes them from an FFT: agreement to ~1e-13 relative, not bitwise.)
  * rocco_hip_negative_part_f64: out = scores - clip(scores, 0, None) (the residual template of the direct-score null).
  * rocco_hip_soft_counts_f64: out = clip(scores - center, 0, None) / scale (the series whose autocorrelation time is taken). */
 int rocco_hip_sort_f64(rocco_hip_solver *solver, const double *x_dev, size_t n, double *sorted_out_dev, void *stream);

@@ -493,15 +493,15 @@ int rocco_hip_sorted_probe_f64(rocco_hip_solver *solver, const double *sorted_de
 int rocco_hip_autocovariance_sums_f64(rocco_hip_solver *solver, const double *x_dev, size_t n, double mean, int max_lag,
                                       double *sums_out, void *stream)
 {
-    if (solver == nullptr || x_dev == nullptr || n == 0 || sums_out == nullptr || max_lag < 0 || max_lag > 1023) {
+    if (solver == nullptr || x_dev == nullptr || n == 0 || sums_out == nullptr || max_lag < 0 || (size_t)max_lag >= n) {
         return ROCCO_HIP_EINVAL;
     }
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
     int rc = solver->dev_misc.reserve(autocov_scratch_bytes(n, max_lag));
     if (rc != ROCCO_HIP_OK) return rc;
-    rc = solver->dev_results.reserve(1024 * sizeof(double));
+    rc = solver->dev_results.reserve(((size_t)max_lag + 1024) * sizeof(double));
     if (rc != ROCCO_HIP_OK) return rc;
-    rc = solver->host_back.reserve(1024 * sizeof(double));
+    rc = solver->host_back.reserve(((size_t)max_lag + 1024) * sizeof(double));
     if (rc != ROCCO_HIP_OK) return rc;
     rc = launch_autocov(x_dev, n, mean, max_lag, (double *)solver->dev_results.ptr, solver->dev_misc.ptr, (hipStream_t)stream);
     if (rc != ROCCO_HIP_OK) return rc;

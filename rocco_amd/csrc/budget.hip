@@ -641,7 +641,7 @@ public:
         }
         // a round on a small level costs its launch latency whatever it evaluates (one tile and 8 penalties per
         // workgroup: up to 256 of them run at once), a pass over a long one its evaluations
-        static const long long small = std::getenv("ROCCO_HIP_POINTS_SMALL") ? std::atoll(std::getenv("ROCCO_HIP_POINTS_SMALL")) : 256000;
+        const long long small = std::getenv("ROCCO_HIP_POINTS_SMALL") ? std::atoll(std::getenv("ROCCO_HIP_POINTS_SMALL")) : 256000;
         int pts = (m > 8000000) ? 3 : ((m > 2000000) ? 4 : ((m > 4 * small) ? 8 : ((m > 2 * small) ? 16 : ((m > small) ? 32 : 64))));
         if (!deep) {
             pts = std::min(pts, 8);
@@ -772,7 +772,7 @@ public:
             if (r.pilot) {
                 // every stride-th tile of the caller's array, each as a chain of its own; nothing is kept
                 const long long all_tiles = (long long)((p.n + kLeanTile - 1) / kLeanTile);
-                static const long long pilot_tiles = std::getenv("ROCCO_HIP_PILOT_TILES") ? std::max(2, std::atoi(std::getenv("ROCCO_HIP_PILOT_TILES"))) : 16;
+                const long long pilot_tiles = std::getenv("ROCCO_HIP_PILOT_TILES") ? std::max(2, std::atoi(std::getenv("ROCCO_HIP_PILOT_TILES"))) : 16;
                 const int stride = (int)std::max(4LL, all_tiles / pilot_tiles);  // about 16 tiles per chromosome
                 const int nt = (int)((all_tiles + stride - 1) / stride);
                 long long sampled = 0;
@@ -940,7 +940,7 @@ public:
         // Penalties per workgroup: a workgroup's time grows with what it carries (about 6 us + 4 us per penalty), a
         // round's with the number of waves of workgroups the device needs (512 at a time).  While the whole round fits
         // at once, carry less per workgroup.
-        static const bool adapt = std::getenv("ROCCO_HIP_LEAN_BATCH") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_BATCH")) != 0;
+        const bool adapt = std::getenv("ROCCO_HIP_LEAN_BATCH") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_BATCH")) != 0;
         auto rebatch = [](std::vector<LeanTask> &ts, int full, int &total_units) {
             for (int b = 2; b < full; b *= 2) {
                 long long u = 0;
@@ -1016,7 +1016,8 @@ public:
         unsigned *error = (unsigned *)(look + 128);
         LeanResult *results_host = (LeanResult *)solver_->host_lean_back.ptr;
         unsigned *error_host = (unsigned *)((char *)solver_->host_lean_back.ptr + (size_t)results * sizeof(LeanResult));
-        *error_host = 0u;
+        error_host[0] = 0u;
+        error_host[1] = 0u;  // second slot: the word of a compaction launched BEHIND the finish kernel
         if (!pre.empty()) {
             if ((rc = launch_lean_compact((const LeanCompactTask *)d, (int)pre.size(), pre_blocks, error, stream_)) != ROCCO_HIP_OK) return rc;
         }
@@ -1052,7 +1053,9 @@ public:
             // (rare since levels are adopted: a final compaction behind the finish kernel reports through a copy)
             if ((rc = launch_lean_compact((const LeanCompactTask *)(d + b_pre + b_tasks + b_points), (int)post.size(), post_blocks,
                                           error, stream_)) != ROCCO_HIP_OK) return rc;
-            ROCCO_HIP_TRY(hipMemcpyAsync(error_host, error, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+            // its own pinned slot: the finish kernel has already written the evaluation's word to slot 0 (and cleared the
+            // device word), and a spin-limit failure recorded there must survive this copy
+            ROCCO_HIP_TRY(hipMemcpyAsync(error_host + 1, error, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
             ROCCO_HIP_TRY(hipMemsetAsync(error, 0, sizeof(unsigned), stream_));
         }
         lean_result_count_ = results;
@@ -1070,7 +1073,8 @@ public:
             return ROCCO_HIP_OK;
         }
         const LeanResult *res = (const LeanResult *)solver_->host_lean_back.ptr;
-        const unsigned error = *(const unsigned *)((const char *)solver_->host_lean_back.ptr + (size_t)lean_result_count_ * sizeof(LeanResult));
+        const unsigned *error_words = (const unsigned *)((const char *)solver_->host_lean_back.ptr + (size_t)lean_result_count_ * sizeof(LeanResult));
+        const unsigned error = error_words[0] | error_words[1];
         if (error & 1u) {
             solver_->lean_look_dirty = 1;  // tiles that gave up left granules behind
             set_last_error("lean evaluation: a tile waited for its predecessor beyond the spin limit");

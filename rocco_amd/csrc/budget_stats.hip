@@ -72,23 +72,33 @@ __global__ __launch_bounds__(64) void sorted_probe_kernel(const double *__restri
 constexpr int kSeg = 4096;       // loci per workgroup
 constexpr int kMaxLag = 1023;    // lags 0..kMaxLag
 
-// partial[(block) * (L + 1) + k] = sum over the block's loci i (in order) of c_i * c_{i+k}, c = x - mean, i + k < n
-__global__ __launch_bounds__(256) void autocov_partial_kernel(const double *__restrict__ x, long long n, double mean, int L,
+// partial[(block) * (L + 1) + k] = sum over the block's loci i (in order) of c_i * c_{i+k0+k}, c = x - mean, i + k0 + k < n:
+// the lags k0 .. k0 + L of one launch (k0 = 0 for the first 1024 lags: both factors then come from one staged segment)
+__global__ __launch_bounds__(256) void autocov_partial_kernel(const double *__restrict__ x, long long n, double mean, int k0, int L,
                                                              double *__restrict__ partial)
 {
-    extern __shared__ double c[];  // kSeg + L values
+    extern __shared__ double c[];  // k0 == 0: kSeg + L values; else kSeg values, then kSeg + L values from k0 on
     const long long base = (long long)blockIdx.x * kSeg;
-    for (int i = threadIdx.x; i < kSeg + L; i += blockDim.x) {
+    const int first = (k0 == 0) ? (kSeg + L) : kSeg;
+    for (int i = threadIdx.x; i < first; i += blockDim.x) {
         const long long j = base + i;
         c[i] = (j < n) ? (x[j] - mean) : 0.0;
+    }
+    const double *ahead = c;
+    if (k0 != 0) {
+        for (int i = threadIdx.x; i < kSeg + L; i += blockDim.x) {
+            const long long j = base + k0 + i;
+            c[kSeg + i] = (j < n) ? (x[j] - mean) : 0.0;
+        }
+        ahead = c + kSeg;
     }
     __syncthreads();
     const long long here = (n - base < kSeg) ? (n - base) : kSeg;
     for (int k = threadIdx.x; k <= L; k += blockDim.x) {
         double acc = 0.0;
         for (int i = 0; i < here; ++i) {
-            if (base + i + k < n) {
-                acc += c[i] * c[i + k];
+            if (base + i + k0 + k < n) {
+                acc += c[i] * ahead[i + k];
             }
         }
         partial[(long long)blockIdx.x * (L + 1) + k] = acc;
@@ -169,21 +179,31 @@ int launch_sorted_probe(const double *sorted_dev, size_t n, const SortedProbe &p
 size_t autocov_scratch_bytes(size_t n, int max_lag)
 {
     const size_t blocks = (n + kSeg - 1) / kSeg;
-    return blocks * (size_t)(max_lag + 1) * sizeof(double) + 256;
+    const size_t lags = (size_t)((max_lag < kMaxLag) ? max_lag : kMaxLag) + 1;  // one chunk of lags at a time
+    return blocks * lags * sizeof(double) + 256;
 }
 
 int launch_autocov(const double *x_dev, size_t n, double mean, int max_lag, double *sums_out_dev, void *scratch_dev,
                    hipStream_t stream)
 {
-    if (n == 0 || max_lag < 0 || max_lag > kMaxLag) {
+    if (n == 0 || max_lag < 0) {
         return ROCCO_HIP_EINVAL;
     }
+    static bool lds_raised = false;  // lag chunks beyond the first stage two segments: 72 KB of LDS
+    if (!lds_raised) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(autocov_partial_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * kSeg + kMaxLag) * sizeof(double))));
+        lds_raised = true;
+    }
     const int blocks = (int)((n + kSeg - 1) / kSeg);
-    const size_t lds = (size_t)(kSeg + max_lag) * sizeof(double);
-    hipLaunchKernelGGL(autocov_partial_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, x_dev, (long long)n, mean, max_lag,
-                       (double *)scratch_dev);
-    hipLaunchKernelGGL(autocov_final_kernel, dim3((unsigned)((max_lag + 256) / 256)), dim3(256), 0, stream,
-                       (const double *)scratch_dev, blocks, max_lag, sums_out_dev);
+    for (int k0 = 0; k0 <= max_lag; k0 += kMaxLag + 1) {  // lags in chunks of 1024, one pair of launches each
+        const int L = ((max_lag - k0) < kMaxLag) ? (max_lag - k0) : kMaxLag;
+        const size_t lds = (size_t)((k0 == 0 ? kSeg : 2 * kSeg) + L) * sizeof(double);
+        hipLaunchKernelGGL(autocov_partial_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, x_dev, (long long)n, mean, k0, L,
+                           (double *)scratch_dev);
+        hipLaunchKernelGGL(autocov_final_kernel, dim3((unsigned)((L + 256) / 256)), dim3(256), 0, stream,
+                           (const double *)scratch_dev, blocks, L, sums_out_dev + k0);
+    }
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }

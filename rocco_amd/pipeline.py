@@ -183,11 +183,13 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
         with torch.cuda.device(device):
             caller_stream = torch.cuda.current_stream(device)
 
-            def work(group: int, idx: List[int], scores: list, scored, stats_h=None):
+            def work(group: int, idx: List[int], scores: list, scored, stats_h=None, stats_rows=None):
                 solver, stream = _group_resources(device.index, group)
                 with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
                     if stats_h is not None:
-                        scored.synchronize()  # the statistics are read on the host
+                        scored.synchronize()  # the statistics are read on the host ...
+                        if stats_rows is not None:  # ... so a group's rows are taken only once the copy has landed
+                            stats_h = stats_h[stats_rows]
                     else:
                         stream.wait_event(scored)
                     res = _solve_group([chroms[i] for i in idx], scores, stats_h)
@@ -211,8 +213,8 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
                     scored = torch.cuda.Event()
                     scored.record(caller_stream)
                     for g, idx in enumerate(members):
-                        stats_g = stats_all[[row[i] for i in idx]] if stats_all is not None else None
-                        futures.append(_pool.submit(work, g, idx, [by_index[i] for i in idx], scored, stats_g))
+                        rows = [row[i] for i in idx] if stats_all is not None else None
+                        futures.append(_pool.submit(work, g, idx, [by_index[i] for i in idx], scored, stats_all, rows))
                 else:
                     for g, idx in enumerate(members):
                         scores, stats_h = score_all([chroms[i] for i in idx])

@@ -333,8 +333,7 @@ def chrom_solution_records(chromosome, intervals, solution, check_gaps_intervals
         diffs = np.diff(intervals_)
         if np.any(diffs != diffs[0]):
             raise ValueError(f"Intervals must be contiguous: {set(diffs.tolist())}")
-    if n > 2 and np.any(np.diff(intervals_) <= 0):
-        raise NotImplementedError("non-increasing `intervals` are not supported by the device decode")
+    monotone = not (n > 2 and np.any(np.diff(intervals_) <= 0))
     if _dp._is_tensor(solution):
         sol_t = solution
         if not sol_t.is_cuda:
@@ -345,9 +344,17 @@ def chrom_solution_records(chromosome, intervals, solution, check_gaps_intervals
     begin_t, end_t = decode_runs_device(sol_t)
     begins = begin_t.cpu().numpy()
     ends = end_t.cpu().numpy()
+    chrom = str(chromosome)
+    if not monotone:
+        # locus starts that do not increase (only reachable with check_gaps_intervals=False or a non-positive step): a
+        # run of selected loci is then not one interval.  The reference emits (intervals[i], intervals[i + 1]) locus by
+        # locus and lets its merge sort them (rocco/rocco.py:180-190); the same here over the selected loci only.
+        loci = np.concatenate([np.arange(b, e) for b, e in zip(begins.tolist(), ends.tolist())]) if len(begins) \
+            else np.zeros(0, dtype=np.int64)
+        return _merge_bed_records([(chrom, int(intervals_[i]), int(intervals_[i + 1])) for i in loci.tolist()],
+                                  min_length_bp=min_length_bp)
     starts_bp = intervals_[begins] if len(begins) else np.zeros(0, dtype=np.int64)
     ends_bp = intervals_[ends] if len(ends) else np.zeros(0, dtype=np.int64)
-    chrom = str(chromosome)
     return [(chrom, int(s), int(e)) for s, e in zip(starts_bp, ends_bp)
             if min_length_bp is None or (int(e) - int(s)) >= int(min_length_bp)]
 

@@ -76,8 +76,13 @@ def test_pipeline_with_and_without_fused_statistics(gpu, monkeypatch):
     outs = {}
     for flag in (True, False):
         monkeypatch.setattr(pipeline, "MEDIAN_STATS", flag)
-        for groups in (1, 2):
-            res = pipeline.solve_rank(works, groups=groups)
-            outs[(flag, groups)] = [(r["selection_penalty"], r["selected_count"], r["begin"].cpu().numpy().tolist()) for r in res]
-    first = outs[(True, 1)]
+        # score_first = 1 with groups: every median in one launch, the statistics of all chromosomes in ONE pinned copy
+        # that each group slices -- only after the copy has landed (the slicing once ran ahead of it)
+        for groups, score_first in ((1, 0), (2, 0), (2, 1), (3, 1)):
+            monkeypatch.setattr(pipeline, "SCORE_FIRST", score_first)
+            for _repeat in range(3 if score_first else 1):
+                res = pipeline.solve_rank(works, groups=groups)
+                outs[(flag, groups, score_first, _repeat)] = [(r["selection_penalty"], r["selected_count"],
+                                                               r["begin"].cpu().numpy().tolist()) for r in res]
+    first = outs[(True, 1, 0, 0)]
     assert all(v == first for v in outs.values())
