@@ -147,17 +147,26 @@ def rehearse(args, rank, world):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    ranks_seen = 1
+    # after the timed region every rank checks its shortest chromosome (here: that the gathered table holds exactly the
+    # rows it fabricated for it; the real run checks the solve against the oracle as well) and the verdicts are summed
+    ok = 1.0
+    if mine:
+        idx = min(mine, key=lambda i: (sizes[i], i))
+        m = 3 + idx % 5
+        want = np.stack([np.arange(m) * 1000 + idx, np.arange(m) * 1000 + idx + 50], axis=1).astype(np.int64)
+        ok = float(idx in merged and np.array_equal(np.asarray(merged[idx]), want))
+    ranks_seen, parity_ranks_ok = 1, int(ok)
     if world > 1:
-        t = torch.tensor([elapsed, 1.0], dtype=torch.float64)
+        t = torch.tensor([elapsed, 1.0, ok], dtype=torch.float64)
         dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
-        elapsed, ranks_seen = float(t[0]), int(round(float(t[1])))
+        dist.all_reduce(t[1:3], op=dist.ReduceOp.SUM)
+        elapsed, ranks_seen, parity_ranks_ok = float(t[0]), int(round(float(t[1]))), int(round(float(t[2])))
     if rank == 0:
         total = int(sum(sizes))
         print(json.dumps({
             "metric": "REHEARSAL (no device work): loci/sec to converged solve", "value": total / (elapsed / max(1, args.steps)),
-            "unit": "loci/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "unit": "loci/s", "n_gpus": world, "ranks_seen": ranks_seen, "parity_ranks_ok": parity_ranks_ok,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "fabricated", "rehearsal": True,
             "config": {"workload": f"{len(genome)} chromosomes, {total} loci", "parallelism": f"chromosome-sharded x{world} (LPT)"},
@@ -268,12 +277,37 @@ def main():
         res, merged = one_step(median_events if rank == 0 else None)
     sync_all()
     elapsed = time.perf_counter() - t0
-    ranks_seen = 1
+    # ---- every rank checks its SHORTEST chromosome against the oracle (after the timed region; N > 1 only -- at N = 1
+    # the `parity` block below does the same on the longest): scores against np.median, penalty / count / solution
+    # against the reference's calibration restated on the CPU, and the rows that came back through the gather against
+    # the records of that solution.  The verdicts are summed into `parity_ranks_ok`: a SCALE record then proves that
+    # every rank produced, and the exchange delivered, the reference's answer.
+    rank_ok, rank_check = 1.0, None
+    if world > 1 and works and not args.headline_only:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+
+        pos = min(range(len(works)), key=lambda k: (works[k].n, k))
+        w, r, unit = works[pos], res[pos], mine[pos]
+        s_h = r["scores"].cpu().numpy()
+        scores_ok = bool(np.array_equal(s_h, np.median(w.matrix_t.cpu().numpy(), axis=0)))
+        o_sol, _o_obj, o_det = po.solve_chrom_exact(s_h, budget=w.budget, gamma=w.gamma, return_details=True)
+        sel = (o_sol[: w.n - 1] > 0).astype(np.int8)
+        edges = np.diff(np.concatenate([[0], sel, [0]]))
+        o_rows = np.stack([np.flatnonzero(edges == 1), np.flatnonzero(edges == -1)], axis=1).astype(np.int64)
+        got_rows = np.asarray(merged.get(unit, np.zeros((0, 2), dtype=np.int64)))
+        rank_check = {"chromosome": w.name, "scores_bit_exact": scores_ok,
+                      "penalty_equal": bool(r["selection_penalty"] == o_det["selection_penalty"]),
+                      "count_equal": bool(r["selected_count"] == o_det["selected_count"]),
+                      "solution_bit_exact": bool(np.array_equal(r["solution"].cpu().numpy(), o_sol)),
+                      "gathered_rows_identical": bool(got_rows.shape == o_rows.shape and np.array_equal(got_rows, o_rows))}
+        rank_ok = float(all(v for k, v in rank_check.items() if k != "chromosome"))
+    ranks_seen, parity_ranks_ok = 1, int(rank_ok)
     if world > 1:
-        t = torch.tensor([elapsed, 1.0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed, 1.0, rank_ok], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
-        elapsed, ranks_seen = float(t[0].item()), int(round(float(t[1].item())))
+        dist.all_reduce(t[1:3], op=dist.ReduceOp.SUM)
+        elapsed, ranks_seen, parity_ranks_ok = float(t[0].item()), int(round(float(t[1].item()))), int(round(float(t[2].item())))
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
     value = total_loci / (elapsed / max(1, args.steps))
 
@@ -463,6 +497,10 @@ def main():
             "unit": "loci/s",
             "n_gpus": world,
             "ranks_seen": ranks_seen,
+            "parity_ranks_ok": parity_ranks_ok if world > 1 else (None if parity is None else int(
+                parity["scores_bit_exact"] and parity["solution_bit_exact"] and parity["bed3_identical"]
+                and parity["penalty_abs_diff"] == 0.0)),
+            "rank0_parity_check": rank_check,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),

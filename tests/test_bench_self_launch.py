@@ -26,6 +26,7 @@ def test_gpus_2_starts_two_ranks_and_reports_them():
     assert len(lines) == 1  # one JSON line, rank 0's
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["rehearsal"] is True
+    assert line["parity_ranks_ok"] == 2  # every rank found its shortest chromosome's rows in the gathered table
     assert line["chromosomes_gathered"] == 24  # every rank's chromosomes arrived
     assert len(line["shard_loci"]) == 2 and sum(line["shard_loci"]) == 61765409
     assert max(line["shard_loci"]) <= 1.01 * 61765409 / 2  # LPT balance
@@ -40,4 +41,4 @@ def test_single_rank_needs_no_launcher():
     proc = _run(["--gpus", "1", "--rehearse", "--steps", "1", "--warmup", "0"])
     assert proc.returncode == 0
     line = json.loads([t for t in proc.stdout.splitlines() if t.startswith("{")][0])
-    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["parity_ranks_ok"] == 1
