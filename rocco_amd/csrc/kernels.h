@@ -38,6 +38,10 @@ struct MedianTask {
     double *partials;  // [wavefront of this task][3] = min, max, sum |.| of its scores (nullptr: not wanted)
 };
 struct MedianBatch {
+    // first workgroup of every task, ascending; unused slots hold 0xFFFFFFFF.  Kept apart from the task records so that
+    // a workgroup finds its task with a few wide scalar loads and compares in registers -- not one dependent scalar
+    // load per task before its first vector load can issue (24 chromosomes: 0.5 ms per genome launch)
+    unsigned block_begin[kMedianBatchMax];
     MedianTask tasks[kMedianBatchMax];
     int n_tasks;
     int K;

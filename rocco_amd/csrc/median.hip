@@ -14,6 +14,12 @@
 
 #include <limits>
 
+#ifndef ROCCO_MEDIAN_NT
+#define ROCCO_MEDIAN_NT 0  // 1: non-temporal loads of the rows of an exact-size column.  Measured on MI355X (same box,
+                           // alternating libraries): 1-5 % faster for one isolated launch, 5-10 % SLOWER and noisy in a stream of
+                           // launches -- off
+#endif
+
 namespace rocco {
 
 namespace {
@@ -64,10 +70,14 @@ __device__ __forceinline__ unsigned xcd_contiguous_block()
 }
 
 // EXACT: K == KP is known at compile time (no padding, unpredicated loads).
+// `col0` is the workgroup's first column and `lane` the thread's distance from it: every row is read at (scalar row
+// base) + (one 32-bit vector offset), so the load phase costs no vector-ALU instruction per row and no address
+// registers -- a wavefront issues its loads while its SIMD partner saturates the FP64 pipe with its network.
 template <typename T, int KP, bool EXACT>
 __device__ __forceinline__ double median_column(const T *__restrict__ m, int K_runtime, long long n, long long stride,
-                                                double *__restrict__ out, long long j)
+                                                double *__restrict__ out, long long col0, unsigned lane)
 {
+    const long long j = col0 + lane;
     if (j >= n) {
         return 0.0;
     }
@@ -78,10 +88,20 @@ __device__ __forceinline__ double median_column(const T *__restrict__ m, int K_r
     double sum = 0.0;  // NaN in the column <=> NaN sum (or +inf and -inf together: checked below)
     // every load unconditional (a load under a per-row condition is waited for before the next is issued): slots past
     // the matrix re-read its last row (a cache hit) and are replaced by the padding afterwards
+    const T *row = m + col0;
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
-        const int row = EXACT ? k : min(k, K - 1);
-        v[k] = (double)m[(long long)row * stride + j];
+        if (EXACT) {
+#if ROCCO_MEDIAN_NT
+            v[k] = (double)__builtin_nontemporal_load(row + lane);
+#else
+            v[k] = (double)row[lane];
+#endif
+            row += stride;
+        } else {
+            v[k] = (double)row[lane];
+            row += (k + 1 < K) ? stride : 0;
+        }
     }
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
@@ -119,8 +139,7 @@ template <typename T, int KP, bool EXACT>
 __global__ __launch_bounds__(256) void median_kernel(const T *__restrict__ m, int K_runtime, long long n,
                                                      long long stride, double *__restrict__ out)
 {
-    const long long j = (long long)xcd_contiguous_block() * blockDim.x + threadIdx.x;
-    median_column<T, KP, EXACT>(m, K_runtime, n, stride, out, j);
+    median_column<T, KP, EXACT>(m, K_runtime, n, stride, out, (long long)xcd_contiguous_block() * 256, threadIdx.x);
 }
 
 // Several matrices of the same K and element type in ONE launch (the chromosomes of a rank): a launch starts
@@ -130,13 +149,17 @@ template <typename T, int KP, bool EXACT>
 __global__ __launch_bounds__(256) void median_batch_kernel(MedianBatch batch)
 {
     const unsigned logical = xcd_contiguous_block();
-    int ti = 0;
-    while (ti + 1 < batch.n_tasks && batch.tasks[ti + 1].block_begin <= logical) {
-        ++ti;
+    // the task of this workgroup: how many tasks begin at or before it (unused slots begin at 0xFFFFFFFF) -- compares
+    // on values that arrive with three wide scalar loads, no dependent load per task
+    int ti = -1;
+#pragma unroll
+    for (int i = 0; i < kMedianBatchMax; ++i) {
+        ti += (batch.block_begin[i] <= logical) ? 1 : 0;
     }
     const MedianTask &task = batch.tasks[ti];
-    const long long j = (long long)(logical - task.block_begin) * blockDim.x + threadIdx.x;
-    const double r = median_column<T, KP, EXACT>((const T *)task.matrix, batch.K, task.n, task.stride, task.out, j);
+    const long long col0 = (long long)(logical - task.block_begin) * 256;
+    const long long j = col0 + threadIdx.x;
+    const double r = median_column<T, KP, EXACT>((const T *)task.matrix, batch.K, task.n, task.stride, task.out, col0, threadIdx.x);
     if (task.partials != nullptr) {
         // min / max / sum |.| of this WAVEFRONT's scores (fmin / fmax skip NaN as the solve's own statistics pass
         // does, the sum carries it): the budgeted solve starts from these instead of reading the scores again.
@@ -786,6 +809,9 @@ int launch_median_batch(const void *const *matrices_dev, int dtype, size_t K, co
         int final_index[kMedianBatchMax];
         batch.K = (int)K;
         batch.n_tasks = 0;
+        for (int i = 0; i < kMedianBatchMax; ++i) {
+            batch.block_begin[i] = 0xFFFFFFFFu;
+        }
         unsigned blocks = 0;
         const size_t first = at;
         while (at < count && batch.n_tasks < kMedianBatchMax) {
@@ -800,6 +826,7 @@ int launch_median_batch(const void *const *matrices_dev, int dtype, size_t K, co
                 t.n = (long long)n[at];
                 t.stride = (long long)row_strides[at];
                 t.block_begin = blocks;
+                batch.block_begin[batch.n_tasks - 1] = blocks;
                 t.partials = want_stats ? partials_dev + 3 * partial_at : nullptr;
                 blocks += (unsigned)nb;
                 partial_at += 4 * nb;
