@@ -229,34 +229,20 @@ def main():
 
     median_events = []
 
-    units_of_mine = None  # (device tensor of this rank's unit indices, built once)
-
     def one_step(timing=None):
-        nonlocal units_of_mine
-        res = pipeline.solve_rank(works, median_timing=timing)
-        counts = [int(r["begin"].numel()) for r in res]
+        # the decode leaves every owned chromosome's runs in ONE table of rows (unit, begin, end) -- unit = the
+        # chromosome's genome-wide index -- on the device and, after the decode's one synchronisation, in pinned host memory
+        res = pipeline.solve_rank(works, median_timing=timing, units=mine)
         if world > 1:
-            # rows (unit, start, end) stay on the device until every rank's have been gathered (RCCL), then ONE
-            # transfer to the host; under Gloo (CPU rehearsal of this path) they are moved to the CPU first
-            if units_of_mine is None:
-                units_of_mine = torch.tensor(mine, dtype=torch.int64, device=device)
-            if sum(counts):
-                units = torch.repeat_interleave(units_of_mine, torch.tensor(counts, dtype=torch.int64, device=device))
-                rows = torch.stack([units, torch.cat([r["begin"] for r in res]), torch.cat([r["end"] for r in res])], dim=1)
+            # the rows go to the gather as they are (RCCL: device tensors, ONE transfer to the host after the exchange;
+            # Gloo, the CPU rehearsal of this path: the host copy)
+            if backend == "nccl":
+                merged = shard.gather_interval_rows(pipeline.interval_rows(res, host=False))
             else:
-                rows = torch.zeros((0, 3), dtype=torch.int64, device=device)
-            merged = shard.gather_interval_rows(rows if backend == "nccl" else rows.cpu())
+                merged = shard.gather_interval_rows(torch.from_numpy(np.ascontiguousarray(pipeline.interval_rows(res, host=True))))
             return res, merged
-        # intervals of every owned chromosome to the host in ONE transfer
-        if sum(counts):
-            # (two concatenations and one interleave for the whole rank, not one small launch per chromosome)
-            flat = torch.stack([torch.cat([r["begin"] for r in res]), torch.cat([r["end"] for r in res])], dim=1).cpu().numpy()
-        else:
-            flat = np.zeros((0, 2), dtype=np.int64)
-        local, at = {}, 0
-        for idx, c in zip(mine, counts):
-            local[idx] = flat[at:at + c]
-            at += c
+        # per chromosome: its rows of the pinned table (a view: valid until the next step's decode)
+        local = {idx: r["rows_host"][r["row_range"][0]:r["row_range"][1], 1:] for idx, r in zip(mine, res)}
         return res, local
 
     def sync_all():

@@ -251,6 +251,16 @@ int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev,
 /* The same for `count` solutions in three launches and ONE synchronisation (the chromosomes a rank owns; the loop
  * over chromosomes of rocco/rocco.py:1176-1196).  Host arrays of `count` entries; n_runs_out[i] may exceed
  * capacities[i] (then only the first capacities[i] runs were written: call again with more room). */
+/* The same as ONE table: the runs of solution i, in ascending order, are rows row_offsets_out[i] .. row_offsets_out[i + 1]
+ * of table_dev, each row three int64 (units[i], run_begin, run_end) -- what a rank hands to the interval gather
+ * (exchange 2) or reads back to write its BED records.  count <= 48.  row_offsets_out has
+ * count + 1 entries; when row_offsets_out[count] > capacity_rows only the first capacity_rows rows were written: call
+ * again with more room.  table_host_out (may be NULL): receives a pointer to the table in pinned host memory owned by
+ * the solver, valid until the next call on this solver (NULL when the table did not fit).  `eager_rows` rows are copied
+ * to the host in front of the call's one synchronisation; only a longer table costs a second copy and synchronisation. */
+int rocco_hip_decode_runs_table(rocco_hip_solver *solver, size_t count, const uint8_t *const *solutions_dev, const size_t *n,
+                                const long long *units, int64_t *table_dev, size_t capacity_rows, size_t eager_rows,
+                                size_t *row_offsets_out, const int64_t **table_host_out, void *stream);
 int rocco_hip_decode_runs_batch(rocco_hip_solver *solver, size_t count, const uint8_t *const *solutions_dev, const size_t *n,
                                 int64_t *const *run_begin_dev, int64_t *const *run_end_dev, const size_t *capacities,
                                 size_t *n_runs_out, void *stream);

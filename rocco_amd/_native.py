@@ -153,6 +153,9 @@ PROTOTYPES = [
     ("rocco_hip_bh_adjust_f64", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     ("rocco_hip_log_scale_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_decode_runs_table", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), c_size_p, c_ll_p, ctypes.c_void_p, ctypes.c_size_t,
+      ctypes.c_size_t, c_size_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     ("rocco_hip_decode_runs_batch", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), c_size_p, ctypes.POINTER(ctypes.c_void_p),
       ctypes.POINTER(ctypes.c_void_p), c_size_p, c_size_p, ctypes.c_void_p]),

@@ -2,6 +2,7 @@
 #include "kernels.h"
 #include "budget.h"
 
+#include <algorithm>
 #include <cmath>
 #include <new>
 
@@ -124,6 +125,7 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->host_lean_back.release();
     solver->host_stage.release();
     solver->host_back.release();
+    solver->host_table.release();
     delete solver;
 }
 
@@ -578,6 +580,81 @@ int rocco_hip_decode_runs_batch(rocco_hip_solver *solver, size_t count, const ui
         for (int i = 0; i < batch.n_tasks; ++i) {
             n_runs_out[owner[i]] = (size_t)back[2 * i];
         }
+    }
+    return ROCCO_HIP_OK;
+}
+
+int rocco_hip_decode_runs_table(rocco_hip_solver *solver, size_t count, const uint8_t *const *solutions_dev, const size_t *n,
+                                const long long *units, int64_t *table_dev, size_t capacity_rows, size_t eager_rows,
+                                size_t *row_offsets_out, const int64_t **table_host_out, void *stream)
+{
+    if (solver == nullptr || row_offsets_out == nullptr || count > (size_t)kDecodeBatchMax ||
+        (count > 0 && (solutions_dev == nullptr || n == nullptr || units == nullptr)) || (capacity_rows > 0 && table_dev == nullptr)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    if (table_host_out != nullptr) {
+        *table_host_out = nullptr;
+    }
+    DecodeBatch batch;
+    batch.n_tasks = 0;
+    batch.pad = 0;
+    long long tiles = 0;
+    size_t owner[kDecodeBatchMax];
+    for (size_t at = 0; at < count; ++at) {
+        row_offsets_out[at] = 0;
+        if (n[at] > 1) {
+            if (solutions_dev[at] == nullptr) {
+                return ROCCO_HIP_EINVAL;
+            }
+            DecodeTask &t = batch.tasks[batch.n_tasks];
+            t.solution = solutions_dev[at];
+            t.n = (long long)n[at];
+            t.tile_begin = tiles;
+            t.run_begin = table_dev;
+            t.run_end = nullptr;
+            t.capacity = (unsigned long long)capacity_rows;
+            t.unit = units[at];
+            owner[batch.n_tasks++] = at;
+            tiles += decode_tiles(n[at]);
+        }
+    }
+    row_offsets_out[count] = 0;
+    if (batch.n_tasks == 0) {
+        return ROCCO_HIP_OK;
+    }
+    int rc = solver->dev_misc.reserve(decode_batch_scratch_bytes(tiles, batch.n_tasks));
+    if (rc != ROCCO_HIP_OK) return rc;
+    rc = solver->host_back.reserve((size_t)batch.n_tasks * 16 + 64);
+    if (rc != ROCCO_HIP_OK) return rc;
+    const bool want_host = (table_host_out != nullptr);
+    const size_t eager = want_host ? std::min(eager_rows, capacity_rows) : 0;
+    if (want_host) {
+        rc = solver->host_table.reserve(std::max<size_t>(capacity_rows, 1) * 3 * sizeof(int64_t));
+        if (rc != ROCCO_HIP_OK) return rc;
+    }
+    unsigned long long *back = (unsigned long long *)solver->host_back.ptr;
+    int64_t *host_rows = want_host ? (int64_t *)solver->host_table.ptr : nullptr;
+    rc = launch_decode_runs_table(batch, tiles, solver->dev_misc.ptr, table_dev, back, host_rows, eager, (hipStream_t)stream);
+    if (rc != ROCCO_HIP_OK) return rc;
+    // per-solution row ranges: row_offsets_out[i] .. row_offsets_out[i + 1]
+    size_t total = 0;
+    int next = 0;
+    for (size_t at = 0; at < count; ++at) {
+        row_offsets_out[at] = total;
+        if (next < batch.n_tasks && owner[next] == at) {
+            total += (size_t)back[2 * next];
+            ++next;
+        }
+    }
+    row_offsets_out[count] = total;
+    if (want_host && total <= capacity_rows) {
+        if (total > eager) {  // the eager copy did not cover the table: the rest, and one more synchronisation
+            ROCCO_HIP_TRY(hipMemcpyAsync(host_rows + 3 * eager, table_dev + 3 * eager, (total - eager) * 3 * sizeof(int64_t),
+                                         hipMemcpyDeviceToHost, (hipStream_t)stream));
+            ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        }
+        *table_host_out = host_rows;
     }
     return ROCCO_HIP_OK;
 }

@@ -371,6 +371,78 @@ __global__ __launch_bounds__(kThreads) void decode_write_batch_kernel(DecodeBatc
     }
 }
 
+// Table form of the write: every task's runs as rows (unit, begin, end) of ONE table, task after task.  A task's first
+// row is the number of runs of the tasks before it (the scan kernel's per-task totals: at most kDecodeBatchMax
+// independent loads); inside the task the tile offsets are the scan's.
+__global__ __launch_bounds__(kThreads) void decode_write_table_kernel(DecodeBatch batch,
+                                                                     const unsigned long long *__restrict__ tile_offsets,
+                                                                     const unsigned long long *__restrict__ totals)
+{
+    int ti = 0;
+    while (ti + 1 < batch.n_tasks && batch.tasks[ti + 1].tile_begin <= (long long)blockIdx.x) {
+        ++ti;
+    }
+    const DecodeTask &task = batch.tasks[ti];
+    unsigned long long row0 = 0;
+    for (int q = 0; q < ti; ++q) {
+        row0 += totals[2 * q];
+    }
+    const long long tile = (long long)blockIdx.x - task.tile_begin;
+    const long long i0 = (tile * kThreads + threadIdx.x) * kPerLane;
+    LaneBits b = {0U, 0U};
+    if (i0 < task.n) {
+        b = lane_bits(task.solution, task.n, i0);
+    }
+    const unsigned ns = (unsigned)__popc(b.starts);
+    const unsigned ne = (unsigned)__popc(b.ends);
+    unsigned is = ns, ie = ne;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned a = __shfl_up(is, off);
+        const unsigned c = __shfl_up(ie, off);
+        if (lane >= off) {
+            is += a;
+            ie += c;
+        }
+    }
+    __shared__ unsigned ws[kThreads / 64], we[kThreads / 64];
+    if (lane == 63) {
+        ws[wave] = is;
+        we[wave] = ie;
+    }
+    __syncthreads();
+    unsigned long long ps = row0 + tile_offsets[2 * blockIdx.x];
+    unsigned long long pe = row0 + tile_offsets[2 * blockIdx.x + 1];
+    for (int w = 0; w < wave; ++w) {
+        ps += ws[w];
+        pe += we[w];
+    }
+    ps += is - ns;
+    pe += ie - ne;
+    int64_t *table = task.run_begin;
+    unsigned sb = b.starts;
+    while (sb) {
+        const int t = __ffs(sb) - 1;
+        sb &= sb - 1;
+        if (ps < task.capacity) {
+            table[3 * ps] = (int64_t)task.unit;
+            table[3 * ps + 1] = (int64_t)(i0 + t);
+        }
+        ++ps;
+    }
+    unsigned eb = b.ends;
+    while (eb) {
+        const int t = __ffs(eb) - 1;
+        eb &= eb - 1;
+        if (pe < task.capacity) {
+            table[3 * pe + 2] = (int64_t)(i0 + t + 1);
+        }
+        ++pe;
+    }
+}
+
 }  // namespace
 
 long long decode_tiles(size_t n) { return (long long)((n + kTileLoci - 1) / kTileLoci); }
@@ -401,6 +473,36 @@ int launch_decode_runs_batch(const DecodeBatch &batch, long long total_tiles, vo
     ROCCO_HIP_TRY(hipGetLastError());
     ROCCO_HIP_TRY(hipMemcpyAsync(totals_host_pinned, totals, (size_t)batch.n_tasks * 2 * sizeof(unsigned long long),
                                  hipMemcpyDeviceToHost, stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+    return ROCCO_HIP_OK;
+}
+
+int launch_decode_runs_table(const DecodeBatch &batch, long long total_tiles, void *scratch_dev, int64_t *table_dev,
+                             unsigned long long *totals_host_pinned, int64_t *table_host_pinned, size_t eager_rows,
+                             hipStream_t stream)
+{
+    if (batch.n_tasks <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    char *base = (char *)scratch_dev;
+    unsigned long long *totals = (unsigned long long *)base;
+    unsigned long long *offsets = (unsigned long long *)(base + (((size_t)batch.n_tasks * 16 + 255) / 256) * 256);
+    unsigned *counts = (unsigned *)((char *)offsets + (size_t)total_tiles * 2 * sizeof(unsigned long long));
+    if (total_tiles > 0) {
+        hipLaunchKernelGGL(decode_count_batch_kernel, dim3((unsigned)total_tiles), dim3(kThreads), 0, stream, batch, counts);
+    }
+    hipLaunchKernelGGL(decode_scan_batch_kernel, dim3((unsigned)batch.n_tasks), dim3(1024), 0, stream, batch, counts, offsets,
+                       totals);
+    if (total_tiles > 0) {
+        hipLaunchKernelGGL(decode_write_table_kernel, dim3((unsigned)total_tiles), dim3(kThreads), 0, stream, batch, offsets,
+                           (const unsigned long long *)totals);
+    }
+    ROCCO_HIP_TRY(hipGetLastError());
+    ROCCO_HIP_TRY(hipMemcpyAsync(totals_host_pinned, totals, (size_t)batch.n_tasks * 2 * sizeof(unsigned long long),
+                                 hipMemcpyDeviceToHost, stream));
+    if (table_host_pinned != nullptr && eager_rows > 0) {
+        ROCCO_HIP_TRY(hipMemcpyAsync(table_host_pinned, table_dev, eager_rows * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    }
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));
     return ROCCO_HIP_OK;
 }

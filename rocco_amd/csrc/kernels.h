@@ -75,9 +75,10 @@ struct DecodeTask {
     const uint8_t *solution;
     long long n;
     long long tile_begin;  // first tile of this task in the launches (decode_tiles(n) tiles each)
-    int64_t *run_begin;
-    int64_t *run_end;
-    unsigned long long capacity;
+    int64_t *run_begin;    // (table form: the table itself, rows of 3 values)
+    int64_t *run_end;      // (table form: unused)
+    unsigned long long capacity;  // (table form: rows of the whole table)
+    long long unit;        // table form: what the first column of this task's rows holds
 };
 struct DecodeBatch {
     DecodeTask tasks[kDecodeBatchMax];
@@ -89,6 +90,12 @@ size_t decode_batch_scratch_bytes(long long total_tiles, int n_tasks);
 // totals_host_pinned: 2 * n_tasks values (runs begun, runs ended -- equal) after the synchronisation
 int launch_decode_runs_batch(const DecodeBatch &batch, long long total_tiles, void *scratch_dev,
                              unsigned long long *totals_host_pinned, hipStream_t stream);
+// the same as ONE table of (unit, begin, end) rows, task after task; `eager_rows` rows are copied to
+// `table_host_pinned` in front of the synchronisation, together with the totals (no synchronisation of its own
+// when eager_rows covers the table)
+int launch_decode_runs_table(const DecodeBatch &batch, long long total_tiles, void *scratch_dev, int64_t *table_dev,
+                             unsigned long long *totals_host_pinned, int64_t *table_host_pinned, size_t eager_rows,
+                             hipStream_t stream);
 
 // ---- objective.hip --------------------------------------------------------------------------
 size_t objective_scratch_bytes(size_t n);

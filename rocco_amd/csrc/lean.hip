@@ -1156,32 +1156,42 @@ __global__ __launch_bounds__(kLeanThreads) void lean_wcap_count_kernel(const Lea
     }
 }
 
-__global__ __launch_bounds__(64) void lean_wcap_sum_kernel(const LeanWcapTask *__restrict__ tasks, int n_tasks)
+// one workgroup of 128 threads per task: every thread fetches (and clears) the counters of its exponent at once, then
+// ONE thread adds the terms in ascending exponent order from LDS -- the same additions in the same order as a lone
+// thread walking the counters in memory, without its 128 dependent round trips (39 us per launch -> 3)
+__global__ __launch_bounds__(128) void lean_wcap_sum_kernel(const LeanWcapTask *__restrict__ tasks, int n_tasks)
 {
-    const int ti = blockIdx.x * 64 + threadIdx.x;
+    __shared__ unsigned st_s[128], tn_s[128];
+    const int ti = blockIdx.x;
     if (ti >= n_tasks) {
         return;
     }
     const LeanWcapTask task = tasks[ti];
-    const double q = ldexp(1.0, task.qexp);
-    double sum = 0.0, base = 0.0;
-    for (int b = 0; b < 128; ++b) {
-        const int e = b - kModelMapBias;
-        const unsigned st = task.counters[b], tn = task.counters[128 + b];
-        if (st != 0u) {
-            const double hb = ldexp(1.0, e + 2 - 53);
-            sum += (double)st * (4.0 * hb + q);
-            base = 9.0 * hb + 2.0 * q;  // exponents ascend: the largest base stays
+    const int b = threadIdx.x;
+    st_s[b] = task.counters[b];
+    tn_s[b] = task.counters[128 + b];
+    task.clean_chunks[b] = task.counters[256 + b];  // kept: a penalty that ties on this grid turns them hazard
+    task.counters[b] = 0u;
+    task.counters[128 + b] = 0u;
+    task.counters[256 + b] = 0u;
+    __syncthreads();
+    if (b == 0) {
+        const double q = ldexp(1.0, task.qexp);
+        double sum = 0.0, base = 0.0;
+        for (int k = 0; k < 128; ++k) {
+            const int e = k - kModelMapBias;
+            const unsigned st = st_s[k], tn = tn_s[k];
+            if (st != 0u) {
+                const double hb = ldexp(1.0, e + 2 - 53);
+                sum += (double)st * (4.0 * hb + q);
+                base = 9.0 * hb + 2.0 * q;  // exponents ascend: the largest base stays
+            }
+            if (tn != 0u) {
+                sum += (double)tn * ldexp(1.0, e - 52);
+            }
         }
-        if (tn != 0u) {
-            sum += (double)tn * ldexp(1.0, e - 52);
-        }
-        task.clean_chunks[b] = task.counters[256 + b];  // kept: a penalty that ties on this grid turns them hazard
-        task.counters[b] = 0u;
-        task.counters[128 + b] = 0u;
-        task.counters[256 + b] = 0u;
+        task.wcap[0] = sum + base;
     }
-    task.wcap[0] = sum + base;
 }
 
 int launch_eval_all(const LeanLaunch &L, hipStream_t stream)
@@ -1235,7 +1245,7 @@ int launch_lean_wcap(const LeanWcapTask *tasks_dev, int n_tasks, int n_blocks, h
         return ROCCO_HIP_OK;
     }
     hipLaunchKernelGGL(lean_wcap_count_kernel, dim3((unsigned)n_blocks), dim3(kLeanThreads), 0, stream, tasks_dev, n_tasks);
-    hipLaunchKernelGGL(lean_wcap_sum_kernel, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, stream, tasks_dev, n_tasks);
+    hipLaunchKernelGGL(lean_wcap_sum_kernel, dim3((unsigned)n_tasks), dim3(128), 0, stream, tasks_dev, n_tasks);
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }

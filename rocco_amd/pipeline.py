@@ -82,7 +82,7 @@ def _score_wls(c: ChromWork):
     return s_t
 
 
-def _solve_group(chroms: Sequence[ChromWork], scores: list, score_stats=None) -> list:
+def _solve_group(chroms: Sequence[ChromWork], scores: list, score_stats=None, units: Optional[Sequence[int]] = None) -> list:
     """Calibrate and decode the given chromosomes on the calling thread's current stream / solver; count-path
     chromosomes (scores[i] is None) are scored here first, so that the groups' chain kernels -- one latency-bound
     wavefront per row and parity -- run side by side as well."""
@@ -92,14 +92,27 @@ def _solve_group(chroms: Sequence[ChromWork], scores: list, score_stats=None) ->
     targets = [int(np.floor(c.n * c.budget)) for c in chroms]  # rocco/dp.py:197
     solved = _dp.calibrate_batch_device(scores, [c.gamma for c in chroms], targets, score_stats=score_stats)
     out = []
-    runs = _rocco.decode_runs_batch_device([sol_t for (_p, sol_t, _v, _c, _i) in solved],
-                                           capacities=[max(1024, c.n // 64) for c in chroms])
-    for c, s_t, (penalty, sol_t, value, count, info), (begin_t, end_t) in zip(chroms, scores, solved, runs):
+    # every chromosome's runs as ONE table of (unit, begin, end) rows: three launches, one synchronisation, and the
+    # table reaches pinned host memory in the same breath (a run has at least one selected locus and on real tracks
+    # about twenty: a fifth of the selected loci, never less than 4096 rows, travels before the synchronisation)
+    selected = sum(int(count) for (_p, _s, _v, count, _i) in solved)
+    if len(chroms) <= 48:
+        table_t, offsets, host_rows = _rocco.decode_runs_table_device(
+            [sol_t for (_p, sol_t, _v, _c, _i) in solved], units=units, capacity_rows=max(1024, selected // 2 + 64),
+            eager_rows=max(4096, selected // 5))
+        runs = [(table_t[offsets[i]:offsets[i + 1], 1], table_t[offsets[i]:offsets[i + 1], 2]) for i in range(len(chroms))]
+    else:
+        table_t, offsets, host_rows = None, None, None
+        runs = _rocco.decode_runs_batch_device([sol_t for (_p, sol_t, _v, _c, _i) in solved],
+                                               capacities=[max(1024, c.n // 64) for c in chroms])
+    for i, (c, s_t, (penalty, sol_t, value, count, info), (begin_t, end_t)) in enumerate(zip(chroms, scores, solved, runs)):
         out.append({
             "name": c.name, "n": c.n, "selected_count": count, "selection_penalty": penalty,
             "penalized_objective": value, "path": info["path"], "info": info,
             "begin": begin_t, "end": end_t, "solution": sol_t, "step": c.step, "start": c.start,
             "effect_mean": getattr(c, "_effect_mean", None), "scores": s_t,
+            # the group's whole table (device; host view valid until this device's next decode) and this chromosome's rows
+            "rows": table_t, "rows_host": host_rows, "row_range": None if offsets is None else (offsets[i], offsets[i + 1]),
         })
     return out
 
@@ -119,7 +132,7 @@ def _group_chunks(order: List[int], n_groups: int) -> List[List[int]]:
 
 
 def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, groups: Optional[int] = None,
-               median_timing: Optional[list] = None):
+               median_timing: Optional[list] = None, units: Optional[Sequence[int]] = None):
     """Score, solve and decode every chromosome of this rank.
 
     Returns a list of dicts (in the order of `chroms`): name, n, selected_count, selection_penalty,
@@ -135,6 +148,10 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
 
     `median_timing`: a list that receives one (start event, end event, algorithmic bytes) per median launch,
     recorded on the stream the launch goes to (for bench.py's roofline block).
+
+    `units`: the number every chromosome's interval rows carry in their first column (default: its position in
+    `chroms`) -- a rank of a sharded run passes the chromosomes' genome-wide indices, and the rows go to the gather as
+    they are (`interval_rows`).
     """
     import torch
 
@@ -144,6 +161,7 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
     device = chroms[0].matrix_t.device
     n_groups = max(1, min(int(groups if groups is not None else SOLVE_GROUPS), len(chroms)))
     out: List[Optional[dict]] = [None] * len(chroms)
+    units = list(range(len(chroms))) if units is None else [int(u) for u in units]
 
     def score_all(members: Sequence[ChromWork]):
         # the medians of a group in one launch (count-path chromosomes are scored inside their group), together
@@ -176,7 +194,7 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
         scores, stats_h = score_all(chroms)
         if stats_h is not None:
             torch.cuda.current_stream(device).synchronize()
-        out = _solve_group(chroms, scores, stats_h)
+        out = _solve_group(chroms, scores, stats_h, units)
     else:
         order = sorted(range(len(chroms)), key=lambda i: -chroms[i].n)
         members = _group_chunks(order, n_groups)
@@ -192,11 +210,15 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
                             stats_h = stats_h[stats_rows]
                     else:
                         stream.wait_event(scored)
-                    res = _solve_group([chroms[i] for i in idx], scores, stats_h)
+                    res = _solve_group([chroms[i] for i in idx], scores, stats_h, [units[i] for i in idx])
                     stream.synchronize()
+                    # the pinned table is the group solver's: the next decode there overwrites it
+                    kept = None if not res or res[0]["rows_host"] is None else res[0]["rows_host"].copy()
+                    for r in res:
+                        r["rows_host"] = kept
                 # the results were allocated on the group's stream and are handed to the caller's
                 for r in res:
-                    for key in ("begin", "end", "solution", "scores", "effect_mean"):
+                    for key in ("begin", "end", "solution", "scores", "effect_mean", "rows"):
                         t = r.get(key)
                         if t is not None and hasattr(t, "record_stream"):
                             t.record_stream(caller_stream)
@@ -236,6 +258,29 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
     if scores_out is not None:
         scores_out.extend(r["scores"] for r in out)
     return out
+
+
+def interval_rows(results: Sequence[dict], host: bool = True):
+    """All interval rows (unit, begin, end) of a `solve_rank` result as one int64 array [m, 3]: the NumPy view in pinned
+    host memory (`host=True`; valid until the device's next decode) or the CUDA tensor the gather takes.  With one
+    group (the default) this is the table the decode wrote, untouched; with several groups their tables are joined."""
+    import torch
+
+    tables, seen = [], set()
+    for r in results:
+        t = r["rows_host"] if host else r["rows"]
+        if t is None:  # more chromosomes than one table holds: rows from the per-chromosome tensors
+            unit = torch.full_like(r["begin"], -1)
+            rows = torch.stack([unit, r["begin"], r["end"]], dim=1)
+            tables.append(rows.cpu().numpy() if host else rows)
+        elif id(t) not in seen:
+            seen.add(id(t))
+            tables.append(t)
+    if len(tables) == 1:
+        return tables[0]
+    if host:
+        return np.concatenate(tables, axis=0) if tables else np.zeros((0, 3), dtype=np.int64)
+    return torch.cat(tables, dim=0)
 
 
 def runs_to_records(result: dict, min_length_bp: Optional[int] = None) -> List[Tuple[str, int, int]]:

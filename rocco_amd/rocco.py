@@ -318,6 +318,50 @@ def decode_runs_batch_device(solutions, capacities=None):
     return out
 
 
+def decode_runs_table_device(solutions, units=None, capacity_rows: Optional[int] = None, eager_rows: Optional[int] = None,
+                             to_host: bool = True):
+    """The maximal runs of several uint8 CUDA solution tensors (at most 48) as ONE int64 table of rows
+    (unit, begin, end), solution after solution (rocco_hip_decode_runs_table): three launches and one synchronisation.
+
+    Returns ``(table_t, offsets, host_rows)``: the rows of solution i are ``table_t[offsets[i]:offsets[i + 1]]``;
+    ``host_rows`` is the same table as a NumPy array in pinned memory owned by the solver -- a VIEW that the next
+    decode on this device overwrites (copy it to keep it) -- or None with ``to_host=False``.  `eager_rows`: how many
+    rows travel to the host in front of the synchronisation (a longer table costs a second copy)."""
+    import torch
+
+    solutions = [s.contiguous() for s in solutions]
+    count = len(solutions)
+    if count == 0 or count > 48 or any(s.dtype != torch.uint8 for s in solutions):
+        raise ValueError("decode_runs_table_device takes 1 to 48 uint8 solution tensors")
+    dev = solutions[0].device
+    ns = [int(s.shape[0]) for s in solutions]
+    units = list(range(count)) if units is None else [int(u) for u in units]
+    cap = int(capacity_rows) if capacity_rows is not None else max(1024, sum(ns) // 128)
+    solver = _native.solver_for(dev.index)
+    lib = _native.load()
+    while True:
+        table_t = torch.empty((cap, 3), dtype=torch.int64, device=dev)
+        offsets = (ctypes.c_size_t * (count + 1))()
+        host_ptr = ctypes.c_void_p()
+        eager = cap if eager_rows is None else min(int(eager_rows), cap)
+        _native.check(lib.rocco_hip_decode_runs_table(
+            solver.handle, count, (ctypes.c_void_p * count)(*[s.data_ptr() for s in solutions]),
+            (ctypes.c_size_t * count)(*ns), (ctypes.c_longlong * count)(*units), table_t.data_ptr(), cap, eager if to_host else 0,
+            offsets, ctypes.byref(host_ptr) if to_host else None, _dp._stream_ptr(solutions[0])), "rocco_hip_decode_runs_table")
+        total = int(offsets[count])
+        if total <= cap:
+            break
+        cap = total
+    host_rows = None
+    if to_host:
+        if total == 0:
+            host_rows = np.zeros((0, 3), dtype=np.int64)
+        else:
+            raw = (ctypes.c_int64 * (3 * total)).from_address(host_ptr.value)
+            host_rows = np.frombuffer(raw, dtype=np.int64).reshape(total, 3)
+    return table_t[:total], [int(v) for v in offsets], host_rows
+
+
 def chrom_solution_records(chromosome, intervals, solution, check_gaps_intervals=True,
                            min_length_bp=None) -> List[Record]:
     """The merged records chrom_solution_to_bed writes (rocco/rocco.py:165-190), as a list."""

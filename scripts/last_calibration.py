@@ -4,7 +4,7 @@ import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 def short(n):
-    n = n.replace('void ', '').split('(')[0]
+    n = n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
     return n.split('::')[-1][:40]
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']), int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))) for r in rows]
 stats = [i for i, e in enumerate(ev) if 'stats' in e[2]]

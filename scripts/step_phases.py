@@ -25,9 +25,15 @@ for rep in range(reps + 5):
     solved = dp.calibrate_batch_device(scores, gammas, targets)
     ev[2].record()
     h2 = time.perf_counter()
-    runs = rr.decode_runs_batch_device([s[1] for s in solved], capacities=caps)
-    ev[3].record()
-    flat = torch.cat([torch.stack([b, e], dim=1) for b, e in runs if b.numel()]).cpu().numpy()
+    if os.environ.get("STEP_PHASES_OLD_DECODE"):
+        runs = rr.decode_runs_batch_device([s[1] for s in solved], capacities=caps)
+        ev[3].record()
+        flat = torch.cat([torch.stack([b, e], dim=1) for b, e in runs if b.numel()]).cpu().numpy()
+    else:  # round 3: one table of (unit, begin, end) rows, in pinned host memory when the call returns
+        selected = sum(int(s[3]) for s in solved)
+        table_t, offsets, flat = rr.decode_runs_table_device([s[1] for s in solved], capacity_rows=max(1024, selected // 2 + 64),
+                                                             eager_rows=max(4096, selected // 5))
+        ev[3].record()
     ev[4].record()
     torch.cuda.synchronize()
     h3 = time.perf_counter()
