@@ -2186,6 +2186,7 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_COMPACT")) opt.use_compaction = std::atoi(e) != 0;
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_ROUNDS")) opt.pilot_rounds = std::atoi(e);
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_POINTS")) opt.pilot_points = std::atoi(e);
+    if (const char *e = std::getenv("ROCCO_HIP_ALIGN_MAPS")) opt.align_maps = std::atoi(e) != 0;
     struct LeanOverride {  // ROCCO_HIP_LEAN overrides the solver's setting for this call only
         rocco_hip_solver *solver;
         int saved;

@@ -419,6 +419,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
         std::vector<size_t> probe_owner, window_owner, exact_owner, map_owner, spine_owner, compact_owner;
         std::vector<WindowRequest> surveys;
         std::vector<CompactRequest> compacts;
+        std::vector<size_t> first_maps;  // positions in `maps` of maps asked for right after a threshold search
 
         // speculation depth of this iteration's probe rounds, from the loci they will cover
         double round_loci = 0.0;
@@ -672,6 +673,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     r.problem = b;
                     r.lambda_ref = s.req_ref;
                     r.margin = s.req_margin;
+                    first_maps.push_back(maps.size());
                     maps.push_back(r);
                     map_owner.push_back(b);
                     break;
@@ -775,6 +777,21 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
             }
             case State::kDone:
                 break;
+            }
+        }
+        if (opt.align_maps && !first_maps.empty()) {
+            // while another problem of the batch is still in its threshold search (or its pilot), the first maps wait:
+            // the problems that ask for them sit this round out and ask again in the next one (plan_map has no effect
+            // that the next call does not overwrite)
+            bool searching_elsewhere = false;
+            for (size_t b = 0; b < B; ++b) {
+                searching_elsewhere = searching_elsewhere || (st[b].phase != State::kDone && (st[b].bound_round || st[b].pilot_round));
+            }
+            if (searching_elsewhere) {
+                for (size_t k = first_maps.size(); k-- > 0;) {
+                    maps.erase(maps.begin() + (long)first_maps[k]);
+                    map_owner.erase(map_owner.begin() + (long)first_maps[k]);
+                }
             }
         }
         if (probes.empty() && windows.empty() && exacts.empty() && maps.empty() && spines.empty() && compacts.empty()) {

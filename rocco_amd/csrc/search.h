@@ -265,6 +265,11 @@ struct SearchOptions {
     bool use_compaction = true;  // after the threshold search: continue on the loci that can still be selected
     int pilot_rounds = 2;        // sampled estimates that place the first certified evaluations (0: none)
     int pilot_points = 32;
+    // A problem whose threshold search has ended asks for its binade map (six small launches and the tolerance cap).
+    // Problems of one batch end their search in different rounds; every round is shared and lasts as long as its
+    // kernels, so a problem that waits for the others loses nothing -- the batch ends with its slowest member either
+    // way -- and the maps of all of them take ONE set of launches instead of one per straggler.
+    bool align_maps = true;
 };
 
 // Calibrate every problem of the batch; solutions are left in the evaluator's solution buffers.
