@@ -274,6 +274,12 @@ int rocco_hip_decode_runs_batch(rocco_hip_solver *solver, size_t count, const ui
 int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, const double *matrix_dev,
                                                      size_t rows, size_t cols, double penalty_lambda,
                                                      double *baseline_out_dev, void *stream);
+/* The same for `count` matrices of ONE penalty -- the chromosomes of a genome -- in one pair of launches: every group of
+ * 32 rows of every matrix is a workgroup, and the pair lasts as long as the longest row (the loop over chromosomes of
+ * rocco/rocco.py:948-1018 around the call of rocco/inference.py:198-206).  Host arrays of `count` entries. */
+int rocco_hip_crossfit_whittaker_baseline_batch_f64(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev,
+                                                    const size_t *rows, const size_t *cols, double penalty_lambda,
+                                                    double *const *baselines_dev, void *stream);
 
 /* ---- centred-WLS locus scores ------------------------------------
  * Replaces rocco_score_centered_wls_f64 (rocco/native/wls_backend.h:11-28, wls_backend.c:744-947) as

@@ -162,6 +162,9 @@ PROTOTYPES = [
     ("rocco_hip_decode_runs", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
       ctypes.c_size_t, c_size_p, ctypes.c_void_p]),
+    ("rocco_hip_crossfit_whittaker_baseline_batch_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), c_size_p, c_size_p, ctypes.c_double,
+      ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     ("rocco_hip_crossfit_whittaker_baseline_matrix_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_void_p,
       ctypes.c_void_p]),

@@ -685,6 +685,73 @@ int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev,
     return rc;
 }
 
+namespace {
+
+// The LDL^T factor depends on the penalty and (at its last two entries only) on the length: the solver keeps the one of
+// the longest row seen with this penalty (the recurrence is sequential: ~0.19 s per million loci).  A longer row with the
+// same penalty extends the factor instead of starting over; a new penalty starts a new one.
+int ensure_whittaker_factor(rocco_hip_solver *solver, size_t cols, double penalty_lambda, hipStream_t stream)
+{
+    if (cols < 25 || (solver->factor_cap >= cols && solver->factor_lambda == penalty_lambda)) {
+        return ROCCO_HIP_OK;
+    }
+    const size_t cap = cols;
+    rocco::DeviceBuffer grown;
+    int rc;
+    if ((rc = grown.reserve(6 * cap * sizeof(double))) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    const bool extend = solver->factor_cap > 0 && solver->factor_lambda == penalty_lambda;
+    rc = launch_whittaker_factor(cap, penalty_lambda, (double *)grown.ptr, stream,
+                                 extend ? (const double *)solver->dev_factor.ptr : nullptr, extend ? solver->factor_cap : 0);
+    if (rc == ROCCO_HIP_OK && hipStreamSynchronize(stream) != hipSuccess) {
+        rc = ROCCO_HIP_EHIP;
+    }
+    if (rc != ROCCO_HIP_OK) {
+        grown.release();
+        return rc;
+    }
+    solver->dev_factor.release();
+    solver->dev_factor = grown;
+    solver->factor_cap = cap;
+    solver->factor_lambda = penalty_lambda;
+    return ROCCO_HIP_OK;
+}
+
+}  // namespace
+
+int rocco_hip_crossfit_whittaker_baseline_batch_f64(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev,
+                                                    const size_t *rows, const size_t *cols, double penalty_lambda,
+                                                    double *const *baselines_dev, void *stream)
+{
+    if (solver == nullptr || (count > 0 && (matrices_dev == nullptr || rows == nullptr || cols == nullptr || baselines_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    size_t longest = 0, groups = 0;
+    for (size_t i = 0; i < count; ++i) {
+        if (rows[i] * cols[i] > 0 && (matrices_dev[i] == nullptr || baselines_dev[i] == nullptr)) {
+            return ROCCO_HIP_EINVAL;
+        }
+        if (rows[i] > 0) {
+            longest = std::max(longest, cols[i]);
+            groups += (rows[i] + 31) / 32;
+        }
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_misc.reserve(whittaker_batch_scratch_bytes(rows, cols, count))) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->host_stage.reserve(2 * groups * sizeof(WhittakerRowTask) + 64)) != ROCCO_HIP_OK) return rc;
+    if ((rc = ensure_whittaker_factor(solver, longest, penalty_lambda, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
+    rc = launch_crossfit_whittaker_batch(matrices_dev, rows, cols, count, penalty_lambda, (const double *)solver->dev_factor.ptr,
+                                         solver->factor_cap, baselines_dev, solver->dev_misc.ptr,
+                                         (WhittakerRowTask *)solver->host_stage.ptr, (hipStream_t)stream);
+    if (rc != ROCCO_HIP_OK) {
+        return rc;
+    }
+    ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the scratch buffers are the solver's
+    return ROCCO_HIP_OK;
+}
+
 int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, const double *matrix_dev,
                                                      size_t rows, size_t cols, double penalty_lambda,
                                                      double *baseline_out_dev, void *stream)
@@ -692,45 +759,8 @@ int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, c
     if (solver == nullptr || ((matrix_dev == nullptr || baseline_out_dev == nullptr) && rows * cols > 0)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
-    int rc;
-    if ((rc = solver->dev_misc.reserve(whittaker_scratch_bytes(rows, cols))) != ROCCO_HIP_OK) {
-        return rc;
-    }
-    if (rows > 0 && cols >= 25 &&
-        !(solver->factor_cap >= cols && solver->factor_lambda == penalty_lambda)) {
-        // the factor depends on the penalty and (at its last two entries only) on the length: keep the
-        // one of the longest rows seen with this penalty
-        // (the recurrence is sequential: ~0.19 s per million loci)  A longer row with the same penalty extends the
-        // factor instead of starting over; a new penalty starts a new one
-        const size_t cap = cols;
-        rocco::DeviceBuffer grown;
-        if ((rc = grown.reserve(6 * cap * sizeof(double))) != ROCCO_HIP_OK) {
-            return rc;
-        }
-        const bool extend = solver->factor_cap > 0 && solver->factor_lambda == penalty_lambda;
-        rc = launch_whittaker_factor(cap, penalty_lambda, (double *)grown.ptr, (hipStream_t)stream,
-                                     extend ? (const double *)solver->dev_factor.ptr : nullptr,
-                                     extend ? solver->factor_cap : 0);
-        if (rc == ROCCO_HIP_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
-            rc = ROCCO_HIP_EHIP;
-        }
-        if (rc != ROCCO_HIP_OK) {
-            grown.release();
-            return rc;
-        }
-        solver->dev_factor.release();
-        solver->dev_factor = grown;
-        solver->factor_cap = cap;
-        solver->factor_lambda = penalty_lambda;
-    }
-    rc = launch_crossfit_whittaker(matrix_dev, rows, cols, penalty_lambda, (const double *)solver->dev_factor.ptr,
-                                   solver->factor_cap, baseline_out_dev, solver->dev_misc.ptr, (hipStream_t)stream);
-    if (rc != ROCCO_HIP_OK) {
-        return rc;
-    }
-    ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the scratch buffer is the solver's
-    return ROCCO_HIP_OK;
+    return rocco_hip_crossfit_whittaker_baseline_batch_f64(solver, 1, &matrix_dev, &rows, &cols, penalty_lambda, &baseline_out_dev,
+                                                           stream);
 }
 
 int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *centered_dev, size_t K, size_t n,

@@ -124,9 +124,20 @@ int launch_objective_batch(const ObjectiveTask *tasks_dev, int n_tasks, long lon
 size_t whittaker_scratch_bytes(size_t rows, size_t cols);
 int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_dev, hipStream_t stream,
                             const double *old_factor_dev = nullptr, size_t old_cap = 0);
-int launch_crossfit_whittaker(const double *matrix_dev, size_t rows, size_t cols, double penalty_lambda,
-                              const double *factor_dev, size_t factor_cap, double *baseline_out_dev,
-                              void *scratch_dev, hipStream_t stream);
+// one group of up to 32 rows of one matrix: a workgroup of the row-parallel sweeps (whittaker.hip)
+struct WhittakerRowTask {
+    const double *src0, *src1;
+    double *dst0, *dst1;
+    long long n;
+    int row0, rows;
+    const double *tail;  // the three factor entries per parity that depend on the length
+};
+// several matrices of one penalty (the chromosomes of a genome) in ONE pair of launches; tasks_host_pinned: room for
+// 2 x (groups of 32 rows over all matrices) records, must stay untouched until the stream has passed the copy
+size_t whittaker_batch_scratch_bytes(const size_t *rows, const size_t *cols, size_t count);
+int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const size_t *rows, const size_t *cols, size_t count,
+                                    double penalty_lambda, const double *factor_dev, size_t factor_cap, double *const *baselines_dev,
+                                    void *scratch_dev, WhittakerRowTask *tasks_host_pinned, hipStream_t stream);
 
 // ---- wls.hip --------------------------------------------------------------------------------
 // scratch: at least wls_scratch_bytes(K, n) bytes; synchronises the stream before returning

@@ -20,6 +20,8 @@
 //     design keeps everything else off the chain wavefront and lets K rows x 2 parities run side by side.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace rocco {
 
 namespace {
@@ -361,6 +363,224 @@ __global__ __launch_bounds__(2 * kLanes + kSweepHelpers) void whittaker_sweep_ke
     }
 }
 
+// ---- the same sweeps with 64 chains per wavefront (round 3) ---------------------------------------------------------
+// A chain advances one locus per ~20 ns whatever its wavefront's other 63 lanes do, so a wavefront that carries ONE chain
+// wastes them: above, K rows keep K workgroups busy for n x 25 ns, and the 2 400 rows of a genome's count matrices take
+// sum(n) x 25 ns / (workgroups in flight).  Here lane L of the chain wavefront is chain (parity L / 32, row L % 32) of a
+// group of 32 rows: both parities of a row read the same input, and all 64 chains step through the loci in lockstep with
+// the same instructions as one did before.  The rows of EVERY matrix of a batch (the chromosomes of a genome) are groups
+// of one launch; the launch lasts as long as its longest row, ~n_max x 20 ns.
+//   * the helpers load a tile of 64 loci of each row (512 contiguous bytes per wavefront instruction) and store it
+//     TRANSPOSED in LDS -- element (locus t, chain L) at t * 65 + L: the chain wavefront's 64 lanes read 64 consecutive
+//     doubles, a helper's 64 lanes (one row, 64 loci) write at a stride of 65 doubles = 2 banks: no conflicts either way;
+//   * the multipliers of a locus are the same for every row: one (a, b) pair per parity and locus, read as a broadcast;
+//   * two input and two output tiles alternate (chain on k, staging of k + 1, write-back of k - 1), one barrier per tile.
+constexpr int kRowTile = 64;    // loci per tile
+constexpr int kGroupRows = 32;  // rows per workgroup (x 2 parities = 64 lanes)
+constexpr int kPitch = 65;
+#ifndef ROCCO_ROW_HELPERS
+#define ROCCO_ROW_HELPERS 4
+#endif
+constexpr int kRowHelpers = ROCCO_ROW_HELPERS;  // helper wavefronts
+
+struct RowTiles {
+    double in[2][kRowTile * kPitch];
+    double out[2][kRowTile * kPitch];
+    double coef[2][2][kRowTile][2];  // [buffer][parity][locus] = multipliers of the previous / one-before-previous value
+};
+
+struct RowRegs {  // what a helper lane holds of one tile between its loads and its LDS stores
+    double x0[kGroupRows / kRowHelpers], x1[kGroupRows / kRowHelpers];
+    double d0, d1;        // backward: the diagonal entries of the lane's locus (z = f / d on the way into LDS)
+    double ca[2], cb[2];  // wavefront 0 of the helpers: the multipliers of the lane's locus, per parity
+};
+
+// forward (BACKWARD = false): src0 = the matrix (rhs = W_p y); dst0 / dst1 = f of parity 0 / 1, the forward substitution
+// BEFORE its division by the diagonal (baseline_backend.c:142-156) -- the division rides on the backward sweep's staging,
+// where the diagonal entry arrives with the tile's other loads instead of queueing for three tiles in registers.
+// backward: src0 / src1 = f of parity 0 / 1, dst0 = the baseline 0.5 (x0 + x1) (158-172, 296-299); dst0 may be src0.
+template <bool BACKWARD>
+__global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kernel(const WhittakerRowTask *__restrict__ tasks,
+                                                                                  long long cap, const double *__restrict__ factor)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    RowTiles &T = *reinterpret_cast<RowTiles *>(smem);
+    const WhittakerRowTask task = tasks[blockIdx.x];
+    const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
+    const int h = wave - 1;  // helper number
+    const long long n = task.n;
+    const Factor f0 = factor_of(factor, task.tail, n, cap, 0), f1 = factor_of(factor, task.tail, n, cap, 1);
+    const long long n_tiles = (n + kRowTile - 1) / kRowTile;
+    auto tile_base = [&](long long k) { return (BACKWARD ? (n_tiles - 1 - k) : k) * kRowTile; };
+    constexpr int kMine = kGroupRows / kRowHelpers;  // rows a helper wavefront moves per tile
+
+    // helpers: lane = locus of the tile.  A tile is loaded into registers TWO trips before it is stored to LDS (two
+    // register sets take turns), every load of a trip issued before anything waits for one: a load has two chains of a
+    // tile -- several memory latencies -- to arrive.
+    auto stage_load = [&](long long k, RowRegs &R) {
+        const long long i = tile_base(k) + lane;
+        const long long ii = (i < n) ? i : (n - 1);  // loads without branches
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) {
+            const int r = h + q * kRowHelpers;
+            const long long at = (long long)(task.row0 + ((r < task.rows) ? r : 0)) * n + ii;
+            R.x0[q] = task.src0[at];
+            R.x1[q] = BACKWARD ? task.src1[at] : 0.0;
+        }
+        if (BACKWARD) {
+            R.d0 = f0.dd(ii);
+            R.d1 = f1.dd(ii);
+        }
+        if (h == 0) {
+            // the multipliers of locus i, end cases as zeros: forward l1[i-1], l2[i-2] (baseline_backend.c:142-151),
+            // backward l1[i], l2[i] (158-172); Factor::ll1 / ll2 hold the entries that depend on the length
+            const long long i1 = BACKWARD ? ii : ((ii >= 1) ? (ii - 1) : 0), i2 = BACKWARD ? ii : ((ii >= 2) ? (ii - 2) : 0);
+            const bool has1 = BACKWARD ? (i < n - 1) : (i >= 1 && i < n), has2 = BACKWARD ? (i < n - 2) : (i >= 2 && i < n);
+            const double a0 = f0.ll1(i1), a1 = f1.ll1(i1), b0 = f0.ll2(i2), b1 = f1.ll2(i2);
+            R.ca[0] = has1 ? a0 : 0.0;
+            R.ca[1] = has1 ? a1 : 0.0;
+            R.cb[0] = has2 ? b0 : 0.0;
+            R.cb[1] = has2 ? b1 : 0.0;
+        }
+    };
+    auto stage_store = [&](long long k, const RowRegs &R) {
+        const int buf = (int)(k & 1);
+        const long long i = tile_base(k) + lane;
+        const bool inside = i < n;
+        const long long ii = inside ? i : (n - 1);
+        double *__restrict__ in = T.in[buf];
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) {
+            const int r = h + q * kRowHelpers;
+            const bool live = inside && r < task.rows;
+            double v0, v1;
+            if (BACKWARD) {
+                v0 = R.x0[q] / R.d0;  // z = f / d (baseline_backend.c:153-156)
+                v1 = R.x1[q] / R.d1;
+            } else {
+                v0 = rhs_value(R.x0[q], ii, n, 0);
+                v1 = rhs_value(R.x0[q], ii, n, 1);
+            }
+            in[lane * kPitch + r] = live ? v0 : 0.0;
+            in[lane * kPitch + kGroupRows + r] = live ? v1 : 0.0;
+        }
+        if (h == 0) {
+            T.coef[buf][0][lane][0] = R.ca[0];
+            T.coef[buf][0][lane][1] = R.cb[0];
+            T.coef[buf][1][lane][0] = R.ca[1];
+            T.coef[buf][1][lane][1] = R.cb[1];
+        }
+    };
+    auto write_back = [&](long long k) {
+        const double *__restrict__ out = T.out[k & 1];
+        const long long i = tile_base(k) + lane;
+        if (i >= n) {
+            return;
+        }
+        for (int r = h; r < task.rows; r += kRowHelpers) {
+            const long long at = (long long)(task.row0 + r) * n + i;
+            if (BACKWARD) {
+                task.dst0[at] = 0.5 * (out[lane * kPitch + r] + out[lane * kPitch + kGroupRows + r]);
+            } else {
+                task.dst0[at] = out[lane * kPitch + r];
+                task.dst1[at] = out[lane * kPitch + kGroupRows + r];
+            }
+        }
+    };
+
+    double p1 = 0.0, p2 = 0.0;
+    const int parity = lane / kGroupRows;
+    auto chain = [&](long long k) {
+        const double *__restrict__ in = T.in[k & 1];
+        double *__restrict__ out = T.out[k & 1];
+        const double(*__restrict__ coef)[2] = T.coef[k & 1][parity];
+        // batches of 8 loci in sweep order; the operands of the next batch are fetched while this one's chain runs
+        double v[8], a[8], b[8], v2[8], a2[8], b2[8], r[8];
+        auto start = [](int j) { return BACKWARD ? (kRowTile - 8 - 8 * j) : (8 * j); };
+        auto fetch = [&](double(&vv)[8], double(&aa)[8], double(&bb)[8], int j) {
+            const int t0 = start((j < kRowTile / 8) ? j : (kRowTile / 8 - 1));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                vv[q] = in[(t0 + q) * kPitch + lane];
+                aa[q] = coef[t0 + q][0];
+                bb[q] = coef[t0 + q][1];
+            }
+        };
+        auto run = [&](const double(&vv)[8], const double(&aa)[8], const double(&bb)[8], int j) {
+            const int t0 = start(j);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int qq = BACKWARD ? (7 - q) : q;
+                r[qq] = chain_step(vv[qq], aa[qq], bb[qq], p1, p2);
+                p2 = p1;
+                p1 = r[qq];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                out[(t0 + q) * kPitch + lane] = r[q];
+            }
+        };
+        fetch(v, a, b, 0);
+#pragma unroll 1
+        for (int j = 0; j < kRowTile / 8; j += 2) {
+            fetch(v2, a2, b2, j + 1);
+            run(v, a, b, j);
+            fetch(v, a, b, j + 2);
+            run(v2, a2, b2, j + 1);
+        }
+    };
+    // one trip: the chain wavefront runs tile k; the helpers store tile k + 1 (in `set` since two trips), refill `set`
+    // with tile k + 3 and carry tile k - 1 to memory
+    auto trip = [&](long long k, RowRegs &set) {
+#ifdef ROCCO_ROWS_NOCHAIN  // (timing experiments only)
+        if (false) {
+#else
+        if (wave == 0) {
+#endif
+            chain(k);
+#ifdef ROCCO_ROWS_NOHELP
+        } else if (false) {
+#else
+        } else if (wave > 0) {
+#endif
+            if (k + 1 < n_tiles) {
+                stage_store(k + 1, set);
+            }
+            if (k + 3 < n_tiles) {
+                stage_load(k + 3, set);
+            }
+            if (k > 0) {
+                write_back(k - 1);
+            }
+        }
+        __syncthreads();
+    };
+
+    RowRegs A, B;
+    if (wave > 0) {
+        stage_load(0, A);
+        stage_store(0, A);
+        if (n_tiles > 1) {
+            stage_load(1, B);
+        }
+        if (n_tiles > 2) {
+            stage_load(2, A);
+        }
+    } else {
+        __builtin_amdgcn_s_setprio(3);  // the chain wavefront shares its SIMD with a helper: its instructions go first
+    }
+    __syncthreads();
+    for (long long k = 0; k < n_tiles; k += 2) {
+        trip(k, B);  // even trips store odd tiles (set B), odd trips even tiles (set A)
+        if (k + 1 < n_tiles) {
+            trip(k + 1, A);
+        }
+    }
+    if (wave > 0) {
+        write_back(n_tiles - 1);
+    }
+}
+
 __global__ void zero_kernel(double *out, long long count)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -373,7 +593,7 @@ __global__ void zero_kernel(double *out, long long count)
 
 size_t whittaker_scratch_bytes(size_t rows, size_t cols)
 {
-    return (rows * cols + 8) * sizeof(double) + 256;
+    return whittaker_batch_scratch_bytes(&rows, &cols, 1);
 }
 
 int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_dev, hipStream_t stream,
@@ -394,42 +614,94 @@ int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_de
     return ROCCO_HIP_OK;
 }
 
-int launch_crossfit_whittaker(const double *matrix_dev, size_t rows, size_t cols, double penalty_lambda,
-                              const double *factor_dev, size_t factor_cap, double *baseline_out_dev,
-                              void *scratch_dev, hipStream_t stream)
+namespace {
+
+int configure_rows_kernels()
 {
-    if (rows == 0 || cols == 0) {
-        return ROCCO_HIP_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_rows_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowTiles)));
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_rows_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowTiles)));
+        attr_set = true;
     }
-    if (cols < 25) {  // baseline_backend.c:265-272
-        const long long count = (long long)(rows * cols);
-        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
-                           baseline_out_dev, count);
+    return ROCCO_HIP_OK;
+}
+
+}  // namespace
+
+size_t whittaker_batch_scratch_bytes(const size_t *rows, const size_t *cols, size_t count)
+{
+    // per matrix: the z of parity 1 (rows x cols doubles) and 8 doubles of end entries; per group of 32 rows two task records
+    size_t bytes = 256;
+    for (size_t i = 0; i < count; ++i) {
+        bytes += (rows[i] * cols[i] + 8) * sizeof(double) + 2 * ((rows[i] + kGroupRows - 1) / kGroupRows) * sizeof(WhittakerRowTask) + 256;
+    }
+    return bytes;
+}
+
+int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const size_t *rows, const size_t *cols, size_t count,
+                                    double penalty_lambda, const double *factor_dev, size_t factor_cap, double *const *baselines_dev,
+                                    void *scratch_dev, WhittakerRowTask *tasks_host_pinned, hipStream_t stream)
+{
+    int rc;
+    if ((rc = configure_rows_kernels()) != ROCCO_HIP_OK) return rc;
+    // scratch: [tasks forward | tasks backward] then per matrix [tail (8 doubles) | z1]
+    size_t n_tasks = 0;
+    for (size_t i = 0; i < count; ++i) {
+        if (rows[i] > 0 && cols[i] >= 25) {
+            n_tasks += (rows[i] + kGroupRows - 1) / kGroupRows;
+        }
+    }
+    char *at = (char *)scratch_dev;
+    WhittakerRowTask *tasks_dev = (WhittakerRowTask *)at;
+    at += ((2 * n_tasks * sizeof(WhittakerRowTask) + 255) / 256) * 256;
+    size_t t = 0;
+    for (size_t i = 0; i < count; ++i) {
+        if (rows[i] == 0 || cols[i] == 0) {
+            continue;
+        }
+        if (cols[i] < 25) {  // baseline_backend.c:265-272
+            const long long total = (long long)(rows[i] * cols[i]);
+            hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, baselines_dev[i], total);
+            continue;
+        }
+        if (factor_dev == nullptr || factor_cap < cols[i]) {
+            return ROCCO_HIP_EINVAL;
+        }
+        double *tail = (double *)at;
+        double *z1 = tail + 8;
+        at += ((rows[i] * cols[i] + 8) * sizeof(double) + 255) / 256 * 256;
+        hipLaunchKernelGGL(whittaker_tail_kernel, dim3(1), dim3(64), 0, stream, (long long)cols[i], (long long)factor_cap, penalty_lambda,
+                           factor_dev, tail);
+        for (size_t r0 = 0; r0 < rows[i]; r0 += kGroupRows, ++t) {
+            WhittakerRowTask &fw = tasks_host_pinned[t], &bw = tasks_host_pinned[n_tasks + t];
+            fw.src0 = matrices_dev[i];
+            fw.src1 = nullptr;
+            fw.dst0 = baselines_dev[i];  // z of parity 0 lives in the output until the backward sweep replaces it
+            fw.dst1 = z1;
+            fw.n = (long long)cols[i];
+            fw.row0 = (int)r0;
+            fw.rows = (int)std::min<size_t>(kGroupRows, rows[i] - r0);
+            fw.tail = tail;
+            bw = fw;
+            bw.src0 = baselines_dev[i];
+            bw.src1 = z1;
+            bw.dst0 = baselines_dev[i];
+            bw.dst1 = nullptr;
+        }
+    }
+    if (n_tasks == 0) {
         ROCCO_HIP_TRY(hipGetLastError());
         return ROCCO_HIP_OK;
     }
-    if (factor_dev == nullptr || factor_cap < cols) {
-        return ROCCO_HIP_EINVAL;
-    }
-    double *tail = (double *)scratch_dev;  // 6 doubles
-    double *z1 = tail + 8;
-    const long long n = (long long)cols, cap = (long long)factor_cap;
-    hipLaunchKernelGGL(whittaker_tail_kernel, dim3(1), dim3(64), 0, stream, n, cap, penalty_lambda, factor_dev, tail);
-    const dim3 block(2 * kLanes + kSweepHelpers);
-    const size_t lds = 3 * sizeof(SweepTile);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_sweep_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_sweep_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(whittaker_sweep_kernel<false>, dim3((unsigned)rows), block, lds, stream, matrix_dev,
-                       (const double *)nullptr, n, cap, factor_dev, tail, baseline_out_dev, z1);
-    hipLaunchKernelGGL(whittaker_sweep_kernel<true>, dim3((unsigned)rows), block, lds, stream,
-                       (const double *)baseline_out_dev, (const double *)z1, n, cap, factor_dev, tail, baseline_out_dev,
-                       (double *)nullptr);
+    ROCCO_HIP_TRY(hipMemcpyAsync(tasks_dev, tasks_host_pinned, 2 * n_tasks * sizeof(WhittakerRowTask), hipMemcpyHostToDevice, stream));
+    const dim3 block(kLanes * (1 + kRowHelpers));
+    hipLaunchKernelGGL(whittaker_rows_kernel<false>, dim3((unsigned)n_tasks), block, sizeof(RowTiles), stream,
+                       (const WhittakerRowTask *)tasks_dev, (long long)factor_cap, factor_dev);
+    hipLaunchKernelGGL(whittaker_rows_kernel<true>, dim3((unsigned)n_tasks), block, sizeof(RowTiles), stream,
+                       (const WhittakerRowTask *)(tasks_dev + n_tasks), (long long)factor_cap, factor_dev);
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }

@@ -67,6 +67,38 @@ def crossfit_whittaker_baseline_device(values_t, penalty_lambda: float, out_t=No
     return out_t
 
 
+def crossfit_whittaker_baseline_batch_device(values_list, penalty_lambda: float, outs=None):
+    """The cross-fit baselines of several [rows_i, cols_i] float64 CUDA matrices of ONE penalty -- the chromosomes of a
+    genome -- in one pair of launches (rocco_hip_crossfit_whittaker_baseline_batch_f64): every group of 32 rows of every
+    matrix is a workgroup whose 64 lanes carry the 64 chains (32 rows x 2 parities) in lockstep, and the pair of launches
+    lasts as long as the longest row.  Returns the list of baseline tensors (`outs` when given: distinct tensors of the
+    same shapes)."""
+    import ctypes
+
+    import torch
+
+    values_list = list(values_list)
+    if not values_list:
+        return []
+    for v in values_list:
+        if v.dim() != 2 or v.dtype != torch.float64 or not v.is_cuda or not v.is_contiguous():
+            raise ValueError("every matrix must be a contiguous two-dimensional float64 CUDA tensor")
+    if outs is None:
+        outs = [torch.empty_like(v) for v in values_list]
+    for v, o in zip(values_list, outs):
+        if o.shape != v.shape or o.dtype != torch.float64 or not o.is_contiguous() or o.data_ptr() == v.data_ptr():
+            raise ValueError("every output must be a distinct contiguous float64 tensor of its matrix's shape")
+    count = len(values_list)
+    solver = _native.solver_for(values_list[0].device.index)
+    _native.check(_native.load().rocco_hip_crossfit_whittaker_baseline_batch_f64(
+        solver.handle, count, (ctypes.c_void_p * count)(*[v.data_ptr() for v in values_list]),
+        (ctypes.c_size_t * count)(*[int(v.shape[0]) for v in values_list]),
+        (ctypes.c_size_t * count)(*[int(v.shape[1]) for v in values_list]), float(penalty_lambda),
+        (ctypes.c_void_p * count)(*[o.data_ptr() for o in outs]), _dp._stream_ptr(values_list[0])),
+        "rocco_hip_crossfit_whittaker_baseline_batch_f64")
+    return outs
+
+
 def crossfit_whittaker_baseline(values, penalty_lambda: float) -> np.ndarray:
     """Same call as the reference's extension (rocco/_baseline.c:16-104): ``values`` 1-D or 2-D,
     returns a float64 array of the same shape with the cross-fit baseline of every row."""
