@@ -289,6 +289,22 @@ def use_solver(solver: Solver):
         _tls.solver = previous
 
 
+def max_side_streams() -> int:
+    """How many HIP streams besides the caller's may carry work at the same time.
+
+    The HIP runtime multiplexes a process's streams onto a fixed number of hardware queues (4 unless GPU_MAX_HW_QUEUES
+    says otherwise).  Measured on MI355X / ROCm 7.2 (round 3, the count path of a genome at K = 100): with the caller's
+    stream plus THREE worker streams everything completes; with a fourth worker -- five streams on four queues -- two of
+    the workers' streams stop for good (their host threads never return from hipStreamSynchronize; the process has to
+    be killed), and the same run with GPU_MAX_HW_QUEUES=8 completes.  So the side streams are capped at the number of
+    hardware queues minus the caller's."""
+    try:
+        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        queues = 4
+    return max(1, queues - 1)
+
+
 def solver_for(device: int) -> Solver:
     """Process-wide solver handle per device (scratch buffers are reused across calls), or the calling
     thread's own (`use_solver`)."""

@@ -781,10 +781,13 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
     if ((rc = solver->dev_misc.reserve(wls_scratch_bytes(K, n, spatial_window))) != ROCCO_HIP_OK) {
         return rc;
     }
+    if ((rc = solver->host_back.reserve(256)) != ROCCO_HIP_OK) {
+        return rc;
+    }
     return launch_score_centered_wls(centered_dev, K, n, lower_bound_z, prior_df, min_effect, use_min_effect,
                                      spatial_window, precision_floor_ratio, mean_dev, raw_var_dev, prior_var_dev,
                                      mod_var_dev, se_dev, scores_dev, solver->dev_misc.ptr, df_out, window_out,
-                                     (hipStream_t)stream);
+                                     (hipStream_t)stream, (int *)solver->host_back.ptr);
 }
 
 int rocco_hip_log_scale_f64(rocco_hip_solver *solver, const double *values_dev, size_t count, double pseudocount, double *out_dev,
@@ -799,7 +802,9 @@ int rocco_hip_log_scale_f64(rocco_hip_solver *solver, const double *values_dev, 
     int *bad = (int *)solver->dev_results.ptr;
     ROCCO_HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), (hipStream_t)stream));
     if ((rc = launch_log_scale(values_dev, out_dev, count, pseudocount, bad, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
-    int bad_host = 0;
+    if ((rc = solver->host_back.reserve(256)) != ROCCO_HIP_OK) return rc;
+    int &bad_host = *(int *)solver->host_back.ptr;  // (pinned: see launch_score_centered_wls)
+    bad_host = 0;
     ROCCO_HIP_TRY(hipMemcpyAsync(&bad_host, bad, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (bad_host != 0) {
@@ -823,8 +828,11 @@ int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *
     if ((rc = solver->dev_misc.reserve(log_scale_scratch_bytes(K, n))) != ROCCO_HIP_OK) {
         return rc;
     }
+    if ((rc = solver->host_back.reserve(256)) != ROCCO_HIP_OK) {
+        return rc;
+    }
     return launch_log_scale_center_rows(counts_dev, K, n, pseudocount, apply_log2, centered_out_dev, row_offsets_out_dev,
-                                        solver->dev_misc.ptr, (hipStream_t)stream);
+                                        solver->dev_misc.ptr, (hipStream_t)stream, (int *)solver->host_back.ptr);
 }
 
 int rocco_hip_subtract_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,

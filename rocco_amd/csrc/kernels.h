@@ -148,13 +148,13 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
                               double min_effect, int use_min_effect, int spatial_window,
                               double precision_floor_ratio, double *mean_dev, double *raw_var_dev,
                               double *prior_var_dev, double *mod_var_dev, double *se_dev, double *scores_dev,
-                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream);
+                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream, int *flag_host_pinned);
 
 // row a2 glue (wls.hip): log2(max(x, 0) + pseudocount), row medians subtracted; out may alias the input
 size_t log_scale_scratch_bytes(size_t K, size_t n);
 int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount, int apply_log,
                                  double *centered_out_dev, double *row_offsets_out_dev, void *scratch_dev,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int *flag_host_pinned);
 // out = log2(max(in, 0) + pseudocount), correctly rounded; *bad_dev |= 1 if a value is not finite
 int launch_log_scale(const double *in_dev, double *out_dev, size_t count, double pseudocount, int *bad_dev, hipStream_t stream);
 int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream);

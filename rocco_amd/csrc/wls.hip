@@ -380,8 +380,13 @@ __global__ void wls_knots_kernel(const unsigned long long *__restrict__ ys_sorte
         return;
     }
     const double fallback = s_fallback;
-    double bc[kMaxBins], bv[kMaxBins], bw[kMaxBins], fitv[kMaxBins];
-    long long bl[kMaxBins];
+    // the pooling's working arrays live in LDS, not in the thread's private memory: indexed by run-time values they
+    // would be 2.6 KB of scratch per lane -- a kernel whose scratch demand (per lane x every wavefront slot of the device)
+    // exceeds the runtime's per-queue limit takes the "large scratch" path of the HSA runtime on every dispatch, and with
+    // four or more streams dispatching it side by side (the count path of a genome, one stream per chromosome) streams
+    // stopped for good (round 3: two of four workers never returned; the process had to be killed)
+    __shared__ double bc[kMaxBins], bv[kMaxBins], bw[kMaxBins], fitv[kMaxBins];
+    __shared__ long long bl[kMaxBins];
     int used = 0;
     for (int b = 0; b < bins; ++b) {
         if (s_bw[b] > 0.0) {
@@ -712,7 +717,7 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
                               double min_effect, int use_min_effect, int spatial_window,
                               double precision_floor_ratio, double *mean_dev, double *raw_var_dev,
                               double *prior_var_dev, double *mod_var_dev, double *se_dev, double *scores_dev,
-                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream)
+                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream, int *flag_host_pinned)
 {
     const double pdf = std::fmax(prior_df, 0.0), floor_ratio = std::fmax(precision_floor_ratio, 0.0);
     const int window = wls_spatial_window(n, spatial_window);
@@ -790,10 +795,12 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     hipLaunchKernelGGL(wls_final_kernel, dim3(blocks256), dim3(256), 0, stream, sums, nn, (double)K, lower_bound_z,
                        min_effect, use_min_effect, mean_dev, raw_var_dev, prior_var_dev, mod_var_dev, se_dev, scores_dev);
     ROCCO_HIP_TRY(hipGetLastError());
-    int bad_host = 0;
-    ROCCO_HIP_TRY(hipMemcpyAsync(&bad_host, bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+    // (the flag lands in the solver's pinned memory: several host threads run this at once, each with a solver of its
+    // own, and a device-to-host copy into a thread's stack page has the runtime pin that page on the fly)
+    *flag_host_pinned = 0;
+    ROCCO_HIP_TRY(hipMemcpyAsync(flag_host_pinned, bad, sizeof(int), hipMemcpyDeviceToHost, stream));
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));  // also: the scratch buffer is the solver's
-    if (bad_host != 0) {
+    if (*flag_host_pinned != 0) {
         set_last_error("rocco_hip_score_centered_wls_f64: non-finite values in the centred matrix");
         return ROCCO_HIP_EINVAL;
     }
@@ -809,7 +816,7 @@ size_t log_scale_scratch_bytes(size_t K, size_t n)
 
 int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount, int apply_log,
                                  double *centered_out_dev, double *row_offsets_out_dev, void *scratch_dev,
-                                 hipStream_t stream)
+                                 hipStream_t stream, int *flag_host_pinned)
 {
     const long long count = (long long)(K * n), nn = (long long)n;
     char *sc = (char *)scratch_dev;
@@ -834,10 +841,10 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
         ROCCO_HIP_TRY(hipMemcpyAsync(row_offsets_out_dev, med, K * 8, hipMemcpyDeviceToDevice, stream));
     }
     ROCCO_HIP_TRY(hipGetLastError());
-    int bad_host = 0;
-    ROCCO_HIP_TRY(hipMemcpyAsync(&bad_host, bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+    *flag_host_pinned = 0;
+    ROCCO_HIP_TRY(hipMemcpyAsync(flag_host_pinned, bad, sizeof(int), hipMemcpyDeviceToHost, stream));
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));  // also: the scratch buffer is the solver's
-    if (bad_host != 0) {
+    if (*flag_host_pinned != 0) {
         set_last_error("`chrom_matrix` contains non-finite values");
         return ROCCO_HIP_EINVAL;
     }

@@ -13,6 +13,7 @@ every host.  There is no CPU fallback: without the library or a GPU these raise.
 """
 from __future__ import annotations
 
+import os
 from typing import Tuple
 
 import numpy as np
@@ -303,6 +304,156 @@ def score_loci_wls_device(counts_t, lower_bound_z: float = 1.0, prior_df: float 
         "centered_matrix": centered,
     }
     return scores, details
+
+
+# ---- the count-path scoring of several chromosomes at once ---------------------------------------------------------
+# Worker streams of the batch: one (solver handle, HIP stream, host thread) each, created on first use and kept -- the
+# native calls synchronise their stream and release the GIL, so the per-matrix phases of different chromosomes (row
+# medians and the three radix sorts of every row's trend fit, the rolling chains) overlap on the device.
+_batch_lock = None
+_batch_pool = None
+_batch_workers = {}
+
+
+def _batch_worker(device_index: int, slot: int):
+    import torch
+
+    key = (int(device_index), int(slot))
+    if key not in _batch_workers:
+        _batch_workers[key] = (_native.Solver(int(device_index)), torch.cuda.Stream(device=int(device_index)))
+    return _batch_workers[key]
+
+
+def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
+                                precision_floor_ratio: float = 0.01, overwrite_input: bool = False,
+                                input_scale: str = "counts", workers: int = 3):
+    """`score_loci_wls_device` for several [K_i, n_i] float64 CUDA count matrices -- the chromosomes a rank owns
+    (the loop of rocco/rocco.py:948-1018 around rocco/inference.py:302-379).  Returns one (scores, details) pair per
+    matrix, bit for bit what the single-matrix call returns.  What is shared: every matrix whose local-baseline window
+    gives the same Whittaker penalty (all of 101 loci or more) has its baselines fitted in ONE pair of launches
+    (`crossfit_whittaker_baseline_batch_device`: the pair lasts as long as the longest row, not as long as all rows one
+    after the other); the per-matrix phases before and after it (log scale + row medians; rolling variances, trend
+    fits, accumulation) run `workers` matrices side by side on streams and solver handles of their own -- at most
+    `_native.max_side_streams()` of them (three: one hardware queue per stream, see there)."""
+    import concurrent.futures
+    import threading
+
+    import torch
+
+    global _batch_lock, _batch_pool
+    counts_list = list(counts_list)
+    if not counts_list:
+        return []
+    if input_scale not in ("counts", "log2p1"):
+        raise ValueError("input_scale must be 'counts' or 'log2p1'")
+    for c in counts_list:
+        if c.dim() != 2 or c.dtype != torch.float64 or not c.is_cuda or not c.is_contiguous():
+            raise ValueError("every matrix must be a contiguous two-dimensional float64 CUDA tensor")
+        if int(c.shape[0]) == 0 or int(c.shape[1]) == 0:
+            raise ValueError("`chrom_matrix` must be non-empty")
+    device = counts_list[0].device
+    if _batch_lock is None:
+        _batch_lock = threading.Lock()
+    workers = max(1, min(int(workers), len(counts_list), _native.max_side_streams()))  # never more streams than hardware queues
+    caller_stream = torch.cuda.current_stream(device)
+    order = sorted(range(len(counts_list)), key=lambda i: -int(counts_list[i].shape[0]) * int(counts_list[i].shape[1]))
+
+    def fan_out(job):
+        """job(i) for every matrix, longest first, on the worker streams; results by index."""
+        start = torch.cuda.Event()
+        start.record(caller_stream)
+        out = [None] * len(counts_list)
+        slots = list(range(workers))
+        free = threading.Semaphore(workers)
+        guard = threading.Lock()
+
+        def run(i):
+            free.acquire()
+            with guard:
+                slot = slots.pop()
+            try:
+                solver, stream = _batch_worker(device.index, slot)
+                with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
+                    stream.wait_event(start)
+                    res = job(i)
+                    stream.synchronize()
+                return i, res
+            finally:
+                with guard:
+                    slots.append(slot)
+                free.release()
+
+        futures = [_batch_pool.submit(run, i) for i in order]
+        first_error = None
+        for f in futures:
+            try:
+                i, res = f.result()
+                out[i] = res
+            except BaseException as exc:  # noqa: BLE001
+                first_error = first_error or exc
+        if first_error is not None:
+            raise first_error
+        return out
+
+    with _batch_lock:
+        if _batch_pool is None:
+            _batch_pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-count")
+        trace = os.environ.get("ROCCO_BATCH_TRACE")
+        if trace:
+            print("[batch] phase 1", flush=True)
+        # phase 1: log scale, pilot offset (rocco/inference.py:325, 333-334)
+        centred = fan_out(lambda i: log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite_input else None,
+                                                                 apply_log2=(input_scale == "counts"))[0])
+        if trace:
+            print("[batch] phase 2", flush=True)
+        # phase 2: local baselines (335), matrices of one penalty together
+        windows = [_resolve_local_baseline_window(int(c.shape[1]), target_window=101) for c in centred]
+        penalties = [0.0 if w == 0 else _consenrich_whittaker_lambda(w) for w in windows]
+        baselines = [None] * len(centred)
+        for lam in sorted({p for p, w in zip(penalties, windows) if w != 0}):
+            idx = [i for i, (p, w) in enumerate(zip(penalties, windows)) if w != 0 and p == lam]
+            outs = crossfit_whittaker_baseline_batch_device([centred[i] for i in idx], lam)
+            for i, b in zip(idx, outs):
+                baselines[i] = b
+
+        if trace:
+            print("[batch] phase 3", flush=True)
+
+        # phase 3: subtraction (338) and the centred WLS (342-348) per matrix
+        def score(i):
+            c = centred[i]
+            if trace:
+                print(f"[batch] score {i} start", flush=True)
+            K, n = int(c.shape[0]), int(c.shape[1])
+            if baselines[i] is not None:
+                if not bool(torch.isfinite(baselines[i]).all()):
+                    raise ValueError("Local baseline fit produced non-finite values")
+                solver = _native.solver_for(c.device.index)
+                _native.check(_native.load().rocco_hip_subtract_f64(solver.handle, c.data_ptr(), baselines[i].data_ptr(), c.data_ptr(),
+                                                                    K * n, _dp._stream_ptr(c)), "rocco_hip_subtract_f64")
+                baselines[i] = None
+            floor_ratio = float(max(precision_floor_ratio, 0.0))
+            scores, mean, raw, prior, mod, se, total_df, resolved_window = score_centered_wls_device(
+                c, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df), min_effect=min_effect, spatial_window=31,
+                precision_floor_ratio=floor_ratio)
+            z_scores = mean / torch.clamp_min(se, 1.0e-8)
+            if not bool(torch.isfinite(torch.stack([scores, mean, raw, prior, mod, se, z_scores])).all()):
+                raise ValueError("EB scoring produced non-finite values")
+            details = {
+                "input_scale": "log2p1", "local_baseline_window": int(windows[i]), "local_baseline_lambda": float(penalties[i]),
+                "mean": mean, "raw_variance": raw, "prior_variance": prior, "moderated_variance": mod, "standard_error": se,
+                "z_scores": z_scores, "min_effect": float(0.0 if min_effect is None else max(min_effect, 0.0)),
+                "precision_floor_ratio": floor_ratio, "prior_spatial_window": int(resolved_window),
+                "degrees_of_freedom": torch.full((n,), float(total_df), dtype=torch.float64, device=c.device),
+                "centered_matrix": c,
+            }
+            for t in (scores, mean, raw, prior, mod, se, z_scores, details["degrees_of_freedom"]):
+                t.record_stream(caller_stream)
+            if trace:
+                print(f"[batch] score {i} done", flush=True)
+            return scores, details
+
+        return fan_out(score)
 
 
 def score_loci_wls(chrom_matrix, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,

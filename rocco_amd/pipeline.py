@@ -159,7 +159,8 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
     if len(chroms) == 0:
         return []
     device = chroms[0].matrix_t.device
-    n_groups = max(1, min(int(groups if groups is not None else SOLVE_GROUPS), len(chroms)))
+    # (never more group streams than hardware queues besides the caller's: _native.max_side_streams)
+    n_groups = max(1, min(int(groups if groups is not None else SOLVE_GROUPS), len(chroms), _native.max_side_streams()))
     out: List[Optional[dict]] = [None] * len(chroms)
     units = list(range(len(chroms))) if units is None else [int(u) for u in units]
 

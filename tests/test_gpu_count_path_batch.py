@@ -1,0 +1,69 @@
+"""GPU: the count-path scoring of several chromosomes at once (rocco_amd.inference.score_loci_wls_batch_device: the
+Whittaker baselines of every matrix in one pair of launches, 64 chains per wavefront; the per-matrix phases side by side
+on worker streams) against the single-matrix path and the oracle -- every track bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TRACKS = ("mean", "raw_variance", "prior_variance", "moderated_variance", "standard_error", "z_scores", "centered_matrix")
+
+
+def _counts(rng, K, n):
+    k = rng.integers(0, 4, size=(K, n))
+    for c in rng.integers(0, max(1, n - 40), size=max(1, n // 1500)):
+        k[:, c:c + int(rng.integers(4, 40))] += rng.integers(2, 7, size=(K, 1))
+    return np.ldexp(1.0, k) - 1.0  # 2^k - 1: log2(count + 1) is exact, every track must agree bit for bit
+
+
+@pytest.mark.parametrize("shapes", [[(3, 5000)], [(33, 9000), (1, 64), (2, 24), (40, 100), (65, 4097), (7, 30000)],
+                                    [(100, 20000), (100, 8191), (100, 63), (100, 128)]])
+def test_batch_equals_single_and_oracle(gpu, oracle, shapes):
+    import torch
+    from rocco_amd import inference
+
+    rng = np.random.default_rng(len(shapes))
+    hosts = [_counts(rng, K, n) for K, n in shapes]
+    mats = [torch.from_numpy(h).to(gpu) for h in hosts]
+    batch = inference.score_loci_wls_batch_device(mats, workers=3)
+    assert len(batch) == len(mats)
+    for i, (h, m, (scores, details)) in enumerate(zip(hosts, mats, batch)):
+        single_scores, single_details = inference.score_loci_wls_device(m)
+        assert torch.equal(scores, single_scores), i
+        for key in TRACKS:
+            assert torch.equal(details[key], single_details[key]), (i, key)
+        assert details["local_baseline_window"] == single_details["local_baseline_window"]
+        if i < 2 or h.size < 400000:
+            o_scores, o_details = oracle.score_loci_wls(h)
+            assert scores.cpu().numpy().tobytes() == o_scores.tobytes(), i
+            assert details["centered_matrix"].cpu().numpy().tobytes() == np.asarray(o_details["centered_matrix"]).tobytes(), i
+
+
+def test_whittaker_batch_row_groups_and_lengths(gpu, oracle):
+    """Row counts around the 32-row groups, lengths around the 64-locus tiles and the 25-locus floor, one penalty."""
+    import torch
+    from rocco_amd import inference
+
+    rng = np.random.default_rng(9)
+    lam = inference._consenrich_whittaker_lambda(101)
+    shapes = [(1, 25), (31, 63), (32, 64), (33, 65), (64, 127), (65, 128), (100, 129), (2, 24), (5, 4096), (3, 20001)]
+    hosts = [rng.normal(size=s) for s in shapes]
+    outs = inference.crossfit_whittaker_baseline_batch_device([torch.from_numpy(h).to(gpu) for h in hosts], lam)
+    for h, o in zip(hosts, outs):
+        assert o.cpu().numpy().tobytes() == oracle.crossfit_whittaker_baseline(h, lam).tobytes(), h.shape
+    with pytest.raises(ValueError):
+        m = torch.from_numpy(hosts[0]).to(gpu)
+        inference.crossfit_whittaker_baseline_batch_device([m], lam, outs=[m])
+
+
+def test_batch_errors(gpu):
+    import torch
+    from rocco_amd import inference
+
+    ok = torch.ones((2, 300), dtype=torch.float64, device=gpu)
+    bad = ok.clone()
+    bad[1, 7] = float("nan")
+    with pytest.raises(ValueError):
+        inference.score_loci_wls_batch_device([ok, bad])
+    with pytest.raises(ValueError):
+        inference.score_loci_wls_batch_device([ok.to(torch.float32)])
+    assert inference.score_loci_wls_batch_device([]) == []
