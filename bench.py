@@ -468,13 +468,41 @@ def main():
         o_scores, _ = po.score_loci_wls(sub_h)
         t_cpu = time.perf_counter() - t0
         g_scores = inference.score_loci_wls_device(sub)[0].cpu().numpy()
+        # the oracle above takes this host's np.log2, as the reference does; the device's log2 is correctly rounded: on
+        # integer counts below 7956 the two agree (tests/test_gpu_score_loci_wls.py)
         next_rows = {"score_loci_wls": {
             "value": round(n_s / t_gpu, 1), "unit": "loci/s", "workload": f"{sample} (n={n_s}), K={K} count matrix",
             "cpu_oracle_values_per_s": round(sub_h.size / t_cpu, 1), "cpu_sample": f"{ks} x {ns}",
             "gpu_values_per_s": round(K * n_s / t_gpu, 1),
-            "scores_bit_exact_vs_oracle": bool(np.array_equal(g_scores, o_scores)),
+            "scores_bit_exact_vs_oracle_numpy_log2": bool(np.array_equal(g_scores, o_scores)),
             "max_rel_score_diff_vs_oracle": float(np.abs(g_scores - o_scores).max() / np.abs(o_scores).max())}}
         del counts_t, wls_scores
+        # the same scoring over EVERY chromosome of the workload at once (rocco_amd.inference.score_loci_wls_batch_device:
+        # baselines of all chromosomes in one pair of launches, the per-matrix phases on worker streams): the benchmark's
+        # matrices are turned into counts in place, so this leg comes last
+        if len(works) > 1:
+            mats = []
+            for w in works:
+                w.matrix_t.mul_(20.0).round_()
+                mats.append(w.matrix_t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            batch = inference.score_loci_wls_batch_device(mats, overwrite_input=True)
+            torch.cuda.synchronize()
+            t_batch = time.perf_counter() - t0
+            # log scale + row medians, 2 baseline sweeps, subtraction, rolling sums, trend pairs, accumulation: every
+            # pass reads (and most write) the K x n matrix once -- about 9 passes of 8 B per value as a floor
+            passes_bytes = 9 * 8 * K * total_loci
+            next_rows["score_loci_wls_whole_workload"] = {
+                "value": round(total_loci / t_batch, 1), "unit": "loci/s", "seconds": round(t_batch, 3),
+                "workload": f"{len(works)} chromosomes, {total_loci} loci, K={K} count matrices, one call",
+                "gpu_values_per_s": round(K * total_loci / t_batch, 1),
+                "hbm_floor": {"bytes": int(passes_bytes), "achieved_GBps": round(passes_bytes / t_batch / 1e9, 1),
+                              "frac_of_peak": round(passes_bytes / t_batch / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "9 passes x 8 B per value; the row sorts of the trend fit (3 radix sorts per row) and the "
+                                      "sequential chains (bit-exactness pins their order) keep it far from the roof"},
+                "scores_finite": bool(all(bool(torch.isfinite(sc).all()) for sc, _d in batch))}
+            del batch, mats
 
     if rank == 0:
         line = {

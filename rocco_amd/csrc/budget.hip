@@ -2187,6 +2187,16 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_ROUNDS")) opt.pilot_rounds = std::atoi(e);
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_POINTS")) opt.pilot_points = std::atoi(e);
     if (const char *e = std::getenv("ROCCO_HIP_ALIGN_MAPS")) opt.align_maps = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ROCCO_HIP_PILOT_LEVELS")) {  // comma list, e.g. "2.2" or "2.2,1.0"
+        opt.pilot_levels.clear();
+        for (const char *q = e; *q != '\0';) {
+            char *end = nullptr;
+            const double v = std::strtod(q, &end);
+            if (end == q) break;
+            if (v > 0.0) opt.pilot_levels.push_back(v);
+            q = (*end == ',') ? end + 1 : end;
+        }
+    }
     struct LeanOverride {  // ROCCO_HIP_LEAN overrides the solver's setting for this call only
         rocco_hip_solver *solver;
         int saved;

@@ -523,8 +523,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     // the target, one that should select less (four: one register batch of the evaluation kernel)
                     s.pilot_hint = false;
                     std::sort(s.pilot_evals.begin(), s.pilot_evals.end());
-                    const double levels[4] = {2.2, 1.35, 1.08, 0.8};
-                    for (double mult : levels) {
+                    for (double mult : opt.pilot_levels) {
                         const double want = mult * (double)s.target;
                         double x = 0.0;
                         bool found = false;

@@ -265,6 +265,8 @@ struct SearchOptions {
     bool use_compaction = true;  // after the threshold search: continue on the loci that can still be selected
     int pilot_rounds = 2;        // sampled estimates that place the first certified evaluations (0: none)
     int pilot_points = 32;
+    // multiples of the target at which the first certified round evaluates (where the pilot's estimate crosses them)
+    std::vector<double> pilot_levels = {2.2, 1.35, 1.08, 0.8};
     // A problem whose threshold search has ended asks for its binade map (six small launches and the tolerance cap).
     // Problems of one batch end their search in different rounds; every round is shared and lasts as long as its
     // kernels, so a problem that waits for the others loses nothing -- the batch ends with its slowest member either

@@ -646,6 +646,35 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
                                     void *scratch_dev, WhittakerRowTask *tasks_host_pinned, hipStream_t stream)
 {
     int rc;
+    if (count == 1 && rows[0] > 0 && cols[0] >= 25) {
+        // ONE matrix: a workgroup per row with one chain per wavefront steps ~25 ns per locus, the 64-chain wavefronts
+        // below ~36 ns (they move 32 rows' tiles through LDS per step of the chain) -- both last as long as one row, so
+        // the lone matrix takes the faster step; two matrices or more take the launch that lasts as long as its longest
+        if (factor_dev == nullptr || factor_cap < cols[0]) {
+            return ROCCO_HIP_EINVAL;
+        }
+        double *tail = (double *)scratch_dev;  // 6 doubles
+        double *z1 = tail + 8;
+        const long long n = (long long)cols[0], cap = (long long)factor_cap;
+        hipLaunchKernelGGL(whittaker_tail_kernel, dim3(1), dim3(64), 0, stream, n, cap, penalty_lambda, factor_dev, tail);
+        const dim3 block(2 * kLanes + kSweepHelpers);
+        const size_t lds = 3 * sizeof(SweepTile);
+        static bool attr_set = false;
+        if (!attr_set) {
+            ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_sweep_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_sweep_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(whittaker_sweep_kernel<false>, dim3((unsigned)rows[0]), block, lds, stream, matrices_dev[0],
+                           (const double *)nullptr, n, cap, factor_dev, tail, baselines_dev[0], z1);
+        hipLaunchKernelGGL(whittaker_sweep_kernel<true>, dim3((unsigned)rows[0]), block, lds, stream,
+                           (const double *)baselines_dev[0], (const double *)z1, n, cap, factor_dev, tail, baselines_dev[0],
+                           (double *)nullptr);
+        ROCCO_HIP_TRY(hipGetLastError());
+        return ROCCO_HIP_OK;
+    }
     if ((rc = configure_rows_kernels()) != ROCCO_HIP_OK) return rc;
     // scratch: [tasks forward | tasks backward] then per matrix [tail (8 doubles) | z1]
     size_t n_tasks = 0;
