@@ -781,7 +781,7 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
     if ((rc = solver->dev_misc.reserve(wls_scratch_bytes(K, n, spatial_window))) != ROCCO_HIP_OK) {
         return rc;
     }
-    if ((rc = solver->host_back.reserve(256)) != ROCCO_HIP_OK) {
+    if ((rc = solver->host_back.reserve(256 + K * sizeof(int))) != ROCCO_HIP_OK) {  // the non-finite flag + one flag per row
         return rc;
     }
     return launch_score_centered_wls(centered_dev, K, n, lower_bound_z, prior_df, min_effect, use_min_effect,

@@ -13,6 +13,8 @@
 //     segmented sort of each bin's variances; pooling (262-339) and knots run in one thread per row;
 //   * rows are accumulated into the per-locus precision sums in row order (858-910), one launch per row.
 #include "kernels.h"
+
+#include <vector>
 #include "log2_cr.h"
 
 #include <hipcub/hipcub.hpp>
@@ -31,6 +33,7 @@ constexpr int kStream = kTile + kMaxWindow + 9;  // values a tile of start posit
 static_assert(kTile % 16 == 0, "two batches of 8 start positions per trip");
 constexpr int kStage = (kStream + kHelpers - 1) / kHelpers;
 constexpr int kMaxBins = 64;
+constexpr long long kTrendSelectMin = 4096;  // rows at least this long fit their trend without sorting the pairs
 
 // ---- rolling AR(1) innovation variance (wls_backend.c:610-742) --------------------------------------
 // vas[row][s] for s = 0 .. max_start (the caller indexes it with clamp(i - half, 0, max_start), 727-738).
@@ -447,6 +450,510 @@ __global__ void wls_knots_kernel(const unsigned long long *__restrict__ ys_sorte
     }
 }
 
+__device__ __forceinline__ double key_to_double(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// ---- np.median of every row without sorting it (round 3) ----------------------------------------------------------------
+// The median is one order statistic (two for an even length): a radix SELECT over the order-preserving keys finds the key
+// of rank (n - 1) / 2 of EVERY row in six passes over the matrix -- digits of 11, 11, 11, 11, 11 and 9 bits from the top,
+// each pass counting, per row, the digits of the keys that still match the row's prefix -- and one more pass finds the
+// next key above it.  56 bytes read per value and 14 launches per MATRIX, against a full radix sort (8 passes, 16 bytes
+// moved per value and pass) and ~12 launches per ROW: 2 400 sorts and 30 000 launches less per genome.
+constexpr int kSelectBuckets = 2048;
+constexpr int kSelectChunk = 8192;  // values per workgroup of a pass
+
+struct RowSelect {  // per row, in device memory
+    unsigned long long prefix;   // the bits of the wanted key found so far (right-aligned)
+    long long rank;              // rank of the wanted key among the keys that match the prefix
+    unsigned long long above;    // smallest key above the wanted one (~0: none)
+    long long count_le;          // keys at or below the wanted one
+};
+
+__device__ __forceinline__ unsigned long long order_key(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+
+// pass `p` looks at the `width` bits above bit `low`; hist[row][digit] += keys of the row matching its prefix
+__global__ __launch_bounds__(256) void row_select_count_kernel(const double *__restrict__ matrix, long long n, int low, int width,
+                                                              const RowSelect *__restrict__ state, unsigned *__restrict__ hist)
+{
+    __shared__ unsigned local[kSelectBuckets];
+    const long long row = blockIdx.y;
+    for (int b = threadIdx.x; b < kSelectBuckets; b += 256) {
+        local[b] = 0u;
+    }
+    __syncthreads();
+    const unsigned long long prefix = state[row].prefix;
+    const int above_bits = low + width;  // the prefix holds bits above_bits .. 63
+    const unsigned long long mask = (1ULL << width) - 1ULL;
+    const double *__restrict__ x = matrix + row * n;
+    const long long base = (long long)blockIdx.x * kSelectChunk;
+#pragma unroll 4
+    for (int j = 0; j < kSelectChunk / 256; ++j) {
+        const long long i = base + threadIdx.x + 256LL * j;
+        if (i < n) {
+            const unsigned long long k = order_key(x[i]);
+            if (above_bits >= 64 || (k >> above_bits) == prefix) {
+                atomicAdd(&local[(unsigned)((k >> low) & mask)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned *__restrict__ mine = hist + row * kSelectBuckets;
+    for (int b = threadIdx.x; b < kSelectBuckets; b += 256) {
+        if (local[b] != 0u) {
+            atomicAdd(&mine[b], local[b]);
+        }
+    }
+}
+
+// one workgroup per row: the digit whose bucket holds the wanted rank joins the prefix; the histogram is cleared for the next pass
+__global__ __launch_bounds__(256) void row_select_pick_kernel(RowSelect *__restrict__ state, unsigned *__restrict__ hist, int width)
+{
+    __shared__ unsigned part[256];
+    __shared__ unsigned long long chosen[2];
+    const long long row = blockIdx.x;
+    unsigned *__restrict__ mine = hist + row * kSelectBuckets;
+    const int per = kSelectBuckets / 256;  // 8 consecutive buckets per thread
+    unsigned c[8], sum = 0u;
+#pragma unroll
+    for (int q = 0; q < per; ++q) {
+        c[q] = mine[threadIdx.x * per + q];
+        sum += c[q];
+        mine[threadIdx.x * per + q] = 0u;
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long rank = state[row].rank;
+        int t = 0;
+        while (t < 255 && (long long)part[t] <= rank) {
+            rank -= (long long)part[t];
+            ++t;
+        }
+        chosen[0] = (unsigned long long)t;
+        chosen[1] = (unsigned long long)rank;
+    }
+    __syncthreads();
+    if (threadIdx.x == (unsigned)chosen[0]) {
+        long long rank = (long long)chosen[1];
+        int q = 0;
+        while (q < per - 1 && (long long)c[q] <= rank) {
+            rank -= (long long)c[q];
+            ++q;
+        }
+        const unsigned long long digit = (unsigned long long)(threadIdx.x * per + q);
+        state[row].prefix = (width >= 64) ? digit : ((state[row].prefix << width) | digit);
+        state[row].rank = rank;
+    }
+}
+
+// with the wanted key known: how many keys lie at or below it, and the smallest key above it
+__global__ __launch_bounds__(256) void row_select_above_kernel(const double *__restrict__ matrix, long long n,
+                                                              RowSelect *__restrict__ state)
+{
+    const long long row = blockIdx.y;
+    const unsigned long long want = state[row].prefix;
+    const double *__restrict__ x = matrix + row * n;
+    const long long base = (long long)blockIdx.x * kSelectChunk;
+    long long le = 0;
+    unsigned long long above = ~0ULL;
+#pragma unroll 4
+    for (int j = 0; j < kSelectChunk / 256; ++j) {
+        const long long i = base + threadIdx.x + 256LL * j;
+        if (i < n) {
+            const unsigned long long k = order_key(x[i]);
+            le += (k <= want) ? 1 : 0;
+            above = (k > want && k < above) ? k : above;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        le += __shfl_xor(le, off);
+        const unsigned long long o = __shfl_xor(above, off);
+        above = (o < above) ? o : above;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (le != 0) {
+            atomicAdd((unsigned long long *)&state[row].count_le, (unsigned long long)le);
+        }
+        if (above != ~0ULL) {
+            atomicMin(&state[row].above, above);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void row_select_init_kernel(RowSelect *__restrict__ state, unsigned *__restrict__ hist, long long rows,
+                                                             long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) {
+        state[i].prefix = 0ULL;
+        state[i].rank = (n - 1) / 2;  // the lower middle element
+        state[i].above = ~0ULL;
+        state[i].count_le = 0;
+    }
+    if (i < rows * kSelectBuckets) {
+        hist[i] = 0u;
+    }
+}
+
+// np.median: the middle value, or the mean of the two middle values (the upper one is the wanted key again when it occurs
+// more than once beyond its rank, else the next key above it)
+__global__ __launch_bounds__(256) void row_select_median_kernel(const RowSelect *__restrict__ state, long long rows, long long n,
+                                                               double *__restrict__ med)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) {
+        return;
+    }
+    const double lo = key_to_double(state[i].prefix);
+    if (n & 1LL) {
+        med[i] = lo;
+    } else {
+        const double hi = (state[i].count_le >= n / 2 + 1) ? lo : key_to_double(state[i].above);
+        med[i] = (lo + hi) / 2.0;
+    }
+}
+
+// ---- the trend fit without sorting the pairs (round 3) ------------------------------------------------------------------
+// What the fit needs of the (x, y)-sorted sequence (wls_backend.c:454-520) is, per bin, the median x and the median y.  The
+// bins are contiguous rank ranges of the x order, so: ONE keys-only sort of x per row gives every bin's first x (its
+// boundary) and median x; with the boundaries every pair knows its bin from its x alone -- unless a boundary falls inside
+// a run of equal x, where the reference's order inside the run (by y) decides: such a row (`tie`) takes the sorted path
+// below, as do short rows; the y values of ALL rows of the matrix are then dealt into per-bin segments (order inside a
+// segment does not matter) and every segment's median is one radix select (the row-median kernels of the count-path
+// glue, per segment).  Per value: one 8-byte key sorted instead of two 16-byte pairs and a byte, 24 B to deal, 56 B to
+// select; per row 10 launches instead of 40, the rest of the work in launches over the whole matrix.
+struct TrendRow {
+    double bound[kMaxBins];  // bound[b] (b >= 1): the x of the first pair of bin b
+    double cov[kMaxBins];    // median x of the bin
+    double var[kMaxBins];    // median y of the bin
+    int tie;                 // 1: this row takes the sorted path
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void wls_xkeys_kernel(const double *__restrict__ row, long long n, unsigned long long *__restrict__ key_x,
+                                                       int *__restrict__ bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const double x = fabs(row[i]);
+    if (!isfinite(x)) {
+        atomicOr(bad, 1);
+    }
+    key_x[i] = (unsigned long long)__double_as_longlong(x);  // non-negative doubles order like their bit patterns
+}
+
+// one wavefront per row: lane b = bin b of the x-sorted keys
+__global__ __launch_bounds__(64) void wls_bounds_kernel(const unsigned long long *__restrict__ xs, long long n, int bins, TrendRow *row)
+{
+    const int b = threadIdx.x;
+    if (b == 0) {
+        row->tie = 0;
+    }
+    __syncthreads();
+    if (b >= bins) {
+        return;
+    }
+    const long long left = ((long long)b * n) / bins, right = ((long long)(b + 1) * n) / bins;
+    const long long width = right - left;
+    double c = 0.0;
+    if (width > 0) {
+        c = (width & 1LL) ? bits_to_double(xs[left + width / 2])
+                          : 0.5 * (bits_to_double(xs[left + width / 2 - 1]) + bits_to_double(xs[left + width / 2]));
+    }
+    row->cov[b] = c;
+    row->bound[b] = (left < n) ? bits_to_double(xs[left]) : INFINITY;
+    if (width <= 0 || (b >= 1 && left >= 1 && xs[left - 1] == xs[left])) {
+        atomicOr(&row->tie, 1);  // an empty bin, or a boundary inside a run of equal x
+    }
+}
+
+constexpr int kDealChunk = 4096;  // pairs per workgroup of the dealing kernel (16 per thread)
+
+// every pair's y to its bin's segment of ypart (row-major, bin b of a row at [left_b, right_b)); cursor[row][b] counts
+__global__ __launch_bounds__(256) void wls_deal_kernel(const double *__restrict__ matrix, const double *__restrict__ vas, long long n,
+                                                      long long half, long long max_start, int bins, const TrendRow *__restrict__ rows,
+                                                      unsigned *__restrict__ cursor, double *__restrict__ ypart, int *__restrict__ bad)
+{
+    __shared__ double sb[kMaxBins];
+    __shared__ unsigned cnt[kMaxBins], base[kMaxBins];
+    const long long r = blockIdx.y;
+    const TrendRow &tr = rows[r];
+    if (tr.tie != 0) {
+        return;
+    }
+    const int t = threadIdx.x;
+    if (t < kMaxBins) {
+        sb[t] = (t >= 1 && t < bins) ? tr.bound[t] : ((t == 0) ? -1.0 : INFINITY);
+        cnt[t] = 0u;
+    }
+    __syncthreads();
+    const double *__restrict__ row = matrix + r * n;
+    const double *__restrict__ vas_row = vas + r * (max_start + 1);
+    const long long first = (long long)blockIdx.x * kDealChunk;
+    unsigned char mine[kDealChunk / 256];
+#pragma unroll
+    for (int j = 0; j < kDealChunk / 256; ++j) {
+        const long long i = first + t + 256LL * j;
+        int b = 0;
+        if (i < n) {
+            const double x = fabs(row[i]);
+            // the bin: how many boundaries lie at or below x (sb ascending, +inf beyond the last bin)
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                b += (b + step < kMaxBins && sb[b + step] <= x) ? step : 0;
+            }
+            atomicAdd(&cnt[b], 1u);
+        }
+        mine[j] = (unsigned char)b;
+    }
+    __syncthreads();
+    if (t < bins) {
+        const unsigned c = cnt[t];
+        base[t] = (c != 0u) ? atomicAdd(&cursor[r * kMaxBins + t], c) : 0u;
+        cnt[t] = 0u;
+    }
+    __syncthreads();
+    double *__restrict__ out = ypart + r * n;
+#pragma unroll
+    for (int j = 0; j < kDealChunk / 256; ++j) {
+        const long long i = first + t + 256LL * j;
+        if (i < n) {
+            const int b = mine[j];
+            const double y = fmax(obs_variance_at(vas_row, i, half, max_start), 1.0e-8);  // wls_backend.c:429-430
+            if (!isfinite(y)) {
+                atomicOr(bad, 1);
+            }
+            const long long left = ((long long)b * n) / bins, right = ((long long)(b + 1) * n) / bins;
+            const long long pos = left + (long long)base[b] + (long long)atomicAdd(&cnt[b], 1u);
+            if (pos < right) {  // (never false when the boundaries are what they should be: checked by the cursor afterwards)
+                out[pos] = y;
+            }
+        }
+    }
+}
+
+// median of every (row, bin) segment of ypart: the radix select of the row medians, one "row" per segment
+typedef RowSelect SegSelect;
+
+__device__ __forceinline__ void segment_of(long long seg, long long n, int bins, long long &offset, long long &width)
+{
+    const long long r = seg / bins, b = seg % bins;
+    const long long left = (b * n) / bins, right = ((b + 1) * n) / bins;
+    offset = r * n + left;
+    width = right - left;
+}
+
+__global__ __launch_bounds__(256) void seg_select_init_kernel(SegSelect *__restrict__ state, unsigned *__restrict__ hist, long long segs,
+                                                             long long n, int bins, unsigned *__restrict__ cursor, long long rows)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < segs) {
+        long long off, w;
+        segment_of(i, n, bins, off, w);
+        state[i].prefix = 0ULL;
+        state[i].rank = (w - 1) / 2;
+        state[i].above = ~0ULL;
+        state[i].count_le = 0;
+    }
+    if (i < segs * kSelectBuckets) {
+        hist[i] = 0u;
+    }
+    if (i < rows * kMaxBins) {
+        cursor[i] = 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_select_count_kernel(const double *__restrict__ ypart, long long n, int bins, int low, int width,
+                                                              const SegSelect *__restrict__ state, const TrendRow *__restrict__ rows,
+                                                              unsigned *__restrict__ hist)
+{
+    __shared__ unsigned local[kSelectBuckets];
+    const long long seg = blockIdx.y;
+    if (rows[seg / bins].tie != 0) {
+        return;
+    }
+    long long off, w;
+    segment_of(seg, n, bins, off, w);
+    const long long base = (long long)blockIdx.x * kSelectChunk;
+    if (base >= w) {
+        return;
+    }
+    for (int b = threadIdx.x; b < kSelectBuckets; b += 256) {
+        local[b] = 0u;
+    }
+    __syncthreads();
+    const unsigned long long prefix = state[seg].prefix;
+    const int above_bits = low + width;
+    const unsigned long long mask = (1ULL << width) - 1ULL;
+    const double *__restrict__ y = ypart + off;
+#pragma unroll 4
+    for (int j = 0; j < kSelectChunk / 256; ++j) {
+        const long long i = base + threadIdx.x + 256LL * j;
+        if (i < w) {
+            const unsigned long long k = (unsigned long long)__double_as_longlong(y[i]);  // y > 0: bit order = numeric order
+            if (above_bits >= 64 || (k >> above_bits) == prefix) {
+                atomicAdd(&local[(unsigned)((k >> low) & mask)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned *__restrict__ mine = hist + seg * kSelectBuckets;
+    for (int b = threadIdx.x; b < kSelectBuckets; b += 256) {
+        if (local[b] != 0u) {
+            atomicAdd(&mine[b], local[b]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_select_above_kernel(const double *__restrict__ ypart, long long n, int bins,
+                                                              SegSelect *__restrict__ state, const TrendRow *__restrict__ rows)
+{
+    const long long seg = blockIdx.y;
+    if (rows[seg / bins].tie != 0) {
+        return;
+    }
+    long long off, w;
+    segment_of(seg, n, bins, off, w);
+    const long long base = (long long)blockIdx.x * kSelectChunk;
+    if (base >= w) {
+        return;
+    }
+    const unsigned long long want = state[seg].prefix;
+    const double *__restrict__ y = ypart + off;
+    long long le = 0;
+    unsigned long long above = ~0ULL;
+#pragma unroll 4
+    for (int j = 0; j < kSelectChunk / 256; ++j) {
+        const long long i = base + threadIdx.x + 256LL * j;
+        if (i < w) {
+            const unsigned long long k = (unsigned long long)__double_as_longlong(y[i]);
+            le += (k <= want) ? 1 : 0;
+            above = (k > want && k < above) ? k : above;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        le += __shfl_xor(le, o);
+        const unsigned long long other = __shfl_xor(above, o);
+        above = (other < above) ? other : above;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (le != 0) {
+            atomicAdd((unsigned long long *)&state[seg].count_le, (unsigned long long)le);
+        }
+        if (above != ~0ULL) {
+            atomicMin(&state[seg].above, above);
+        }
+    }
+}
+
+// the segment medians into the rows' tables; a row whose pairs did not fill every bin exactly (cannot happen with clean
+// boundaries; kept as a guard) is sent to the sorted path
+__global__ __launch_bounds__(64) void seg_select_finish_kernel(const SegSelect *__restrict__ state, long long n, int bins,
+                                                              const unsigned *__restrict__ cursor, TrendRow *__restrict__ rows)
+{
+    const long long r = blockIdx.x;
+    const int b = threadIdx.x;
+    if (b >= bins || rows[r].tie != 0) {
+        return;
+    }
+    long long off, w;
+    segment_of(r * bins + b, n, bins, off, w);
+    if ((long long)cursor[r * kMaxBins + b] != w) {
+        atomicOr(&rows[r].tie, 1);
+        return;
+    }
+    const SegSelect &st = state[r * bins + b];
+    const double lo = bits_to_double(st.prefix);
+    double med = lo;
+    if ((w & 1LL) == 0) {
+        const double hi = (st.count_le >= w / 2 + 1) ? lo : bits_to_double(st.above);
+        med = 0.5 * (lo + hi);
+    }
+    rows[r].var[b] = med;
+}
+
+__global__ __launch_bounds__(256) void wls_tie_flags_kernel(const TrendRow *__restrict__ rows, long long count, int *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) {
+        out[i] = rows[i].tie;
+    }
+}
+
+// one workgroup per row: bins -> pooled fit -> knots, from the row's table (the same steps as wls_knots_kernel below)
+__global__ __launch_bounds__(64) void wls_knots_rows_kernel(const TrendRow *__restrict__ rows, long long n, int bins, TrendFit *fits)
+{
+    __shared__ double bc[kMaxBins], bv[kMaxBins], bw[kMaxBins], fitv[kMaxBins];
+    __shared__ long long bl[kMaxBins];
+    const long long r = blockIdx.x;
+    const TrendRow &tr = rows[r];
+    if (tr.tie != 0 || threadIdx.x != 0) {
+        return;
+    }
+    TrendFit *fit = fits + r;
+    int used = 0;
+    for (int b = 0; b < bins; ++b) {
+        const long long width = (((long long)(b + 1) * n) / bins) - (((long long)b * n) / bins);
+        if (width > 0) {
+            bc[used] = tr.cov[b];
+            bv[used] = tr.var[b];
+            bw[used] = (double)width;
+            ++used;
+        }
+    }
+    fit->mode = 0;
+    fit->knots = 0;
+    if (used == 1) {
+        fit->value = fmax(bv[0], 1.0e-8);
+        return;
+    }
+    int nb = 0;
+    for (int i = 0; i < used; ++i) {  // pool adjacent violators (wls_backend.c:262-339)
+        fitv[nb] = bv[i];
+        bw[nb] = fmax(bw[i], 1.0e-8);
+        bl[nb] = 1;
+        ++nb;
+        while (nb >= 2 && fitv[nb - 2] > fitv[nb - 1]) {
+            const double tw = bw[nb - 2] + bw[nb - 1];
+            const double mv = ((fitv[nb - 2] * bw[nb - 2]) + (fitv[nb - 1] * bw[nb - 1])) / tw;
+            fitv[nb - 2] = mv;
+            bw[nb - 2] = tw;
+            bl[nb - 2] += bl[nb - 1];
+            --nb;
+        }
+    }
+    int knots = 0, idx = 0;
+    for (int b = 0; b < nb; ++b) {  // expand blocks and build the knots (wls_backend.c:541-552)
+        for (long long q = 0; q < bl[b]; ++q, ++idx) {
+            const double cv = bc[idx], vv = fmax(fitv[b], 1.0e-8);
+            if (knots > 0 && cv <= fit->kc[knots - 1]) {
+                fit->kv[knots - 1] = fmax(fit->kv[knots - 1], vv);
+                continue;
+            }
+            fit->kc[knots] = cv;
+            fit->kv[knots] = vv;
+            ++knots;
+        }
+    }
+    fit->knots = knots;
+    if (knots == 1) {
+        fit->value = fmax(fit->kv[0], 1.0e-8);
+    } else {
+        fit->mode = 2;
+    }
+}
+
 // wls_backend.c:341-392
 __device__ __forceinline__ double linear_interp(const double *xs, const double *ys, int count, double t)
 {
@@ -624,11 +1131,6 @@ __global__ __launch_bounds__(256) void order_key_kernel(const double *__restrict
     }
 }
 
-__device__ __forceinline__ double key_to_double(unsigned long long k)
-{
-    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
-    return __longlong_as_double((long long)b);
-}
 
 // np.median of one sorted row: the middle value, or the mean of the two middle values
 __global__ void row_median_kernel(const unsigned long long *__restrict__ sorted_keys, long long n, double *__restrict__ med)
@@ -639,171 +1141,6 @@ __global__ void row_median_kernel(const unsigned long long *__restrict__ sorted_
         } else {
             *med = (key_to_double(sorted_keys[n / 2 - 1]) + key_to_double(sorted_keys[n / 2])) / 2.0;
         }
-    }
-}
-
-// ---- np.median of every row without sorting it (round 3) ----------------------------------------------------------------
-// The median is one order statistic (two for an even length): a radix SELECT over the order-preserving keys finds the key
-// of rank (n - 1) / 2 of EVERY row in six passes over the matrix -- digits of 11, 11, 11, 11, 11 and 9 bits from the top,
-// each pass counting, per row, the digits of the keys that still match the row's prefix -- and one more pass finds the
-// next key above it.  56 bytes read per value and 14 launches per MATRIX, against a full radix sort (8 passes, 16 bytes
-// moved per value and pass) and ~12 launches per ROW: 2 400 sorts and 30 000 launches less per genome.
-constexpr int kSelectBuckets = 2048;
-constexpr int kSelectChunk = 8192;  // values per workgroup of a pass
-
-struct RowSelect {  // per row, in device memory
-    unsigned long long prefix;   // the bits of the wanted key found so far (right-aligned)
-    long long rank;              // rank of the wanted key among the keys that match the prefix
-    unsigned long long above;    // smallest key above the wanted one (~0: none)
-    long long count_le;          // keys at or below the wanted one
-};
-
-__device__ __forceinline__ unsigned long long order_key(double v)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
-}
-
-// pass `p` looks at the `width` bits above bit `low`; hist[row][digit] += keys of the row matching its prefix
-__global__ __launch_bounds__(256) void row_select_count_kernel(const double *__restrict__ matrix, long long n, int low, int width,
-                                                              const RowSelect *__restrict__ state, unsigned *__restrict__ hist)
-{
-    __shared__ unsigned local[kSelectBuckets];
-    const long long row = blockIdx.y;
-    for (int b = threadIdx.x; b < kSelectBuckets; b += 256) {
-        local[b] = 0u;
-    }
-    __syncthreads();
-    const unsigned long long prefix = state[row].prefix;
-    const int above_bits = low + width;  // the prefix holds bits above_bits .. 63
-    const unsigned long long mask = (1ULL << width) - 1ULL;
-    const double *__restrict__ x = matrix + row * n;
-    const long long base = (long long)blockIdx.x * kSelectChunk;
-#pragma unroll 4
-    for (int j = 0; j < kSelectChunk / 256; ++j) {
-        const long long i = base + threadIdx.x + 256LL * j;
-        if (i < n) {
-            const unsigned long long k = order_key(x[i]);
-            if (above_bits >= 64 || (k >> above_bits) == prefix) {
-                atomicAdd(&local[(unsigned)((k >> low) & mask)], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    unsigned *__restrict__ mine = hist + row * kSelectBuckets;
-    for (int b = threadIdx.x; b < kSelectBuckets; b += 256) {
-        if (local[b] != 0u) {
-            atomicAdd(&mine[b], local[b]);
-        }
-    }
-}
-
-// one workgroup per row: the digit whose bucket holds the wanted rank joins the prefix; the histogram is cleared for the next pass
-__global__ __launch_bounds__(256) void row_select_pick_kernel(RowSelect *__restrict__ state, unsigned *__restrict__ hist, int width)
-{
-    __shared__ unsigned part[256];
-    __shared__ unsigned long long chosen[2];
-    const long long row = blockIdx.x;
-    unsigned *__restrict__ mine = hist + row * kSelectBuckets;
-    const int per = kSelectBuckets / 256;  // 8 consecutive buckets per thread
-    unsigned c[8], sum = 0u;
-#pragma unroll
-    for (int q = 0; q < per; ++q) {
-        c[q] = mine[threadIdx.x * per + q];
-        sum += c[q];
-        mine[threadIdx.x * per + q] = 0u;
-    }
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long rank = state[row].rank;
-        int t = 0;
-        while (t < 255 && (long long)part[t] <= rank) {
-            rank -= (long long)part[t];
-            ++t;
-        }
-        chosen[0] = (unsigned long long)t;
-        chosen[1] = (unsigned long long)rank;
-    }
-    __syncthreads();
-    if (threadIdx.x == (unsigned)chosen[0]) {
-        long long rank = (long long)chosen[1];
-        int q = 0;
-        while (q < per - 1 && (long long)c[q] <= rank) {
-            rank -= (long long)c[q];
-            ++q;
-        }
-        const unsigned long long digit = (unsigned long long)(threadIdx.x * per + q);
-        state[row].prefix = (width >= 64) ? digit : ((state[row].prefix << width) | digit);
-        state[row].rank = rank;
-    }
-}
-
-// with the wanted key known: how many keys lie at or below it, and the smallest key above it
-__global__ __launch_bounds__(256) void row_select_above_kernel(const double *__restrict__ matrix, long long n,
-                                                              RowSelect *__restrict__ state)
-{
-    const long long row = blockIdx.y;
-    const unsigned long long want = state[row].prefix;
-    const double *__restrict__ x = matrix + row * n;
-    const long long base = (long long)blockIdx.x * kSelectChunk;
-    long long le = 0;
-    unsigned long long above = ~0ULL;
-#pragma unroll 4
-    for (int j = 0; j < kSelectChunk / 256; ++j) {
-        const long long i = base + threadIdx.x + 256LL * j;
-        if (i < n) {
-            const unsigned long long k = order_key(x[i]);
-            le += (k <= want) ? 1 : 0;
-            above = (k > want && k < above) ? k : above;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        le += __shfl_xor(le, off);
-        const unsigned long long o = __shfl_xor(above, off);
-        above = (o < above) ? o : above;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (le != 0) {
-            atomicAdd((unsigned long long *)&state[row].count_le, (unsigned long long)le);
-        }
-        if (above != ~0ULL) {
-            atomicMin(&state[row].above, above);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void row_select_init_kernel(RowSelect *__restrict__ state, unsigned *__restrict__ hist, long long rows,
-                                                             long long n)
-{
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < rows) {
-        state[i].prefix = 0ULL;
-        state[i].rank = (n - 1) / 2;  // the lower middle element
-        state[i].above = ~0ULL;
-        state[i].count_le = 0;
-    }
-    if (i < rows * kSelectBuckets) {
-        hist[i] = 0u;
-    }
-}
-
-// np.median: the middle value, or the mean of the two middle values (the upper one is the wanted key again when it occurs
-// more than once beyond its rank, else the next key above it)
-__global__ __launch_bounds__(256) void row_select_median_kernel(const RowSelect *__restrict__ state, long long rows, long long n,
-                                                               double *__restrict__ med)
-{
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows) {
-        return;
-    }
-    const double lo = key_to_double(state[i].prefix);
-    if (n & 1LL) {
-        med[i] = lo;
-    } else {
-        const double hi = (state[i].count_le >= n / 2 + 1) ? lo : key_to_double(state[i].above);
-        med[i] = (lo + hi) / 2.0;
     }
 }
 
@@ -874,8 +1211,15 @@ size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window)
 {
     // windows above the tiled kernel's limit keep the three running sums of every row in memory
     const size_t general = (wls_spatial_window(n, spatial_window) > kMaxWindow) ? align_up(3 * K * n * 8, 256) : 0;
-    return general + align_up(K * n * 8, 256) + 6 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256) + 2 * align_up(n, 256) +
-           align_up(4 * n * 8, 256) + sort_temp_bytes(n) + 4096;
+    // the sort-free trend fit (rows of kTrendSelectMin loci or more): the dealt y of every row, the rows' tables, the
+    // segment selects' state and histograms, the cursors, one fit per row
+    const size_t segs = K * (size_t)kMaxBins;
+    const size_t dealt = (n >= (size_t)kTrendSelectMin)
+                             ? align_up(K * n * 8, 256) + align_up(K * sizeof(TrendRow), 256) + align_up(segs * sizeof(RowSelect), 256) +
+                                   align_up(segs * kSelectBuckets * sizeof(unsigned), 256) + align_up(segs * sizeof(unsigned), 256)
+                             : 0;
+    return general + dealt + align_up(K * sizeof(TrendFit), 256) + align_up(K * n * 8, 256) + 6 * align_up(n * 8, 256) +
+           2 * align_up(n * 4, 256) + 2 * align_up(n, 256) + align_up(4 * n * 8, 256) + sort_temp_bytes(n) + 4096;
 }
 
 int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, double lower_bound_z, double prior_df,
@@ -908,9 +1252,16 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     unsigned *iota = (unsigned *)carve(n * 4), *perm = (unsigned *)carve(n * 4);
     unsigned char *bin_a = (unsigned char *)carve(n), *bin_b = (unsigned char *)carve(n);
     double *sums = (double *)carve(4 * n * 8);
-    TrendFit *fit = (TrendFit *)carve(sizeof(TrendFit));
+    TrendFit *fits = (TrendFit *)carve(K * sizeof(TrendFit));  // one per row
     int *bad = (int *)carve(256);
     double *general_sums = (window > kMaxWindow) ? (double *)carve(3 * K * n * 8) : nullptr;
+    const bool select_path = nn >= kTrendSelectMin && window > 0;
+    const size_t segs = K * (size_t)kMaxBins;
+    double *ypart = select_path ? (double *)carve(K * n * 8) : nullptr;
+    TrendRow *trows = select_path ? (TrendRow *)carve(K * sizeof(TrendRow)) : nullptr;
+    RowSelect *seg_state = select_path ? (RowSelect *)carve(segs * sizeof(RowSelect)) : nullptr;
+    unsigned *seg_hist = select_path ? (unsigned *)carve(segs * kSelectBuckets * sizeof(unsigned)) : nullptr;
+    unsigned *cursor = select_path ? (unsigned *)carve(segs * sizeof(unsigned)) : nullptr;
     void *tmp = sc + off;
     const size_t tmp_bytes = sort_temp_bytes(n);
     ROCCO_HIP_TRY(hipMemsetAsync(sums, 0, 4 * n * 8, stream));
@@ -935,14 +1286,14 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
             set_last_error("rocco_hip_score_centered_wls_f64: more than 64 trend bins");
             return ROCCO_HIP_EINVAL;
         }
-        hipLaunchKernelGGL(wls_iota_kernel, dim3(blocks256), dim3(256), 0, stream, iota, nn);
-        for (size_t k = 0; k < K; ++k) {
+        // the sorted path of one row (short rows; rows whose bin boundaries fall into runs of equal |value|): the reference
+        // sorts the pairs under the total order (x, then y), so the sorted sequence is unique
+        auto sorted_row = [&](size_t k) -> int {
             const double *row = centered_dev + k * n;
             const double *vas_row = vas + k * vas_stride;
             hipLaunchKernelGGL(wls_pairs_kernel, dim3(blocks256), dim3(256), 0, stream, row, vas_row, nn, half, max_start,
                                key_a, val_a, bad);
-            // The reference sorts the pairs under the total order (x, then y): the sorted sequence is unique.
-            // By y carrying x (key_b = every y ascending, also the fallback median) ...
+            // by y carrying x (key_b = every y ascending, also the fallback median) ...
             size_t t = tmp_bytes;
             ROCCO_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, t, key_a, key_b, val_a, val_b, (int)n, 0, 64, stream));
             // ... then -- stable -- by x carrying the y-rank: key_c = x in (x, y) order, perm = y-rank by (x, y)-rank
@@ -952,9 +1303,57 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
             hipLaunchKernelGGL(wls_bin_scatter_kernel, dim3(blocks256), dim3(256), 0, stream, perm, nn, bins, bin_a);
             t = tmp_bytes;
             ROCCO_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, t, bin_a, bin_b, key_b, key_d, (int)n, 0, 6, stream));
-            hipLaunchKernelGGL(wls_knots_kernel, dim3(1), dim3(kMaxBins), 0, stream, key_b, key_c, key_d, nn, bins, fit);
-            hipLaunchKernelGGL(wls_accumulate_kernel, dim3(blocks256), dim3(256), 0, stream, row, vas_row, nn, half,
-                               max_start, fit, local_df, pdf, total_df, floor_ratio, sums);
+            hipLaunchKernelGGL(wls_knots_kernel, dim3(1), dim3(kMaxBins), 0, stream, key_b, key_c, key_d, nn, bins, fits + k);
+            return ROCCO_HIP_OK;
+        };
+        hipLaunchKernelGGL(wls_iota_kernel, dim3(blocks256), dim3(256), 0, stream, iota, nn);
+        std::vector<int> tie(K, 1);
+        if (select_path) {
+            // x side, row by row: one keys-only sort -> the bins' first and median x
+            for (size_t k = 0; k < K; ++k) {
+                hipLaunchKernelGGL(wls_xkeys_kernel, dim3(blocks256), dim3(256), 0, stream, centered_dev + k * n, nn, key_a, bad);
+                size_t t = tmp_bytes;
+                ROCCO_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(tmp, t, key_a, key_b, (int)n, 0, 63, stream));  // (bit 63 is 0)
+                hipLaunchKernelGGL(wls_bounds_kernel, dim3(1), dim3(64), 0, stream, key_b, nn, bins, trows + k);
+            }
+            // y side, every row of the matrix at once: deal the y to the bins' segments, select every segment's median
+            const long long n_segs = (long long)K * bins;
+            hipLaunchKernelGGL(seg_select_init_kernel, dim3((unsigned)((n_segs * kSelectBuckets + 255) / 256)), dim3(256), 0, stream,
+                               seg_state, seg_hist, n_segs, nn, bins, cursor, (long long)K);
+            hipLaunchKernelGGL(wls_deal_kernel, dim3((unsigned)((nn + kDealChunk - 1) / kDealChunk), (unsigned)K), dim3(256), 0, stream,
+                               centered_dev, (const double *)vas, nn, half, max_start, bins, (const TrendRow *)trows, cursor, ypart, bad);
+            const long long widest = (nn + bins - 1) / bins + 1;
+            const dim3 seg_grid((unsigned)((widest + kSelectChunk - 1) / kSelectChunk), (unsigned)n_segs);
+            const int lows[6] = {53, 42, 31, 20, 9, 0}, widths[6] = {11, 11, 11, 11, 11, 9};
+            for (int p = 0; p < 6; ++p) {
+                hipLaunchKernelGGL(seg_select_count_kernel, seg_grid, dim3(256), 0, stream, (const double *)ypart, nn, bins, lows[p],
+                                   widths[p], (const RowSelect *)seg_state, (const TrendRow *)trows, seg_hist);
+                hipLaunchKernelGGL(row_select_pick_kernel, dim3((unsigned)n_segs), dim3(256), 0, stream, seg_state, seg_hist,
+                                   (p == 0) ? 64 : widths[p]);
+            }
+            hipLaunchKernelGGL(seg_select_above_kernel, seg_grid, dim3(256), 0, stream, (const double *)ypart, nn, bins, seg_state,
+                               (const TrendRow *)trows);
+            hipLaunchKernelGGL(seg_select_finish_kernel, dim3((unsigned)K), dim3(64), 0, stream, (const RowSelect *)seg_state, nn, bins,
+                               (const unsigned *)cursor, trows);
+            hipLaunchKernelGGL(wls_knots_rows_kernel, dim3((unsigned)K), dim3(64), 0, stream, (const TrendRow *)trows, nn, bins, fits);
+            // which rows must take the sorted path after all: K flags through the solver's pinned memory (behind the
+            // first 64 ints of it, where the non-finite flag lands at the end)
+            int *tie_dev = (int *)cursor;  // (the cursors have been checked: their room serves the flags)
+            hipLaunchKernelGGL(wls_tie_flags_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, stream, (const TrendRow *)trows,
+                               (long long)K, tie_dev);
+            ROCCO_HIP_TRY(hipMemcpyAsync(flag_host_pinned + 64, tie_dev, K * sizeof(int), hipMemcpyDeviceToHost, stream));
+            ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+            for (size_t k = 0; k < K; ++k) {
+                tie[k] = flag_host_pinned[64 + k];
+            }
+        }
+        for (size_t k = 0; k < K; ++k) {
+            if (tie[k] != 0) {
+                int rc = sorted_row(k);
+                if (rc != ROCCO_HIP_OK) return rc;
+            }
+            hipLaunchKernelGGL(wls_accumulate_kernel, dim3(blocks256), dim3(256), 0, stream, centered_dev + k * n, vas + k * vas_stride, nn,
+                               half, max_start, fits + k, local_df, pdf, total_df, floor_ratio, sums);
         }
     }
     hipLaunchKernelGGL(wls_final_kernel, dim3(blocks256), dim3(256), 0, stream, sums, nn, (double)K, lower_bound_z,

@@ -99,3 +99,34 @@ def test_wrapper_details(gpu, oracle):
     assert details["mean"].tobytes() == o[1].tobytes() and details["standard_error"].tobytes() == o[5].tobytes()
     assert details["prior_spatial_window"] == 31.0 and details["min_effect"] == 0.1
     assert np.all(details["degrees_of_freedom"] == o[6])
+
+
+@pytest.mark.parametrize("kind", ["quantised", "few_levels", "zeros_and_noise", "boundary_tie_only"])
+def test_trend_fit_with_runs_of_equal_values(gpu, oracle, kind):
+    """Rows of 4096 loci or more fit their variance trend without sorting the pairs: one keys-only sort of |value| gives the
+    bins' boundaries, and a pair knows its bin from its |value| alone -- unless a boundary falls inside a run of equal
+    |value|, where the reference's order inside the run (by variance) decides: such rows take the sorted path.  Rows
+    full of ties, rows with a single tie exactly at a boundary, and clean rows side by side in one matrix."""
+    from rocco_amd.inference import score_centered_wls
+
+    rng = np.random.default_rng(hash(kind) % 1000)
+    K, n = 5, 30011
+    m = rng.normal(0.0, 0.8, size=(K, n))
+    if kind == "quantised":
+        m = np.round(m, 1)  # ~60 distinct |values|: every boundary inside a run
+    elif kind == "few_levels":
+        m = rng.choice(np.array([-2.0, -0.5, 0.0, 0.5, 1.5]), size=(K, n))
+    elif kind == "zeros_and_noise":
+        m[:, rng.random(n) < 0.6] = 0.0
+        m[3] = rng.normal(size=n)  # one clean row among them
+    else:
+        # rows 0 and 2 clean; row 1: exactly two equal |values| placed at the ranks around one bin boundary
+        bins = int(np.floor(1.0 + np.log2(n + 1.0)))
+        order = np.argsort(np.abs(m[1]))
+        left = (7 * n) // bins
+        m[1, order[left]] = -m[1, order[left - 1]]
+    got = score_centered_wls(m)
+    want = oracle.score_centered_wls(m)
+    for g, w in zip(got[:6], want[:6]):
+        assert np.asarray(g).tobytes() == np.asarray(w).tobytes(), kind
+    assert got[6:] == want[6:]
