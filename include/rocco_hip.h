@@ -296,6 +296,19 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
                                      int spatial_window, double precision_floor_ratio, double *mean_dev,
                                      double *raw_var_dev, double *prior_var_dev, double *mod_var_dev, double *se_dev,
                                      double *scores_dev, double *df_out, int *window_out, void *stream);
+/* The first step of the scoring above -- every row's rolling AR(1) innovation variances (wls_backend.c:610-742) -- for the
+ * rows of `count` matrices in ONE launch (the chromosomes of a genome; one workgroup per row, two per compute unit):
+ * variances_dev[i] receives K[i] x (n[i] - window_i + 1) doubles, window_i = the spatial window the scoring resolves for
+ * n[i] (at most 63 here).  rocco_hip_score_centered_wls_given_variances_f64 is the scoring with that step already done
+ * (variances_dev == NULL: the plain call). */
+int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t count, const double *const *centered_dev,
+                                              const size_t *K, const size_t *n, int spatial_window, double *const *variances_dev,
+                                              void *stream);
+int rocco_hip_score_centered_wls_given_variances_f64(rocco_hip_solver *solver, const double *centered_dev, size_t K, size_t n,
+                                                     double lower_bound_z, double prior_df, double min_effect, int use_min_effect,
+                                                     int spatial_window, double precision_floor_ratio, const double *variances_dev,
+                                                     double *mean_dev, double *raw_var_dev, double *prior_var_dev, double *mod_var_dev,
+                                                     double *se_dev, double *scores_dev, double *df_out, int *window_out, void *stream);
 
 /* ---- count-path glue of score_loci_wls ---------------------------------
  * Replaces the NumPy statements of rocco/inference.py:40-47 (`_log_scale_wls_matrix`) and 330-331 (pilot
@@ -322,6 +335,10 @@ int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *
  * out_dev may alias a_dev or b_dev. */
 int rocco_hip_subtract_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,
                            size_t count, void *stream);
+/* out = a - b with the reference's check on b folded in (rocco/inference.py:207-208, "Local baseline fit produced non-finite
+ * values"): ROCCO_HIP_EINVAL when b holds a non-finite value.  Synchronises the stream. */
+int rocco_hip_subtract_finite_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,
+                                  size_t count, void *stream);
 
 /* ---- narrowPeak summit offsets ---------------------------------------
  * Replaces the per-peak NumPy statements of rocco/rocco.py:838-872 (`_write_narrowpeak_summit_offsets`) over the

@@ -172,9 +172,18 @@ PROTOTYPES = [
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_double,
       ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_int_p, ctypes.c_void_p]),
+    ("rocco_hip_wls_rolling_variances_batch_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), c_size_p, c_size_p, ctypes.c_int,
+      ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    ("rocco_hip_score_centered_wls_given_variances_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_double,
+      ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_int_p, ctypes.c_void_p]),
     ("rocco_hip_log_scale_center_rows_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_subtract_finite_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("rocco_hip_subtract_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("rocco_hip_narrowpeak_summit_offsets", ctypes.c_int,

@@ -763,11 +763,73 @@ int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, c
                                                            stream);
 }
 
+int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t count, const double *const *centered_dev,
+                                              const size_t *K, const size_t *n, int spatial_window, double *const *variances_dev,
+                                              void *stream)
+{
+    if (solver == nullptr || (count > 0 && (centered_dev == nullptr || K == nullptr || n == nullptr || variances_dev == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    size_t rows = 0;
+    for (size_t i = 0; i < count; ++i) {
+        const int window = wls_spatial_window(n[i], spatial_window);
+        if (window > wls_max_window()) {
+            set_last_error("rocco_hip_wls_rolling_variances_batch_f64: spatial windows above 63 loci go through the single-matrix call");
+            return ROCCO_HIP_EINVAL;
+        }
+        if (window > 0 && n[i] >= 4) {
+            if (centered_dev[i] == nullptr || variances_dev[i] == nullptr) {
+                return ROCCO_HIP_EINVAL;
+            }
+            rows += K[i];
+        }
+    }
+    if (rows == 0) {
+        return ROCCO_HIP_OK;
+    }
+    int rc;
+    if ((rc = solver->dev_tasks.reserve(rows * sizeof(WlsRollingTask))) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->host_stage.reserve(rows * sizeof(WlsRollingTask))) != ROCCO_HIP_OK) return rc;
+    WlsRollingTask *host = (WlsRollingTask *)solver->host_stage.ptr;
+    size_t t = 0;
+    for (size_t i = 0; i < count; ++i) {
+        const int window = wls_spatial_window(n[i], spatial_window);
+        if (window <= 0 || n[i] < 4) {
+            continue;
+        }
+        const size_t stride = n[i] - (size_t)window + 1;
+        for (size_t k = 0; k < K[i]; ++k, ++t) {
+            host[t].row = centered_dev[i] + k * n[i];
+            host[t].n = (long long)n[i];
+            host[t].window = window;
+            host[t].pad = 0;
+            host[t].out = variances_dev[i] + k * stride;
+        }
+    }
+    ROCCO_HIP_TRY(hipMemcpyAsync(solver->dev_tasks.ptr, host, rows * sizeof(WlsRollingTask), hipMemcpyHostToDevice, (hipStream_t)stream));
+    if ((rc = launch_wls_rolling_batch((const WlsRollingTask *)solver->dev_tasks.ptr, rows, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
+    ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the task table is the solver's
+    return ROCCO_HIP_OK;
+}
+
 int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *centered_dev, size_t K, size_t n,
                                      double lower_bound_z, double prior_df, double min_effect, int use_min_effect,
                                      int spatial_window, double precision_floor_ratio, double *mean_dev,
                                      double *raw_var_dev, double *prior_var_dev, double *mod_var_dev, double *se_dev,
                                      double *scores_dev, double *df_out, int *window_out, void *stream)
+{
+    return rocco_hip_score_centered_wls_given_variances_f64(solver, centered_dev, K, n, lower_bound_z, prior_df, min_effect,
+                                                            use_min_effect, spatial_window, precision_floor_ratio, nullptr, mean_dev,
+                                                            raw_var_dev, prior_var_dev, mod_var_dev, se_dev, scores_dev, df_out,
+                                                            window_out, stream);
+}
+
+int rocco_hip_score_centered_wls_given_variances_f64(rocco_hip_solver *solver, const double *centered_dev, size_t K, size_t n,
+                                                     double lower_bound_z, double prior_df, double min_effect, int use_min_effect,
+                                                     int spatial_window, double precision_floor_ratio, const double *variances_dev,
+                                                     double *mean_dev, double *raw_var_dev, double *prior_var_dev, double *mod_var_dev,
+                                                     double *se_dev, double *scores_dev, double *df_out, int *window_out, void *stream)
 {
     // argument checks of rocco_score_centered_wls_f64 (wls_backend.c:770-776)
     if (solver == nullptr || centered_dev == nullptr || mean_dev == nullptr || raw_var_dev == nullptr ||
@@ -778,16 +840,20 @@ int rocco_hip_score_centered_wls_f64(rocco_hip_solver *solver, const double *cen
     }
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
     int rc;
-    if ((rc = solver->dev_misc.reserve(wls_scratch_bytes(K, n, spatial_window))) != ROCCO_HIP_OK) {
+    if ((rc = solver->dev_misc.reserve(wls_scratch_bytes(K, n, spatial_window, variances_dev == nullptr))) != ROCCO_HIP_OK) {
         return rc;
     }
     if ((rc = solver->host_back.reserve(256 + K * sizeof(int))) != ROCCO_HIP_OK) {  // the non-finite flag + one flag per row
         return rc;
     }
+    if (variances_dev != nullptr && wls_spatial_window(n, spatial_window) > wls_max_window()) {
+        set_last_error("rocco_hip_score_centered_wls_given_variances_f64: windows above 63 loci compute their own variances");
+        return ROCCO_HIP_EINVAL;
+    }
     return launch_score_centered_wls(centered_dev, K, n, lower_bound_z, prior_df, min_effect, use_min_effect,
                                      spatial_window, precision_floor_ratio, mean_dev, raw_var_dev, prior_var_dev,
                                      mod_var_dev, se_dev, scores_dev, solver->dev_misc.ptr, df_out, window_out,
-                                     (hipStream_t)stream, (int *)solver->host_back.ptr);
+                                     (hipStream_t)stream, (int *)solver->host_back.ptr, variances_dev);
 }
 
 int rocco_hip_log_scale_f64(rocco_hip_solver *solver, const double *values_dev, size_t count, double pseudocount, double *out_dev,
@@ -833,6 +899,30 @@ int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *
     }
     return launch_log_scale_center_rows(counts_dev, K, n, pseudocount, apply_log2, centered_out_dev, row_offsets_out_dev,
                                         solver->dev_misc.ptr, (hipStream_t)stream, (int *)solver->host_back.ptr);
+}
+
+int rocco_hip_subtract_finite_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,
+                                  size_t count, void *stream)
+{
+    if (solver == nullptr || ((a_dev == nullptr || b_dev == nullptr || out_dev == nullptr) && count > 0)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc = solver->dev_results.reserve(256);
+    if (rc != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->host_back.reserve(256)) != ROCCO_HIP_OK) return rc;
+    int *bad = (int *)solver->dev_results.ptr;
+    ROCCO_HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), (hipStream_t)stream));
+    if ((rc = launch_subtract(a_dev, b_dev, out_dev, count, (hipStream_t)stream, bad)) != ROCCO_HIP_OK) return rc;
+    int &bad_host = *(int *)solver->host_back.ptr;
+    bad_host = 0;
+    ROCCO_HIP_TRY(hipMemcpyAsync(&bad_host, bad, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (bad_host != 0) {
+        set_last_error("Local baseline fit produced non-finite values");
+        return ROCCO_HIP_EINVAL;
+    }
+    return ROCCO_HIP_OK;
 }
 
 int rocco_hip_subtract_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,

@@ -142,13 +142,22 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
 // ---- wls.hip --------------------------------------------------------------------------------
 // scratch: at least wls_scratch_bytes(K, n) bytes; synchronises the stream before returning
 int wls_spatial_window(size_t n, int requested);
+// one row of one matrix for the batched rolling launch: out = window variances of the row's n - window + 1 starts
+struct WlsRollingTask {
+    const double *row;
+    long long n;
+    int window;
+    int pad;
+    double *out;
+};
+int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, hipStream_t stream);
 int wls_max_window();
-size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window = 0);
+size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window = 0, bool own_variances = true);
 int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, double lower_bound_z, double prior_df,
                               double min_effect, int use_min_effect, int spatial_window,
                               double precision_floor_ratio, double *mean_dev, double *raw_var_dev,
                               double *prior_var_dev, double *mod_var_dev, double *se_dev, double *scores_dev,
-                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream, int *flag_host_pinned);
+                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream, int *flag_host_pinned, const double *vas_given = nullptr);
 
 // row a2 glue (wls.hip): log2(max(x, 0) + pseudocount), row medians subtracted; out may alias the input
 size_t log_scale_scratch_bytes(size_t K, size_t n);
@@ -157,7 +166,7 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
                                  hipStream_t stream, int *flag_host_pinned);
 // out = log2(max(in, 0) + pseudocount), correctly rounded; *bad_dev |= 1 if a value is not finite
 int launch_log_scale(const double *in_dev, double *out_dev, size_t count, double pseudocount, int *bad_dev, hipStream_t stream);
-int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream);
+int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream, int *bad_dev = nullptr);
 
 // ---- summit.hip -----------------------------------------------------------------------------
 int launch_summit_offsets(const int64_t *intervals_dev, size_t n_intervals, const int64_t *centers_dev,

@@ -114,15 +114,29 @@ __device__ __forceinline__ void rolling_variances(const RollingTile &tile, doubl
     }
 }
 
+// `tasks` (may be null: then every workgroup is a row of `matrix`): one record per workgroup -- the rows of SEVERAL matrices
+// (the chromosomes of a genome) in one launch, two workgroups per compute unit, instead of one launch of K workgroups
+// per matrix on a stream of its own
 __global__ __launch_bounds__(kLanes + kHelpers) void wls_rolling_kernel(const double *__restrict__ matrix, long long n,
-                                                                       int window, double *__restrict__ vas)
+                                                                       int window, double *__restrict__ vas,
+                                                                       const WlsRollingTask *__restrict__ tasks)
 {
     __shared__ RollingTile tiles[3];  // the tile the chains run on, the previous one (variances), the next one (staging)
     const int lane = threadIdx.x, hl = (int)threadIdx.x - kLanes;
     const bool helper = hl >= 0;
-    const double *__restrict__ row = matrix + (long long)blockIdx.x * n;
+    const double *__restrict__ row;
+    double *__restrict__ out;
+    if (tasks != nullptr) {
+        const WlsRollingTask task = tasks[blockIdx.x];
+        n = task.n;
+        window = task.window;
+        row = task.row;
+        out = task.out;
+    } else {
+        row = matrix + (long long)blockIdx.x * n;
+        out = vas + (long long)blockIdx.x * (n - window + 1);
+    }
     const long long max_start = n - window;
-    double *__restrict__ out = vas + (long long)blockIdx.x * (max_start + 1);
     const long long n_tiles = (max_start + kTile) / kTile;  // ceil((max_start + 1) / kTile)
     StagedValues staged;
     if (helper) {
@@ -1153,12 +1167,18 @@ __global__ __launch_bounds__(256) void subtract_row_offset_kernel(double *__rest
     }
 }
 
+// out = a - b; `bad` (may be null) is raised when b holds a non-finite value (the check the reference makes on its local
+// baselines, rocco/inference.py:207-208, without a pass of its own)
 __global__ __launch_bounds__(256) void subtract_kernel(const double *__restrict__ a, const double *__restrict__ b,
-                                                      double *__restrict__ out, long long count)
+                                                      double *__restrict__ out, long long count, int *__restrict__ bad)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) {
-        out[i] = a[i] - b[i];
+        const double bv = b[i];
+        if (bad != nullptr && !isfinite(bv)) {
+            atomicOr(bad, 1);
+        }
+        out[i] = a[i] - bv;
     }
 }
 
@@ -1207,7 +1227,7 @@ size_t sort_temp_bytes(size_t n)
     return align_up(std::max(a, std::max(b, c)), 256);
 }
 
-size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window)
+size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window, bool own_variances)
 {
     // windows above the tiled kernel's limit keep the three running sums of every row in memory
     const size_t general = (wls_spatial_window(n, spatial_window) > kMaxWindow) ? align_up(3 * K * n * 8, 256) : 0;
@@ -1218,7 +1238,7 @@ size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window)
                              ? align_up(K * n * 8, 256) + align_up(K * sizeof(TrendRow), 256) + align_up(segs * sizeof(RowSelect), 256) +
                                    align_up(segs * kSelectBuckets * sizeof(unsigned), 256) + align_up(segs * sizeof(unsigned), 256)
                              : 0;
-    return general + dealt + align_up(K * sizeof(TrendFit), 256) + align_up(K * n * 8, 256) + 6 * align_up(n * 8, 256) +
+    return general + dealt + align_up(K * sizeof(TrendFit), 256) + (own_variances ? align_up(K * n * 8, 256) : 0) + 6 * align_up(n * 8, 256) +
            2 * align_up(n * 4, 256) + 2 * align_up(n, 256) + align_up(4 * n * 8, 256) + sort_temp_bytes(n) + 4096;
 }
 
@@ -1226,7 +1246,8 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
                               double min_effect, int use_min_effect, int spatial_window,
                               double precision_floor_ratio, double *mean_dev, double *raw_var_dev,
                               double *prior_var_dev, double *mod_var_dev, double *se_dev, double *scores_dev,
-                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream, int *flag_host_pinned)
+                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream, int *flag_host_pinned,
+                              const double *vas_given)
 {
     const double pdf = std::fmax(prior_df, 0.0), floor_ratio = std::fmax(precision_floor_ratio, 0.0);
     const int window = wls_spatial_window(n, spatial_window);
@@ -1246,7 +1267,8 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
         off += align_up(bytes, 256);
         return p;
     };
-    double *vas = (double *)carve(K * n * 8);
+    // given: the local variances of a batched rolling launch (launch_wls_rolling_batch), no room of their own in the scratch
+    double *vas = (vas_given != nullptr) ? const_cast<double *>(vas_given) : (double *)carve(K * n * 8);
     u64 *key_a = (u64 *)carve(n * 8), *key_b = (u64 *)carve(n * 8), *val_a = (u64 *)carve(n * 8);
     u64 *val_b = (u64 *)carve(n * 8), *key_c = (u64 *)carve(n * 8), *key_d = (u64 *)carve(n * 8);
     unsigned *iota = (unsigned *)carve(n * 4), *perm = (unsigned *)carve(n * 4);
@@ -1274,7 +1296,10 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
         const long long half = window / 2, max_start = nn - window;
         const size_t vas_stride = (size_t)(max_start + 1);
         if (window <= kMaxWindow) {
-            hipLaunchKernelGGL(wls_rolling_kernel, dim3((unsigned)K), dim3(kLanes + kHelpers), 0, stream, centered_dev, nn, window, vas);
+            if (vas_given == nullptr) {
+                hipLaunchKernelGGL(wls_rolling_kernel, dim3((unsigned)K), dim3(kLanes + kHelpers), 0, stream, centered_dev, nn, window, vas,
+                                   (const WlsRollingTask *)nullptr);
+            }
         } else {
             hipLaunchKernelGGL(wls_rolling_general_sums_kernel, dim3((unsigned)K), dim3(kLanes), 0, stream, centered_dev, nn, window,
                                general_sums);
@@ -1371,6 +1396,16 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     return ROCCO_HIP_OK;
 }
 
+int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, hipStream_t stream)
+{
+    if (n_tasks > 0) {
+        hipLaunchKernelGGL(wls_rolling_kernel, dim3((unsigned)n_tasks), dim3(kLanes + kHelpers), 0, stream, (const double *)nullptr, 0LL, 0,
+                           (double *)nullptr, tasks_dev);
+        ROCCO_HIP_TRY(hipGetLastError());
+    }
+    return ROCCO_HIP_OK;
+}
+
 size_t log_scale_scratch_bytes(size_t K, size_t n)
 {
     (void)n;
@@ -1432,13 +1467,13 @@ int launch_log_scale(const double *in_dev, double *out_dev, size_t count, double
     return ROCCO_HIP_OK;
 }
 
-int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream)
+int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream, int *bad_dev)
 {
     if (count == 0) {
         return ROCCO_HIP_OK;
     }
     hipLaunchKernelGGL(subtract_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, a_dev, b_dev, out_dev,
-                       (long long)count);
+                       (long long)count, bad_dev);
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }

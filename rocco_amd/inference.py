@@ -140,12 +140,53 @@ def _estimate_local_background_matrix(centered_matrix, target_window: int = 101)
     return local_baselines, window, penalty_lambda
 
 
+def wls_spatial_window(n: int, requested: int = 31) -> int:
+    """The spatial window the scoring resolves for a row of n loci (wls_backend.c:229-259): odd, at least 5, at most n;
+    0 for fewer than 5 loci."""
+    n = int(n)
+    if n < 5:
+        return 0
+    w = int(requested) if int(requested) > 0 else 31
+    w = min(max(w, 5), n)
+    if w % 2 == 0:
+        w = w - 1 if w == n else w + 1
+    return w if w >= 5 else 0
+
+
+def wls_rolling_variances_batch_device(centered_list, spatial_window: int = 31):
+    """Every row's rolling AR(1) innovation variances (wls_backend.c:610-742) for the rows of SEVERAL centred matrices in
+    one launch (rocco_hip_wls_rolling_variances_batch_f64).  Returns one tensor [K_i, n_i - window_i + 1] per matrix
+    (None where the scoring does not use them: fewer than 5 loci)."""
+    import ctypes
+
+    import torch
+
+    centered_list = list(centered_list)
+    count = len(centered_list)
+    outs = []
+    for c in centered_list:
+        K, n = int(c.shape[0]), int(c.shape[1])
+        w = wls_spatial_window(n, spatial_window)
+        outs.append(torch.empty((K, n - w + 1), dtype=torch.float64, device=c.device) if (w > 0 and n >= 4) else None)
+    if count == 0:
+        return outs
+    solver = _native.solver_for(centered_list[0].device.index)
+    _native.check(_native.load().rocco_hip_wls_rolling_variances_batch_f64(
+        solver.handle, count, (ctypes.c_void_p * count)(*[c.data_ptr() for c in centered_list]),
+        (ctypes.c_size_t * count)(*[int(c.shape[0]) for c in centered_list]),
+        (ctypes.c_size_t * count)(*[int(c.shape[1]) for c in centered_list]), int(spatial_window),
+        (ctypes.c_void_p * count)(*[(o.data_ptr() if o is not None else None) for o in outs]),
+        _dp._stream_ptr(centered_list[0])), "rocco_hip_wls_rolling_variances_batch_f64")
+    return outs
+
+
 def score_centered_wls_device(centered_t, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
-                              spatial_window: int = 31, precision_floor_ratio: float = 0.01):
+                              spatial_window: int = 31, precision_floor_ratio: float = 0.01, variances_t=None):
     """Device-resident form of the reference extension's ``score_centered_wls`` (rocco/_wls.c over
     rocco/native/wls_backend.c:744-947): ``centered_t`` is a contiguous float64 CUDA tensor [K, n]; returns
     (scores, mean, raw_variance, prior_variance, moderated_variance, standard_error, total_df, window)
-    with the six tracks as CUDA tensors of n doubles."""
+    with the six tracks as CUDA tensors of n doubles.  ``variances_t``: the rows' rolling variances when a batched launch
+    has made them already (`wls_rolling_variances_batch_device`)."""
     import ctypes
 
     import torch
@@ -160,10 +201,11 @@ def score_centered_wls_device(centered_t, lower_bound_z: float = 1.0, prior_df: 
     tracks = torch.empty((6, n), dtype=torch.float64, device=centered_t.device)
     df, win = ctypes.c_double(), ctypes.c_int()
     solver = _native.solver_for(centered_t.device.index)
-    _native.check(_native.load().rocco_hip_score_centered_wls_f64(
+    _native.check(_native.load().rocco_hip_score_centered_wls_given_variances_f64(
         solver.handle, centered_t.data_ptr(), K, n, float(lower_bound_z), float(prior_df),
         float(0.0 if min_effect is None else min_effect), 0 if min_effect is None else 1, int(spatial_window),
-        float(precision_floor_ratio), *[tracks[i].data_ptr() for i in range(6)], ctypes.byref(df), ctypes.byref(win),
+        float(precision_floor_ratio), None if variances_t is None else variances_t.data_ptr(),
+        *[tracks[i].data_ptr() for i in range(6)], ctypes.byref(df), ctypes.byref(win),
         _dp._stream_ptr(centered_t)), "rocco_hip_score_centered_wls_f64")
     mean, raw, prior, mod, se, scores = (tracks[i] for i in range(6))
     return scores, mean, raw, prior, mod, se, float(df.value), int(win.value)
@@ -399,13 +441,19 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         if _batch_pool is None:
             _batch_pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-count")
         trace = os.environ.get("ROCCO_BATCH_TRACE")
-        if trace:
-            print("[batch] phase 1", flush=True)
+        import time as _time
+        t_start = _time.perf_counter()
+
+        def stamp(what):
+            if trace:
+                torch.cuda.synchronize(device)
+                print(f"[batch] {what} at {1e3 * (_time.perf_counter() - t_start):.1f} ms", flush=True)
+
+        stamp("phase 1 (log scale, row medians) starts")
         # phase 1: log scale, pilot offset (rocco/inference.py:325, 333-334)
         centred = fan_out(lambda i: log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite_input else None,
                                                                  apply_log2=(input_scale == "counts"))[0])
-        if trace:
-            print("[batch] phase 2", flush=True)
+        stamp("phase 2 (baselines) starts")
         # phase 2: local baselines (335), matrices of one penalty together
         windows = [_resolve_local_baseline_window(int(c.shape[1]), target_window=101) for c in centred]
         penalties = [0.0 if w == 0 else _consenrich_whittaker_lambda(w) for w in windows]
@@ -416,26 +464,36 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
             for i, b in zip(idx, outs):
                 baselines[i] = b
 
-        if trace:
-            print("[batch] phase 3", flush=True)
+        # phase 2 continued: subtraction (338) per matrix, then the rolling variances of EVERY row of every matrix in one
+        # launch (one workgroup per row, two per compute unit: 512 rows at a time instead of three matrices' worth)
+        def subtract(i):
+            c = centred[i]
+            if baselines[i] is not None:
+                solver = _native.solver_for(c.device.index)
+                rc = _native.load().rocco_hip_subtract_finite_f64(solver.handle, c.data_ptr(), baselines[i].data_ptr(), c.data_ptr(),
+                                                                  int(c.shape[0]) * int(c.shape[1]), _dp._stream_ptr(c))
+                if rc == _native.EINVAL:
+                    raise ValueError("Local baseline fit produced non-finite values")
+                _native.check(rc, "rocco_hip_subtract_finite_f64")
+            return True
+
+        stamp("subtraction starts")
+        fan_out(subtract)
+        baselines = [None] * len(centred)
+        stamp("rolling variances start")
+        variances = wls_rolling_variances_batch_device(centred, spatial_window=31)
+        stamp("phase 3 (trend fits, accumulation) starts")
 
         # phase 3: subtraction (338) and the centred WLS (342-348) per matrix
         def score(i):
             c = centred[i]
-            if trace:
-                print(f"[batch] score {i} start", flush=True)
+
             K, n = int(c.shape[0]), int(c.shape[1])
-            if baselines[i] is not None:
-                if not bool(torch.isfinite(baselines[i]).all()):
-                    raise ValueError("Local baseline fit produced non-finite values")
-                solver = _native.solver_for(c.device.index)
-                _native.check(_native.load().rocco_hip_subtract_f64(solver.handle, c.data_ptr(), baselines[i].data_ptr(), c.data_ptr(),
-                                                                    K * n, _dp._stream_ptr(c)), "rocco_hip_subtract_f64")
-                baselines[i] = None
             floor_ratio = float(max(precision_floor_ratio, 0.0))
             scores, mean, raw, prior, mod, se, total_df, resolved_window = score_centered_wls_device(
                 c, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df), min_effect=min_effect, spatial_window=31,
-                precision_floor_ratio=floor_ratio)
+                precision_floor_ratio=floor_ratio, variances_t=variances[i])
+            variances[i] = None
             z_scores = mean / torch.clamp_min(se, 1.0e-8)
             if not bool(torch.isfinite(torch.stack([scores, mean, raw, prior, mod, se, z_scores])).all()):
                 raise ValueError("EB scoring produced non-finite values")
@@ -449,11 +507,11 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
             }
             for t in (scores, mean, raw, prior, mod, se, z_scores, details["degrees_of_freedom"]):
                 t.record_stream(caller_stream)
-            if trace:
-                print(f"[batch] score {i} done", flush=True)
             return scores, details
 
-        return fan_out(score)
+        result = fan_out(score)
+        stamp("done")
+        return result
 
 
 def score_loci_wls(chrom_matrix, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
