@@ -1,4 +1,7 @@
 // rocco_amd/csrc/api.hip -- C ABI entry points of librocco_hip.so (see include/rocco_hip.h).
+#include <map>
+#include <memory>
+#include <mutex>
 #include "kernels.h"
 #include "budget.h"
 
@@ -39,6 +42,8 @@ void DeviceBuffer::release()
     ptr = nullptr;
     bytes = 0;
 }
+
+SharedFactor::~SharedFactor() { buf.release(); }
 
 int PinnedBuffer::reserve(size_t want)
 {
@@ -114,7 +119,7 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->dev_solution.release();
     solver->dev_maps.release();
     solver->dev_frozen.release();
-    solver->dev_factor.release();
+    solver->factor.reset();
     solver->dev_lean_pool.release();
     solver->dev_lean_round.release();
     solver->dev_lean_look.release();
@@ -690,31 +695,41 @@ namespace {
 // The LDL^T factor depends on the penalty and (at its last two entries only) on the length: the solver keeps the one of
 // the longest row seen with this penalty (the recurrence is sequential: ~0.19 s per million loci).  A longer row with the
 // same penalty extends the factor instead of starting over; a new penalty starts a new one.
+std::mutex g_factor_mutex;
+// per device; on the heap and never destroyed: at process exit the HIP runtime may be gone before static destructors run
+std::map<int, std::shared_ptr<rocco::SharedFactor>> &g_factors = *new std::map<int, std::shared_ptr<rocco::SharedFactor>>();
+
+// the device's factor covers `cols` loci at this penalty when this returns; solver->factor holds it for the call
 int ensure_whittaker_factor(rocco_hip_solver *solver, size_t cols, double penalty_lambda, hipStream_t stream)
 {
-    if (cols < 25 || (solver->factor_cap >= cols && solver->factor_lambda == penalty_lambda)) {
+    if (cols < 25) {
         return ROCCO_HIP_OK;
     }
-    const size_t cap = cols;
-    rocco::DeviceBuffer grown;
+    std::lock_guard<std::mutex> lock(g_factor_mutex);  // (a second thread waits for the first one's factor rather than building its own)
+    std::shared_ptr<rocco::SharedFactor> &current = g_factors[solver->device];
+    if (current && current->cap >= cols && current->lambda == penalty_lambda) {
+        solver->factor = current;
+        return ROCCO_HIP_OK;
+    }
+    auto grown = std::make_shared<rocco::SharedFactor>();
+    grown->device = solver->device;
     int rc;
-    if ((rc = grown.reserve(6 * cap * sizeof(double))) != ROCCO_HIP_OK) {
+    if ((rc = grown->buf.reserve(6 * cols * sizeof(double))) != ROCCO_HIP_OK) {
         return rc;
     }
-    const bool extend = solver->factor_cap > 0 && solver->factor_lambda == penalty_lambda;
-    rc = launch_whittaker_factor(cap, penalty_lambda, (double *)grown.ptr, stream,
-                                 extend ? (const double *)solver->dev_factor.ptr : nullptr, extend ? solver->factor_cap : 0);
+    const bool extend = current && current->cap > 0 && current->lambda == penalty_lambda;
+    rc = launch_whittaker_factor(cols, penalty_lambda, (double *)grown->buf.ptr, stream,
+                                 extend ? (const double *)current->buf.ptr : nullptr, extend ? current->cap : 0);
     if (rc == ROCCO_HIP_OK && hipStreamSynchronize(stream) != hipSuccess) {
         rc = ROCCO_HIP_EHIP;
     }
     if (rc != ROCCO_HIP_OK) {
-        grown.release();
         return rc;
     }
-    solver->dev_factor.release();
-    solver->dev_factor = grown;
-    solver->factor_cap = cap;
-    solver->factor_lambda = penalty_lambda;
+    grown->cap = cols;
+    grown->lambda = penalty_lambda;
+    current = grown;
+    solver->factor = grown;
     return ROCCO_HIP_OK;
 }
 
@@ -742,8 +757,10 @@ int rocco_hip_crossfit_whittaker_baseline_batch_f64(rocco_hip_solver *solver, si
     if ((rc = solver->dev_misc.reserve(whittaker_batch_scratch_bytes(rows, cols, count))) != ROCCO_HIP_OK) return rc;
     if ((rc = solver->host_stage.reserve(2 * groups * sizeof(WhittakerRowTask) + 64)) != ROCCO_HIP_OK) return rc;
     if ((rc = ensure_whittaker_factor(solver, longest, penalty_lambda, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
-    rc = launch_crossfit_whittaker_batch(matrices_dev, rows, cols, count, penalty_lambda, (const double *)solver->dev_factor.ptr,
-                                         solver->factor_cap, baselines_dev, solver->dev_misc.ptr,
+    const rocco::SharedFactor *factor = (longest >= 25) ? solver->factor.get() : nullptr;
+    rc = launch_crossfit_whittaker_batch(matrices_dev, rows, cols, count, penalty_lambda,
+                                         factor != nullptr ? (const double *)factor->buf.ptr : nullptr,
+                                         factor != nullptr ? factor->cap : 0, baselines_dev, solver->dev_misc.ptr,
                                          (WhittakerRowTask *)solver->host_stage.ptr, (hipStream_t)stream);
     if (rc != ROCCO_HIP_OK) {
         return rc;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <memory>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -40,6 +41,17 @@ struct PinnedBuffer {
     void release();
 };
 
+// Whittaker LDL^T factor of the longest row seen on a device: read-only once built, so every solver of the device shares it
+// (the host threads of the count-path batch run one solver each); a longer or differently penalised one replaces it as a
+// whole and the old one lives until the last call using it has returned.
+struct SharedFactor {
+    DeviceBuffer buf;
+    double lambda = 0.0;
+    size_t cap = 0;
+    int device = 0;
+    ~SharedFactor();
+};
+
 }  // namespace rocco
 
 struct rocco_hip_solver {
@@ -59,9 +71,7 @@ struct rocco_hip_solver {
     rocco::DeviceBuffer dev_solution; // solution scratch when the caller wants counts only
     rocco::DeviceBuffer dev_maps;     // per-chunk binade maps of the problems being solved
     rocco::DeviceBuffer dev_frozen;   // per-block frozen summaries of the problems being solved
-    rocco::DeviceBuffer dev_factor;   // Whittaker LDL^T factor of the longest row seen (whittaker.hip)
-    double factor_lambda = 0.0;       // ... its penalty
-    size_t factor_cap = 0;            // ... and length (0: none)
+    std::shared_ptr<rocco::SharedFactor> factor;  // the device's Whittaker LDL^T factor this solver last used (whittaker.hip)
     rocco::DeviceBuffer dev_lean_pool;   // compacted levels of the problems being solved (lean.hip)
     rocco::DeviceBuffer dev_lean_round;  // per-round scratch of the lean evaluation (tile records)
     rocco::DeviceBuffer dev_lean_look;   // its tickets, error word and hand-off granules (restored by every round)

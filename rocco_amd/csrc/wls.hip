@@ -637,13 +637,14 @@ __global__ __launch_bounds__(256) void row_select_median_kernel(const RowSelect 
 
 // ---- the trend fit without sorting the pairs (round 3) ------------------------------------------------------------------
 // What the fit needs of the (x, y)-sorted sequence (wls_backend.c:454-520) is, per bin, the median x and the median y.  The
-// bins are contiguous rank ranges of the x order, so: ONE keys-only sort of x per row gives every bin's first x (its
-// boundary) and median x; with the boundaries every pair knows its bin from its x alone -- unless a boundary falls inside
-// a run of equal x, where the reference's order inside the run (by y) decides: such a row (`tie`) takes the sorted path
-// below, as do short rows; the y values of ALL rows of the matrix are then dealt into per-bin segments (order inside a
-// segment does not matter) and every segment's median is one radix select (the row-median kernels of the count-path
-// glue, per segment).  Per value: one 8-byte key sorted instead of two 16-byte pairs and a byte, 24 B to deal, 56 B to
-// select; per row 10 launches instead of 40, the rest of the work in launches over the whole matrix.
+// bins are contiguous rank ranges of the x order, so a handful of order statistics of x per bin (found for every row of the
+// matrix at once, see "the x side" below) give every bin's first x (its boundary) and median x; with the boundaries every
+// pair knows its bin from its x alone -- unless a boundary falls inside a run of equal x, where the reference's order
+// inside the run (by y) decides: such a row (`tie`) takes the sorted path below, as do short rows; the y values of ALL
+// rows of the matrix are then dealt into per-bin segments (order inside a segment does not matter) and every segment's
+// median is one radix select (the row-median kernels of the count-path glue, per segment).  Per value: 24 B read for the
+// x ranks, 24 B to deal, 56 B to select, in ~30 launches per MATRIX; the sorted path moves ~600 B per value in 40 launches
+// per ROW.
 struct TrendRow {
     double bound[kMaxBins];  // bound[b] (b >= 1): the x of the first pair of bin b
     double cov[kMaxBins];    // median x of the bin
@@ -652,42 +653,442 @@ struct TrendRow {
     int pad;
 };
 
-__global__ __launch_bounds__(256) void wls_xkeys_kernel(const double *__restrict__ row, long long n, unsigned long long *__restrict__ key_x,
-                                                       int *__restrict__ bad)
+// ---- the x side: the wanted order statistics of every row without sorting it ------------------------------------------------
+// Per bin the fit reads FOUR ranks of the row's |x| order: the last of the bin before and the first of the bin (the
+// boundary and its tie check) and the one or two middle ones (the bin's median x) -- at most 128 ranks for the 32 bins a
+// row of fewer than 2^32 loci can have.  Three passes over the MATRIX find them all: (0) a histogram of the top 14 key
+// bits of every row (bits 62..49: exponent + 3 mantissa bits; the sign bit of |x| is 0), from which every rank knows its
+// bucket; (1) inside the buckets that hold a rank ("slots", at most 128, in practice ~30), a histogram of the next
+// 6..11 bits, all slots at once in 8192 LDS counters; (2) the values of the ~22-bit cells that hold a rank -- about
+// n / 2^11 each, some 2 % of the row in all -- are gathered, and one workgroup per cell sorts its few hundred values in
+// LDS and reads the ranks off.  24 bytes read per value and 8 launches per matrix, against a keys-only radix sort per row
+// (8 passes, 16 bytes moved per value and pass, ~25 launches and memsets per row).  A row with a cell of more than 8192
+// values (heavy runs of equal x) takes the sorted path like a row with a tie at a boundary.
+constexpr int kRankTargets = 128;     // 4 per bin
+constexpr int kRankBuckets0 = 16384;  // first digit: key bits 62..49
+constexpr int kRankShift0 = 49;
+constexpr int kRankCells1 = 8192;     // counters of the second pass: slots << width1
+constexpr int kRankChunk = 32768;     // values per workgroup of the histogram passes
+constexpr int kGatherChunk = 16384;   // values per workgroup of the gathering pass
+constexpr int kRankSortMax = 8192;    // values of one cell
+
+struct RankRow {
+    int slots0, width1, slots1, pad;
+    unsigned short bucket0[kRankTargets];  // the first digit of slot s
+    unsigned short cell1[kRankTargets];    // (slot << width1 | second digit) of cell c
+    unsigned count1[kRankTargets], offset1[kRankTargets], cursor1[kRankTargets];
+    long long rank[kRankTargets];          // -1: unused; the rank inside the slot / cell as the passes go
+    unsigned char slot[kRankTargets];
+    unsigned long long key[kRankTargets];  // the answer
+};
+
+__device__ __forceinline__ long long rank_of_target(int t, long long n, int bins)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
-        return;
+    const int b = t >> 2, which = t & 3;
+    if (b >= bins) {
+        return -1;
     }
-    const double x = fabs(row[i]);
-    if (!isfinite(x)) {
-        atomicOr(bad, 1);
+    const long long left = ((long long)b * n) / bins, right = ((long long)(b + 1) * n) / bins, w = right - left;
+    if (w <= 0) {
+        return -1;
     }
-    key_x[i] = (unsigned long long)__double_as_longlong(x);  // non-negative doubles order like their bit patterns
+    switch (which) {
+    case 0: return (b >= 1 && left >= 1) ? left - 1 : -1;
+    case 1: return (b >= 1) ? left : -1;
+    case 2: return ((w & 1LL) == 0) ? left + w / 2 - 1 : -1;
+    default: return left + w / 2;
+    }
 }
 
-// one wavefront per row: lane b = bin b of the x-sorted keys
-__global__ __launch_bounds__(64) void wls_bounds_kernel(const unsigned long long *__restrict__ xs, long long n, int bins, TrendRow *row)
+__global__ __launch_bounds__(256) void rank_init_kernel(RankRow *__restrict__ rr, unsigned *__restrict__ hist0, TrendRow *__restrict__ trows,
+                                                       long long rows, long long n, int bins)
 {
-    const int b = threadIdx.x;
-    if (b == 0) {
-        row->tie = 0;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows * kRankBuckets0) {
+        hist0[i] = 0u;
+    }
+    if (i < rows * kRankTargets) {
+        rr[i / kRankTargets].rank[i % kRankTargets] = rank_of_target((int)(i % kRankTargets), n, bins);
+    }
+    if (i < rows) {
+        trows[i].tie = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_hist0_kernel(const double *__restrict__ matrix, long long n, unsigned *__restrict__ hist0,
+                                                        int *__restrict__ bad)
+{
+    __shared__ unsigned local[kRankBuckets0];
+    const long long row = blockIdx.y;
+    for (int b = threadIdx.x; b < kRankBuckets0; b += 256) {
+        local[b] = 0u;
     }
     __syncthreads();
-    if (b >= bins) {
+    const double *__restrict__ x = matrix + row * n;
+    const long long base = (long long)blockIdx.x * kRankChunk;
+    bool finite = true;
+#pragma unroll 4
+    for (int j = 0; j < kRankChunk / 256; ++j) {
+        const long long i = base + threadIdx.x + 256LL * j;
+        if (i < n) {
+            const double v = fabs(x[i]);
+            finite = finite && isfinite(v);
+            atomicAdd(&local[(unsigned)((unsigned long long)__double_as_longlong(v) >> kRankShift0)], 1u);
+        }
+    }
+    if (!finite) {
+        atomicOr(bad, 1);
+    }
+    __syncthreads();
+    unsigned *__restrict__ mine = hist0 + row * kRankBuckets0;
+    for (int b = threadIdx.x; b < kRankBuckets0; b += 256) {
+        if (local[b] != 0u) {
+            atomicAdd(&mine[b], local[b]);
+        }
+    }
+}
+
+// one workgroup per row: which counter of `cells` (count of them a multiple of 256 * per) holds each rank.  On return
+// found[t] = the counter, and rank[t] the rank inside it.  `origin[t]`: the counter the rank is counted from.
+template <int PER>
+__device__ __forceinline__ void rank_locate(const unsigned *__restrict__ cells, const int *origin, long long *rank, int *found,
+                                            unsigned long long *part_base)
+{
+    unsigned long long sum = 0;
+    for (int q = 0; q < PER; ++q) {
+        sum += cells[threadIdx.x * PER + q];
+    }
+    part_base[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int c = 0; c < 256; ++c) {
+            const unsigned long long v = part_base[c];
+            part_base[c] = run;
+            run += v;
+        }
+        part_base[256] = run;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < kRankTargets) {
+        found[t] = -1;
+        if (rank[t] >= 0) {
+            const unsigned long long want = part_base[origin[t] / PER] + (unsigned long long)rank[t];  // (origins sit on part boundaries)
+            int lo = 0, hi = 256;  // the last part whose base is <= want
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (part_base[mid] <= want) {
+                    lo = mid;
+                } else {
+                    hi = mid;
+                }
+            }
+            unsigned long long run = part_base[lo];
+            int c = lo * PER;
+            for (int q = 0; q < PER; ++q, ++c) {
+                const unsigned long long here = cells[c];
+                if (want < run + here) {
+                    break;
+                }
+                run += here;
+            }
+            found[t] = (c < 256 * PER) ? c : -1;  // (-1: the rank lies beyond the counted values -- cannot happen)
+            rank[t] = (long long)(want - run);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void rank_plan0_kernel(RankRow *__restrict__ rr, const unsigned *__restrict__ hist0,
+                                                        unsigned *__restrict__ hist1, TrendRow *__restrict__ trows)
+{
+    __shared__ unsigned long long part_base[257];
+    __shared__ long long rank[kRankTargets];
+    __shared__ int origin[kRankTargets], found[kRankTargets];
+    RankRow &r = rr[blockIdx.x];
+    const int t = threadIdx.x;
+    if (t < kRankTargets) {
+        rank[t] = r.rank[t];
+        origin[t] = 0;
+    }
+    for (int c = t; c < kRankCells1; c += 256) {
+        hist1[(long long)blockIdx.x * kRankCells1 + c] = 0u;
+    }
+    __syncthreads();
+    rank_locate<kRankBuckets0 / 256>(hist0 + (long long)blockIdx.x * kRankBuckets0, origin, rank, found, part_base);
+    if (t == 0) {
+        int slots = 0, prev = -1, lost = 0;
+        for (int q = 0; q < kRankTargets; ++q) {  // the ranks ascend with q, so do their buckets
+            if (rank[q] < 0) {
+                continue;
+            }
+            if (found[q] < 0) {
+                lost = 1;
+                continue;
+            }
+            if (found[q] != prev) {
+                prev = found[q];
+                r.bucket0[slots++] = (unsigned short)prev;
+            }
+            r.slot[q] = (unsigned char)(slots - 1);
+        }
+        int width = 11;
+        while (width > 0 && (slots << width) > kRankCells1) {
+            --width;
+        }
+        r.slots0 = lost ? 0 : slots;
+        r.width1 = width;
+        r.slots1 = 0;
+        if (lost) {
+            trows[blockIdx.x].tie = 1;
+        }
+    }
+    if (t < kRankTargets) {
+        r.rank[t] = rank[t];
+    }
+}
+
+__device__ __forceinline__ void rank_slot_map(const RankRow &r, unsigned char *map0)
+{
+    for (int b = threadIdx.x; b < kRankBuckets0 / 4; b += 256) {
+        ((unsigned *)map0)[b] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < r.slots0) {
+        map0[r.bucket0[threadIdx.x]] = (unsigned char)threadIdx.x;
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_hist1_kernel(const double *__restrict__ matrix, long long n, const RankRow *__restrict__ rr,
+                                                        unsigned *__restrict__ hist1)
+{
+    __shared__ unsigned local[kRankCells1];
+    __shared__ unsigned char map0[kRankBuckets0];
+    const long long row = blockIdx.y;
+    const RankRow &r = rr[row];
+    if (r.slots0 == 0) {
         return;
     }
-    const long long left = ((long long)b * n) / bins, right = ((long long)(b + 1) * n) / bins;
-    const long long width = right - left;
-    double c = 0.0;
-    if (width > 0) {
-        c = (width & 1LL) ? bits_to_double(xs[left + width / 2])
-                          : 0.5 * (bits_to_double(xs[left + width / 2 - 1]) + bits_to_double(xs[left + width / 2]));
+    const int width = r.width1, cells = r.slots0 << width;
+    for (int b = threadIdx.x; b < cells; b += 256) {
+        local[b] = 0u;
     }
-    row->cov[b] = c;
-    row->bound[b] = (left < n) ? bits_to_double(xs[left]) : INFINITY;
-    if (width <= 0 || (b >= 1 && left >= 1 && xs[left - 1] == xs[left])) {
-        atomicOr(&row->tie, 1);  // an empty bin, or a boundary inside a run of equal x
+    rank_slot_map(r, map0);
+    __syncthreads();
+    const double *__restrict__ x = matrix + row * n;
+    const long long base = (long long)blockIdx.x * kRankChunk;
+    const int low = kRankShift0 - width;
+    const unsigned mask = (1u << width) - 1u;
+#pragma unroll 4
+    for (int j = 0; j < kRankChunk / 256; ++j) {
+        const long long i = base + threadIdx.x + 256LL * j;
+        if (i < n) {
+            const unsigned long long k = (unsigned long long)__double_as_longlong(fabs(x[i]));
+            const unsigned s = map0[(unsigned)(k >> kRankShift0) & (kRankBuckets0 - 1)];
+            if (s != 255u) {
+                atomicAdd(&local[(s << width) | ((unsigned)(k >> low) & mask)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned *__restrict__ mine = hist1 + row * kRankCells1;
+    for (int b = threadIdx.x; b < cells; b += 256) {
+        if (local[b] != 0u) {
+            atomicAdd(&mine[b], local[b]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_plan1_kernel(RankRow *__restrict__ rr, const unsigned *__restrict__ hist1, long long capacity,
+                                                        TrendRow *__restrict__ trows)
+{
+    __shared__ unsigned long long part_base[257];
+    __shared__ long long rank[kRankTargets];
+    __shared__ int origin[kRankTargets], found[kRankTargets];
+    RankRow &r = rr[blockIdx.x];
+    if (r.slots0 == 0) {
+        return;
+    }
+    const int t = threadIdx.x;
+    if (t < kRankTargets) {
+        rank[t] = r.rank[t];
+        origin[t] = (rank[t] >= 0) ? ((int)r.slot[t] << r.width1) : 0;  // (width1 >= 6: a multiple of the 32 counters of a part)
+    }
+    __syncthreads();
+    const unsigned *__restrict__ cells = hist1 + (long long)blockIdx.x * kRankCells1;  // (zero beyond slots0 << width1)
+    rank_locate<kRankCells1 / 256>(cells, origin, rank, found, part_base);
+    if (t == 0) {
+        int count = 0, prev = -1, lost = 0;
+        unsigned long long total = 0;
+        for (int q = 0; q < kRankTargets; ++q) {
+            if (rank[q] < 0) {
+                continue;
+            }
+            if (found[q] < 0 || (found[q] >> r.width1) != (int)r.slot[q]) {
+                lost = 1;  // (cannot happen: the rank lies inside its slot)
+                continue;
+            }
+            if (found[q] != prev) {
+                prev = found[q];
+                const unsigned here = cells[prev];
+                r.cell1[count] = (unsigned short)prev;
+                r.count1[count] = here;
+                r.offset1[count] = (unsigned)total;
+                r.cursor1[count] = 0u;
+                total += here;
+                if (here > (unsigned)kRankSortMax) {
+                    lost = 1;  // a cell too full to sort in LDS: runs of equal or nearly equal x
+                }
+                ++count;
+            }
+            r.slot[q] = (unsigned char)(count - 1);
+        }
+        if (lost || total > (unsigned long long)capacity) {
+            trows[blockIdx.x].tie = 1;
+            count = 0;
+        }
+        r.slots1 = count;
+    }
+    if (t < kRankTargets) {
+        r.rank[t] = rank[t];
+    }
+}
+
+// the values of the cells that hold a rank, cell by cell, into the row's room of `cand`
+__global__ __launch_bounds__(256) void rank_gather_kernel(const double *__restrict__ matrix, long long n, RankRow *__restrict__ rr,
+                                                         unsigned long long *__restrict__ cand, long long capacity)
+{
+    __shared__ unsigned char map0[kRankBuckets0], map1[kRankCells1];
+    __shared__ unsigned cnt[kRankTargets], base_of[kRankTargets];
+    const long long row = blockIdx.y;
+    RankRow &r = rr[row];
+    if (r.slots1 == 0) {
+        return;
+    }
+    const int width = r.width1, t = threadIdx.x;
+    for (int b = t; b < kRankCells1 / 4; b += 256) {
+        ((unsigned *)map1)[b] = 0xFFFFFFFFu;
+    }
+    if (t < kRankTargets) {
+        cnt[t] = 0u;
+    }
+    rank_slot_map(r, map0);
+    __syncthreads();
+    if (t < r.slots1) {
+        map1[r.cell1[t]] = (unsigned char)t;
+    }
+    __syncthreads();
+    const double *__restrict__ x = matrix + row * n;
+    const long long first = (long long)blockIdx.x * kGatherChunk;
+    const int low = kRankShift0 - width;
+    const unsigned mask = (1u << width) - 1u;
+    unsigned char mine[kGatherChunk / 256];
+#pragma unroll
+    for (int j = 0; j < kGatherChunk / 256; ++j) {
+        const long long i = first + t + 256LL * j;
+        unsigned c = 255u;
+        if (i < n) {
+            const unsigned long long k = (unsigned long long)__double_as_longlong(fabs(x[i]));
+            const unsigned s = map0[(unsigned)(k >> kRankShift0) & (kRankBuckets0 - 1)];
+            if (s != 255u) {
+                c = map1[(s << width) | ((unsigned)(k >> low) & mask)];
+                if (c != 255u) {
+                    atomicAdd(&cnt[c], 1u);
+                }
+            }
+        }
+        mine[j] = (unsigned char)c;
+    }
+    __syncthreads();
+    if (t < r.slots1) {
+        const unsigned c = cnt[t];
+        base_of[t] = (c != 0u) ? atomicAdd(&r.cursor1[t], c) : 0u;
+        cnt[t] = 0u;
+    }
+    __syncthreads();
+    unsigned long long *__restrict__ out = cand + row * capacity;
+#pragma unroll
+    for (int j = 0; j < kGatherChunk / 256; ++j) {
+        const unsigned c = mine[j];
+        if (c != 255u) {
+            const long long i = first + t + 256LL * j;
+            const unsigned at = base_of[c] + atomicAdd(&cnt[c], 1u);
+            if (at < r.count1[c]) {  // (never false: the count is the histogram's)
+                out[(long long)r.offset1[c] + at] = (unsigned long long)__double_as_longlong(fabs(x[i]));
+            }
+        }
+    }
+}
+
+// one workgroup per (cell, row): bitonic sort of the cell's values in LDS, then the ranks that live in it
+__global__ __launch_bounds__(256) void rank_sort_kernel(RankRow *__restrict__ rr, const unsigned long long *__restrict__ cand,
+                                                       long long capacity, TrendRow *__restrict__ trows)
+{
+    __shared__ unsigned long long v[kRankSortMax];
+    const long long row = blockIdx.y;
+    const int c = blockIdx.x, t = threadIdx.x;
+    RankRow &r = rr[row];
+    if (c >= r.slots1) {
+        return;
+    }
+    const int count = (int)r.count1[c];
+    if (r.cursor1[c] != r.count1[c]) {  // (guard: every counted value must have arrived)
+        if (t == 0) {
+            atomicOr(&trows[row].tie, 1);
+        }
+        return;
+    }
+    int padded = 64;
+    while (padded < count) {
+        padded <<= 1;
+    }
+    const unsigned long long *__restrict__ in = cand + row * capacity + r.offset1[c];
+    for (int i = t; i < padded; i += 256) {
+        v[i] = (i < count) ? in[i] : ~0ULL;
+    }
+    __syncthreads();
+    for (int k = 2; k <= padded; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < padded; i += 256) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const unsigned long long a = v[i], b = v[partner];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        v[i] = b;
+                        v[partner] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (t < kRankTargets && r.rank[t] >= 0 && (int)r.slot[t] == c) {
+        r.key[t] = (r.rank[t] < count) ? v[r.rank[t]] : ~0ULL;
+    }
+}
+
+// one wavefront per row: lane b = bin b; the boundaries, the tie check and the median x from the ranks' keys
+__global__ __launch_bounds__(64) void rank_finish_kernel(const RankRow *__restrict__ rr, long long n, int bins, TrendRow *__restrict__ trows)
+{
+    const long long row = blockIdx.x;
+    const int b = threadIdx.x;
+    const RankRow &r = rr[row];
+    TrendRow &tr = trows[row];
+    if (b >= bins || tr.tie != 0) {
+        return;
+    }
+    const long long left = ((long long)b * n) / bins, right = ((long long)(b + 1) * n) / bins, w = right - left;
+    if (w <= 0) {
+        atomicOr(&tr.tie, 1);  // an empty bin
+        return;
+    }
+    const unsigned long long *key = r.key + 4 * b;
+    tr.cov[b] = (w & 1LL) ? bits_to_double(key[3]) : 0.5 * (bits_to_double(key[2]) + bits_to_double(key[3]));
+    tr.bound[b] = (b >= 1) ? bits_to_double(key[1]) : -1.0;
+    if (b >= 1 && left >= 1 && key[0] == key[1]) {
+        atomicOr(&tr.tie, 1);  // a boundary inside a run of equal x
     }
 }
 
@@ -993,42 +1394,58 @@ __device__ __forceinline__ double linear_interp(const double *xs, const double *
     return ys[left] + (w * (ys[right] - ys[left]));
 }
 
-// one row into the per-locus sums (wls_backend.c:885-910); sums = weighted | precision | raw | prior, n each
-__global__ __launch_bounds__(256) void wls_accumulate_kernel(const double *__restrict__ row, const double *__restrict__ vas_row,
-                                                            long long n, long long half, long long max_start,
-                                                            const TrendFit *__restrict__ fit, double local_df,
-                                                            double prior_df, double total_df, double floor_ratio,
-                                                            double *__restrict__ sums)
+// sums = weighted | precision | raw | prior, n each
+// every row into the per-locus sums, one thread per locus walking the rows in order (the order the reference adds them in,
+// wls_backend.c:885-910) with the four sums in registers: 16 B read per value instead of 80 (the sums no longer go
+// through memory once per row), one launch per matrix instead of one per row
+__global__ __launch_bounds__(256) void wls_accumulate_rows_kernel(const double *__restrict__ matrix, const double *__restrict__ vas,
+                                                                 long long rows, long long n, long long half, long long max_start,
+                                                                 const TrendFit *__restrict__ fits, double local_df, double prior_df,
+                                                                 double total_df, double floor_ratio, double *__restrict__ sums)
 {
-    __shared__ double kc[kMaxBins], kv[kMaxBins];
-    const int mode = fit->mode, knots = fit->knots;
-    if (threadIdx.x < kMaxBins) {
-        kc[threadIdx.x] = fit->kc[threadIdx.x];
-        kv[threadIdx.x] = fit->kv[threadIdx.x];
-    }
-    __syncthreads();
+    __shared__ double kc[2][kMaxBins], kv[2][kMaxBins];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
-        return;
+    const long long vas_stride = max_start + 1;
+    if (threadIdx.x < kMaxBins) {
+        kc[0][threadIdx.x] = fits[0].kc[threadIdx.x];
+        kv[0][threadIdx.x] = fits[0].kv[threadIdx.x];
     }
-    const double value = row[i];
-    const double obs_value = fmax(obs_variance_at(vas_row, i, half, max_start), 1.0e-8);
-    double prior_track = fit->value;
-    if (mode == 2) {
-        prior_track = fmax(linear_interp(kc, kv, knots, fabs(value)), 1.0e-8);  // wls_backend.c:590-592
+    double weighted = 0.0, precision = 0.0, raw = 0.0, prior = 0.0;
+    for (long long k = 0; k < rows; ++k) {
+        __syncthreads();  // row k's knots are in place; everyone is done with row k - 1's
+        const int cur = (int)(k & 1LL);
+        if (k + 1 < rows && threadIdx.x < kMaxBins) {
+            kc[cur ^ 1][threadIdx.x] = fits[k + 1].kc[threadIdx.x];
+            kv[cur ^ 1][threadIdx.x] = fits[k + 1].kv[threadIdx.x];
+        }
+        if (i < n) {
+            const TrendFit &fit = fits[k];
+            const double value = matrix[k * n + i];
+            const double obs_value = fmax(obs_variance_at(vas + k * vas_stride, i, half, max_start), 1.0e-8);
+            double prior_track = fit.value;
+            if (fit.mode == 2) {
+                prior_track = fmax(linear_interp(kc[cur], kv[cur], fit.knots, fabs(value)), 1.0e-8);  // wls_backend.c:590-592
+            }
+            const double prior_value = fmax(prior_track, 1.0e-8);
+            double posterior_variance = ((local_df * obs_value) + (prior_df * prior_value)) / fmax(total_df, 1.0);
+            const double variance_floor = floor_ratio * prior_value;
+            if (posterior_variance < variance_floor) {
+                posterior_variance = variance_floor;
+            }
+            posterior_variance = fmax(posterior_variance, 1.0e-8);
+            const double posterior_precision = 1.0 / posterior_variance;
+            raw += 1.0 / obs_value;
+            prior += 1.0 / prior_value;
+            precision += posterior_precision;
+            weighted += posterior_precision * value;
+        }
     }
-    const double prior_value = fmax(prior_track, 1.0e-8);
-    double posterior_variance = ((local_df * obs_value) + (prior_df * prior_value)) / fmax(total_df, 1.0);
-    const double variance_floor = floor_ratio * prior_value;
-    if (posterior_variance < variance_floor) {
-        posterior_variance = variance_floor;
+    if (i < n) {
+        sums[2 * n + i] = raw;
+        sums[3 * n + i] = prior;
+        sums[1 * n + i] = precision;
+        sums[0 * n + i] = weighted;
     }
-    posterior_variance = fmax(posterior_variance, 1.0e-8);
-    const double posterior_precision = 1.0 / posterior_variance;
-    sums[2 * n + i] += 1.0 / obs_value;
-    sums[3 * n + i] += 1.0 / prior_value;
-    sums[1 * n + i] += posterior_precision;
-    sums[0 * n + i] += posterior_precision * value;
 }
 
 // rows of fewer than 5 loci (no window): robust scale of the row for every locus (wls_backend.c:834-851)
@@ -1227,6 +1644,9 @@ size_t sort_temp_bytes(size_t n)
     return align_up(std::max(a, std::max(b, c)), 256);
 }
 
+// room per row for the values of the cells that hold a rank (about 2 % of the row; a row that needs more sorts instead)
+static size_t rank_capacity(size_t n) { return std::min(n, n / 4 + 65536); }
+
 size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window, bool own_variances)
 {
     // windows above the tiled kernel's limit keep the three running sums of every row in memory
@@ -1236,7 +1656,9 @@ size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window, bool own_varian
     const size_t segs = K * (size_t)kMaxBins;
     const size_t dealt = (n >= (size_t)kTrendSelectMin)
                              ? align_up(K * n * 8, 256) + align_up(K * sizeof(TrendRow), 256) + align_up(segs * sizeof(RowSelect), 256) +
-                                   align_up(segs * kSelectBuckets * sizeof(unsigned), 256) + align_up(segs * sizeof(unsigned), 256)
+                                   align_up(segs * kSelectBuckets * sizeof(unsigned), 256) + align_up(segs * sizeof(unsigned), 256) +
+                                   align_up(K * sizeof(RankRow), 256) + align_up(K * (size_t)kRankBuckets0 * sizeof(unsigned), 256) +
+                                   align_up(K * (size_t)kRankCells1 * sizeof(unsigned), 256) + align_up(K * rank_capacity(n) * 8, 256)
                              : 0;
     return general + dealt + align_up(K * sizeof(TrendFit), 256) + (own_variances ? align_up(K * n * 8, 256) : 0) + 6 * align_up(n * 8, 256) +
            2 * align_up(n * 4, 256) + 2 * align_up(n, 256) + align_up(4 * n * 8, 256) + sort_temp_bytes(n) + 4096;
@@ -1284,6 +1706,10 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     RowSelect *seg_state = select_path ? (RowSelect *)carve(segs * sizeof(RowSelect)) : nullptr;
     unsigned *seg_hist = select_path ? (unsigned *)carve(segs * kSelectBuckets * sizeof(unsigned)) : nullptr;
     unsigned *cursor = select_path ? (unsigned *)carve(segs * sizeof(unsigned)) : nullptr;
+    RankRow *rank_rows = select_path ? (RankRow *)carve(K * sizeof(RankRow)) : nullptr;
+    unsigned *rank_hist0 = select_path ? (unsigned *)carve(K * (size_t)kRankBuckets0 * sizeof(unsigned)) : nullptr;
+    unsigned *rank_hist1 = select_path ? (unsigned *)carve(K * (size_t)kRankCells1 * sizeof(unsigned)) : nullptr;
+    unsigned long long *rank_cand = select_path ? (unsigned long long *)carve(K * rank_capacity(n) * 8) : nullptr;
     void *tmp = sc + off;
     const size_t tmp_bytes = sort_temp_bytes(n);
     ROCCO_HIP_TRY(hipMemsetAsync(sums, 0, 4 * n * 8, stream));
@@ -1334,13 +1760,21 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
         hipLaunchKernelGGL(wls_iota_kernel, dim3(blocks256), dim3(256), 0, stream, iota, nn);
         std::vector<int> tie(K, 1);
         if (select_path) {
-            // x side, row by row: one keys-only sort -> the bins' first and median x
-            for (size_t k = 0; k < K; ++k) {
-                hipLaunchKernelGGL(wls_xkeys_kernel, dim3(blocks256), dim3(256), 0, stream, centered_dev + k * n, nn, key_a, bad);
-                size_t t = tmp_bytes;
-                ROCCO_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(tmp, t, key_a, key_b, (int)n, 0, 63, stream));  // (bit 63 is 0)
-                hipLaunchKernelGGL(wls_bounds_kernel, dim3(1), dim3(64), 0, stream, key_b, nn, bins, trows + k);
-            }
+            // x side, every row of the matrix at once: the ranks the bins need (their first and median x), three passes
+            hipLaunchKernelGGL(rank_init_kernel, dim3((unsigned)((K * (size_t)kRankBuckets0 + 255) / 256)), dim3(256), 0, stream, rank_rows,
+                               rank_hist0, trows, (long long)K, nn, bins);
+            const dim3 rank_grid((unsigned)((nn + kRankChunk - 1) / kRankChunk), (unsigned)K);
+            hipLaunchKernelGGL(rank_hist0_kernel, rank_grid, dim3(256), 0, stream, centered_dev, nn, rank_hist0, bad);
+            hipLaunchKernelGGL(rank_plan0_kernel, dim3((unsigned)K), dim3(256), 0, stream, rank_rows, (const unsigned *)rank_hist0, rank_hist1,
+                               trows);
+            hipLaunchKernelGGL(rank_hist1_kernel, rank_grid, dim3(256), 0, stream, centered_dev, nn, (const RankRow *)rank_rows, rank_hist1);
+            hipLaunchKernelGGL(rank_plan1_kernel, dim3((unsigned)K), dim3(256), 0, stream, rank_rows, (const unsigned *)rank_hist1,
+                               (long long)rank_capacity(n), trows);
+            hipLaunchKernelGGL(rank_gather_kernel, dim3((unsigned)((nn + kGatherChunk - 1) / kGatherChunk), (unsigned)K), dim3(256), 0, stream,
+                               centered_dev, nn, rank_rows, rank_cand, (long long)rank_capacity(n));
+            hipLaunchKernelGGL(rank_sort_kernel, dim3(kRankTargets, (unsigned)K), dim3(256), 0, stream, rank_rows,
+                               (const unsigned long long *)rank_cand, (long long)rank_capacity(n), trows);
+            hipLaunchKernelGGL(rank_finish_kernel, dim3((unsigned)K), dim3(64), 0, stream, (const RankRow *)rank_rows, nn, bins, trows);
             // y side, every row of the matrix at once: deal the y to the bins' segments, select every segment's median
             const long long n_segs = (long long)K * bins;
             hipLaunchKernelGGL(seg_select_init_kernel, dim3((unsigned)((n_segs * kSelectBuckets + 255) / 256)), dim3(256), 0, stream,
@@ -1377,9 +1811,9 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
                 int rc = sorted_row(k);
                 if (rc != ROCCO_HIP_OK) return rc;
             }
-            hipLaunchKernelGGL(wls_accumulate_kernel, dim3(blocks256), dim3(256), 0, stream, centered_dev + k * n, vas + k * vas_stride, nn,
-                               half, max_start, fits + k, local_df, pdf, total_df, floor_ratio, sums);
         }
+        hipLaunchKernelGGL(wls_accumulate_rows_kernel, dim3(blocks256), dim3(256), 0, stream, centered_dev, (const double *)vas, (long long)K,
+                           nn, half, max_start, (const TrendFit *)fits, local_df, pdf, total_df, floor_ratio, sums);
     }
     hipLaunchKernelGGL(wls_final_kernel, dim3(blocks256), dim3(256), 0, stream, sums, nn, (double)K, lower_bound_z,
                        min_effect, use_min_effect, mean_dev, raw_var_dev, prior_var_dev, mod_var_dev, se_dev, scores_dev);

@@ -37,6 +37,8 @@ for rep in range(2):
           f"{K * total / dt / 1e9:.2f} G values/s; least free device memory so far {low[0] / 1e9:.1f} GB", flush=True)
     ref = [o[0] for o in out]
     del out
+if os.environ.get("PROBE_BATCH_ONLY"):
+    sys.exit(0)
 mats = make()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 seq = [inference.score_loci_wls_device(m, overwrite_input=True)[0] for m in mats]
