@@ -310,6 +310,11 @@ int rocco_hip_score_centered_wls_given_variances_f64(rocco_hip_solver *solver, c
                                                      double *mean_dev, double *raw_var_dev, double *prior_var_dev, double *mod_var_dev,
                                                      double *se_dev, double *scores_dev, double *df_out, int *window_out, void *stream);
 
+/* How many rows of this solver's last centred-WLS call fitted their variance trend on the sorted path (two radix sorts of the
+ * row's pairs: rows shorter than 4096 loci, rows with a run of equal |value| across a bin boundary, rows with more than 8192
+ * values in one cell of the rank finder) instead of the sort-free one.  Diagnostic: the results are the same either way. */
+int rocco_hip_wls_sorted_rows(const rocco_hip_solver *solver);
+
 /* ---- count-path glue of score_loci_wls ---------------------------------
  * Replaces the NumPy statements of rocco/inference.py:40-47 (`_log_scale_wls_matrix`) and 330-331 (pilot
  * offset): centered_out[k][i] = log2(max(counts[k][i], 0) + pseudocount) - median_i(log2(...)[k][:]).

@@ -870,8 +870,10 @@ int rocco_hip_score_centered_wls_given_variances_f64(rocco_hip_solver *solver, c
     return launch_score_centered_wls(centered_dev, K, n, lower_bound_z, prior_df, min_effect, use_min_effect,
                                      spatial_window, precision_floor_ratio, mean_dev, raw_var_dev, prior_var_dev,
                                      mod_var_dev, se_dev, scores_dev, solver->dev_misc.ptr, df_out, window_out,
-                                     (hipStream_t)stream, (int *)solver->host_back.ptr, variances_dev);
+                                     (hipStream_t)stream, (int *)solver->host_back.ptr, variances_dev, &solver->wls_sorted_rows);
 }
+
+int rocco_hip_wls_sorted_rows(const rocco_hip_solver *solver) { return solver != nullptr ? solver->wls_sorted_rows : -1; }
 
 int rocco_hip_log_scale_f64(rocco_hip_solver *solver, const double *values_dev, size_t count, double pseudocount, double *out_dev,
                             void *stream)

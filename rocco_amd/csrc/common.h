@@ -82,5 +82,6 @@ struct rocco_hip_solver {
     rocco::PinnedBuffer host_lean_back;  // ... and the readback of its results
     rocco::PinnedBuffer host_stage;   // pinned staging for uploads
     rocco::PinnedBuffer host_back;    // pinned staging for readbacks
+    int wls_sorted_rows = 0;          // rows of the last centred-WLS call whose trend fit sorted its pairs (wls.hip)
     rocco::PinnedBuffer host_table;   // the interval table of the last rocco_hip_decode_runs_table call
 };

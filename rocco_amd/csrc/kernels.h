@@ -157,7 +157,8 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
                               double min_effect, int use_min_effect, int spatial_window,
                               double precision_floor_ratio, double *mean_dev, double *raw_var_dev,
                               double *prior_var_dev, double *mod_var_dev, double *se_dev, double *scores_dev,
-                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream, int *flag_host_pinned, const double *vas_given = nullptr);
+                              void *scratch_dev, double *df_out, int *window_out, hipStream_t stream, int *flag_host_pinned, const double *vas_given = nullptr,
+                              int *sorted_rows_out = nullptr);
 
 // row a2 glue (wls.hip): log2(max(x, 0) + pseudocount), row medians subtracted; out may alias the input
 size_t log_scale_scratch_bytes(size_t K, size_t n);

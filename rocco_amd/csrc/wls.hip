@@ -1669,8 +1669,11 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
                               double precision_floor_ratio, double *mean_dev, double *raw_var_dev,
                               double *prior_var_dev, double *mod_var_dev, double *se_dev, double *scores_dev,
                               void *scratch_dev, double *df_out, int *window_out, hipStream_t stream, int *flag_host_pinned,
-                              const double *vas_given)
+                              const double *vas_given, int *sorted_rows_out)
 {
+    if (sorted_rows_out != nullptr) {
+        *sorted_rows_out = 0;
+    }
     const double pdf = std::fmax(prior_df, 0.0), floor_ratio = std::fmax(precision_floor_ratio, 0.0);
     const int window = wls_spatial_window(n, spatial_window);
     const double local_df = window > 0 ? std::fmax(4.0, (double)window - 3.0) : 1.0;
@@ -1810,6 +1813,9 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
             if (tie[k] != 0) {
                 int rc = sorted_row(k);
                 if (rc != ROCCO_HIP_OK) return rc;
+                if (sorted_rows_out != nullptr) {
+                    ++*sorted_rows_out;
+                }
             }
         }
         hipLaunchKernelGGL(wls_accumulate_rows_kernel, dim3(blocks256), dim3(256), 0, stream, centered_dev, (const double *)vas, (long long)K,

@@ -180,6 +180,12 @@ def wls_rolling_variances_batch_device(centered_list, spatial_window: int = 31):
     return outs
 
 
+def wls_sorted_rows(device_index: int = 0) -> int:
+    """Rows of the calling thread's last centred-WLS call on this device whose trend fit took the sorted path
+    (rocco_hip_wls_sorted_rows): 0 for matrices of long rows without runs of equal |value| at the bin boundaries."""
+    return int(_native.load().rocco_hip_wls_sorted_rows(_native.solver_for(int(device_index)).handle))
+
+
 def score_centered_wls_device(centered_t, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
                               spatial_window: int = 31, precision_floor_ratio: float = 0.01, variances_t=None):
     """Device-resident form of the reference extension's ``score_centered_wls`` (rocco/_wls.c over

@@ -103,13 +103,13 @@ def test_wrapper_details(gpu, oracle):
 
 @pytest.mark.parametrize("kind", ["quantised", "few_levels", "zeros_and_noise", "boundary_tie_only"])
 def test_trend_fit_with_runs_of_equal_values(gpu, oracle, kind):
-    """Rows of 4096 loci or more fit their variance trend without sorting the pairs: one keys-only sort of |value| gives the
+    """Rows of 4096 loci or more fit their variance trend without sorting the pairs: a few order statistics of |value| give the
     bins' boundaries, and a pair knows its bin from its |value| alone -- unless a boundary falls inside a run of equal
     |value|, where the reference's order inside the run (by variance) decides: such rows take the sorted path.  Rows
     full of ties, rows with a single tie exactly at a boundary, and clean rows side by side in one matrix."""
-    from rocco_amd.inference import score_centered_wls
+    from rocco_amd.inference import score_centered_wls, wls_sorted_rows
 
-    rng = np.random.default_rng(hash(kind) % 1000)
+    rng = np.random.default_rng(sum(map(ord, kind)))
     K, n = 5, 30011
     m = rng.normal(0.0, 0.8, size=(K, n))
     if kind == "quantised":
@@ -126,6 +126,43 @@ def test_trend_fit_with_runs_of_equal_values(gpu, oracle, kind):
         left = (7 * n) // bins
         m[1, order[left]] = -m[1, order[left - 1]]
     got = score_centered_wls(m)
+    assert wls_sorted_rows() == {"quantised": 5, "few_levels": 5, "zeros_and_noise": 4, "boundary_tie_only": 1}[kind]
+    want = oracle.score_centered_wls(m)
+    for g, w in zip(got[:6], want[:6]):
+        assert np.asarray(g).tobytes() == np.asarray(w).tobytes(), kind
+    assert got[6:] == want[6:]
+
+
+@pytest.mark.parametrize("kind", ["wide_range", "dense_cell", "tiny_values", "two_binades"])
+def test_trend_fit_rank_finder_shapes(gpu, oracle, kind):
+    """The order statistics of |value| the bins need come from two histogram passes (14 key bits, then 6..11 more inside
+    the buckets that hold a wanted rank) and a gather of the cells that hold one (csrc/wls.hip, "the x side"): rows whose
+    ranks spread over more than a hundred buckets (narrow second digit), rows with more than 8192 distinct values in one
+    cell (sorted path instead), rows of subnormal and zero values, rows inside two binades (wide second digit)."""
+    from rocco_amd.inference import score_centered_wls, wls_sorted_rows
+
+    rng = np.random.default_rng(11)
+    K, n = 3, 70001
+    if kind == "wide_range":
+        m = np.exp(rng.normal(0.0, 12.0, size=(K, n))) * rng.choice([-1.0, 1.0], size=(K, n))
+    elif kind == "dense_cell":
+        n = 200003
+        m = rng.normal(0.0, 0.8, size=(K, n))
+        # 9000 distinct values that share their top 40 key bits, inside one bin of row 1 (its median among them)
+        bins = int(np.floor(1.0 + np.log2(n + 1.0)))
+        width = n // bins
+        order = np.argsort(np.abs(m[1]))
+        lo = 6 * n // bins + (width - 9000) // 2
+        base = abs(m[1, order[lo]])
+        m[1, order[lo:lo + 9000]] = base * (1.0 + np.arange(9000) * 2.0 ** -50)
+        assert np.unique(np.abs(m[1])).size == n
+    elif kind == "tiny_values":
+        m = rng.normal(0.0, 1.0, size=(K, n)) * 1.0e-310
+        m[0, rng.random(n) < 0.001] = 0.0
+    else:
+        m = rng.uniform(1.0, 4.0, size=(K, n)) * rng.choice([-1.0, 1.0], size=(K, n))
+    got = score_centered_wls(m)
+    assert wls_sorted_rows() == (1 if kind == "dense_cell" else 0)  # the sort-free path is the one that ran
     want = oracle.score_centered_wls(m)
     for g, w in zip(got[:6], want[:6]):
         assert np.asarray(g).tobytes() == np.asarray(w).tobytes(), kind
