@@ -690,6 +690,7 @@ public:
     // has been synchronised.
     int lean_enqueue(std::vector<LeanReq> &reqs)
     {
+        const double le0 = now_us();
         lean_inflight_.clear();
         if (reqs.empty()) {
             return ROCCO_HIP_OK;
@@ -984,7 +985,16 @@ public:
         std::memcpy(h + b_pre + b_tasks, points.data(), points.size() * sizeof(double));
         if (!post.empty()) std::memcpy(h + b_pre + b_tasks + b_points, post.data(), post.size() * sizeof(LeanCompactTask));
         if (!wcap_tasks.empty()) std::memcpy(h + b_pre + b_tasks + b_points + b_post, wcap_tasks.data(), wcap_tasks.size() * sizeof(LeanWcapTask));
+        const double le1 = now_us();
         ROCCO_HIP_TRY(hipMemcpyAsync(d, h, desc, hipMemcpyHostToDevice, stream_));
+        const double le2 = now_us();
+        t_lean_cpu_ += le1 - le0;
+        t_lean_h2d_ += le2 - le1;
+        struct Launches {
+            double &acc;
+            double t0;
+            ~Launches() { acc += now_us() - t0; }
+        } launches{t_lean_launch_, le2};
         if (!wcap_tasks.empty()) {
             if ((rc = launch_lean_wcap((const LeanWcapTask *)(d + b_pre + b_tasks + b_points + b_post), (int)wcap_tasks.size(), wcap_blocks,
                                        stream_)) != ROCCO_HIP_OK) return rc;
@@ -1383,6 +1393,7 @@ private:
 
 public:
     double t_prep_ = 0.0, t_launch_ = 0.0, t_wait_ = 0.0, t_consume_ = 0.0, t_round_ = 0.0;
+    double t_lean_cpu_ = 0.0, t_lean_h2d_ = 0.0, t_lean_launch_ = 0.0;
     int rounds_all = 0;
     static double now_us()
     {
@@ -2212,6 +2223,9 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
                              "+ reading results %.0f + preparing and submitting %.0f; search logic and the rest %.0f us\n",
                      total, ev.rounds_all, ev.rounds, ev.t_round_, ev.t_wait_, ev.t_consume_,
                      ev.t_round_ - ev.t_wait_ - ev.t_consume_, total - ev.t_round_);
+        std::fprintf(stderr, "[host] lean rounds: building the descriptors %.0f us, their upload call %.0f, the launch calls %.0f; general rounds: "
+                             "preparing %.0f, launching %.0f\n",
+                     ev.t_lean_cpu_, ev.t_lean_h2d_, ev.t_lean_launch_, ev.t_prep_, ev.t_launch_);
     }
     for (size_t t = 0; t < n_tasks; ++t) {
         results[t].selection_penalty = res[t].selection_penalty;

@@ -679,14 +679,82 @@ def _solve_cached_chromosomes(chrom_cache: dict, chrom_budgets: dict, args: dict
     return [out for _chrom, _objective, _details, out in solved]
 
 
-def run_chromosomes(chroms_to_process: list, signal_inputs, args: dict, run_id: Optional[str] = None) -> str:
+def _world_size(group=None) -> int:
+    import torch.distributed as dist
+
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def _run_chromosomes_sharded(chroms_to_process: list, signal_inputs, args: dict, run_id: str, group=None) -> str:
+    """`run_chromosomes` over the ranks of a torch.distributed job, one process per GPU: the
+    chromosomes are dealt longest first to the least loaded rank (`shard.lpt_partition`); every rank builds the cache
+    entries of ITS chromosomes; exchange 1 -- every chromosome's (budget_count_hat, total_count), the only two numbers
+    the pooling reads (rocco/rocco.py:1117-1127) -- then the SAME empirical-Bayes fit on every rank, in the order of
+    `chroms_to_process`; every rank solves its chromosomes; exchange 2 -- the merged intervals as (unit, start, end)
+    rows; rank 0 writes the per-chromosome files, combines them and removes them.  Every rank returns the output path."""
+    import torch
+    import torch.distributed as dist
+
+    from . import shard as _shard
+
+    this = globals()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    exchange_device = f"cuda:{_dp._device_index()}" if on_gpu else "cpu"
+    # loci per chromosome where the caller's inputs say so (matrices in memory); else every chromosome weighs the same
+    sizes = []
+    for chrom_ in chroms_to_process:
+        entry = signal_inputs.get(chrom_) if isinstance(signal_inputs, dict) else None
+        sizes.append(int(len(entry[0])) if entry is not None and entry[0] is not None else 1)
+    mine = sorted(_shard.lpt_partition(sizes, world)[rank])
+    my_chroms = [chroms_to_process[u] for u in mine]
+    chrom_cache = this["_build_chrom_cache"](my_chroms, signal_inputs, args)
+    unit_of = {chrom_: u for u, chrom_ in enumerate(chroms_to_process)}
+    pairs = _shard.gather_budget_counts({unit_of[c]: (d["budget_count_hat"], d["total_count"]) for c, d in chrom_cache.items()},
+                                        len(chroms_to_process), device=exchange_device, group=group)
+    pooled_view = {chroms_to_process[u]: {"budget_count_hat": pairs[u][0], "total_count": pairs[u][1]} for u in sorted(pairs)}
+    chrom_budgets, _ = this["_resolve_budgets"](pooled_view, args)
+    solved = solve_cached_chromosomes(chrom_cache, {c: chrom_budgets[c] for c in chrom_cache},
+                                      selection_penalty=args["selection_penalty"], min_length_bp=args["min_length_bp"],
+                                      run_id=run_id, write_files=False)
+    rows = [(unit_of[chrom_], int(start), int(end)) for chrom_, _objective, _details, records in solved for _c, start, end in records]
+    rows_t = torch.tensor(rows, dtype=torch.int64, device=exchange_device).reshape(-1, 3)
+    everyone = _shard.gather_interval_rows(rows_t, group=group)
+    if rank == 0:
+        files = []
+        for u in sorted(pairs):  # every chromosome that had data, in the caller's order (also those without intervals)
+            chrom_ = chroms_to_process[u]
+            records = [(chrom_, int(a), int(b)) for a, b in everyone.get(u, np.zeros((0, 2), dtype=np.int64))]
+            files.append(_write_bed_records(records, f"rocco_{run_id}_{chrom_}.bed"))
+        combine_chrom_results(files, args["output"], name_features=False)
+        for tmp_file in files:
+            try:
+                os.remove(tmp_file)
+            except OSError as exc:
+                logger.info("Could not remove chromosome-specific temp. file %s\n%s", tmp_file, exc)
+    for chrom_data in chrom_cache.values():
+        summit_track_file = chrom_data.pop("summit_track_file", None)
+        if summit_track_file is not None:
+            try:
+                os.remove(summit_track_file)
+            except OSError as exc:
+                logger.info("Could not remove narrowPeak summit temp. file %s\n%s", summit_track_file, exc)
+    dist.barrier(group=group)
+    return args["output"]
+
+
+def run_chromosomes(chroms_to_process: list, signal_inputs, args: dict, run_id: Optional[str] = None, group=None) -> str:
     """What the reference's `main` does between its argument parsing and its narrowPeak step (rocco/rocco.py:1269-1300):
     cache -> pooled budgets -> solve -> combined BED at `args["output"]`; the per-chromosome files are removed.  Returns
-    the path of the combined BED.  (`rocco_amd.pipeline.solve_rank` is the multi-GPU form with user-given budgets.)"""
+    the path of the combined BED.  Inside an initialised torch.distributed job of more than one rank the chromosomes are
+    sharded over the ranks (`_run_chromosomes_sharded`: same file, written by rank 0); `run_id` must then be given, the
+    same on every rank.  (`rocco_amd.pipeline.solve_rank` is the multi-GPU form with user-given budgets.)"""
     import uuid
 
     run_id = str(int(uuid.uuid4().hex[:5], base=16)) if run_id is None else str(run_id)
     this = globals()
+    if _world_size(group) > 1:
+        return _run_chromosomes_sharded(chroms_to_process, signal_inputs, args, run_id, group)
     chrom_cache = this["_build_chrom_cache"](chroms_to_process, signal_inputs, args)
     chrom_budgets, _ = this["_resolve_budgets"](chrom_cache, args)
     tmp_chrom_bed_files = this["_solve_cached_chromosomes"](chrom_cache, chrom_budgets, args, run_id)
