@@ -715,25 +715,35 @@ __global__ __launch_bounds__(256) void rank_init_kernel(RankRow *__restrict__ rr
     }
 }
 
-__global__ __launch_bounds__(256) void rank_hist0_kernel(const double *__restrict__ matrix, long long n, unsigned *__restrict__ hist0,
-                                                        int *__restrict__ bad)
+constexpr int kRankThreads = 1024;  // the histogram passes: 16 wavefronts per workgroup (their 48-64 KB of LDS allow two or three per CU)
+
+__global__ __launch_bounds__(kRankThreads) void rank_hist0_kernel(const double *__restrict__ matrix, long long n, unsigned *__restrict__ hist0,
+                                                                 int *__restrict__ bad)
 {
     __shared__ unsigned local[kRankBuckets0];
     const long long row = blockIdx.y;
-    for (int b = threadIdx.x; b < kRankBuckets0; b += 256) {
+    for (int b = threadIdx.x; b < kRankBuckets0; b += kRankThreads) {
         local[b] = 0u;
     }
     __syncthreads();
     const double *__restrict__ x = matrix + row * n;
     const long long base = (long long)blockIdx.x * kRankChunk;
     bool finite = true;
-#pragma unroll 4
-    for (int j = 0; j < kRankChunk / 256; ++j) {
-        const long long i = base + threadIdx.x + 256LL * j;
-        if (i < n) {
-            const double v = fabs(x[i]);
-            finite = finite && isfinite(v);
-            atomicAdd(&local[(unsigned)((unsigned long long)__double_as_longlong(v) >> kRankShift0)], 1u);
+    constexpr int kBatch = 16;  // loads of a batch are issued before its LDS atomics
+#pragma unroll 1
+    for (int j0 = 0; j0 < kRankChunk / kRankThreads; j0 += kBatch) {
+        double v[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const long long i = base + threadIdx.x + (long long)kRankThreads * (j0 + j);
+            v[j] = (i < n) ? fabs(x[i]) : -1.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            if (v[j] >= 0.0 || v[j] != v[j]) {  // (a NaN is counted too: the call fails with the flag below)
+                finite = finite && isfinite(v[j]);
+                atomicAdd(&local[(unsigned)((unsigned long long)__double_as_longlong(v[j]) >> kRankShift0) & (kRankBuckets0 - 1)], 1u);
+            }
         }
     }
     if (!finite) {
@@ -741,7 +751,7 @@ __global__ __launch_bounds__(256) void rank_hist0_kernel(const double *__restric
     }
     __syncthreads();
     unsigned *__restrict__ mine = hist0 + row * kRankBuckets0;
-    for (int b = threadIdx.x; b < kRankBuckets0; b += 256) {
+    for (int b = threadIdx.x; b < kRankBuckets0; b += kRankThreads) {
         if (local[b] != 0u) {
             atomicAdd(&mine[b], local[b]);
         }
@@ -851,7 +861,7 @@ __global__ __launch_bounds__(256) void rank_plan0_kernel(RankRow *__restrict__ r
 
 __device__ __forceinline__ void rank_slot_map(const RankRow &r, unsigned char *map0)
 {
-    for (int b = threadIdx.x; b < kRankBuckets0 / 4; b += 256) {
+    for (int b = threadIdx.x; b < kRankBuckets0 / 4; b += blockDim.x) {
         ((unsigned *)map0)[b] = 0xFFFFFFFFu;
     }
     __syncthreads();
@@ -860,8 +870,8 @@ __device__ __forceinline__ void rank_slot_map(const RankRow &r, unsigned char *m
     }
 }
 
-__global__ __launch_bounds__(256) void rank_hist1_kernel(const double *__restrict__ matrix, long long n, const RankRow *__restrict__ rr,
-                                                        unsigned *__restrict__ hist1)
+__global__ __launch_bounds__(kRankThreads) void rank_hist1_kernel(const double *__restrict__ matrix, long long n,
+                                                                 const RankRow *__restrict__ rr, unsigned *__restrict__ hist1)
 {
     __shared__ unsigned local[kRankCells1];
     __shared__ unsigned char map0[kRankBuckets0];
@@ -871,7 +881,7 @@ __global__ __launch_bounds__(256) void rank_hist1_kernel(const double *__restric
         return;
     }
     const int width = r.width1, cells = r.slots0 << width;
-    for (int b = threadIdx.x; b < cells; b += 256) {
+    for (int b = threadIdx.x; b < cells; b += kRankThreads) {
         local[b] = 0u;
     }
     rank_slot_map(r, map0);
@@ -880,20 +890,28 @@ __global__ __launch_bounds__(256) void rank_hist1_kernel(const double *__restric
     const long long base = (long long)blockIdx.x * kRankChunk;
     const int low = kRankShift0 - width;
     const unsigned mask = (1u << width) - 1u;
-#pragma unroll 4
-    for (int j = 0; j < kRankChunk / 256; ++j) {
-        const long long i = base + threadIdx.x + 256LL * j;
-        if (i < n) {
-            const unsigned long long k = (unsigned long long)__double_as_longlong(fabs(x[i]));
-            const unsigned s = map0[(unsigned)(k >> kRankShift0) & (kRankBuckets0 - 1)];
-            if (s != 255u) {
-                atomicAdd(&local[(s << width) | ((unsigned)(k >> low) & mask)], 1u);
+    constexpr int kBatch = 16;
+#pragma unroll 1
+    for (int j0 = 0; j0 < kRankChunk / kRankThreads; j0 += kBatch) {
+        unsigned long long k[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const long long i = base + threadIdx.x + (long long)kRankThreads * (j0 + j);
+            k[j] = (i < n) ? (unsigned long long)__double_as_longlong(fabs(x[i])) : ~0ULL;  // (no |x| has its sign bit set)
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            if (k[j] != ~0ULL) {
+                const unsigned s = map0[(unsigned)(k[j] >> kRankShift0) & (kRankBuckets0 - 1)];
+                if (s != 255u) {
+                    atomicAdd(&local[(s << width) | ((unsigned)(k[j] >> low) & mask)], 1u);
+                }
             }
         }
     }
     __syncthreads();
     unsigned *__restrict__ mine = hist1 + row * kRankCells1;
-    for (int b = threadIdx.x; b < cells; b += 256) {
+    for (int b = threadIdx.x; b < cells; b += kRankThreads) {
         if (local[b] != 0u) {
             atomicAdd(&mine[b], local[b]);
         }
@@ -1767,10 +1785,10 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
             hipLaunchKernelGGL(rank_init_kernel, dim3((unsigned)((K * (size_t)kRankBuckets0 + 255) / 256)), dim3(256), 0, stream, rank_rows,
                                rank_hist0, trows, (long long)K, nn, bins);
             const dim3 rank_grid((unsigned)((nn + kRankChunk - 1) / kRankChunk), (unsigned)K);
-            hipLaunchKernelGGL(rank_hist0_kernel, rank_grid, dim3(256), 0, stream, centered_dev, nn, rank_hist0, bad);
+            hipLaunchKernelGGL(rank_hist0_kernel, rank_grid, dim3(kRankThreads), 0, stream, centered_dev, nn, rank_hist0, bad);
             hipLaunchKernelGGL(rank_plan0_kernel, dim3((unsigned)K), dim3(256), 0, stream, rank_rows, (const unsigned *)rank_hist0, rank_hist1,
                                trows);
-            hipLaunchKernelGGL(rank_hist1_kernel, rank_grid, dim3(256), 0, stream, centered_dev, nn, (const RankRow *)rank_rows, rank_hist1);
+            hipLaunchKernelGGL(rank_hist1_kernel, rank_grid, dim3(kRankThreads), 0, stream, centered_dev, nn, (const RankRow *)rank_rows, rank_hist1);
             hipLaunchKernelGGL(rank_plan1_kernel, dim3((unsigned)K), dim3(256), 0, stream, rank_rows, (const unsigned *)rank_hist1,
                                (long long)rank_capacity(n), trows);
             hipLaunchKernelGGL(rank_gather_kernel, dim3((unsigned)((nn + kGatherChunk - 1) / kGatherChunk), (unsigned)K), dim3(256), 0, stream,
