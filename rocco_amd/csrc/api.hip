@@ -799,7 +799,7 @@ int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t c
             if (centered_dev[i] == nullptr || variances_dev[i] == nullptr) {
                 return ROCCO_HIP_EINVAL;
             }
-            rows += K[i];
+            rows += (K[i] + kWlsRollingGroup - 1) / kWlsRollingGroup;  // task records: groups of rows
         }
     }
     if (rows == 0) {
@@ -816,11 +816,11 @@ int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t c
             continue;
         }
         const size_t stride = n[i] - (size_t)window + 1;
-        for (size_t k = 0; k < K[i]; ++k, ++t) {
+        for (size_t k = 0; k < K[i]; k += kWlsRollingGroup, ++t) {
             host[t].row = centered_dev[i] + k * n[i];
             host[t].n = (long long)n[i];
             host[t].window = window;
-            host[t].pad = 0;
+            host[t].rows = (int)std::min((size_t)kWlsRollingGroup, K[i] - k);
             host[t].out = variances_dev[i] + k * stride;
         }
     }

@@ -142,14 +142,16 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
 // ---- wls.hip --------------------------------------------------------------------------------
 // scratch: at least wls_scratch_bytes(K, n) bytes; synchronises the stream before returning
 int wls_spatial_window(size_t n, int requested);
-// one row of one matrix for the batched rolling launch: out = window variances of the row's n - window + 1 starts
+// up to 8 consecutive rows of one matrix for the rolling launch: `row` the first of them (the next n doubles further),
+// out = window variances of the row's n - window + 1 starts (the next row's right behind)
 struct WlsRollingTask {
     const double *row;
     long long n;
     int window;
-    int pad;
+    int rows;
     double *out;
 };
+constexpr int kWlsRollingGroup = 8;
 int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, hipStream_t stream);
 int wls_max_window();
 size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window = 0, bool own_variances = true);

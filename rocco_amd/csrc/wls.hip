@@ -4,9 +4,9 @@
 // rocco/inference.py:231-299).  Results equal the reference's bit for bit on finite inputs, so every
 // order-dependent sum keeps the reference's order:
 //   * rolling AR(1) innovation variance (610-742): the three running sums are updated by subtract-then-add
-//     along the row -- one lane per row runs them in sequence (16 rows per workgroup, tiles of 256 start
-//     positions through LDS), then all 64 lanes turn the sums of the tile into variances (the divisions
-//     are not part of the dependent chain);
+//     along the row -- one lane per running sum, eight rows per workgroup, tiles of 64 start positions through
+//     LDS -- and helper wavefronts turn the sums of a tile into variances (the divisions are not part of the
+//     dependent chain);
 //   * monotone variance trend (394-608): the reference sorts the (|value|, variance) pairs of a row with
 //     qsort under a total order (x, then y), so the sorted sequence is unique: two stable device radix
 //     sorts (by y, then by x) give the same sequence; bin medians are order statistics, taken from a
@@ -25,187 +25,210 @@ namespace rocco {
 
 namespace {
 
-constexpr int kTile = 512;   // start positions per tile of the rolling kernel
 constexpr int kLanes = 64;
-constexpr int kHelpers = 3 * kLanes;  // lanes of the helper wavefronts of the rolling kernel
-constexpr int kMaxWindow = 63;
-constexpr int kStream = kTile + kMaxWindow + 9;  // values a tile of start positions touches (+ one prefetched batch)
-static_assert(kTile % 16 == 0, "two batches of 8 start positions per trip");
-constexpr int kStage = (kStream + kHelpers - 1) / kHelpers;
+constexpr int kMaxWindow = 63;  // the rolling kernel's tiles hold windows up to here
 constexpr int kMaxBins = 64;
 constexpr long long kTrendSelectMin = 4096;  // rows at least this long fit their trend without sorting the pairs
 
 // ---- rolling AR(1) innovation variance (wls_backend.c:610-742) --------------------------------------
 // vas[row][s] for s = 0 .. max_start (the caller indexes it with clamp(i - half, 0, max_start), 727-738).
-// One workgroup of four wavefronts per row.  The three running sums of the reference are independent
-// chains  s <- (s - P[t]) + P[t + off]  over the streams  P0 = v, P1 = v*v, P2 = v[i]*v[i+1]
-// (off = window, window, window - 1): lanes 0..2 of the first wavefront run one chain each -- two dependent
-// additions per start position, the order of the reference (711-722) -- while the other three wavefronts
-// turn the previous tile's sums into variances (667-709; its divisions are off the chain) and stage the
-// next tile's streams in a third LDS buffer (loads issued before, stored after the variance arithmetic).
-struct RollingTile {
-    double P[3][kStream];
-    double S[3][kTile];
+// The three running sums of the reference are independent chains  s <- (s - P[t]) + P[t + off]  over the streams
+// P0 = v, P1 = v*v, P2 = v[i]*v[i+1]  (off = window, window, window - 1): two dependent additions per start position, in
+// the order of the reference (711-722); the variances (667-709; their divisions are off the chains) follow from the sums.
+// Eight rows per workgroup (round 3): lane L < 24 of the chain wavefront runs chain L % 3 of row L / 3 -- the chains of a
+// wavefront cost what one costs (two dependent FP64 additions per start position whatever the lane count), so a row's
+// 15.7 ns per locus become 8 rows' -- over a ring of 256 LDS lines, line t & 255 holding (v, v^2, v v_next) of locus t
+// for the eight rows at 3 r + c.  Eight helper wavefronts (lane = locus within a chunk of 64, one row each) store the chunk
+// two tiles ahead, load the one after it, and turn the previous tile's sums into variances; one barrier per tile of 64
+// start positions.  A matrix of K rows is ceil(K / 8) workgroups, the rows of a genome's 24 matrices 312: all resident at
+// once (two workgroups per CU by LDS), so a launch lasts what its longest row lasts.
+constexpr int kRowsTile = 64;                 // start positions per tile = loci per staged chunk
+constexpr int kRowsRing = 4 * kRowsTile;      // lines: the chunks of the tiles k - 1 .. k + 2
+constexpr int kRowsPitch = 3 * kWlsRollingGroup + 1;  // doubles per line (odd: lane = locus accesses spread over the banks)
+constexpr int kRowsHelperWaves = 8;            // one row each: their dependent FP64 sequences (three divisions per variance) overlap across wavefronts
+constexpr int kRowsHelpers = kRowsHelperWaves * kLanes;
+constexpr int kRowsPerHelper = kWlsRollingGroup / kRowsHelperWaves;
+static_assert(kRowsTile >= kMaxWindow + 1, "a tile's chains read at most one chunk ahead");
+
+struct RollingRows {
+    double P[kRowsRing][kRowsPitch];
+    double S[2][kRowsTile][kRowsPitch];
 };
 
-struct StagedValues {
-    double v[kStage], nx[kStage];
-};
-
-__device__ __forceinline__ void rolling_stage_load(StagedValues &r, const double *__restrict__ row, long long n,
-                                                   long long base, int hl)
+// the chains of one tile: batches of 8 start positions, the operand registers ping-pong (the next batch's operands are
+// fetched while this batch's chain runs); past the row's last start the updates read staged zeros, results unused
+template <bool WRAP>
+__device__ __forceinline__ void rolling_rows_tile(RollingRows &T, long long tile, int a0, int b0, int col, double &sum)
 {
+    double(*__restrict__ S)[kRowsPitch] = T.S[tile & 1];
+    const double(*__restrict__ A)[kRowsPitch] = T.P + a0;
+    auto leaving = [&](int t) -> double { return A[t][col]; };
+    auto entering = [&](int t) -> double { return WRAP ? T.P[(b0 + t) & (kRowsRing - 1)][col] : T.P[b0 + t][col]; };
+    double a[8], b[8], a2[8], b2[8];
 #pragma unroll
-    for (int j = 0; j < kStage; ++j) {
-        const long long i = base + hl + j * kHelpers;
-        const long long i0 = (i < n) ? i : (n - 1), i1 = (i + 1 < n) ? (i + 1) : (n - 1);  // loads without branches
-        const double v = row[i0], nx = row[i1];
-        r.v[j] = (i < n) ? v : 0.0;
-        r.nx[j] = (i + 1 < n) ? nx : 0.0;
+    for (int u = 0; u < 8; ++u) {
+        a[u] = leaving(u);
+        b[u] = entering(u);
     }
-}
-
-__device__ __forceinline__ void rolling_stage_store(RollingTile &tile, const StagedValues &r, int hl)
-{
+#pragma unroll 1
+    for (int t = 0; t < kRowsTile; t += 16) {
 #pragma unroll
-    for (int j = 0; j < kStage; ++j) {
-        const int c = hl + j * kHelpers;
-        if (c < kStream) {
-            tile.P[0][c] = r.v[j];
-            tile.P[1][c] = r.v[j] * r.v[j];
-            tile.P[2][c] = r.v[j] * r.nx[j];
+        for (int u = 0; u < 8; ++u) {
+            a2[u] = leaving(t + 8 + u);
+            b2[u] = entering(t + 8 + u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            S[t + u][col] = sum;
+            sum = (sum - a[u]) + b[u];  // wls_backend.c:711-722
+        }
+        // (unconditional: a branch here would make the compiler wait for every outstanding LDS access where the paths join;
+        // past the tile's end the last batch is read again)
+        const int next = (t + 16 < kRowsTile) ? (t + 16) : t;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = leaving(next + u);
+            b[u] = entering(next + u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            S[t + 8 + u][col] = sum;
+            sum = (sum - a2[u]) + b2[u];
         }
     }
 }
 
-__device__ __forceinline__ void rolling_variances(const RollingTile &tile, double *__restrict__ out, int T, int window,
-                                                  int hl)
+__global__ __launch_bounds__(kLanes + kRowsHelpers) void wls_rolling_rows_kernel(const WlsRollingTask *__restrict__ tasks)
 {
-    const double wd = (double)window, pair_count = (double)(window - 1);
-    for (int t = hl; t < T; t += kHelpers) {
-        const double sy = tile.S[0][t], ssq = tile.S[1][t], slag = tile.S[2][t];
-        const double leaving = tile.P[0][t], entering = tile.P[0][t + window - 1];
-        const double sum_x_seq = sy - entering, sum_y_seq = sy - leaving;
-        const double mean_all = sy / wd;
-        double g0n = ssq - (wd * mean_all * mean_all);
-        if (g0n < 0.0) {
-            g0n = 0.0;
-        }
-        const double g1n = slag - (mean_all * sum_x_seq) - (mean_all * sum_y_seq) + (pair_count * mean_all * mean_all);
-        const double lambda_eff = 1.0 / (wd + 1.0);
-        const double scale_floor = 1.0e-4 * (g0n + 1.0);
-        const double denom = (g0n * (1.0 + lambda_eff)) + scale_floor;
-        const double eps = 1.0e-12 * (g0n + 1.0);
-        double beta1 = 0.0;
-        if (denom > eps) {
-            beta1 = g1n / denom;
-        }
-        if (beta1 > 0.99) {
-            beta1 = 0.99;
-        } else if (beta1 < 0.0) {
-            beta1 = 0.0;
-        }
-        const double gamma0 = g0n / wd;
-        double omb = 1.0 - (beta1 * beta1);
-        if (omb < 0.0) {
-            omb = 0.0;
-        }
-        out[t] = fmax(gamma0 * omb, 0.0);
-    }
-}
-
-// `tasks` (may be null: then every workgroup is a row of `matrix`): one record per workgroup -- the rows of SEVERAL matrices
-// (the chromosomes of a genome) in one launch, two workgroups per compute unit, instead of one launch of K workgroups
-// per matrix on a stream of its own
-__global__ __launch_bounds__(kLanes + kHelpers) void wls_rolling_kernel(const double *__restrict__ matrix, long long n,
-                                                                       int window, double *__restrict__ vas,
-                                                                       const WlsRollingTask *__restrict__ tasks)
-{
-    __shared__ RollingTile tiles[3];  // the tile the chains run on, the previous one (variances), the next one (staging)
+    extern __shared__ __align__(16) unsigned char rolling_rows_lds[];
+    RollingRows &T = *reinterpret_cast<RollingRows *>(rolling_rows_lds);
+    const WlsRollingTask task = tasks[blockIdx.x];
+    const long long n = task.n;
+    const int window = task.window, rows = task.rows;
+    const long long max_start = n - window, stride_out = max_start + 1;
+    const long long n_tiles = (max_start + kRowsTile) / kRowsTile;  // ceil((max_start + 1) / kRowsTile)
     const int lane = threadIdx.x, hl = (int)threadIdx.x - kLanes;
     const bool helper = hl >= 0;
-    const double *__restrict__ row;
-    double *__restrict__ out;
-    if (tasks != nullptr) {
-        const WlsRollingTask task = tasks[blockIdx.x];
-        n = task.n;
-        window = task.window;
-        row = task.row;
-        out = task.out;
-    } else {
-        row = matrix + (long long)blockIdx.x * n;
-        out = vas + (long long)blockIdx.x * (n - window + 1);
-    }
-    const long long max_start = n - window;
-    const long long n_tiles = (max_start + kTile) / kTile;  // ceil((max_start + 1) / kTile)
-    StagedValues staged;
+    const int ht = hl & (kLanes - 1), hs = hl >> 6;  // helper: locus within the chunk, the first of its rows (hs, hs + waves, ...)
+    double rv[kRowsPerHelper] = {}, rnx[kRowsPerHelper] = {};
+
+    auto load_chunk = [&](long long chunk) {  // (zeros past the row's end and for rows the task does not have)
+        const long long i = chunk * kRowsTile + ht;
+        const long long i0 = (i < n) ? i : (n - 1), i1 = (i + 1 < n) ? (i + 1) : (n - 1);
+#pragma unroll
+        for (int q = 0; q < kRowsPerHelper; ++q) {
+            const int r = hs + kRowsHelperWaves * q;
+            const double *__restrict__ row = task.row + (long long)((r < rows) ? r : 0) * n;
+            const double v = row[i0], nx = row[i1];
+            rv[q] = (r < rows && i < n) ? v : 0.0;
+            rnx[q] = (r < rows && i + 1 < n) ? nx : 0.0;
+        }
+    };
+    auto store_chunk = [&](long long chunk) {
+        double *__restrict__ line = T.P[(int)((chunk * kRowsTile + ht) & (kRowsRing - 1))];
+#pragma unroll
+        for (int q = 0; q < kRowsPerHelper; ++q) {
+            const int r = hs + kRowsHelperWaves * q;
+            line[3 * r] = rv[q];
+            line[3 * r + 1] = rv[q] * rv[q];
+            line[3 * r + 2] = rv[q] * rnx[q];
+        }
+    };
+    // the variances of tile `tile` from its sums (wls_backend.c:667-709; the divisions are off the chains)
+    auto variances = [&](long long tile) {
+        const long long t = tile * kRowsTile + ht;
+        if (t > max_start) {
+            return;
+        }
+        const double wd = (double)window, pair_count = (double)(window - 1);
+        const double *__restrict__ sums = T.S[tile & 1][ht];
+        const double *__restrict__ first = T.P[(int)(t & (kRowsRing - 1))];
+        const double *__restrict__ last = T.P[(int)((t + window - 1) & (kRowsRing - 1))];
+#pragma unroll
+        for (int q = 0; q < kRowsPerHelper; ++q) {
+            const int r = hs + kRowsHelperWaves * q;
+            if (r >= rows) {
+                continue;
+            }
+            const double sy = sums[3 * r], ssq = sums[3 * r + 1], slag = sums[3 * r + 2];
+            const double leaving = first[3 * r], entering = last[3 * r];
+            const double sum_x_seq = sy - entering, sum_y_seq = sy - leaving;
+            const double mean_all = sy / wd;
+            double g0n = ssq - (wd * mean_all * mean_all);
+            if (g0n < 0.0) {
+                g0n = 0.0;
+            }
+            const double g1n = slag - (mean_all * sum_x_seq) - (mean_all * sum_y_seq) + (pair_count * mean_all * mean_all);
+            const double lambda_eff = 1.0 / (wd + 1.0);
+            const double scale_floor = 1.0e-4 * (g0n + 1.0);
+            const double denom = (g0n * (1.0 + lambda_eff)) + scale_floor;
+            const double eps = 1.0e-12 * (g0n + 1.0);
+            double beta1 = 0.0;
+            if (denom > eps) {
+                beta1 = g1n / denom;
+            }
+            if (beta1 > 0.99) {
+                beta1 = 0.99;
+            } else if (beta1 < 0.0) {
+                beta1 = 0.0;
+            }
+            const double gamma0 = g0n / wd;
+            double omb = 1.0 - (beta1 * beta1);
+            if (omb < 0.0) {
+                omb = 0.0;
+            }
+            task.out[(long long)r * stride_out + t] = fmax(gamma0 * omb, 0.0);
+        }
+    };
+
     if (helper) {
-        rolling_stage_load(staged, row, n, 0, hl);
-        rolling_stage_store(tiles[0], staged, hl);
+        load_chunk(0);
+        store_chunk(0);
+        load_chunk(1);
+        store_chunk(1);
+        load_chunk(2);
     }
     __syncthreads();
+    const int chain = lane % 3;
+    const int off = (chain == 2) ? (window - 1) : window;
+    const bool runs = !helper && lane < 3 * kWlsRollingGroup;
+    const int col = runs ? lane : 0;
     double sum = 0.0;
-    const int off = (lane == 2) ? (window - 1) : window;
-    const int chain = (lane < 3) ? lane : 0;
-    if (lane < 3) {
-        // wls_backend.c:652-661
-        const int terms = (lane == 2) ? (window - 1) : window;
-        for (int i = 0; i < terms; ++i) {
-            sum += tiles[0].P[chain][i];
+    if (!helper) {
+        __builtin_amdgcn_s_setprio(3);  // the chain wavefront shares its SIMD with helpers: its instructions go first
+    }
+    if (runs) {
+        for (int i = 0; i < off; ++i) {  // wls_backend.c:652-661 (window terms, window - 1 for the lagged products)
+            sum += T.P[i][col];
         }
     }
     for (long long tile = 0; tile < n_tiles; ++tile) {
-        RollingTile &cur = tiles[tile % 3], &prev = tiles[(tile + 2) % 3], &next = tiles[(tile + 1) % 3];
-        if (!helper) {
-            if (lane < 3) {
-                const double *__restrict__ P = cur.P[chain];
-                double *__restrict__ S = cur.S[chain];
-                // (past the row's last start the update reads staged zeros and its result is not used)
-                double a[8], b[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    a[u] = P[u];
-                    b[u] = P[u + off];
-                }
-#pragma unroll 1
-                for (int t = 0; t < kTile; t += 16) {
-                    // two batches per trip, the operand registers ping-pong: the next batch's operands are
-                    // fetched while this batch's chain runs
-                    double a2[8], b2[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        a2[u] = P[t + 8 + u];
-                        b2[u] = P[t + 8 + u + off];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        S[t + u] = sum;
-                        sum = (sum - a[u]) + b[u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        a[u] = P[t + 16 + u];
-                        b[u] = P[t + 16 + u + off];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        S[t + 8 + u] = sum;
-                        sum = (sum - a2[u]) + b2[u];
-                    }
-                }
+#ifdef ROCCO_ROLL_NOCHAIN  // (timing experiments only)
+        if (false) {
+#else
+        if (runs) {
+#endif
+            // a tile's own lines are 64 consecutive ring lines; the lines `off` further on are consecutive too unless the
+            // ring's end falls among them (every fourth tile): only then is the line index masked per access
+            const int a0 = (int)((tile * kRowsTile) & (kRowsRing - 1)), b0 = (a0 + off) & (kRowsRing - 1);
+            if (b0 + kRowsTile <= kRowsRing) {
+                rolling_rows_tile<false>(T, tile, a0, b0, col, sum);
+            } else {
+                rolling_rows_tile<true>(T, tile, a0, b0, col, sum);
             }
-        } else {
-            rolling_stage_load(staged, row, n, (tile + 1) * kTile, hl);  // (zeros past the row's end)
+        } else if (helper) {
+            store_chunk(tile + 2);  // (in the registers since the tile before)
+            load_chunk(tile + 3);
+#ifndef ROCCO_ROLL_NOVAR
             if (tile > 0) {
-                rolling_variances(prev, out + (tile - 1) * kTile, kTile, window, hl);
+                variances(tile - 1);
             }
-            rolling_stage_store(next, staged, hl);
+#endif
         }
         __syncthreads();
     }
     if (helper) {
-        const long long last = n_tiles - 1;
-        rolling_variances(tiles[last % 3], out + last * kTile, (int)(max_start + 1 - last * kTile), window, hl);
+        variances(n_tiles - 1);
     }
 }
 
@@ -1642,6 +1665,33 @@ int wls_spatial_window(size_t n, int requested)
 
 int wls_max_window() { return kMaxWindow; }
 
+namespace {
+
+__global__ void wls_rolling_tasks_kernel(WlsRollingTask *tasks, const double *matrix, long long K, long long n, int window, double *vas)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g * kWlsRollingGroup < K) {
+        const long long first = g * kWlsRollingGroup;
+        tasks[g].row = matrix + first * n;
+        tasks[g].n = n;
+        tasks[g].window = window;
+        tasks[g].rows = (int)((K - first < kWlsRollingGroup) ? (K - first) : kWlsRollingGroup);
+        tasks[g].out = vas + first * (n - window + 1);
+    }
+}
+
+// the rolling variances of one matrix: its groups' task records are written by a kernel (no host staging, no synchronisation)
+int launch_wls_rolling_matrix(const double *matrix, size_t K, size_t n, int window, double *vas, WlsRollingTask *tasks_dev,
+                              hipStream_t stream)
+{
+    const size_t groups = (K + kWlsRollingGroup - 1) / kWlsRollingGroup;
+    hipLaunchKernelGGL(wls_rolling_tasks_kernel, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, stream, tasks_dev, matrix, (long long)K,
+                       (long long)n, window, vas);
+    return launch_wls_rolling_batch(tasks_dev, groups, stream);
+}
+
+}  // namespace
+
 int trend_bins(size_t n)
 {
     // wls_backend.c:461 -- the same expression, evaluated on the host like the reference's
@@ -1679,7 +1729,8 @@ size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window, bool own_varian
                                    align_up(K * (size_t)kRankCells1 * sizeof(unsigned), 256) + align_up(K * rank_capacity(n) * 8, 256)
                              : 0;
     return general + dealt + align_up(K * sizeof(TrendFit), 256) + (own_variances ? align_up(K * n * 8, 256) : 0) + 6 * align_up(n * 8, 256) +
-           2 * align_up(n * 4, 256) + 2 * align_up(n, 256) + align_up(4 * n * 8, 256) + sort_temp_bytes(n) + 4096;
+           2 * align_up(n * 4, 256) + 2 * align_up(n, 256) + align_up(4 * n * 8, 256) + sort_temp_bytes(n) + 4096 +
+           align_up(((K + kWlsRollingGroup - 1) / kWlsRollingGroup) * sizeof(WlsRollingTask), 256);
 }
 
 int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, double lower_bound_z, double prior_df,
@@ -1719,6 +1770,7 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     double *sums = (double *)carve(4 * n * 8);
     TrendFit *fits = (TrendFit *)carve(K * sizeof(TrendFit));  // one per row
     int *bad = (int *)carve(256);
+    void *rolling_tasks = carve(((K + kWlsRollingGroup - 1) / kWlsRollingGroup) * sizeof(WlsRollingTask));
     double *general_sums = (window > kMaxWindow) ? (double *)carve(3 * K * n * 8) : nullptr;
     const bool select_path = nn >= kTrendSelectMin && window > 0;
     const size_t segs = K * (size_t)kMaxBins;
@@ -1744,8 +1796,8 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
         const size_t vas_stride = (size_t)(max_start + 1);
         if (window <= kMaxWindow) {
             if (vas_given == nullptr) {
-                hipLaunchKernelGGL(wls_rolling_kernel, dim3((unsigned)K), dim3(kLanes + kHelpers), 0, stream, centered_dev, nn, window, vas,
-                                   (const WlsRollingTask *)nullptr);
+                int rc = launch_wls_rolling_matrix(centered_dev, K, n, window, vas, (WlsRollingTask *)rolling_tasks, stream);
+                if (rc != ROCCO_HIP_OK) return rc;
             }
         } else {
             hipLaunchKernelGGL(wls_rolling_general_sums_kernel, dim3((unsigned)K), dim3(kLanes), 0, stream, centered_dev, nn, window,
@@ -1857,8 +1909,14 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
 int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, hipStream_t stream)
 {
     if (n_tasks > 0) {
-        hipLaunchKernelGGL(wls_rolling_kernel, dim3((unsigned)n_tasks), dim3(kLanes + kHelpers), 0, stream, (const double *)nullptr, 0LL, 0,
-                           (double *)nullptr, tasks_dev);
+        static bool attr_set = false;
+        if (!attr_set) {
+            ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wls_rolling_rows_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RollingRows)));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wls_rolling_rows_kernel, dim3((unsigned)n_tasks), dim3(kLanes + kRowsHelpers), sizeof(RollingRows), stream,
+                           tasks_dev);
         ROCCO_HIP_TRY(hipGetLastError());
     }
     return ROCCO_HIP_OK;
