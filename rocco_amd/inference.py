@@ -373,7 +373,7 @@ def _batch_worker(device_index: int, slot: int):
 
 def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
                                 precision_floor_ratio: float = 0.01, overwrite_input: bool = False,
-                                input_scale: str = "counts", workers: int = 2):
+                                input_scale: str = "counts", workers: int = 3):
     """`score_loci_wls_device` for several [K_i, n_i] float64 CUDA count matrices -- the chromosomes a rank owns
     (the loop of rocco/rocco.py:948-1018 around rocco/inference.py:302-379).  Returns one (scores, details) pair per
     matrix, bit for bit what the single-matrix call returns.  What is shared: the matrices are dealt to `workers`
@@ -383,8 +383,9 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
     the pair lasts as long as the longest row, not as long as all rows one after the other) and the rolling variances
     of every row come from ONE launch (`wls_rolling_variances_batch_device`); the per-matrix steps (log scale + row
     medians; rank finding, dealing, selects and accumulation of the trend fit) are launches over whole matrices.
-    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values): 0.99 s with one pipeline, 0.92 s with two,
-    1.02 s with three (the chains of concurrent baseline launches slow each other down)."""
+    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values): 0.88 s with one pipeline, 0.70 s with two,
+    0.67 s with three (the default; the baselines of the longest rows -- 5 M loci x 36 ns x 2 sweeps -- are 0.36-0.41 s
+    of it whatever runs beside them)."""
     import concurrent.futures
     import threading
 
