@@ -799,12 +799,13 @@ int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t c
             if (centered_dev[i] == nullptr || variances_dev[i] == nullptr) {
                 return ROCCO_HIP_EINVAL;
             }
-            rows += (K[i] + kWlsRollingGroup - 1) / kWlsRollingGroup;  // task records: groups of rows
+            rows += K[i];
         }
     }
     if (rows == 0) {
         return ROCCO_HIP_OK;
     }
+    const size_t group = (size_t)wls_rolling_group_rows(rows);  // rows per workgroup (one task record each)
     int rc;
     if ((rc = solver->dev_tasks.reserve(rows * sizeof(WlsRollingTask))) != ROCCO_HIP_OK) return rc;
     if ((rc = solver->host_stage.reserve(rows * sizeof(WlsRollingTask))) != ROCCO_HIP_OK) return rc;
@@ -816,16 +817,16 @@ int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t c
             continue;
         }
         const size_t stride = n[i] - (size_t)window + 1;
-        for (size_t k = 0; k < K[i]; k += kWlsRollingGroup, ++t) {
+        for (size_t k = 0; k < K[i]; k += group, ++t) {
             host[t].row = centered_dev[i] + k * n[i];
             host[t].n = (long long)n[i];
             host[t].window = window;
-            host[t].rows = (int)std::min((size_t)kWlsRollingGroup, K[i] - k);
+            host[t].rows = (int)std::min(group, K[i] - k);
             host[t].out = variances_dev[i] + k * stride;
         }
     }
-    ROCCO_HIP_TRY(hipMemcpyAsync(solver->dev_tasks.ptr, host, rows * sizeof(WlsRollingTask), hipMemcpyHostToDevice, (hipStream_t)stream));
-    if ((rc = launch_wls_rolling_batch((const WlsRollingTask *)solver->dev_tasks.ptr, rows, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
+    ROCCO_HIP_TRY(hipMemcpyAsync(solver->dev_tasks.ptr, host, t * sizeof(WlsRollingTask), hipMemcpyHostToDevice, (hipStream_t)stream));
+    if ((rc = launch_wls_rolling_batch((const WlsRollingTask *)solver->dev_tasks.ptr, t, (int)group, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
     ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the task table is the solver's
     return ROCCO_HIP_OK;
 }

@@ -142,8 +142,9 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
 // ---- wls.hip --------------------------------------------------------------------------------
 // scratch: at least wls_scratch_bytes(K, n) bytes; synchronises the stream before returning
 int wls_spatial_window(size_t n, int requested);
-// up to 8 consecutive rows of one matrix for the rolling launch: `row` the first of them (the next n doubles further),
-// out = window variances of the row's n - window + 1 starts (the next row's right behind)
+// up to `group_rows` (1, 2, 4 or 8: wls_rolling_group_rows) consecutive rows of one matrix for the rolling launch: `row` the
+// first of them (the next n doubles further), out = window variances of the row's n - window + 1 starts (the next row's
+// right behind)
 struct WlsRollingTask {
     const double *row;
     long long n;
@@ -152,7 +153,8 @@ struct WlsRollingTask {
     double *out;
 };
 constexpr int kWlsRollingGroup = 8;
-int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, hipStream_t stream);
+int wls_rolling_group_rows(size_t total_rows);
+int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, int group_rows, hipStream_t stream);
 int wls_max_window();
 size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window = 0, bool own_variances = true);
 int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, double lower_bound_z, double prior_df,

@@ -20,6 +20,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
+#include <cstdlib>
 
 namespace rocco {
 
@@ -35,150 +36,144 @@ constexpr long long kTrendSelectMin = 4096;  // rows at least this long fit thei
 // The three running sums of the reference are independent chains  s <- (s - P[t]) + P[t + off]  over the streams
 // P0 = v, P1 = v*v, P2 = v[i]*v[i+1]  (off = window, window, window - 1): two dependent additions per start position, in
 // the order of the reference (711-722); the variances (667-709; their divisions are off the chains) follow from the sums.
-// Eight rows per workgroup (round 3): lane L < 24 of the chain wavefront runs chain L % 3 of row L / 3 -- the chains of a
-// wavefront cost what one costs (two dependent FP64 additions per start position whatever the lane count), so a row's
-// 15.7 ns per locus become 8 rows' -- over a ring of 256 LDS lines, line t & 255 holding (v, v^2, v v_next) of locus t
-// for the eight rows at 3 r + c.  Eight helper wavefronts (lane = locus within a chunk of 64, one row each) store the chunk
-// two tiles ahead, load the one after it, and turn the previous tile's sums into variances; one barrier per tile of 64
-// start positions.  A matrix of K rows is ceil(K / 8) workgroups, the rows of a genome's 24 matrices 312: all resident at
-// once (two workgroups per CU by LDS), so a launch lasts what its longest row lasts.
-constexpr int kRowsTile = 64;                 // start positions per tile = loci per staged chunk
-constexpr int kRowsRing = 4 * kRowsTile;      // lines: the chunks of the tiles k - 1 .. k + 2
-constexpr int kRowsPitch = 3 * kWlsRollingGroup + 1;  // doubles per line (odd: lane = locus accesses spread over the banks)
-constexpr int kRowsHelperWaves = 8;            // one row each: their dependent FP64 sequences (three divisions per variance) overlap across wavefronts
-constexpr int kRowsHelpers = kRowsHelperWaves * kLanes;
-constexpr int kRowsPerHelper = kWlsRollingGroup / kRowsHelperWaves;
-static_assert(kRowsTile >= kMaxWindow + 1, "a tile's chains read at most one chunk ahead");
+// G rows per workgroup (round 3; G = 8, 4, 2 or 1): lane L < 3 G of the chain wavefront runs chain L % 3 of row L / 3 -- the
+// chains of a wavefront cost what one costs (two dependent FP64 additions per start position whatever the lane count), so
+// one row's time per locus serves G rows -- over a ring of 4 TILE lines in LDS, line t mod 4 TILE holding (v, v^2, v v_next)
+// of locus t for the G rows at 3 r + c.  Eight helper wavefronts (512 lanes = G rows x TILE loci of a chunk) store the chunk
+// two tiles ahead, load the one after it, and turn the previous tile's sums into variances (their long dependent FP64
+// sequences -- three divisions per variance -- overlap across the wavefronts); one barrier per tile of TILE = 512 / G
+// start positions.  The launch lasts what its longest row lasts as long as every workgroup is resident (two per CU by LDS
+// for G >= 4, one for G <= 2), so G is the smallest that makes the rows of a call fit: a genome's 2 400 rows take G = 8 and
+// 23 ns per locus of the longest row, one matrix of 100 rows G = 1 and a tile of 512 (fewer barriers per locus).
+constexpr int kRowsHelpers = 8 * kLanes;
 
+template <int G>
+struct RollingShape {
+    static constexpr int kTile = kRowsHelpers / G;        // start positions per tile = loci per staged chunk
+    static constexpr int kRing = 4 * kTile;               // lines: the chunks of the tiles k - 1 .. k + 2
+    static constexpr int kPitch = (3 * G) % 2 ? 3 * G + 2 : 3 * G + 1;  // doubles per line, odd: lane = locus accesses spread over the banks
+    static_assert(kTile >= kMaxWindow + 1, "a tile's chains read at most one chunk ahead");
+    static_assert(kPitch % 2 == 1, "odd pitch");
+};
+
+template <int G>
 struct RollingRows {
-    double P[kRowsRing][kRowsPitch];
-    double S[2][kRowsTile][kRowsPitch];
+    double S[2][RollingShape<G>::kTile][RollingShape<G>::kPitch];  // (first: within reach of immediate offsets in every shape)
+    double P[RollingShape<G>::kRing][RollingShape<G>::kPitch];
 };
 
 // the chains of one tile: batches of 8 start positions, the operand registers ping-pong (the next batch's operands are
 // fetched while this batch's chain runs); past the row's last start the updates read staged zeros, results unused
-template <bool WRAP>
-__device__ __forceinline__ void rolling_rows_tile(RollingRows &T, long long tile, int a0, int b0, int col, double &sum)
+template <int G, bool WRAP>
+__device__ __forceinline__ void rolling_rows_tile(RollingRows<G> &T, long long tile, int a0, int b0, int col, double &sum)
 {
-    double(*__restrict__ S)[kRowsPitch] = T.S[tile & 1];
-    const double(*__restrict__ A)[kRowsPitch] = T.P + a0;
+    constexpr int kTile = RollingShape<G>::kTile, kRing = RollingShape<G>::kRing, kPitch = RollingShape<G>::kPitch;
+    double(*__restrict__ S)[kPitch] = T.S[tile & 1];
+    const double(*__restrict__ A)[kPitch] = T.P + a0;
     auto leaving = [&](int t) -> double { return A[t][col]; };
-    auto entering = [&](int t) -> double { return WRAP ? T.P[(b0 + t) & (kRowsRing - 1)][col] : T.P[b0 + t][col]; };
-    double a[8], b[8], a2[8], b2[8];
+    auto entering = [&](int t) -> double { return WRAP ? T.P[(b0 + t) & (kRing - 1)][col] : T.P[b0 + t][col]; };
+    // four operand sets in rotation, fetched TWO batches ahead: when a batch starts, the only LDS accesses younger than its
+    // operands' are one batch's worth (the compiler can wait for exactly those; with the next batch's fetch issued right
+    // before, it waits for everything and the chain stalls for an LDS round trip per batch)
+    double a[4][8], b[4][8];
+    constexpr int kBatches = kTile / 8;
+    static_assert(kBatches % 4 == 0, "four batches per trip");
+    auto fetch = [&](int set, int batch) {
+        const int t = 8 * ((batch < kBatches) ? batch : (kBatches - 1));  // (past the tile's end: the last batch again)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        a[u] = leaving(u);
-        b[u] = entering(u);
-    }
+        for (int u = 0; u < 8; ++u) {
+            a[set][u] = leaving(t + u);
+            b[set][u] = entering(t + u);
+        }
+    };
+    auto run = [&](int set, int batch) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            S[8 * batch + u][col] = sum;
+            sum = (sum - a[set][u]) + b[set][u];  // wls_backend.c:711-722
+        }
+    };
+    fetch(0, 0);
+    fetch(1, 1);
 #pragma unroll 1
-    for (int t = 0; t < kRowsTile; t += 16) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            a2[u] = leaving(t + 8 + u);
-            b2[u] = entering(t + 8 + u);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            S[t + u][col] = sum;
-            sum = (sum - a[u]) + b[u];  // wls_backend.c:711-722
-        }
-        // (unconditional: a branch here would make the compiler wait for every outstanding LDS access where the paths join;
-        // past the tile's end the last batch is read again)
-        const int next = (t + 16 < kRowsTile) ? (t + 16) : t;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            a[u] = leaving(next + u);
-            b[u] = entering(next + u);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            S[t + 8 + u][col] = sum;
-            sum = (sum - a2[u]) + b2[u];
-        }
+    for (int j = 0; j < kBatches; j += 4) {
+        fetch(2, j + 2);
+        run(0, j);
+        fetch(3, j + 3);
+        run(1, j + 1);
+        fetch(0, j + 4);
+        run(2, j + 2);
+        fetch(1, j + 5);
+        run(3, j + 3);
     }
 }
 
+template <int G>
 __global__ __launch_bounds__(kLanes + kRowsHelpers) void wls_rolling_rows_kernel(const WlsRollingTask *__restrict__ tasks)
 {
+    constexpr int kTile = RollingShape<G>::kTile, kRing = RollingShape<G>::kRing;
     extern __shared__ __align__(16) unsigned char rolling_rows_lds[];
-    RollingRows &T = *reinterpret_cast<RollingRows *>(rolling_rows_lds);
+    RollingRows<G> &T = *reinterpret_cast<RollingRows<G> *>(rolling_rows_lds);
     const WlsRollingTask task = tasks[blockIdx.x];
     const long long n = task.n;
     const int window = task.window, rows = task.rows;
     const long long max_start = n - window, stride_out = max_start + 1;
-    const long long n_tiles = (max_start + kRowsTile) / kRowsTile;  // ceil((max_start + 1) / kRowsTile)
+    const long long n_tiles = (max_start + kTile) / kTile;  // ceil((max_start + 1) / kTile)
     const int lane = threadIdx.x, hl = (int)threadIdx.x - kLanes;
     const bool helper = hl >= 0;
-    const int ht = hl & (kLanes - 1), hs = hl >> 6;  // helper: locus within the chunk, the first of its rows (hs, hs + waves, ...)
-    double rv[kRowsPerHelper] = {}, rnx[kRowsPerHelper] = {};
+    const int ht = hl & (kTile - 1), hr = hl / kTile;  // helper: locus within the chunk, row of the group
+    double rv = 0.0, rnx = 0.0;
+    const double *__restrict__ my_row = task.row + (long long)((helper && hr < rows) ? hr : 0) * n;
 
     auto load_chunk = [&](long long chunk) {  // (zeros past the row's end and for rows the task does not have)
-        const long long i = chunk * kRowsTile + ht;
+        const long long i = chunk * kTile + ht;
         const long long i0 = (i < n) ? i : (n - 1), i1 = (i + 1 < n) ? (i + 1) : (n - 1);
-#pragma unroll
-        for (int q = 0; q < kRowsPerHelper; ++q) {
-            const int r = hs + kRowsHelperWaves * q;
-            const double *__restrict__ row = task.row + (long long)((r < rows) ? r : 0) * n;
-            const double v = row[i0], nx = row[i1];
-            rv[q] = (r < rows && i < n) ? v : 0.0;
-            rnx[q] = (r < rows && i + 1 < n) ? nx : 0.0;
-        }
+        const double v = my_row[i0], nx = my_row[i1];
+        rv = (hr < rows && i < n) ? v : 0.0;
+        rnx = (hr < rows && i + 1 < n) ? nx : 0.0;
     };
     auto store_chunk = [&](long long chunk) {
-        double *__restrict__ line = T.P[(int)((chunk * kRowsTile + ht) & (kRowsRing - 1))];
-#pragma unroll
-        for (int q = 0; q < kRowsPerHelper; ++q) {
-            const int r = hs + kRowsHelperWaves * q;
-            line[3 * r] = rv[q];
-            line[3 * r + 1] = rv[q] * rv[q];
-            line[3 * r + 2] = rv[q] * rnx[q];
-        }
+        double *__restrict__ line = T.P[(int)((chunk * kTile + ht) & (kRing - 1))];
+        line[3 * hr] = rv;
+        line[3 * hr + 1] = rv * rv;
+        line[3 * hr + 2] = rv * rnx;
     };
     // the variances of tile `tile` from its sums (wls_backend.c:667-709; the divisions are off the chains)
     auto variances = [&](long long tile) {
-        const long long t = tile * kRowsTile + ht;
-        if (t > max_start) {
+        const long long t = tile * kTile + ht;
+        if (t > max_start || hr >= rows) {
             return;
         }
         const double wd = (double)window, pair_count = (double)(window - 1);
-        const double *__restrict__ sums = T.S[tile & 1][ht];
-        const double *__restrict__ first = T.P[(int)(t & (kRowsRing - 1))];
-        const double *__restrict__ last = T.P[(int)((t + window - 1) & (kRowsRing - 1))];
-#pragma unroll
-        for (int q = 0; q < kRowsPerHelper; ++q) {
-            const int r = hs + kRowsHelperWaves * q;
-            if (r >= rows) {
-                continue;
-            }
-            const double sy = sums[3 * r], ssq = sums[3 * r + 1], slag = sums[3 * r + 2];
-            const double leaving = first[3 * r], entering = last[3 * r];
-            const double sum_x_seq = sy - entering, sum_y_seq = sy - leaving;
-            const double mean_all = sy / wd;
-            double g0n = ssq - (wd * mean_all * mean_all);
-            if (g0n < 0.0) {
-                g0n = 0.0;
-            }
-            const double g1n = slag - (mean_all * sum_x_seq) - (mean_all * sum_y_seq) + (pair_count * mean_all * mean_all);
-            const double lambda_eff = 1.0 / (wd + 1.0);
-            const double scale_floor = 1.0e-4 * (g0n + 1.0);
-            const double denom = (g0n * (1.0 + lambda_eff)) + scale_floor;
-            const double eps = 1.0e-12 * (g0n + 1.0);
-            double beta1 = 0.0;
-            if (denom > eps) {
-                beta1 = g1n / denom;
-            }
-            if (beta1 > 0.99) {
-                beta1 = 0.99;
-            } else if (beta1 < 0.0) {
-                beta1 = 0.0;
-            }
-            const double gamma0 = g0n / wd;
-            double omb = 1.0 - (beta1 * beta1);
-            if (omb < 0.0) {
-                omb = 0.0;
-            }
-            task.out[(long long)r * stride_out + t] = fmax(gamma0 * omb, 0.0);
+        const double *__restrict__ sums = T.S[tile & 1][ht] + 3 * hr;
+        const double sy = sums[0], ssq = sums[1], slag = sums[2];
+        const double leaving = T.P[(int)(t & (kRing - 1))][3 * hr], entering = T.P[(int)((t + window - 1) & (kRing - 1))][3 * hr];
+        const double sum_x_seq = sy - entering, sum_y_seq = sy - leaving;
+        const double mean_all = sy / wd;
+        double g0n = ssq - (wd * mean_all * mean_all);
+        if (g0n < 0.0) {
+            g0n = 0.0;
         }
+        const double g1n = slag - (mean_all * sum_x_seq) - (mean_all * sum_y_seq) + (pair_count * mean_all * mean_all);
+        const double lambda_eff = 1.0 / (wd + 1.0);
+        const double scale_floor = 1.0e-4 * (g0n + 1.0);
+        const double denom = (g0n * (1.0 + lambda_eff)) + scale_floor;
+        const double eps = 1.0e-12 * (g0n + 1.0);
+        double beta1 = 0.0;
+        if (denom > eps) {
+            beta1 = g1n / denom;
+        }
+        if (beta1 > 0.99) {
+            beta1 = 0.99;
+        } else if (beta1 < 0.0) {
+            beta1 = 0.0;
+        }
+        const double gamma0 = g0n / wd;
+        double omb = 1.0 - (beta1 * beta1);
+        if (omb < 0.0) {
+            omb = 0.0;
+        }
+        task.out[(long long)hr * stride_out + t] = fmax(gamma0 * omb, 0.0);
     };
 
     if (helper) {
@@ -191,7 +186,7 @@ __global__ __launch_bounds__(kLanes + kRowsHelpers) void wls_rolling_rows_kernel
     __syncthreads();
     const int chain = lane % 3;
     const int off = (chain == 2) ? (window - 1) : window;
-    const bool runs = !helper && lane < 3 * kWlsRollingGroup;
+    const bool runs = !helper && lane < 3 * G;
     const int col = runs ? lane : 0;
     double sum = 0.0;
     if (!helper) {
@@ -208,13 +203,13 @@ __global__ __launch_bounds__(kLanes + kRowsHelpers) void wls_rolling_rows_kernel
 #else
         if (runs) {
 #endif
-            // a tile's own lines are 64 consecutive ring lines; the lines `off` further on are consecutive too unless the
+            // a tile's own lines are consecutive ring lines; the lines `off` further on are consecutive too unless the
             // ring's end falls among them (every fourth tile): only then is the line index masked per access
-            const int a0 = (int)((tile * kRowsTile) & (kRowsRing - 1)), b0 = (a0 + off) & (kRowsRing - 1);
-            if (b0 + kRowsTile <= kRowsRing) {
-                rolling_rows_tile<false>(T, tile, a0, b0, col, sum);
+            const int a0 = (int)((tile * kTile) & (kRing - 1)), b0 = (a0 + off) & (kRing - 1);
+            if (b0 + kTile <= kRing) {
+                rolling_rows_tile<G, false>(T, tile, a0, b0, col, sum);
             } else {
-                rolling_rows_tile<true>(T, tile, a0, b0, col, sum);
+                rolling_rows_tile<G, true>(T, tile, a0, b0, col, sum);
             }
         } else if (helper) {
             store_chunk(tile + 2);  // (in the registers since the tile before)
@@ -1667,15 +1662,16 @@ int wls_max_window() { return kMaxWindow; }
 
 namespace {
 
-__global__ void wls_rolling_tasks_kernel(WlsRollingTask *tasks, const double *matrix, long long K, long long n, int window, double *vas)
+__global__ void wls_rolling_tasks_kernel(WlsRollingTask *tasks, const double *matrix, long long K, long long n, int window, double *vas,
+                                         int group)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g * kWlsRollingGroup < K) {
-        const long long first = g * kWlsRollingGroup;
+    if (g * group < K) {
+        const long long first = g * group;
         tasks[g].row = matrix + first * n;
         tasks[g].n = n;
         tasks[g].window = window;
-        tasks[g].rows = (int)((K - first < kWlsRollingGroup) ? (K - first) : kWlsRollingGroup);
+        tasks[g].rows = (int)((K - first < group) ? (K - first) : group);
         tasks[g].out = vas + first * (n - window + 1);
     }
 }
@@ -1684,10 +1680,11 @@ __global__ void wls_rolling_tasks_kernel(WlsRollingTask *tasks, const double *ma
 int launch_wls_rolling_matrix(const double *matrix, size_t K, size_t n, int window, double *vas, WlsRollingTask *tasks_dev,
                               hipStream_t stream)
 {
-    const size_t groups = (K + kWlsRollingGroup - 1) / kWlsRollingGroup;
+    const int group = wls_rolling_group_rows(K);
+    const size_t groups = (K + group - 1) / group;
     hipLaunchKernelGGL(wls_rolling_tasks_kernel, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, stream, tasks_dev, matrix, (long long)K,
-                       (long long)n, window, vas);
-    return launch_wls_rolling_batch(tasks_dev, groups, stream);
+                       (long long)n, window, vas, group);
+    return launch_wls_rolling_batch(tasks_dev, groups, group, stream);
 }
 
 }  // namespace
@@ -1730,7 +1727,7 @@ size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window, bool own_varian
                              : 0;
     return general + dealt + align_up(K * sizeof(TrendFit), 256) + (own_variances ? align_up(K * n * 8, 256) : 0) + 6 * align_up(n * 8, 256) +
            2 * align_up(n * 4, 256) + 2 * align_up(n, 256) + align_up(4 * n * 8, 256) + sort_temp_bytes(n) + 4096 +
-           align_up(((K + kWlsRollingGroup - 1) / kWlsRollingGroup) * sizeof(WlsRollingTask), 256);
+           align_up(K * sizeof(WlsRollingTask), 256);
 }
 
 int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, double lower_bound_z, double prior_df,
@@ -1770,7 +1767,7 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     double *sums = (double *)carve(4 * n * 8);
     TrendFit *fits = (TrendFit *)carve(K * sizeof(TrendFit));  // one per row
     int *bad = (int *)carve(256);
-    void *rolling_tasks = carve(((K + kWlsRollingGroup - 1) / kWlsRollingGroup) * sizeof(WlsRollingTask));
+    void *rolling_tasks = carve(K * sizeof(WlsRollingTask));  // (one record per group of 1 .. 8 rows)
     double *general_sums = (window > kMaxWindow) ? (double *)carve(3 * K * n * 8) : nullptr;
     const bool select_path = nn >= kTrendSelectMin && window > 0;
     const size_t segs = K * (size_t)kMaxBins;
@@ -1906,20 +1903,54 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     return ROCCO_HIP_OK;
 }
 
-int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, hipStream_t stream)
+namespace {
+
+template <int G>
+int launch_rolling_rows(const WlsRollingTask *tasks_dev, size_t n_tasks, hipStream_t stream)
 {
-    if (n_tasks > 0) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wls_rolling_rows_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RollingRows)));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(wls_rolling_rows_kernel, dim3((unsigned)n_tasks), dim3(kLanes + kRowsHelpers), sizeof(RollingRows), stream,
-                           tasks_dev);
-        ROCCO_HIP_TRY(hipGetLastError());
+    static bool attr_set = false;
+    if (!attr_set) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wls_rolling_rows_kernel<G>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RollingRows<G>)));
+        attr_set = true;
     }
+    hipLaunchKernelGGL(wls_rolling_rows_kernel<G>, dim3((unsigned)n_tasks), dim3(kLanes + kRowsHelpers), sizeof(RollingRows<G>), stream,
+                       tasks_dev);
+    ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
+}
+
+}  // namespace
+
+// rows per workgroup for a launch over `total_rows` rows: the smallest group whose workgroups are all resident at once
+// (one workgroup per CU for groups of 1 or 2 rows, two for 4 or 8)
+int wls_rolling_group_rows(size_t total_rows)
+{
+    if (const char *e = std::getenv("ROCCO_HIP_ROLLING_GROUP")) {  // (tests: every shape of the kernel on small inputs)
+        const int g = std::atoi(e);
+        if (g == 1 || g == 2 || g == 4 || g == 8) {
+            return g;
+        }
+    }
+    // (half the device: a second pipeline of the count-path batch may be running its rolling launch at the same time)
+    if (total_rows <= 128) return 1;
+    if (total_rows <= 256) return 2;
+    if (total_rows <= 1024) return 4;
+    return kWlsRollingGroup;
+}
+
+int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, int group_rows, hipStream_t stream)
+{
+    if (n_tasks == 0) {
+        return ROCCO_HIP_OK;
+    }
+    switch (group_rows) {
+    case 1: return launch_rolling_rows<1>(tasks_dev, n_tasks, stream);
+    case 2: return launch_rolling_rows<2>(tasks_dev, n_tasks, stream);
+    case 4: return launch_rolling_rows<4>(tasks_dev, n_tasks, stream);
+    case 8: return launch_rolling_rows<8>(tasks_dev, n_tasks, stream);
+    default: set_last_error("launch_wls_rolling_batch: groups of 1, 2, 4 or 8 rows"); return ROCCO_HIP_EINVAL;
+    }
 }
 
 size_t log_scale_scratch_bytes(size_t K, size_t n)

@@ -167,3 +167,21 @@ def test_trend_fit_rank_finder_shapes(gpu, oracle, kind):
     for g, w in zip(got[:6], want[:6]):
         assert np.asarray(g).tobytes() == np.asarray(w).tobytes(), kind
     assert got[6:] == want[6:]
+
+
+@pytest.mark.parametrize("group", [1, 2, 4, 8])
+@pytest.mark.parametrize("K,n,window", [(1, 64, 31), (3, 700, 5), (9, 5000, 31), (17, 1300, 63), (8, 129, 63), (5, 40000, 7)])
+def test_rolling_variances_every_group_shape(gpu, oracle, monkeypatch, group, K, n, window):
+    """The rolling kernel runs 1, 2, 4 or 8 rows per workgroup (tiles of 512 / 256 / 128 / 64 start positions) depending on how
+    many rows a call has; here every shape on the same matrices: row counts that do not fill the last group, rows shorter
+    than a tile, windows at both ends of the tiled range, enough tiles for the ring of LDS lines to wrap several times."""
+    from rocco_amd.inference import score_centered_wls
+
+    monkeypatch.setenv("ROCCO_HIP_ROLLING_GROUP", str(group))
+    rng = np.random.default_rng(K * 1000 + n + window)
+    m = np.round(rng.normal(0.0, 1.0, size=(K, n)) * np.exp(rng.normal(0.0, 0.5, size=(1, n))), 3)
+    got, dfw = stack(score_centered_wls(m, spatial_window=window))
+    want, dfw_o = stack(oracle.score_centered_wls(m, spatial_window=window))
+    for t, label in enumerate(ORDER):
+        assert got[t].tobytes() == want[t].tobytes(), (group, K, n, window, label)
+    assert np.array_equal(dfw, dfw_o)
