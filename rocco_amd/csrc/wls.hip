@@ -1611,12 +1611,20 @@ __global__ void row_median_kernel(const unsigned long long *__restrict__ sorted_
     }
 }
 
+// grid: (chunks of 1024 loci, rows); four loci per thread (no division to find the row)
 __global__ __launch_bounds__(256) void subtract_row_offset_kernel(double *__restrict__ matrix, const double *__restrict__ med,
-                                                                 long long n, long long count)
+                                                                 long long n)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) {
-        matrix[i] = matrix[i] - med[i / n];
+    const long long row = blockIdx.y;
+    const double offset = med[row];
+    double *__restrict__ x = matrix + row * n;
+    const long long base = (long long)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long i = base + 256LL * j;
+        if (i < n) {
+            x[i] = x[i] - offset;
+        }
     }
 }
 
@@ -1988,7 +1996,8 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
     }
     hipLaunchKernelGGL(row_select_median_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, (const RowSelect *)state, rows,
                        nn, med);
-    hipLaunchKernelGGL(subtract_row_offset_kernel, dim3(blocks_all), dim3(256), 0, stream, centered_out_dev, med, nn, count);
+    hipLaunchKernelGGL(subtract_row_offset_kernel, dim3((unsigned)((nn + 1023) / 1024), (unsigned)K), dim3(256), 0, stream, centered_out_dev, med,
+                       nn);
     if (row_offsets_out_dev != nullptr) {
         ROCCO_HIP_TRY(hipMemcpyAsync(row_offsets_out_dev, med, K * 8, hipMemcpyDeviceToDevice, stream));
     }
