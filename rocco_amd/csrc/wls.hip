@@ -1587,30 +1587,6 @@ __global__ __launch_bounds__(256) void log_scale_kernel(const double *__restrict
     }
 }
 
-// order-preserving key of a double (negative values: all bits flipped, others: sign bit set)
-__global__ __launch_bounds__(256) void order_key_kernel(const double *__restrict__ in, unsigned long long *__restrict__ key,
-                                                       long long n)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(in[i]);
-        key[i] = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
-    }
-}
-
-
-// np.median of one sorted row: the middle value, or the mean of the two middle values
-__global__ void row_median_kernel(const unsigned long long *__restrict__ sorted_keys, long long n, double *__restrict__ med)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (n & 1LL) {
-            *med = key_to_double(sorted_keys[n / 2]);
-        } else {
-            *med = (key_to_double(sorted_keys[n / 2 - 1]) + key_to_double(sorted_keys[n / 2])) / 2.0;
-        }
-    }
-}
-
 // grid: (chunks of 1024 loci, rows); four loci per thread (no division to find the row)
 __global__ __launch_bounds__(256) void subtract_row_offset_kernel(double *__restrict__ matrix, const double *__restrict__ med,
                                                                  long long n)
