@@ -749,7 +749,7 @@ int rocco_hip_crossfit_whittaker_baseline_batch_f64(rocco_hip_solver *solver, si
         }
         if (rows[i] > 0) {
             longest = std::max(longest, cols[i]);
-            groups += (rows[i] + 31) / 32;
+            groups += (rows[i] + (size_t)whittaker_group_rows() - 1) / (size_t)whittaker_group_rows();
         }
     }
     ROCCO_HIP_TRY(hipSetDevice(solver->device));

@@ -135,6 +135,7 @@ struct WhittakerRowTask {
 // several matrices of one penalty (the chromosomes of a genome) in ONE pair of launches; tasks_host_pinned: room for
 // 2 x (groups of 32 rows over all matrices) records, must stay untouched until the stream has passed the copy
 size_t whittaker_batch_scratch_bytes(const size_t *rows, const size_t *cols, size_t count);
+int whittaker_group_rows();  // rows per workgroup of the batched sweeps (one task record per group and sweep)
 int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const size_t *rows, const size_t *cols, size_t count,
                                     double penalty_lambda, const double *factor_dev, size_t factor_cap, double *const *baselines_dev,
                                     void *scratch_dev, WhittakerRowTask *tasks_host_pinned, hipStream_t stream);

@@ -376,8 +376,12 @@ __global__ __launch_bounds__(2 * kLanes + kSweepHelpers) void whittaker_sweep_ke
 //   * the multipliers of a locus are the same for every row: one (a, b) pair per parity and locus, read as a broadcast;
 //   * two input and two output tiles alternate (chain on k, staging of k + 1, write-back of k - 1), one barrier per tile.
 constexpr int kRowTile = 64;    // loci per tile
-constexpr int kGroupRows = 32;  // rows per workgroup (x 2 parities = 64 lanes)
-constexpr int kPitch = 65;
+#ifndef ROCCO_GROUP_ROWS
+#define ROCCO_GROUP_ROWS 8
+#endif
+constexpr int kGroupRows = ROCCO_GROUP_ROWS;  // rows per workgroup (x 2 parities <= 64 lanes of the chain wavefront)
+constexpr int kPitch = 2 * kGroupRows + 1;
+static_assert(2 * kGroupRows <= kLanes, "one lane per chain");
 #ifndef ROCCO_ROW_HELPERS
 #define ROCCO_ROW_HELPERS 4
 #endif
@@ -489,7 +493,9 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
     };
 
     double p1 = 0.0, p2 = 0.0;
-    const int parity = lane / kGroupRows;
+    const bool chain_lane = lane < 2 * kGroupRows;  // (groups of fewer than 32 rows leave lanes of the chain wavefront idle)
+    const int col = chain_lane ? lane : 0;
+    const int parity = col / kGroupRows;
     auto chain = [&](long long k) {
         const double *__restrict__ in = T.in[k & 1];
         double *__restrict__ out = T.out[k & 1];
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             const int t0 = start((j < kRowTile / 8) ? j : (kRowTile / 8 - 1));
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                vv[q] = in[(t0 + q) * kPitch + lane];
+                vv[q] = in[(t0 + q) * kPitch + col];
                 aa[q] = coef[t0 + q][0];
                 bb[q] = coef[t0 + q][1];
             }
@@ -517,7 +523,9 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                out[(t0 + q) * kPitch + lane] = r[q];
+                if (chain_lane) {
+                    out[(t0 + q) * kPitch + col] = r[q];
+                }
             }
         };
         fetch(v, a, b, 0);
@@ -630,6 +638,8 @@ int configure_rows_kernels()
 }
 
 }  // namespace
+
+int whittaker_group_rows() { return kGroupRows; }
 
 size_t whittaker_batch_scratch_bytes(const size_t *rows, const size_t *cols, size_t count)
 {
