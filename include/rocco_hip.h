@@ -275,7 +275,7 @@ int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, c
                                                      size_t rows, size_t cols, double penalty_lambda,
                                                      double *baseline_out_dev, void *stream);
 /* The same for `count` matrices of ONE penalty -- the chromosomes of a genome -- in one pair of launches: every group of
- * 32 rows of every matrix is a workgroup, and the pair lasts as long as the longest row (the loop over chromosomes of
+ * 8 rows of every matrix is a workgroup, and the pair lasts as long as the longest row (the loop over chromosomes of
  * rocco/rocco.py:948-1018 around the call of rocco/inference.py:198-206).  Host arrays of `count` entries. */
 int rocco_hip_crossfit_whittaker_baseline_batch_f64(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev,
                                                     const size_t *rows, const size_t *cols, double penalty_lambda,

@@ -363,16 +363,19 @@ __global__ __launch_bounds__(2 * kLanes + kSweepHelpers) void whittaker_sweep_ke
     }
 }
 
-// ---- the same sweeps with 64 chains per wavefront (round 3) ---------------------------------------------------------
-// A chain advances one locus per ~20 ns whatever its wavefront's other 63 lanes do, so a wavefront that carries ONE chain
-// wastes them: above, K rows keep K workgroups busy for n x 25 ns, and the 2 400 rows of a genome's count matrices take
-// sum(n) x 25 ns / (workgroups in flight).  Here lane L of the chain wavefront is chain (parity L / 32, row L % 32) of a
-// group of 32 rows: both parities of a row read the same input, and all 64 chains step through the loci in lockstep with
-// the same instructions as one did before.  The rows of EVERY matrix of a batch (the chromosomes of a genome) are groups
-// of one launch; the launch lasts as long as its longest row, ~n_max x 20 ns.
+// ---- the same sweeps with several chains per wavefront (round 3) ----------------------------------------------------
+// A chain advances one locus per ~25 ns whatever its wavefront's other 63 lanes do (three dependent FP64 operations of
+// ~19 cycles each), so a wavefront that carries ONE chain wastes them: above, K rows keep K workgroups busy for n x 25 ns,
+// and the 2 400 rows of a genome's count matrices take sum(n) x 25 ns / (workgroups in flight).  Here lane L of the chain
+// wavefront is chain (parity L / G, row L % G) of a group of G rows: both parities of a row read the same input, and all
+// 2 G chains step through the loci in lockstep with the same instructions as one did before.  The rows of EVERY matrix of a
+// batch (the chromosomes of a genome) are groups of one launch; the launch lasts as long as its longest row.  G = 8: with
+// 32 rows (all 64 lanes busy) the four helper wavefronts, each streaming 8 far-apart rows in and out, need 39 ns per locus
+// against the chain's 28 and the launch runs at 36; with 8 rows they stay under the chain and the launch runs at 27 ns per
+// locus (a genome's 2 400 rows are 312 workgroups, all resident); 16 rows 29 ns, 4 rows 45 ns (too few lanes per LDS access).
 //   * the helpers load a tile of 64 loci of each row (512 contiguous bytes per wavefront instruction) and store it
-//     TRANSPOSED in LDS -- element (locus t, chain L) at t * 65 + L: the chain wavefront's 64 lanes read 64 consecutive
-//     doubles, a helper's 64 lanes (one row, 64 loci) write at a stride of 65 doubles = 2 banks: no conflicts either way;
+//     TRANSPOSED in LDS -- element (locus t, chain L) at t * (2 G + 1) + L: the chain wavefront's lanes read consecutive
+//     doubles, a helper's 64 lanes (one row, 64 loci) write at an odd stride: no conflicts either way;
 //   * the multipliers of a locus are the same for every row: one (a, b) pair per parity and locus, read as a broadcast;
 //   * two input and two output tiles alternate (chain on k, staging of k + 1, write-back of k - 1), one barrier per tile.
 constexpr int kRowTile = 64;    // loci per tile
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
     };
 
     double p1 = 0.0, p2 = 0.0;
-    const bool chain_lane = lane < 2 * kGroupRows;  // (groups of fewer than 32 rows leave lanes of the chain wavefront idle)
+    const bool chain_lane = lane < 2 * kGroupRows;  // (2 x kGroupRows chains; the other lanes of the chain wavefront idle)
     const int col = chain_lane ? lane : 0;
     const int parity = col / kGroupRows;
     auto chain = [&](long long k) {
@@ -643,7 +646,7 @@ int whittaker_group_rows() { return kGroupRows; }
 
 size_t whittaker_batch_scratch_bytes(const size_t *rows, const size_t *cols, size_t count)
 {
-    // per matrix: the z of parity 1 (rows x cols doubles) and 8 doubles of end entries; per group of 32 rows two task records
+    // per matrix: the z of parity 1 (rows x cols doubles) and 8 doubles of end entries; per group of rows two task records
     size_t bytes = 256;
     for (size_t i = 0; i < count; ++i) {
         bytes += (rows[i] * cols[i] + 8) * sizeof(double) + 2 * ((rows[i] + kGroupRows - 1) / kGroupRows) * sizeof(WhittakerRowTask) + 256;
@@ -657,9 +660,9 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
 {
     int rc;
     if (count == 1 && rows[0] > 0 && cols[0] >= 25) {
-        // ONE matrix: a workgroup per row with one chain per wavefront steps ~25 ns per locus, the 64-chain wavefronts
-        // below ~36 ns (they move 32 rows' tiles through LDS per step of the chain) -- both last as long as one row, so
-        // the lone matrix takes the faster step; two matrices or more take the launch that lasts as long as its longest
+        // ONE matrix: a workgroup per row with one chain per wavefront steps ~25 ns per locus, the grouped wavefronts below
+        // ~27 ns -- both last as long as one row, so the lone matrix takes the faster step; two matrices or more take the
+        // launch that lasts as long as its longest
         if (factor_dev == nullptr || factor_cap < cols[0]) {
             return ROCCO_HIP_EINVAL;
         }

@@ -70,9 +70,9 @@ def crossfit_whittaker_baseline_device(values_t, penalty_lambda: float, out_t=No
 
 def crossfit_whittaker_baseline_batch_device(values_list, penalty_lambda: float, outs=None):
     """The cross-fit baselines of several [rows_i, cols_i] float64 CUDA matrices of ONE penalty -- the chromosomes of a
-    genome -- in one pair of launches (rocco_hip_crossfit_whittaker_baseline_batch_f64): every group of 32 rows of every
-    matrix is a workgroup whose 64 lanes carry the 64 chains (32 rows x 2 parities) in lockstep, and the pair of launches
-    lasts as long as the longest row.  Returns the list of baseline tensors (`outs` when given: distinct tensors of the
+    genome -- in one pair of launches (rocco_hip_crossfit_whittaker_baseline_batch_f64): every group of 8 rows of every
+    matrix is a workgroup whose chain wavefront carries the 16 chains (8 rows x 2 parities) in lockstep, and the pair of
+    launches lasts as long as the longest row (27 ns per locus and sweep).  Returns the list of baseline tensors (`outs` when given: distinct tensors of the
     same shapes)."""
     import ctypes
 
@@ -383,9 +383,9 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
     the pair lasts as long as the longest row, not as long as all rows one after the other) and the rolling variances
     of every row come from ONE launch (`wls_rolling_variances_batch_device`); the per-matrix steps (log scale + row
     medians; rank finding, dealing, selects and accumulation of the trend fit) are launches over whole matrices.
-    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values): 0.88 s with one pipeline, 0.70 s with two,
-    0.67 s with three (the default; the baselines of the longest rows -- 5 M loci x 36 ns x 2 sweeps -- are 0.36-0.41 s
-    of it whatever runs beside them)."""
+    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values): 0.64 s with two pipelines, 0.63 s with three
+    (the default; the baselines of the longest rows -- 5 M loci x 27 ns x 2 sweeps -- are 0.27-0.30 s of it whatever
+    runs beside them)."""
     import concurrent.futures
     import threading
 
