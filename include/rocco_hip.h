@@ -310,6 +310,14 @@ int rocco_hip_score_centered_wls_given_variances_f64(rocco_hip_solver *solver, c
                                                      double *mean_dev, double *raw_var_dev, double *prior_var_dev, double *mod_var_dev,
                                                      double *se_dev, double *scores_dev, double *df_out, int *window_out, void *stream);
 
+/* Diagnostic of the log scale above: the device's log2 is a two-stage evaluation (a fast double-double stage accepted when its
+ * result survives its error bound on either side, else a full one with error ~2^-100); this runs `count` inputs of a family
+ * (0: any positive finite bit pattern, 1: next to 1, 2: the integers first .. first + count - 1, 3: mantissas next to the
+ * table's cell boundaries in random binades, 4: uniform in [0.5, 4)) through both and through the full stage alone and
+ * returns in *mismatches_out how many results differ (0 expected). */
+int rocco_hip_log2_selfcheck(rocco_hip_solver *solver, int family, unsigned long long seed, unsigned long long first, size_t count,
+                             unsigned long long *mismatches_out, void *stream);
+
 /* How many rows of this solver's last centred-WLS call fitted their variance trend on the sorted path (two radix sorts of the
  * row's pairs: rows shorter than 4096 loci, rows with a run of equal |value| across a bin boundary, rows with more than 8192
  * values in one cell of the rank finder) instead of the sort-free one.  Diagnostic: the results are the same either way. */

@@ -183,6 +183,8 @@ PROTOTYPES = [
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ("rocco_hip_wls_sorted_rows", ctypes.c_int, [ctypes.c_void_p]),
+    ("rocco_hip_log2_selfcheck", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]),
     ("rocco_hip_subtract_finite_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("rocco_hip_subtract_f64", ctypes.c_int,

@@ -876,6 +876,25 @@ int rocco_hip_score_centered_wls_given_variances_f64(rocco_hip_solver *solver, c
 
 int rocco_hip_wls_sorted_rows(const rocco_hip_solver *solver) { return solver != nullptr ? solver->wls_sorted_rows : -1; }
 
+int rocco_hip_log2_selfcheck(rocco_hip_solver *solver, int family, unsigned long long seed, unsigned long long first, size_t count,
+                             unsigned long long *mismatches_out, void *stream)
+{
+    if (solver == nullptr || mismatches_out == nullptr || family < 0 || family > 4 || count > ((size_t)1 << 39)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_results.reserve(256)) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->host_back.reserve(256)) != ROCCO_HIP_OK) return rc;
+    unsigned long long *out = (unsigned long long *)solver->dev_results.ptr;
+    ROCCO_HIP_TRY(hipMemsetAsync(out, 0, sizeof(unsigned long long), (hipStream_t)stream));
+    if ((rc = launch_log2_selfcheck(family, seed, first, count, out, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
+    ROCCO_HIP_TRY(hipMemcpyAsync(solver->host_back.ptr, out, sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *mismatches_out = *(unsigned long long *)solver->host_back.ptr;
+    return ROCCO_HIP_OK;
+}
+
 int rocco_hip_log_scale_f64(rocco_hip_solver *solver, const double *values_dev, size_t count, double pseudocount, double *out_dev,
                             void *stream)
 {

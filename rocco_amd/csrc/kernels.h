@@ -165,6 +165,8 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
                               void *scratch_dev, double *df_out, int *window_out, hipStream_t stream, int *flag_host_pinned, const double *vas_given = nullptr,
                               int *sorted_rows_out = nullptr);
 
+int launch_log2_selfcheck(int family, unsigned long long seed, unsigned long long first, size_t count, unsigned long long *out_dev,
+                          hipStream_t stream);
 // row a2 glue (wls.hip): log2(max(x, 0) + pseudocount), row medians subtracted; out may alias the input
 size_t log_scale_scratch_bytes(size_t K, size_t n);
 int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount, int apply_log,

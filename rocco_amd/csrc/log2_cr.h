@@ -46,7 +46,8 @@ __device__ __forceinline__ dd dd_mul(dd a, dd b)
     return dd_quick(p, e);
 }
 
-__device__ __forceinline__ double log2_correctly_rounded(double t)
+// The full evaluation: error ~2^-100 relative (a wrong rounding needs the true value that close to a rounding boundary).
+__device__ __forceinline__ double log2_cr_full(double t)
 {
     // (callers pass finite t > 0)
     long long bits = __double_as_longlong(t);
@@ -90,6 +91,64 @@ __device__ __forceinline__ double log2_correctly_rounded(double t)
     dd sum = dd_add({kLog2C[i][0], kLog2C[i][1]}, l2);
     sum = dd_add({(double)e, 0.0}, sum);
     return sum.hi;
+}
+
+// Two stages (Ziv): the same reduction, then  log1p(r) = r - r^2/2 + r^3 (1/3 - r/4 + ... - r^7/10)  with r and r^2 as
+// double-doubles and the bracket in plain doubles.  Error of this stage: the bracket's rounding, <= ~3 ulp of r^3 / 3 =
+// 2^-53 |r|^3 <= 2^-68 |r| (|r| <= 2^-7.58); truncation |r|^11 / 11 <= 2^-79 |r|; everything else ~2^-104.  Relative to the
+// result y = e + log2(c) + log2(1 + r): y is at least 0.41 in magnitude unless e = 0 and c = 1, where y = log2(1 + r) itself,
+// so the error is below 2^-67 |y| in every case.  The result (hi, lo) is accepted when hi survives an error of 2^-64 |hi|
+// on either side (8x the bound); otherwise -- about one value in two thousand -- the full evaluation decides.
+__device__ __forceinline__ double log2_correctly_rounded(double t)
+{
+    // (callers pass finite t > 0)
+#ifdef ROCCO_LOG2_FULL_ONLY  // (timing experiments only)
+    return log2_cr_full(t);
+#endif
+    const double t_in = t;
+    long long bits = __double_as_longlong(t);
+    int e = (int)((bits >> 52) & 0x7FF);
+    if (e == 0) {  // subnormal: scale up first
+        t *= 0x1p54;
+        bits = __double_as_longlong(t);
+        e = (int)((bits >> 52) & 0x7FF) - 54;
+    }
+    e -= 1023;
+    double m = __longlong_as_double((bits & 0x000FFFFFFFFFFFFFLL) | 0x3FF0000000000000LL);  // [1, 2)
+    if (m >= 1.5) {
+        m *= 0.5;
+        e += 1;
+    }
+    const int i = (int)((m - 0.75) * 128.0 + 0.5);  // nearest c = 0.75 + i / 128, 0 <= i <= 96
+    const double c = 0.75 + (double)i * 0.0078125;
+    const double z = m - c;                           // exact
+    const double h = z / c;
+    const double l = fma(-h, c, z) / c;               // r = h + l to ~2^-106
+    // r^2 as a double-double
+    const double q_hi = h * h;
+    const double q_lo = fma(h, h, -q_hi) + 2.0 * (h * l);
+    // r^3 (1/3 - r/4 + r^2/5 - r^3/6 + r^4/7 - r^5/8 + r^6/9 - r^7/10)
+    double p = -1.0 / 10.0;
+    p = fma(p, h, 1.0 / 9.0);
+    p = fma(p, h, -1.0 / 8.0);
+    p = fma(p, h, 1.0 / 7.0);
+    p = fma(p, h, -1.0 / 6.0);
+    p = fma(p, h, 1.0 / 5.0);
+    p = fma(p, h, -1.0 / 4.0);
+    p = fma(p, h, 1.0 / 3.0);
+    const double cube = (q_hi * h) * p;
+    // log1p(r) = (h - q_hi / 2) + (l - q_lo / 2 + cube)
+    dd s = dd_two_sum(h, -0.5 * q_hi);
+    s.lo += (l - 0.5 * q_lo) + cube;
+    const dd ln1p = dd_quick(s.hi, s.lo);
+    const dd l2 = dd_mul(ln1p, {kInvLn2Hi, kInvLn2Lo});
+    dd sum = dd_add({kLog2C[i][0], kLog2C[i][1]}, l2);
+    sum = dd_add({(double)e, 0.0}, sum);
+    const double slack = fabs(sum.hi) * 0x1p-64;
+    if (sum.hi + (sum.lo + slack) == sum.hi && sum.hi + (sum.lo - slack) == sum.hi) {
+        return sum.hi;
+    }
+    return log2_cr_full(t_in);
 }
 
 }  // namespace rocco

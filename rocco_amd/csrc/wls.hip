@@ -1564,6 +1564,52 @@ __global__ __launch_bounds__(256) void wls_final_kernel(const double *__restrict
     }
 }
 
+// Self-check of the two-stage log2 (log2_cr.h): `count` inputs of a family -- 0: any positive finite bit pattern; 1: 1 +- tiny
+// (the one region where the result is small); 2: the integers first .. first + count - 1 (counts + pseudocount); 3: mantissas
+// next to the table's cell boundaries and centres in random binades; 4: uniform in [0.5, 4) -- through both stages and
+// through the full evaluation alone: out[0] += inputs whose results differ.
+__global__ __launch_bounds__(256) void log2_selfcheck_kernel(int family, unsigned long long seed, unsigned long long first, long long count,
+                                                            unsigned long long *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) {
+        return;
+    }
+    unsigned long long x = seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(i + 1);  // splitmix64
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    double t;
+    if (family == 0) {
+        unsigned long long b = x & 0x7FFFFFFFFFFFFFFFULL;
+        if ((b >> 52) == 0x7FF) {
+            b &= 0x7FEFFFFFFFFFFFFFULL;
+        }
+        t = __longlong_as_double((long long)(b == 0 ? 1ULL : b));
+    } else if (family == 1) {
+        const int shift = (int)(x >> 58) % 40;                       // distance from 1: 2^-13 .. 2^-52
+        const long long steps = (long long)((x >> 12) & ((1ULL << (52 - 13)) - 1)) >> shift;
+        t = ((x >> 11) & 1ULL) ? 1.0 + (double)steps * 0x1p-52 : 1.0 - (double)steps * 0x1p-53;
+    } else if (family == 2) {
+        t = (double)(first + (unsigned long long)i);
+    } else if (family == 3) {
+        const int cell = (int)(x % 194ULL);                          // boundaries (odd) and centres (even) of the 97 cells
+        const double edge = 0.75 + (double)cell * 0.00390625 - 0.00390625;
+        const long long ulps = (long long)((x >> 8) & 0xFFFF) - 0x8000;
+        const double m = edge + (double)ulps * 0x1p-53;
+        const int e = (int)((x >> 24) % 2046ULL) - 1022;
+        t = ldexp(m < 0.7421875 ? 0.7421875 : m, e);
+        if (!(t > 0.0) || !(t < INFINITY)) {
+            t = m;
+        }
+    } else {
+        t = 0.5 + (double)(x >> 11) * (3.5 * 0x1p-53);
+    }
+    if (log2_correctly_rounded(t) != log2_cr_full(t)) {
+        atomicAdd(out, 1ULL);
+    }
+}
+
 // ---- row a2 glue: log scale, pilot offset, centring (rocco/inference.py:40-47, 330-336) ----------------
 __global__ __launch_bounds__(256) void log_scale_kernel(const double *__restrict__ in, double *__restrict__ out,
                                                        long long count, double pseudocount, int apply_log,
@@ -1984,6 +2030,17 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
     if (*flag_host_pinned != 0) {
         set_last_error("`chrom_matrix` contains non-finite values");
         return ROCCO_HIP_EINVAL;
+    }
+    return ROCCO_HIP_OK;
+}
+
+int launch_log2_selfcheck(int family, unsigned long long seed, unsigned long long first, size_t count, unsigned long long *out_dev,
+                          hipStream_t stream)
+{
+    if (count > 0) {
+        hipLaunchKernelGGL(log2_selfcheck_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, family, seed, first,
+                           (long long)count, out_dev);
+        ROCCO_HIP_TRY(hipGetLastError());
     }
     return ROCCO_HIP_OK;
 }

@@ -58,3 +58,26 @@ def test_other_pseudocounts_and_non_finite(gpu):
     bad[17] = np.nan
     with pytest.raises(ValueError):
         log_scale_device(torch.from_numpy(bad).to(gpu))
+
+
+@pytest.mark.parametrize("family,first,count", [(0, 0, 1 << 31), (1, 0, 1 << 30), (2, 1, 1 << 32), (3, 0, 1 << 30), (4, 0, 1 << 31)])
+def test_two_stage_log2_agrees_with_the_full_evaluation(gpu, family, first, count):
+    """The device's log2 accepts a fast double-double stage when its result survives its error bound and falls back to the
+    full evaluation (error ~2^-100) otherwise: both against the full evaluation alone on 2^30 .. 2^32 inputs per family --
+    any positive finite bit pattern, values next to 1 (the only small results), every integer up to 2^32 (counts + 1),
+    mantissas next to the table's cell boundaries and centres, uniform values -- with no differing result."""
+    import ctypes
+
+    from rocco_amd import _native
+
+    solver = _native.solver_for(0)
+    total = ctypes.c_uint64(0)
+    done = 0
+    while done < count:  # (launches of at most 2^30 inputs)
+        step = min(count - done, 1 << 30)
+        out = ctypes.c_uint64(0)
+        _native.check(_native.load().rocco_hip_log2_selfcheck(solver.handle, family, 20240 + done, first + done, step, ctypes.byref(out), None),
+                      "rocco_hip_log2_selfcheck")
+        total.value += out.value
+        done += step
+    assert total.value == 0
