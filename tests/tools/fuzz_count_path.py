@@ -13,9 +13,31 @@ while time.time() < t_end:
     rng = np.random.default_rng(770000 + it)
     K = int(rng.choice([1, 2, 3, 5, 16, 17, 40]))
     n = int(rng.choice([5, 24, 25, 26, 31, 32, 63, 64, 500, 511, 512, 513, 1025, 4000, 8191, 8192, 8193, 30000, 100000]))
-    which = rng.choice(["baseline", "wls", "loci_pow2"])
+    which = rng.choice(["baseline", "wls", "loci_pow2", "batch", "batch"])
+    os.environ["ROCCO_HIP_ROLLING_GROUP"] = str(rng.choice([0, 1, 2, 4, 8]))  # (0: the library's own choice)
     try:
-        if which == "baseline":
+        if which == "batch":
+            # several matrices through the batched launches (grouped baselines, grouped rolling sums, pipelines) against the
+            # oracle's baselines and against the single-matrix scoring
+            import torch
+            count = int(rng.integers(2, 7))
+            mats, lam = [], inference._consenrich_whittaker_lambda(101)
+            for _ in range(count):
+                Ki = int(rng.choice([1, 2, 7, 8, 9, 16, 17, 33]))
+                ni = int(rng.choice([101, 127, 128, 129, 640, 4095, 4096, 4100, 20000, 70001]))
+                mats.append(np.ldexp(1.0, rng.integers(0, 9, (Ki, ni))) - 1.0)
+            dev = [torch.from_numpy(m).to("cuda:0") for m in mats]
+            logs = [torch.log2(d + 1.0) for d in dev]
+            bases = inference.crossfit_whittaker_baseline_batch_device(logs, lam)
+            ok = all(b.cpu().numpy().tobytes() == po.crossfit_whittaker_baseline(l.cpu().numpy(), lam).tobytes() for b, l in zip(bases, logs))
+            batch = inference.score_loci_wls_batch_device(dev, workers=int(rng.integers(1, 4)))
+            for d, (sc, det) in zip(dev, batch):
+                one, one_det = inference.score_loci_wls_device(d)
+                ok = ok and torch.equal(sc, one) and all(torch.equal(det[x], one_det[x]) for x in ("mean", "standard_error", "centered_matrix"))
+            o0, _ = po.score_loci_wls(mats[0])
+            ok = ok and batch[0][0].cpu().numpy().tobytes() == o0.tobytes()
+            K, n = len(mats), max(m.shape[1] for m in mats)
+        elif which == "baseline":
             m = rng.normal(0, rng.choice([1e-6, 1.0, 1e4]), (K, n)); m[rng.random(m.shape) < 0.2] = 0.0
             lam = float(rng.choice([0.01, 7.0 * (3 * 0.15915494) ** 4, inference._consenrich_whittaker_lambda(101), 1e9]))
             ok = inference.crossfit_whittaker_baseline(m, lam).tobytes() == po.crossfit_whittaker_baseline(m, lam).tobytes()
