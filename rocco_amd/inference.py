@@ -371,6 +371,20 @@ def _batch_worker(device_index: int, slot: int):
     return _batch_workers[key]
 
 
+def release_batch_workers() -> None:
+    """Destroy the pipelines' solver handles and with them their scratch buffers (tens of GB after a genome-sized batch: the
+    grouped baseline and rolling launches keep their scratch for the next call).  The next batch creates them again."""
+    global _batch_workers
+    if _batch_lock is not None:
+        with _batch_lock:
+            workers, _batch_workers = _batch_workers, {}
+    else:
+        workers, _batch_workers = _batch_workers, {}
+    for solver, stream in workers.values():
+        stream.synchronize()
+        solver.close()
+
+
 def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
                                 precision_floor_ratio: float = 0.01, overwrite_input: bool = False,
                                 input_scale: str = "counts", workers: int = 3):
@@ -415,6 +429,10 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
     # the bandwidth-bound phases of the other groups (log scale and row medians before, rank finding, dealing, selects
     # and accumulation after) run under them.  The group with the longest rows therefore holds the fewest values.
     shares = [g + 1 for g in range(workers)]
+    if os.environ.get("ROCCO_BATCH_SHARES"):  # (experiments: other splits, e.g. "2,3,4")
+        given = [float(x) for x in os.environ["ROCCO_BATCH_SHARES"].split(",")]
+        if len(given) == workers and all(x > 0 for x in given):
+            shares = given
     bounds = [sum(shares[:g + 1]) / float(sum(shares)) for g in range(workers)]
     groups, g, running, total = [[] for _ in range(workers)], 0, 0, float(sum(sizes))
     for i in order:

@@ -1,6 +1,6 @@
-"""GPU: the count-path scoring of several chromosomes at once (rocco_amd.inference.score_loci_wls_batch_device: the
-Whittaker baselines of every matrix in one pair of launches, 64 chains per wavefront; the per-matrix phases side by side
-on worker streams) against the single-matrix path and the oracle -- every track bit for bit."""
+"""GPU: the count-path scoring of several chromosomes at once (rocco_amd.inference.score_loci_wls_batch_device: pipelines of
+matrices; per pipeline the Whittaker baselines of every matrix in one pair of launches, 16 chains per wavefront, and the
+rolling variances of every row in one launch) against the single-matrix path and the oracle -- every track bit for bit."""
 import numpy as np
 import pytest
 
@@ -67,3 +67,19 @@ def test_batch_errors(gpu):
     with pytest.raises(ValueError):
         inference.score_loci_wls_batch_device([ok.to(torch.float32)])
     assert inference.score_loci_wls_batch_device([]) == []
+
+
+def test_release_batch_workers_then_batch_again(gpu):
+    """The pipelines keep their solver handles (and scratch) between calls; releasing them must leave the next call working
+    and give the memory back."""
+    import torch
+
+    from rocco_amd import inference
+
+    rng = np.random.default_rng(3)
+    mats = [torch.from_numpy(np.ldexp(1.0, rng.integers(0, 8, (6, n))) - 1.0).to("cuda:0") for n in (5000, 333, 70000)]
+    first = [s.clone() for s, _ in inference.score_loci_wls_batch_device(mats)]
+    inference.release_batch_workers()
+    assert inference._batch_workers == {}
+    second = [s for s, _ in inference.score_loci_wls_batch_device(mats)]
+    assert all(torch.equal(a, b) for a, b in zip(first, second))
