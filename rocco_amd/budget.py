@@ -402,6 +402,7 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
     row after row with it, as rocco/inference.py:654-664 does -- and the running moments / stopping rule.  The
     reference's worker pool (`num_processes`) only changes how many draws it finishes between two looks at the
     stopping rule; that batching is kept, the draws themselves run one after another on the GPU."""
+    import os
     import sys
 
     import torch
@@ -448,16 +449,39 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
     product_t = torch.empty_like(template_t)
     staging = torch.empty((2, n), dtype=torch.float64).pin_memory()
     copies = [torch.cuda.Event(), torch.cuda.Event()]
+    # The multipliers of a draw are host work (NumPy's generator and SciPy's FFT convolution) and cost
+    # ~100x the draw's device work on a chromosome-sized matrix.  The reference hands the draws of a batch to a pool of
+    # `num_processes` workers; here the draws of a batch are generated side by side in threads (both libraries release the
+    # GIL in their loops), each into a K x n host array, and consumed IN DRAW ORDER, so the running moments see the same
+    # sequence.  One worker (`--low_memory`): the rows stream through two pinned rows and no K x n host array exists.
+    pool = None
+    if look_every > 1:
+        import concurrent.futures
+
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=min(look_every, os.cpu_count() or 1), thread_name_prefix="rocco-null")
+
+    def host_weights(draw):
+        rng = np.random.default_rng(int(random_seed) + (104729 * (draw + 1)))
+        block = np.empty((K, n), dtype=np.float64)
+        for row in range(K):  # the generator's stream runs through the rows in order
+            block[row] = _generate_dependent_wild_weights(n, taps, rng)
+        return block
+
     for first in range(0, max_draws, look_every):
-        for draw in range(first, min(max_draws, first + look_every)):
-            rng = np.random.default_rng(int(random_seed) + (104729 * (draw + 1)))
-            for row in range(K):  # the generator's stream runs through the rows in order; uploads overlap the next row
-                slot = row & 1
-                if row >= 2:
-                    copies[slot].synchronize()
-                staging[slot].numpy()[:] = _generate_dependent_wild_weights(n, taps, rng)
-                weights_t[row].copy_(staging[slot], non_blocking=True)
-                copies[slot].record()
+        batch = range(first, min(max_draws, first + look_every))
+        pending = {draw: pool.submit(host_weights, draw) for draw in batch} if pool is not None else {}
+        for draw in batch:
+            if pool is not None:
+                weights_t.copy_(torch.from_numpy(pending.pop(draw).result()))
+            else:
+                rng = np.random.default_rng(int(random_seed) + (104729 * (draw + 1)))
+                for row in range(K):  # uploads overlap the next row's generation
+                    slot = row & 1
+                    if row >= 2:
+                        copies[slot].synchronize()
+                    staging[slot].numpy()[:] = _generate_dependent_wild_weights(n, taps, rng)
+                    weights_t[row].copy_(staging[slot], non_blocking=True)
+                    copies[slot].record()
             d_mass, d_units, d_fraction, d_tail = _inf.compute_budget_null_draw_device(
                 template_t, weights_t, lower_bound_z, prior_df, draw_min_effect, floor_ratio, null_center, soft_scale,
                 null_threshold, work_t=product_t)
@@ -471,6 +495,8 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
                 sys.stderr.flush()
         if _stable_enough(units, min_draws, stability_abs_tol, stability_rel_tol):
             break
+    if pool is not None:
+        pool.shutdown(wait=True)
     if progress_label:
         sys.stderr.write("\n")
         sys.stderr.flush()
