@@ -14,6 +14,7 @@ every host.  There is no CPU fallback: without the library or a GPU these raise.
 from __future__ import annotations
 
 import os
+import threading
 from typing import Tuple
 
 import numpy as np
@@ -357,7 +358,7 @@ def score_loci_wls_device(counts_t, lower_bound_z: float = 1.0, prior_df: float 
 # ---- the count-path scoring of several chromosomes at once ---------------------------------------------------------
 # Pipelines of the batch: one (solver handle, HIP stream, host thread) each, created on first use and kept -- the native
 # calls synchronise their stream and release the GIL, so the pipelines overlap on the device.
-_batch_lock = None
+_batch_lock = threading.Lock()  # one batch at a time per process: the pipelines and their scratch are shared
 _batch_pool = None
 _batch_workers = {}
 
@@ -375,10 +376,7 @@ def release_batch_workers() -> None:
     """Destroy the pipelines' solver handles and with them their scratch buffers (tens of GB after a genome-sized batch: the
     grouped baseline and rolling launches keep their scratch for the next call).  The next batch creates them again."""
     global _batch_workers
-    if _batch_lock is not None:
-        with _batch_lock:
-            workers, _batch_workers = _batch_workers, {}
-    else:
+    with _batch_lock:
         workers, _batch_workers = _batch_workers, {}
     for solver, stream in workers.values():
         stream.synchronize()
@@ -401,11 +399,10 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
     (the default; the baselines of the longest rows -- 5 M loci x 27 ns x 2 sweeps -- are 0.27-0.30 s of it whatever
     runs beside them)."""
     import concurrent.futures
-    import threading
 
     import torch
 
-    global _batch_lock, _batch_pool
+    global _batch_pool
     counts_list = list(counts_list)
     if not counts_list:
         return []
@@ -417,8 +414,6 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         if int(c.shape[0]) == 0 or int(c.shape[1]) == 0:
             raise ValueError("`chrom_matrix` must be non-empty")
     device = counts_list[0].device
-    if _batch_lock is None:
-        _batch_lock = threading.Lock()
     workers = max(1, min(int(workers), len(counts_list), _native.max_side_streams()))  # never more streams than hardware queues
     caller_stream = torch.cuda.current_stream(device)
     sizes = [int(c.shape[0]) * int(c.shape[1]) for c in counts_list]
