@@ -80,3 +80,31 @@ def test_fixed_gamma_and_device_tensor_input(gpu, gold):
         assert 1.0 <= entry["total_count"] <= entry["num_loci"] and 0.0 <= entry["budget_count_hat"] <= entry["total_count"]
     budgets, meta = _resolve_budgets(cache, {"budget_posterior_quantile": 0.01, "budget": None, "scale_chrom_budgets": 1.0})
     assert meta["prior_fit_method"] == "beta_binomial_mle" and all(0.005 <= b <= 0.1 for b in budgets.values())
+
+
+def test_host_threads_do_not_change_the_estimate(gpu, gold, monkeypatch):
+    """`num_processes` > 1 runs the FFT convolutions of the draws in host threads, several draws ahead of the one being
+    consumed (the draws' normals still come from the one generator in order): every statistic must be what one worker gives
+    -- also when a draw is degenerate, where the generator is put back and the rest runs in sequence."""
+    from rocco_amd import budget
+
+    for name in list(gold["names"])[:6]:
+        scores = gold[f"{name}_scores"]
+        draws, hint = (int(v) for v in gold[f"{name}_params"])
+        kw = dict(dependence_lag_hint=None if hint < 0 else hint, num_null_draws=draws, return_details=True)
+        one = budget.estimate_budget_nonnull_fraction_from_score_track(scores, num_processes=1, **kw)
+        for workers in (2, 5):
+            many = budget.estimate_budget_nonnull_fraction_from_score_track(scores, num_processes=workers, **kw)
+            assert many == one, (name, workers)
+    # a degenerate draw in the middle: the smoothing of the third draw "fails", signs are drawn instead
+    scores = gold[f"{gold['names'][0]}_scores"]
+    real, calls = budget._smooth_and_standardise, {"n": 0}
+
+    def sometimes_degenerate(normals, taps):
+        calls["n"] += 1
+        return None if normals[0] > 1.2 else real(normals, taps)  # (a property of the draw itself: the same draws in any order)
+
+    monkeypatch.setattr(budget, "_smooth_and_standardise", sometimes_degenerate)
+    one = budget.estimate_budget_nonnull_fraction_from_score_track(scores, num_null_draws=40, min_null_draws=40, num_processes=1, return_details=True)
+    many = budget.estimate_budget_nonnull_fraction_from_score_track(scores, num_null_draws=40, min_null_draws=40, num_processes=4, return_details=True)
+    assert many == one and calls["n"] >= 80
