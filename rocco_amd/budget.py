@@ -516,11 +516,22 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
             block[row] = _generate_dependent_wild_weights(n, taps, rng)
         return block
 
+    # at most `inflight` K x n host arrays at a time: half of the host memory that is free now, and never more than the pool
+    inflight = look_every
+    if pool is not None:
+        try:
+            import psutil
+
+            inflight = int(max(1, min(look_every, (psutil.virtual_memory().available // 2) // max(1, K * n * 8))))
+        except Exception:  # noqa: BLE001 (no psutil: the pool's size is the bound)
+            pass
     for first in range(0, max_draws, look_every):
-        batch = range(first, min(max_draws, first + look_every))
-        pending = {draw: pool.submit(host_weights, draw) for draw in batch} if pool is not None else {}
+        batch = list(range(first, min(max_draws, first + look_every)))
+        pending, to_submit = {}, list(batch)
         for draw in batch:
             if pool is not None:
+                while to_submit and len(pending) < inflight:
+                    pending[to_submit[0]] = pool.submit(host_weights, to_submit.pop(0))
                 weights_t.copy_(torch.from_numpy(pending.pop(draw).result()))
             else:
                 rng = np.random.default_rng(int(random_seed) + (104729 * (draw + 1)))
