@@ -531,7 +531,8 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
         for draw in batch:
             if pool is not None:
                 while to_submit and len(pending) < inflight:
-                    pending[to_submit[0]] = pool.submit(host_weights, to_submit.pop(0))
+                    ahead = to_submit.pop(0)
+                    pending[ahead] = pool.submit(host_weights, ahead)
                 weights_t.copy_(torch.from_numpy(pending.pop(draw).result()))
             else:
                 rng = np.random.default_rng(int(random_seed) + (104729 * (draw + 1)))
