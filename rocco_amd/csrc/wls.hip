@@ -545,11 +545,16 @@ __global__ __launch_bounds__(256) void row_select_count_kernel(const double *__r
 }
 
 // one workgroup per row: the digit whose bucket holds the wanted rank joins the prefix; the histogram is cleared for the next pass
-__global__ __launch_bounds__(256) void row_select_pick_kernel(RowSelect *__restrict__ state, unsigned *__restrict__ hist, int width)
+// (`bucket`, may be null: how many keys the chosen digit's bucket holds; rows whose rank is negative are settled already)
+__global__ __launch_bounds__(256) void row_select_pick_kernel(RowSelect *__restrict__ state, unsigned *__restrict__ hist, int width,
+                                                             unsigned *__restrict__ bucket)
 {
     __shared__ unsigned part[256];
     __shared__ unsigned long long chosen[2];
     const long long row = blockIdx.x;
+    if (state[row].rank < 0) {
+        return;
+    }
     unsigned *__restrict__ mine = hist + row * kSelectBuckets;
     const int per = kSelectBuckets / 256;  // 8 consecutive buckets per thread
     unsigned c[8], sum = 0u;
@@ -582,6 +587,9 @@ __global__ __launch_bounds__(256) void row_select_pick_kernel(RowSelect *__restr
         const unsigned long long digit = (unsigned long long)(threadIdx.x * per + q);
         state[row].prefix = (width >= 64) ? digit : ((state[row].prefix << width) | digit);
         state[row].rank = rank;
+        if (bucket != nullptr) {
+            bucket[row] = c[q];
+        }
     }
 }
 
@@ -1205,12 +1213,14 @@ __device__ __forceinline__ void segment_of(long long seg, long long n, int bins,
 }
 
 __global__ __launch_bounds__(256) void seg_select_init_kernel(SegSelect *__restrict__ state, unsigned *__restrict__ hist, long long segs,
-                                                             long long n, int bins, unsigned *__restrict__ cursor, long long rows)
+                                                             long long n, int bins, unsigned *__restrict__ cursor, long long rows,
+                                                             unsigned *__restrict__ filled)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < segs) {
         long long off, w;
         segment_of(i, n, bins, off, w);
+        filled[i] = 0u;
         state[i].prefix = 0ULL;
         state[i].rank = (w - 1) / 2;
         state[i].above = ~0ULL;
@@ -1230,7 +1240,7 @@ __global__ __launch_bounds__(256) void seg_select_count_kernel(const double *__r
 {
     __shared__ unsigned local[kSelectBuckets];
     const long long seg = blockIdx.y;
-    if (rows[seg / bins].tie != 0) {
+    if (rows[seg / bins].tie != 0 || state[seg].rank < 0) {  // (a negative rank: settled from its gathered cell already)
         return;
     }
     long long off, w;
@@ -1270,7 +1280,7 @@ __global__ __launch_bounds__(256) void seg_select_above_kernel(const double *__r
                                                               SegSelect *__restrict__ state, const TrendRow *__restrict__ rows)
 {
     const long long seg = blockIdx.y;
-    if (rows[seg / bins].tie != 0) {
+    if (rows[seg / bins].tie != 0 || state[seg].rank < 0) {
         return;
     }
     long long off, w;
@@ -1304,6 +1314,104 @@ __global__ __launch_bounds__(256) void seg_select_above_kernel(const double *__r
         }
         if (above != ~0ULL) {
             atomicMin(&state[seg].above, above);
+        }
+    }
+}
+
+// After two passes (22 key bits) the cell that holds a segment's median has a few hundred values when the variances are
+// spread as variances are: instead of four more counting passes and one for the upper middle value, ONE pass gathers the cell
+// (and finds the smallest key of the cells above it), and a workgroup per segment sorts the cell in LDS and reads the two
+// middle values off.  A cell with more than kCellMax values (runs of equal variances) leaves its segment to the remaining
+// passes as before; settled segments carry a negative rank and those passes skip them.
+constexpr int kCellMax = 1024;
+constexpr int kCellBits = 22;  // key bits known after two passes
+
+__global__ __launch_bounds__(256) void seg_gather_kernel(const double *__restrict__ ypart, long long n, int bins, SegSelect *__restrict__ state,
+                                                        const TrendRow *__restrict__ rows, const unsigned *__restrict__ bucket,
+                                                        unsigned long long *__restrict__ cand, unsigned *__restrict__ filled)
+{
+    const long long seg = blockIdx.y;
+    if (rows[seg / bins].tie != 0 || bucket[seg] > (unsigned)kCellMax) {
+        return;
+    }
+    long long off, w;
+    segment_of(seg, n, bins, off, w);
+    const long long base = (long long)blockIdx.x * kSelectChunk;
+    if (base >= w) {
+        return;
+    }
+    const unsigned long long prefix = state[seg].prefix;
+    const double *__restrict__ y = ypart + off;
+    unsigned long long above = ~0ULL;
+#pragma unroll 4
+    for (int j = 0; j < kSelectChunk / 256; ++j) {
+        const long long i = base + threadIdx.x + 256LL * j;
+        if (i < w) {
+            const unsigned long long k = (unsigned long long)__double_as_longlong(y[i]);
+            const unsigned long long cell = k >> (64 - kCellBits);
+            if (cell == prefix) {
+                const unsigned at = atomicAdd(&filled[seg], 1u);
+                if (at < (unsigned)kCellMax) {
+                    cand[seg * kCellMax + at] = k;
+                }
+            } else if (cell > prefix && k < above) {
+                above = k;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(above, o);
+        above = (other < above) ? other : above;
+    }
+    if ((threadIdx.x & 63) == 0 && above != ~0ULL) {
+        atomicMin(&state[seg].above, above);
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_settle_kernel(SegSelect *__restrict__ state, const TrendRow *__restrict__ rows, int bins,
+                                                        const unsigned *__restrict__ bucket, const unsigned long long *__restrict__ cand,
+                                                        const unsigned *__restrict__ filled)
+{
+    __shared__ unsigned long long v[kCellMax];
+    const long long seg = blockIdx.x;
+    const int count = (int)bucket[seg];
+    if (rows[seg / bins].tie != 0 || count > kCellMax || count == 0 || (int)filled[seg] != count) {
+        return;  // (left to the remaining passes)
+    }
+    int padded = 64;
+    while (padded < count) {
+        padded <<= 1;
+    }
+    for (int i = threadIdx.x; i < padded; i += 256) {
+        v[i] = (i < count) ? cand[seg * kCellMax + i] : ~0ULL;
+    }
+    __syncthreads();
+    for (int k = 2; k <= padded; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < padded; i += 256) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const unsigned long long a = v[i], b = v[partner];
+                    if ((a > b) == ((i & k) == 0)) {
+                        v[i] = b;
+                        v[partner] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        SegSelect &st = state[seg];
+        const long long rank = st.rank;  // inside the cell
+        if (rank >= 0 && rank < count) {
+            st.prefix = v[rank];
+            if (rank + 1 < count) {
+                st.above = v[rank + 1];  // the upper middle value (equal to the lower one inside a run)
+            }
+            st.count_le = 0;  // (the finish kernel then takes `above` for the upper middle value)
+            st.rank = -1;     // settled
         }
     }
 }
@@ -1751,7 +1859,8 @@ size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window, bool own_varian
     const size_t segs = K * (size_t)kMaxBins;
     const size_t dealt = (n >= (size_t)kTrendSelectMin)
                              ? align_up(K * n * 8, 256) + align_up(K * sizeof(TrendRow), 256) + align_up(segs * sizeof(RowSelect), 256) +
-                                   align_up(segs * kSelectBuckets * sizeof(unsigned), 256) + align_up(segs * sizeof(unsigned), 256) +
+                                   align_up(segs * kSelectBuckets * sizeof(unsigned), 256) + 3 * align_up(segs * sizeof(unsigned), 256) +
+                                   align_up(segs * (size_t)kCellMax * 8, 256) +
                                    align_up(K * sizeof(RankRow), 256) + align_up(K * (size_t)kRankBuckets0 * sizeof(unsigned), 256) +
                                    align_up(K * (size_t)kRankCells1 * sizeof(unsigned), 256) + align_up(K * rank_capacity(n) * 8, 256)
                              : 0;
@@ -1806,6 +1915,9 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
     RowSelect *seg_state = select_path ? (RowSelect *)carve(segs * sizeof(RowSelect)) : nullptr;
     unsigned *seg_hist = select_path ? (unsigned *)carve(segs * kSelectBuckets * sizeof(unsigned)) : nullptr;
     unsigned *cursor = select_path ? (unsigned *)carve(segs * sizeof(unsigned)) : nullptr;
+    unsigned *seg_bucket = select_path ? (unsigned *)carve(segs * sizeof(unsigned)) : nullptr;
+    unsigned *seg_filled = select_path ? (unsigned *)carve(segs * sizeof(unsigned)) : nullptr;
+    unsigned long long *seg_cand = select_path ? (unsigned long long *)carve(segs * (size_t)kCellMax * 8) : nullptr;
     RankRow *rank_rows = select_path ? (RankRow *)carve(K * sizeof(RankRow)) : nullptr;
     unsigned *rank_hist0 = select_path ? (unsigned *)carve(K * (size_t)kRankBuckets0 * sizeof(unsigned)) : nullptr;
     unsigned *rank_hist1 = select_path ? (unsigned *)carve(K * (size_t)kRankCells1 * sizeof(unsigned)) : nullptr;
@@ -1878,7 +1990,7 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
             // y side, every row of the matrix at once: deal the y to the bins' segments, select every segment's median
             const long long n_segs = (long long)K * bins;
             hipLaunchKernelGGL(seg_select_init_kernel, dim3((unsigned)((n_segs * kSelectBuckets + 255) / 256)), dim3(256), 0, stream,
-                               seg_state, seg_hist, n_segs, nn, bins, cursor, (long long)K);
+                               seg_state, seg_hist, n_segs, nn, bins, cursor, (long long)K, seg_filled);
             hipLaunchKernelGGL(wls_deal_kernel, dim3((unsigned)((nn + kDealChunk - 1) / kDealChunk), (unsigned)K), dim3(256), 0, stream,
                                centered_dev, (const double *)vas, nn, half, max_start, bins, (const TrendRow *)trows, cursor, ypart, bad);
             const long long widest = (nn + bins - 1) / bins + 1;
@@ -1888,7 +2000,13 @@ int launch_score_centered_wls(const double *centered_dev, size_t K, size_t n, do
                 hipLaunchKernelGGL(seg_select_count_kernel, seg_grid, dim3(256), 0, stream, (const double *)ypart, nn, bins, lows[p],
                                    widths[p], (const RowSelect *)seg_state, (const TrendRow *)trows, seg_hist);
                 hipLaunchKernelGGL(row_select_pick_kernel, dim3((unsigned)n_segs), dim3(256), 0, stream, seg_state, seg_hist,
-                                   (p == 0) ? 64 : widths[p]);
+                                   (p == 0) ? 64 : widths[p], (p == 1) ? seg_bucket : (unsigned *)nullptr);
+                if (p == 1) {  // 22 bits known: gather the cells, settle the segments whose cell is small (nearly all)
+                    hipLaunchKernelGGL(seg_gather_kernel, seg_grid, dim3(256), 0, stream, (const double *)ypart, nn, bins, seg_state,
+                                       (const TrendRow *)trows, (const unsigned *)seg_bucket, seg_cand, seg_filled);
+                    hipLaunchKernelGGL(seg_settle_kernel, dim3((unsigned)n_segs), dim3(256), 0, stream, seg_state, (const TrendRow *)trows, bins,
+                                       (const unsigned *)seg_bucket, (const unsigned long long *)seg_cand, (const unsigned *)seg_filled);
+                }
             }
             hipLaunchKernelGGL(seg_select_above_kernel, seg_grid, dim3(256), 0, stream, (const double *)ypart, nn, bins, seg_state,
                                (const TrendRow *)trows);
@@ -2011,7 +2129,8 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
     for (int p = 0; p < 6; ++p) {
         hipLaunchKernelGGL(row_select_count_kernel, grid, dim3(256), 0, stream, (const double *)centered_out_dev, nn, lows[p], widths[p],
                            (const RowSelect *)state, hist);
-        hipLaunchKernelGGL(row_select_pick_kernel, dim3((unsigned)K), dim3(256), 0, stream, state, hist, (p == 0) ? 64 : widths[p]);
+        hipLaunchKernelGGL(row_select_pick_kernel, dim3((unsigned)K), dim3(256), 0, stream, state, hist, (p == 0) ? 64 : widths[p],
+                           (unsigned *)nullptr);
     }
     if ((nn & 1LL) == 0) {
         hipLaunchKernelGGL(row_select_above_kernel, grid, dim3(256), 0, stream, (const double *)centered_out_dev, nn, state);

@@ -28,7 +28,7 @@ threading.Thread(target=watch, daemon=True).start()
 mats = make()
 inference.score_loci_wls_device(mats[0].clone())  # the Whittaker factor of the longest row, once per process
 torch.cuda.synchronize()
-for rep in range(2):
+for rep in range(int(os.environ.get("PROBE_REPS", "2"))):
     mats = make()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = inference.score_loci_wls_batch_device(mats, overwrite_input=True, workers=workers)
