@@ -516,6 +516,9 @@ __global__ __launch_bounds__(256) void row_select_count_kernel(const double *__r
 {
     __shared__ unsigned local[kSelectBuckets];
     const long long row = blockIdx.y;
+    if (state[row].rank < 0) {  // settled from its gathered cell (row_gather_kernel)
+        return;
+    }
     for (int b = threadIdx.x; b < kSelectBuckets; b += 256) {
         local[b] = 0u;
     }
@@ -598,6 +601,9 @@ __global__ __launch_bounds__(256) void row_select_above_kernel(const double *__r
                                                               RowSelect *__restrict__ state)
 {
     const long long row = blockIdx.y;
+    if (state[row].rank < 0) {
+        return;
+    }
     const unsigned long long want = state[row].prefix;
     const double *__restrict__ x = matrix + row * n;
     const long long base = (long long)blockIdx.x * kSelectChunk;
@@ -629,10 +635,11 @@ __global__ __launch_bounds__(256) void row_select_above_kernel(const double *__r
 }
 
 __global__ __launch_bounds__(256) void row_select_init_kernel(RowSelect *__restrict__ state, unsigned *__restrict__ hist, long long rows,
-                                                             long long n)
+                                                             long long n, unsigned *__restrict__ filled)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < rows) {
+        filled[i] = 0u;
         state[i].prefix = 0ULL;
         state[i].rank = (n - 1) / 2;  // the lower middle element
         state[i].above = ~0ULL;
@@ -1323,7 +1330,7 @@ __global__ __launch_bounds__(256) void seg_select_above_kernel(const double *__r
 // (and finds the smallest key of the cells above it), and a workgroup per segment sorts the cell in LDS and reads the two
 // middle values off.  A cell with more than kCellMax values (runs of equal variances) leaves its segment to the remaining
 // passes as before; settled segments carry a negative rank and those passes skip them.
-constexpr int kCellMax = 1024;
+constexpr int kCellMax = 4096;
 constexpr int kCellBits = 22;  // key bits known after two passes
 
 __global__ __launch_bounds__(256) void seg_gather_kernel(const double *__restrict__ ypart, long long n, int bins, SegSelect *__restrict__ state,
@@ -1376,7 +1383,7 @@ __global__ __launch_bounds__(256) void seg_settle_kernel(SegSelect *__restrict__
     __shared__ unsigned long long v[kCellMax];
     const long long seg = blockIdx.x;
     const int count = (int)bucket[seg];
-    if (rows[seg / bins].tie != 0 || count > kCellMax || count == 0 || (int)filled[seg] != count) {
+    if ((rows != nullptr && rows[seg / bins].tie != 0) || count > kCellMax || count == 0 || (int)filled[seg] != count) {
         return;  // (left to the remaining passes)
     }
     int padded = 64;
@@ -1413,6 +1420,46 @@ __global__ __launch_bounds__(256) void seg_settle_kernel(SegSelect *__restrict__
             st.count_le = 0;  // (the finish kernel then takes `above` for the upper middle value)
             st.rank = -1;     // settled
         }
+    }
+}
+
+// the same for the row medians of the count-path glue (keys: order_key, any sign); `seg_settle_kernel` with rows == nullptr
+// settles them
+__global__ __launch_bounds__(256) void row_gather_kernel(const double *__restrict__ matrix, long long n, RowSelect *__restrict__ state,
+                                                        const unsigned *__restrict__ bucket, unsigned long long *__restrict__ cand,
+                                                        unsigned *__restrict__ filled)
+{
+    const long long row = blockIdx.y;
+    if (bucket[row] > (unsigned)kCellMax) {
+        return;
+    }
+    const unsigned long long prefix = state[row].prefix;
+    const double *__restrict__ x = matrix + row * n;
+    const long long base = (long long)blockIdx.x * kSelectChunk;
+    unsigned long long above = ~0ULL;
+#pragma unroll 4
+    for (int j = 0; j < kSelectChunk / 256; ++j) {
+        const long long i = base + threadIdx.x + 256LL * j;
+        if (i < n) {
+            const unsigned long long k = order_key(x[i]);
+            const unsigned long long cell = k >> (64 - kCellBits);
+            if (cell == prefix) {
+                const unsigned at = atomicAdd(&filled[row], 1u);
+                if (at < (unsigned)kCellMax) {
+                    cand[row * kCellMax + at] = k;
+                }
+            } else if (cell > prefix && k < above) {
+                above = k;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(above, o);
+        above = (other < above) ? other : above;
+    }
+    if ((threadIdx.x & 63) == 0 && above != ~0ULL) {
+        atomicMin(&state[row].above, above);
     }
 }
 
@@ -2104,7 +2151,8 @@ int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, in
 size_t log_scale_scratch_bytes(size_t K, size_t n)
 {
     (void)n;
-    return align_up(K * 8, 256) + align_up(K * sizeof(RowSelect), 256) + align_up(K * kSelectBuckets * sizeof(unsigned), 256) + 512;
+    return align_up(K * 8, 256) + align_up(K * sizeof(RowSelect), 256) + align_up(K * kSelectBuckets * sizeof(unsigned), 256) + 512 +
+           2 * align_up(K * sizeof(unsigned), 256) + align_up(K * (size_t)kCellMax * 8, 256);  // gathered cells of the medians
 }
 
 int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount, int apply_log,
@@ -2117,20 +2165,31 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
     RowSelect *state = (RowSelect *)(sc + align_up(K * 8, 256));
     unsigned *hist = (unsigned *)((char *)state + align_up(K * sizeof(RowSelect), 256));
     int *bad = (int *)((char *)hist + align_up(K * kSelectBuckets * sizeof(unsigned), 256));
+    unsigned *bucket = (unsigned *)((char *)bad + 512);
+    unsigned *filled = (unsigned *)((char *)bucket + align_up(K * sizeof(unsigned), 256));
+    unsigned long long *cand = (unsigned long long *)((char *)filled + align_up(K * sizeof(unsigned), 256));
     ROCCO_HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), stream));
     const unsigned blocks_all = (unsigned)((count + 255) / 256);
     hipLaunchKernelGGL(log_scale_kernel, dim3(blocks_all), dim3(256), 0, stream, counts_dev, centered_out_dev, count,
                        pseudocount, apply_log, bad);
     // the median of every row: radix select over the whole matrix, six passes + one (see row_select_count_kernel)
     hipLaunchKernelGGL(row_select_init_kernel, dim3((unsigned)((rows * kSelectBuckets + 255) / 256)), dim3(256), 0, stream, state, hist,
-                       rows, nn);
+                       rows, nn, filled);
     const dim3 grid((unsigned)((nn + kSelectChunk - 1) / kSelectChunk), (unsigned)K);
     const int lows[6] = {53, 42, 31, 20, 9, 0}, widths[6] = {11, 11, 11, 11, 11, 9};
     for (int p = 0; p < 6; ++p) {
         hipLaunchKernelGGL(row_select_count_kernel, grid, dim3(256), 0, stream, (const double *)centered_out_dev, nn, lows[p], widths[p],
                            (const RowSelect *)state, hist);
         hipLaunchKernelGGL(row_select_pick_kernel, dim3((unsigned)K), dim3(256), 0, stream, state, hist, (p == 0) ? 64 : widths[p],
-                           (unsigned *)nullptr);
+                           (p == 1) ? bucket : (unsigned *)nullptr);
+        if (p == 1) {
+            // 22 key bits known: a row whose median's cell holds at most kCellMax values (continuous signal; not a row of small
+            // integer counts, whose median is a run of equal values) is settled from the gathered cell and skips the rest
+            hipLaunchKernelGGL(row_gather_kernel, grid, dim3(256), 0, stream, (const double *)centered_out_dev, nn, state,
+                               (const unsigned *)bucket, cand, filled);
+            hipLaunchKernelGGL(seg_settle_kernel, dim3((unsigned)K), dim3(256), 0, stream, state, (const TrendRow *)nullptr, 1,
+                               (const unsigned *)bucket, (const unsigned long long *)cand, (const unsigned *)filled);
+        }
     }
     if ((nn & 1LL) == 0) {
         hipLaunchKernelGGL(row_select_above_kernel, grid, dim3(256), 0, stream, (const double *)centered_out_dev, nn, state);

@@ -273,3 +273,33 @@ def records_of(solution, name, step):
     sel = (np.asarray(solution[:-1]) > 0).astype(np.int8)
     d = np.diff(np.concatenate([[0], sel, [0]]))
     return [(name, int(a) * step, int(b) * step) for a, b in zip(np.flatnonzero(d == 1), np.flatnonzero(d == -1))]
+
+
+@pytest.mark.parametrize("kind", ["continuous", "integer_ties", "mixed", "one_binade", "constant_row", "huge_cell"])
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 4097, 70000, 70001])
+def test_row_medians_by_select_and_gathered_cell(gpu, kind, n):
+    """Every row's median (rocco/inference.py:330-331) is a radix select: two counting passes, then -- when the median's
+    22-bit cell holds at most 4096 values -- the cell is gathered and sorted, else four more passes and one for the upper
+    middle value.  Signed continuous rows (settled from the cell), rows of few distinct values (never settled), both in
+    one matrix, rows inside one binade, constant rows and rows whose cell is just too large: np.median, bit for bit."""
+    import torch
+    from rocco_amd.inference import log_scale_center_rows_device
+
+    rng = np.random.default_rng(n + len(kind))
+    K = 6
+    m = rng.normal(0.0, 3.0, size=(K, n))
+    if kind == "integer_ties":
+        m = np.round(m)
+    elif kind == "mixed":
+        m[::2] = np.round(m[::2])
+    elif kind == "one_binade":
+        m = rng.uniform(1.0, 2.0, size=(K, n)) * rng.choice([-1.0, 1.0], size=(K, 1))
+    elif kind == "constant_row":
+        m[1] = 2.5
+        m[4] = -0.0
+    elif kind == "huge_cell":
+        m = 1.0 + rng.integers(0, 6000, size=(K, n)) * 2.0 ** -40  # ~6000 distinct values inside one 22-bit cell
+    centred, offsets = log_scale_center_rows_device(torch.from_numpy(m).cuda(), apply_log2=False)
+    want = np.median(m, axis=1)
+    assert np.array_equal(offsets.cpu().numpy(), want), (kind, n)
+    assert np.array_equal(centred.cpu().numpy(), m - want[:, None])
