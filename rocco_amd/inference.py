@@ -395,7 +395,7 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
     the pair lasts as long as the longest row, not as long as all rows one after the other) and the rolling variances
     of every row come from ONE launch (`wls_rolling_variances_batch_device`); the per-matrix steps (log scale + row
     medians; rank finding, dealing, selects and accumulation of the trend fit) are launches over whole matrices.
-    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values): 0.74 s with one pipeline, 0.63 s with two, 0.62 s with three
+    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values): 0.70 s with one pipeline, 0.60 s with two, 0.58 s with three
     (the default; the baselines of the longest rows -- 5 M loci x 27 ns x 2 sweeps -- are 0.27-0.30 s of it whatever
     runs beside them)."""
     import concurrent.futures
