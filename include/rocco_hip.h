@@ -256,8 +256,9 @@ int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev,
  * (exchange 2) or reads back to write its BED records.  count <= 48.  row_offsets_out has
  * count + 1 entries; when row_offsets_out[count] > capacity_rows only the first capacity_rows rows were written: call
  * again with more room.  table_host_out (may be NULL): receives a pointer to the table in pinned host memory owned by
- * the solver, valid until the next call on this solver (NULL when the table did not fit).  `eager_rows` rows are copied
- * to the host in front of the call's one synchronisation; only a longer table costs a second copy and synchronisation. */
+ * the solver, valid until the next call on this solver (NULL when the table did not fit): the rows that exist are copied
+ * there by a kernel in front of the call's one synchronisation (their number is known on the device only; `eager_rows`, the
+ * size of an earlier host-sized copy, is ignored). */
 int rocco_hip_decode_runs_table(rocco_hip_solver *solver, size_t count, const uint8_t *const *solutions_dev, const size_t *n,
                                 const long long *units, int64_t *table_dev, size_t capacity_rows, size_t eager_rows,
                                 size_t *row_offsets_out, const int64_t **table_host_out, void *stream);

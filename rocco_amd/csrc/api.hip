@@ -633,7 +633,8 @@ int rocco_hip_decode_runs_table(rocco_hip_solver *solver, size_t count, const ui
     rc = solver->host_back.reserve((size_t)batch.n_tasks * 16 + 64);
     if (rc != ROCCO_HIP_OK) return rc;
     const bool want_host = (table_host_out != nullptr);
-    const size_t eager = want_host ? std::min(eager_rows, capacity_rows) : 0;
+    (void)eager_rows;  // (was: how many rows to copy before their number is known; the rows that exist are copied by a kernel now)
+    const size_t eager = want_host ? capacity_rows : 0;
     if (want_host) {
         rc = solver->host_table.reserve(std::max<size_t>(capacity_rows, 1) * 3 * sizeof(int64_t));
         if (rc != ROCCO_HIP_OK) return rc;

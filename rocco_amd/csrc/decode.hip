@@ -443,6 +443,30 @@ __global__ __launch_bounds__(kThreads) void decode_write_table_kernel(DecodeBatc
     }
 }
 
+// the rows that exist -- their number is on the device -- from the table to pinned host memory, 16 bytes per lane and contiguous
+// (streaming writes over the host link; a copy sized on the host would have to guess the number or wait for it)
+__global__ __launch_bounds__(256) void decode_table_to_host_kernel(const int64_t *__restrict__ table_dev, int64_t *__restrict__ table_host,
+                                                                  const unsigned long long *__restrict__ totals, int n_tasks,
+                                                                  unsigned long long capacity)
+{
+    unsigned long long rows = 0;
+    for (int q = 0; q < n_tasks; ++q) {
+        rows += totals[2 * q];
+    }
+    if (rows > capacity) {
+        rows = capacity;
+    }
+    const unsigned long long pairs = (rows * 3ULL + 1ULL) / 2ULL;  // 16-byte pieces (an odd tail moves one word of padding too)
+    const unsigned long long words = rows * 3ULL;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const int64_t a = table_dev[2 * i];
+        table_host[2 * i] = a;
+        if (2 * i + 1 < words) {
+            table_host[2 * i + 1] = table_dev[2 * i + 1];
+        }
+    }
+}
+
 }  // namespace
 
 long long decode_tiles(size_t n) { return (long long)((n + kTileLoci - 1) / kTileLoci); }
@@ -500,8 +524,10 @@ int launch_decode_runs_table(const DecodeBatch &batch, long long total_tiles, vo
     ROCCO_HIP_TRY(hipGetLastError());
     ROCCO_HIP_TRY(hipMemcpyAsync(totals_host_pinned, totals, (size_t)batch.n_tasks * 2 * sizeof(unsigned long long),
                                  hipMemcpyDeviceToHost, stream));
-    if (table_host_pinned != nullptr && eager_rows > 0) {
-        ROCCO_HIP_TRY(hipMemcpyAsync(table_host_pinned, table_dev, eager_rows * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    if (table_host_pinned != nullptr && eager_rows > 0) {  // (eager_rows: the rows the host buffer has room for)
+        hipLaunchKernelGGL(decode_table_to_host_kernel, dim3(256), dim3(256), 0, stream, (const int64_t *)table_dev, table_host_pinned,
+                           (const unsigned long long *)totals, batch.n_tasks, (unsigned long long)eager_rows);
+        ROCCO_HIP_TRY(hipGetLastError());
     }
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));
     return ROCCO_HIP_OK;

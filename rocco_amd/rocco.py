@@ -325,8 +325,9 @@ def decode_runs_table_device(solutions, units=None, capacity_rows: Optional[int]
 
     Returns ``(table_t, offsets, host_rows)``: the rows of solution i are ``table_t[offsets[i]:offsets[i + 1]]``;
     ``host_rows`` is the same table as a NumPy array in pinned memory owned by the solver -- a VIEW that the next
-    decode on this device overwrites (copy it to keep it) -- or None with ``to_host=False``.  `eager_rows`: how many
-    rows travel to the host in front of the synchronisation (a longer table costs a second copy)."""
+    decode on this device overwrites (copy it to keep it) -- or None with ``to_host=False``.  The rows that exist travel to
+    the host in front of the synchronisation, copied by a kernel that reads their number on the device (`eager_rows` is
+    accepted and ignored)."""
     import torch
 
     solutions = [s.contiguous() for s in solutions]
