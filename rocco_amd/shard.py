@@ -84,14 +84,29 @@ def gather_interval_rows(rows_t, group=None) -> Dict[int, np.ndarray]:
         dist.all_gather_into_tensor(parts, mine, group=group)
         host = parts.cpu().numpy().reshape(world, width, 3)
         arr = np.concatenate([host[r, : sizes[r]] for r in range(world)], axis=0) if sum(sizes) else np.zeros((0, 3), dtype=np.int64)
+    return _split_rows_by_unit(arr)
+
+
+def _split_rows_by_unit(arr: np.ndarray) -> Dict[int, np.ndarray]:
+    """Rows (unit, start, end) -> {unit: [m_u, 2]}.  Every rank hands its units over one after the other, so a unit's rows
+    are one run of the gathered table: the runs' ends are where the unit column changes (one pass; a stable sort by unit --
+    2 ms for a genome's 60 000 rows, as long as a rank's whole step at N = 8 -- only if some unit comes in two runs)."""
     merged: Dict[int, np.ndarray] = {}
-    if arr.shape[0]:
-        order = np.argsort(arr[:, 0], kind="stable")
-        arr = arr[order]
-        units, first = np.unique(arr[:, 0], return_index=True)
-        bounds = list(first) + [arr.shape[0]]
-        for k, u in enumerate(units):
-            merged[int(u)] = arr[bounds[k]:bounds[k + 1], 1:]
+    if not arr.shape[0]:
+        return merged
+    units = arr[:, 0]
+    cuts = np.flatnonzero(units[1:] != units[:-1]) + 1
+    starts = np.concatenate(([0], cuts))
+    heads = units[starts]
+    if np.unique(heads).size != heads.size:  # a unit in two runs: order by unit first (rows of a unit keep their order)
+        arr = arr[np.argsort(units, kind="stable")]
+        units = arr[:, 0]
+        cuts = np.flatnonzero(units[1:] != units[:-1]) + 1
+        starts = np.concatenate(([0], cuts))
+        heads = units[starts]
+    ends = np.concatenate((cuts, [arr.shape[0]]))
+    for u, a, b in zip(heads.tolist(), starts.tolist(), ends.tolist()):
+        merged[int(u)] = arr[a:b, 1:]
     return merged
 
 
