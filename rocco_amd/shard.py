@@ -62,8 +62,10 @@ def gather_budget_counts(local: Dict[int, Tuple[float, float]], n_units: int, de
 
 def gather_interval_rows(rows_t, group=None) -> Dict[int, np.ndarray]:
     """The same gather from rows that are still on the device: `rows_t` is an int64 tensor [m, 3] of (unit, start, end),
-    on the GPU under RCCL (backend "nccl") or on the CPU under Gloo.  Two collectives (row counts, padded rows) and ONE
-    transfer to the host at the end -- the intervals are not brought to the host first and sent back for the exchange.
+    on the GPU under RCCL (backend "nccl") or on the CPU under Gloo.  Two collectives (row counts, padded rows) the first
+    time, ONE afterwards (a header row + the room the ranks remember from the last exchange; two again when a table has
+    outgrown it), and ONE transfer to the host at the end -- the intervals are not brought to the host first and sent
+    back for the exchange.
     Returns unit -> [m_u, 2] arrays, identical on every rank."""
     import torch
     import torch.distributed as dist
@@ -72,19 +74,42 @@ def gather_interval_rows(rows_t, group=None) -> Dict[int, np.ndarray]:
         arr = rows_t.cpu().numpy()
     else:
         world = dist.get_world_size(group)
-        count = torch.tensor([int(rows_t.shape[0])], dtype=torch.int64, device=rows_t.device)
-        counts = torch.zeros(world, dtype=torch.int64, device=rows_t.device)
-        dist.all_gather_into_tensor(counts, count, group=group)
-        sizes = [int(c) for c in counts.cpu().tolist()]
-        width = max(max(sizes), 1)
-        mine = torch.zeros((width, 3), dtype=torch.int64, device=rows_t.device)
-        if rows_t.shape[0]:
-            mine[: rows_t.shape[0]] = rows_t
-        parts = torch.empty((world * width, 3), dtype=torch.int64, device=rows_t.device)
-        dist.all_gather_into_tensor(parts, mine, group=group)
-        host = parts.cpu().numpy().reshape(world, width, 3)
-        arr = np.concatenate([host[r, : sizes[r]] for r in range(world)], axis=0) if sum(sizes) else np.zeros((0, 3), dtype=np.int64)
+        m = int(rows_t.shape[0])
+        key = (id(group), str(rows_t.device), world)
+        arr = None
+        room = _gather_room.get(key)
+        if room is not None:
+            # ONE collective: a header row (my row count) in front of `room` rows, the room every rank remembers from the
+            # last exchange (twice the longest table then); every rank reads the same headers, so every rank takes the
+            # same decision when some table has outgrown the room
+            mine = torch.zeros((room + 1, 3), dtype=torch.int64, device=rows_t.device)
+            mine[0, 0] = m
+            if m:
+                mine[1:1 + min(m, room)] = rows_t[:room]
+            parts = torch.empty((world * (room + 1), 3), dtype=torch.int64, device=rows_t.device)
+            dist.all_gather_into_tensor(parts, mine, group=group)
+            host = parts.cpu().numpy().reshape(world, room + 1, 3)
+            sizes = [int(v) for v in host[:, 0, 0]]
+            if max(sizes) <= room:
+                arr = np.concatenate([host[r, 1:1 + sizes[r]] for r in range(world)], axis=0) if sum(sizes) else np.zeros((0, 3), dtype=np.int64)
+        if arr is None:
+            count = torch.tensor([m], dtype=torch.int64, device=rows_t.device)
+            counts = torch.zeros(world, dtype=torch.int64, device=rows_t.device)
+            dist.all_gather_into_tensor(counts, count, group=group)
+            sizes = [int(c) for c in counts.cpu().tolist()]
+            width = max(max(sizes), 1)
+            mine = torch.zeros((width, 3), dtype=torch.int64, device=rows_t.device)
+            if m:
+                mine[:m] = rows_t
+            parts = torch.empty((world * width, 3), dtype=torch.int64, device=rows_t.device)
+            dist.all_gather_into_tensor(parts, mine, group=group)
+            host = parts.cpu().numpy().reshape(world, width, 3)
+            arr = np.concatenate([host[r, : sizes[r]] for r in range(world)], axis=0) if sum(sizes) else np.zeros((0, 3), dtype=np.int64)
+        _gather_room[key] = max(1024, 2 * max(sizes))
     return _split_rows_by_unit(arr)
+
+
+_gather_room: Dict[tuple, int] = {}  # per (group, device, world size): rows of room in the one-collective form of the gather
 
 
 def _split_rows_by_unit(arr: np.ndarray) -> Dict[int, np.ndarray]:

@@ -29,6 +29,20 @@ def _worker(rank, world, port, out_dir):
     rows_t = torch.from_numpy(np.concatenate(rows, axis=0) if rows else np.zeros((0, 3), dtype=np.int64))
     again = shard.gather_interval_rows(rows_t)
     assert sorted(again) == sorted(merged) and all(np.array_equal(again[u], merged[u]) for u in merged)
+    # the second exchange takes ONE collective (a header row + the room remembered from the first) ...
+    assert len(shard._gather_room) == 1
+    once_more = shard.gather_interval_rows(rows_t)
+    assert sorted(once_more) == sorted(merged) and all(np.array_equal(once_more[u], merged[u]) for u in merged)
+    # ... a table that has outgrown the room falls back to two (every rank reads the same headers), and the next fits again
+    big = torch.stack([torch.full((3000 + 7 * rank,), 100 + rank, dtype=torch.int64), torch.arange(3000 + 7 * rank),
+                       torch.arange(3000 + 7 * rank) + 1], dim=1)
+    for _ in range(2):
+        grown = shard.gather_interval_rows(big)
+        assert sorted(grown) == [100 + r for r in range(world)]
+        for r in range(world):
+            assert grown[100 + r].shape == (3000 + 7 * r, 2) and np.array_equal(grown[100 + r][:, 0], np.arange(3000 + 7 * r))
+    none = shard.gather_interval_rows(torch.zeros((0, 3), dtype=torch.int64))
+    assert none == {}
     dist.destroy_process_group()
 
 
