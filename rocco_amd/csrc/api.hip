@@ -125,6 +125,8 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->dev_lean_look.release();
     solver->dev_lean_desc.release();
     solver->dev_lean_wcap.release();
+    solver->dev_chain.release();
+    solver->host_chain.release();
     solver->dev_median_partials.release();
     solver->host_lean_stage.release();
     solver->host_lean_back.release();

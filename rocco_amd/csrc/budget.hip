@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "chain.h"
 #include "chain_fast.h"
 #include "lean.h"
 #include "search.h"
@@ -1046,6 +1047,7 @@ public:
         L.error_out = error_host;
         L.self_reset = 1;
         L.pad = 0;
+        L.ctl = nullptr;
         solver_->lean_look_dirty = 1;  // until the finish kernel that restores the scratch is in the stream
         if ((rc = launch_lean_eval(L, stream_)) != ROCCO_HIP_OK) return rc;
         if (!model_tasks.empty()) {
@@ -1383,6 +1385,290 @@ public:
         ROCCO_HIP_TRY(hipMemcpyAsync(solver_->host_back.ptr, d_out, B * 5 * sizeof(double), hipMemcpyDeviceToHost, stream_));
         ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
         std::memcpy(out.data(), solver_->host_back.ptr, B * 5 * sizeof(double));
+        return ROCCO_HIP_OK;
+    }
+
+    // ---- the threshold search as one chain of launches (chain.h) ----
+    // Queues the statistics pass and `rounds` rounds of [director, compaction, evaluation, finish], waits ONCE, and turns
+    // the report into (a) the statistics prepare() needs, (b) the levels of every problem as lean_enqueue would have left
+    // them, (c) the certified counts for calibrate_batch.  `ran` false: nothing was queued (the caller takes the
+    // statistics pass of its own).
+    int chain_rounds_run = 0;
+    int chain_search(const std::vector<ChainProblem> &problems, const SearchOptions &opt, std::vector<double> &stats_out,
+                     std::vector<Presearch> &pre, bool &ran)
+    {
+        ran = false;
+        const size_t B = probs.size();
+        const char *flag = std::getenv("ROCCO_HIP_CHAIN");
+        if ((flag != nullptr && std::atoi(flag) == 0) || solver_->lean == 0 || B == 0 || B > (size_t)kChainMaxProblems ||
+            !opt.use_bounds || opt.force_exact || !opt.use_compaction) {
+            return ROCCO_HIP_OK;
+        }
+        bool any = false;
+        long long tiles0 = 0;
+        for (size_t b = 0; b < B; ++b) {
+            any = any || lean_eligible(b);
+            tiles0 += (long long)((probs[b].n + kLeanTile - 1) / kLeanTile);
+            if (probs[b].n >= ((size_t)1 << 31)) {
+                return ROCCO_HIP_OK;
+            }
+        }
+        if (!any) {
+            return ROCCO_HIP_OK;
+        }
+        int rc;
+        if ((rc = lean_prepare()) != ROCCO_HIP_OK) return rc;
+        ChainTuning tune;
+        tune.pilot_rounds = std::getenv("ROCCO_HIP_CHAIN_PILOT_ROUNDS") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_PILOT_ROUNDS")) : 3;
+        tune.pilot_points = std::getenv("ROCCO_HIP_CHAIN_PILOT_POINTS") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_PILOT_POINTS")) : 8;
+        if (opt.pilot_rounds <= 0) {
+            tune.pilot_rounds = 0;
+        }
+        tune.wgs = std::getenv("ROCCO_HIP_CHAIN_WGS") ? std::max(64, std::atoi(std::getenv("ROCCO_HIP_CHAIN_WGS"))) : 1536;
+        tune.pilot_wgs = std::getenv("ROCCO_HIP_CHAIN_PILOT_WGS") ? std::max(64, std::atoi(std::getenv("ROCCO_HIP_CHAIN_PILOT_WGS"))) : 512;
+        tune.pad = 0;
+        tune.big_points = std::getenv("ROCCO_HIP_CHAIN_BIG_POINTS") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_BIG_POINTS")) : 2;
+        tune.search_gate = opt.search_gate;
+        tune.survey_gate = opt.survey_gate;
+        tune.interpolate = std::getenv("ROCCO_HIP_CHAIN_INTERP") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_INTERP")) : 1;
+        tune.spread = std::getenv("ROCCO_HIP_CHAIN_SPREAD") ? std::atof(std::getenv("ROCCO_HIP_CHAIN_SPREAD")) : 0.005;
+        if (!(tune.spread > 0.0 && tune.spread < 0.5)) {
+            tune.spread = 0.005;
+        }
+        tune.soft_mult = std::getenv("ROCCO_HIP_CHAIN_SOFT") ? std::atof(std::getenv("ROCCO_HIP_CHAIN_SOFT")) : 0.8;
+        {
+            std::vector<double> mults = {2.2, 1.2};
+            if (const char *e = std::getenv("ROCCO_HIP_CHAIN_LEVELS")) {
+                mults.clear();
+                for (const char *q = e; *q != '\0';) {
+                    char *end = nullptr;
+                    const double v = std::strtod(q, &end);
+                    if (end == q) break;
+                    if (v > 0.0) mults.push_back(v);
+                    q = (*end == ',') ? end + 1 : end;
+                }
+            }
+            tune.n_mults = (int)std::min(mults.size(), (size_t)kChainMaxMults);
+            for (int k = 0; k < kChainMaxMults; ++k) {
+                tune.mults[k] = (k < tune.n_mults) ? mults[(size_t)k] : 0.0;
+            }
+        }
+        const int R = std::getenv("ROCCO_HIP_CHAIN_ROUNDS") ? std::max(1, std::atoi(std::getenv("ROCCO_HIP_CHAIN_ROUNDS"))) : 9;
+
+        // ---- statistics pass: descriptors as in compute_stats ----
+        std::vector<int2> blockmap;
+        for (size_t b = 0; b < B; ++b) {
+            const int nb = (int)((probs[b].n + kFastBlockLoci - 1) / kFastBlockLoci);
+            for (int k = 0; k < nb; ++k) {
+                blockmap.push_back(make_int2((int)b, k));
+            }
+        }
+        const size_t nbt = blockmap.size();
+        // ---- one device buffer: [ctl][inputs][stats tasks][blockmap] (uploaded) [probs][stats] (downloaded) [rest] ----
+        size_t off = 0;
+        auto carve = [&off](size_t bytes) {
+            const size_t at = off;
+            off += align_up(bytes, 256);
+            return at;
+        };
+        const size_t o_ctl = carve(sizeof(LeanRoundCtl));
+        const size_t o_in = carve(B * sizeof(ChainInput));
+        const size_t o_stasks = carve(B * sizeof(StatsTask));
+        const size_t o_bmap = carve(nbt * sizeof(int2));
+        const size_t up_bytes = off;
+        const size_t o_probs = carve(B * sizeof(ChainProb));
+        const size_t o_stats = carve(B * 5 * sizeof(double));
+        const size_t o_ctl_back = carve(sizeof(LeanRoundCtl));
+        const size_t down_bytes = off - o_probs;
+        const size_t o_hot = carve(B * sizeof(ChainHot));
+        const size_t o_pilot = carve(B * sizeof(ChainPilot));
+        const size_t o_tasks = carve(B * sizeof(LeanTask));
+        const size_t o_points = carve(B * kLeanMaxPoints * sizeof(double));
+        const size_t o_results = carve(B * kLeanMaxPoints * sizeof(LeanResult));
+        const size_t o_pre = carve(B * sizeof(LeanCompactTask));
+        const size_t o_part = carve(nbt * 5 * sizeof(double));
+        const bool want_trace = std::getenv("ROCCO_HIP_CHAIN_TRACE") != nullptr;
+        const size_t o_trace = carve((size_t)(R + 2) * 8 * sizeof(long long));
+        if ((rc = solver_->dev_chain.reserve(off + 256)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_chain.reserve(std::max(up_bytes, down_bytes) + 256)) != ROCCO_HIP_OK) return rc;
+        char *dv = (char *)solver_->dev_chain.ptr;
+        char *h = (char *)solver_->host_chain.ptr;
+        std::memset(h, 0, o_in);
+        ChainInput *hin = (ChainInput *)(h + o_in);
+        StatsTask *hst = (StatsTask *)(h + o_stasks);
+        for (size_t b = 0; b < B; ++b) {
+            const DevProblem &p = probs[b];
+            hin[b].scores = p.scores;
+            hin[b].n = (long long)p.n;
+            hin[b].gamma = p.gamma;
+            hin[b].target = std::max(0LL, std::min(problems[b].target_count, (long long)p.n));
+            hin[b].pool_begin = lean_[b].pool_begin;
+            hin[b].pool_end = lean_[b].pool_end;
+            hin[b].allowed = lean_eligible(b) ? 1 : 0;
+            hin[b].can_pilot = can_pilot(b) ? 1 : 0;
+            hst[b].scores = p.scores;
+            hst[b].switch_costs = p.costs;
+            hst[b].n = (long long)p.n;
+        }
+        std::memcpy(h + o_bmap, blockmap.data(), nbt * sizeof(int2));
+        ROCCO_HIP_TRY(hipMemcpyAsync(dv, h, up_bytes, hipMemcpyHostToDevice, stream_));
+        if ((rc = launch_stats((const StatsTask *)(dv + o_stasks), (int)B, (const int2 *)(dv + o_bmap), (int)nbt, (double *)(dv + o_part),
+                               (double *)(dv + o_stats), stream_)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+
+        // ---- round scratch (as lean_enqueue keeps it) ----
+        const long long rec_cap = 8 * (tiles0 + (long long)tune.wgs) + 64 * (long long)B;
+        const size_t b_look = align_up(256 + (size_t)rec_cap * 4 * sizeof(unsigned long long), 256);
+        {
+            const void *old_ptr = solver_->dev_lean_look.ptr;
+            const size_t old_bytes = solver_->dev_lean_look.bytes;
+            if ((rc = solver_->dev_lean_look.reserve(b_look)) != ROCCO_HIP_OK) return rc;
+            if (solver_->lean_look_dirty != 0 || solver_->dev_lean_look.ptr != old_ptr || solver_->dev_lean_look.bytes != old_bytes) {
+                ROCCO_HIP_TRY(hipMemsetAsync(solver_->dev_lean_look.ptr, 0xFF, solver_->dev_lean_look.bytes, stream_));
+                ROCCO_HIP_TRY(hipMemsetAsync((char *)solver_->dev_lean_look.ptr + 128, 0, 4, stream_));
+                solver_->lean_look_dirty = 0;
+            }
+        }
+        if ((rc = solver_->dev_lean_round.reserve(align_up((size_t)rec_cap * sizeof(LeanTileRec), 256) + 256)) != ROCCO_HIP_OK) return rc;
+        char *look = (char *)solver_->dev_lean_look.ptr;
+
+        ChainArgs A;
+        A.n_problems = (int)B;
+        A.rec_capacity = (int)std::min<long long>(rec_cap, 0x7FFFFFFF);
+        A.inputs = (const ChainInput *)(dv + o_in);
+        A.probs = (ChainProb *)(dv + o_probs);
+        A.hot = (ChainHot *)(dv + o_hot);
+        A.pilot = (ChainPilot *)(dv + o_pilot);
+        A.stats = (const double *)(dv + o_stats);
+        A.ctl = (LeanRoundCtl *)(dv + o_ctl);
+        A.tasks = (LeanTask *)(dv + o_tasks);
+        A.points = (double *)(dv + o_points);
+        A.results = (LeanResult *)(dv + o_results);
+        A.pre = (LeanCompactTask *)(dv + o_pre);
+        A.pool = (char *)solver_->dev_lean_pool.ptr;
+        A.trace = want_trace ? (long long *)(dv + o_trace) : nullptr;
+        A.tune = tune;
+
+        LeanLaunch L;
+        L.tasks = A.tasks;
+        L.n_tasks = 0;
+        L.n_units = 0;
+        L.points = A.points;
+        L.ticket = (unsigned *)look;
+        L.look = (unsigned long long *)(look + 256);
+        L.recs = (LeanTileRec *)solver_->dev_lean_round.ptr;
+        L.bits = (unsigned *)solver_->dev_lean_pool.ptr;
+        L.tile_off = (unsigned *)solver_->dev_lean_pool.ptr;
+        L.results = A.results;
+        L.error = (unsigned *)(look + 128);
+        L.error_out = nullptr;
+        L.self_reset = 1;
+        L.pad = 0;
+        L.ctl = A.ctl;
+        const int eval_grid = (int)std::min<long long>(512, std::max<long long>(1, tiles0 * 8));
+        const int compact_grid = (int)std::min<long long>(1024, std::max<long long>(1, tiles0));
+        const int finish_grid = (int)std::min<size_t>(2048, B * (size_t)kLeanMaxPoints);
+        solver_->lean_look_dirty = 1;  // until every finish launch that restores the scratch is in the stream
+        for (int r = 0; r < R; ++r) {
+            if ((rc = launch_chain_director(A, r, 0, stream_)) != ROCCO_HIP_OK) return rc;
+            if ((rc = launch_lean_compact_chain(A.pre, A.ctl, compact_grid, stream_)) != ROCCO_HIP_OK) return rc;
+            if ((rc = launch_lean_eval_chain(L, eval_grid, stream_)) != ROCCO_HIP_OK) return rc;
+            if ((rc = launch_lean_finish_chain(L, finish_grid, stream_)) != ROCCO_HIP_OK) return rc;
+        }
+        if ((rc = launch_chain_director(A, R, 1, stream_)) != ROCCO_HIP_OK) return rc;
+        ROCCO_HIP_TRY(hipGetLastError());
+        ROCCO_HIP_TRY(hipMemcpyAsync(dv + o_ctl_back, dv + o_ctl, sizeof(LeanRoundCtl), hipMemcpyDeviceToDevice, stream_));
+        ROCCO_HIP_TRY(hipMemcpyAsync(h, dv + o_probs, down_bytes, hipMemcpyDeviceToHost, stream_));
+        const double ts0 = now_us();
+        ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        t_wait_ += now_us() - ts0;
+        solver_->lean_look_dirty = 0;
+        const ChainProb *rep = (const ChainProb *)h;
+        const double *hstats = (const double *)(h + (o_stats - o_probs));
+        const LeanRoundCtl *ctl = (const LeanRoundCtl *)(h + (o_ctl_back - o_probs));
+        if (ctl->error != 0u) {
+            solver_->lean_look_dirty = 1;
+            set_last_error((ctl->error & 1u) ? "chained search: a tile waited for its predecessor beyond the spin limit"
+                                             : "chained search: a compaction overflowed its level");
+            return ROCCO_HIP_EHIP;
+        }
+        ran = true;
+        chain_rounds_run = ctl->round;
+        if (want_trace) {
+            std::vector<long long> tr((size_t)(R + 1) * 8);
+            ROCCO_HIP_TRY(hipMemcpy(tr.data(), dv + o_trace, tr.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            for (int r = 0; r <= R; ++r) {
+                const long long *t = tr.data() + 8 * r;
+                std::fprintf(stderr, "[chain] director %d: state in %.2f us, results + compaction %.2f, groups %.2f, penalties %.2f, offsets %.2f, descriptors + state out %.2f; since the chain began %.2f\n",
+                             r, 0.01 * (double)(t[1] - t[0]), 0.01 * (double)(t[2] - t[1]), 0.0, 0.01 * (double)(t[3] - t[2]),
+                             0.01 * (double)(t[4] - t[3]), 0.01 * (double)(t[5] - t[4]), 0.01 * (double)(t[0] - tr[0]));
+            }
+        }
+        stats_out.assign(hstats, hstats + 5 * B);
+        pre.assign(B, Presearch());
+        const bool debug = std::getenv("ROCCO_HIP_DEBUG") != nullptr;
+        bool grid_ok = true;
+        for (size_t b = 0; b < B; ++b) {
+            const ChainProb &r = rep[b];
+            if (r.searching == 0) {
+                continue;
+            }
+            // the grid the device evaluated on must be the one the rest of the solve will use
+            const double cmax = (probs[b].costs != nullptr && probs[b].n > 1) ? hstats[5 * b + 3] : probs[b].gamma;
+            if (r.qexp != grid_exponent(std::max(cmax, 0.0), hstats[5 * b + 0], hstats[5 * b + 1])) {
+                grid_ok = false;
+            }
+        }
+        if (!grid_ok) {
+            // (a score range within rounding of a power of two: the host's log2 and the device's exact logarithm disagree;
+            // nothing of the chain is used)
+            if (debug) {
+                std::fprintf(stderr, "[chain] grid exponent differs from the host's: the chain's work is discarded\n");
+            }
+            pre.assign(B, Presearch());
+            return ROCCO_HIP_OK;
+        }
+        for (size_t b = 0; b < B; ++b) {
+            const ChainProb &r = rep[b];
+            if (r.searching == 0 || r.n_evals == 0) {
+                continue;
+            }
+            Presearch &ps = pre[b];
+            for (int i = 0; i < r.n_evals; ++i) {
+                ps.evals.emplace_back(r.eval_x[i], r.eval_c[i]);
+            }
+            ps.rounds = r.rounds + r.pilots;
+            ps.done = (r.done == 1);
+            LeanState &ls = lean_[b];
+            ls.levels.clear();
+            for (int k = 0; k < r.n_levels; ++k) {
+                LeanLevel lv;
+                lv.s = r.levels[k].s;
+                lv.orig = r.levels[k].orig;
+                lv.m = r.levels[k].m;
+                lv.base = r.levels[k].base;
+                lv.sep = r.levels[k].sep;
+                lv.has_eval = false;
+                lv.bits = r.levels[k].bits;
+                lv.tile_off = r.levels[k].tile_off;
+                lv.cap_points = r.levels[k].cap_points;
+                lv.pool_mark = (size_t)r.levels[k].pool_mark;
+                ls.levels.push_back(lv);
+            }
+            ls.pool_at = (size_t)r.pool_at;
+            if (std::getenv("ROCCO_HIP_CHAIN_DEBUG") != nullptr) {
+                for (int i = 0; i < r.n_evals; ++i) {
+                    std::fprintf(stderr, "[chain] problem %zu count(%.17g) = %lld%s\n", b, r.eval_x[i], r.eval_c[i],
+                                 r.eval_c[i] > std::max(0LL, std::min(problems[b].target_count, (long long)probs[b].n)) ? "  >" : "");
+                }
+            }
+            if (debug) {
+                std::fprintf(stderr, "[chain] problem %zu (n=%zu): %d pilot + %d certified rounds, %d counts, %d levels (deepest m=%lld, base %.17g)%s\n",
+                             b, probs[b].n, r.pilots, r.rounds, r.n_evals, r.n_levels, r.levels[r.n_levels - 1].m,
+                             r.levels[r.n_levels - 1].base, r.done == 1 ? ", ended" : (r.done == 2 ? ", given up" : ", out of rounds"));
+            }
+        }
         return ROCCO_HIP_OK;
     }
 
@@ -1856,10 +2142,13 @@ private:
 
 // Fill ChainProblem / DevProblem statistics from one stats pass.
 int prepare(HipEvaluator &ev, std::vector<ChainProblem> &problems, const std::vector<double> *fixed_lambdas,
-            const double *score_stats_host = nullptr)
+            const double *score_stats_host = nullptr, const std::vector<double> *stats5 = nullptr)
 {
     std::vector<double> stats;
-    bool given = (score_stats_host != nullptr);
+    if (stats5 != nullptr && stats5->size() == 5 * problems.size()) {
+        stats = *stats5;  // (the chained search ran the statistics pass)
+    }
+    bool given = (score_stats_host != nullptr) && stats.empty();
     for (size_t b = 0; given && b < problems.size(); ++b) {
         given = (ev.probs[b].costs == nullptr || ev.probs[b].n <= 1);  // cost vectors need their own extremes
     }
@@ -1870,7 +2159,7 @@ int prepare(HipEvaluator &ev, std::vector<ChainProblem> &problems, const std::ve
             stats[5 * b + 1] = score_stats_host[3 * b + 1];
             stats[5 * b + 4] = score_stats_host[3 * b + 2];
         }
-    } else {
+    } else if (stats.empty()) {
         const int rc = ev.compute_stats(stats);
         if (rc != ROCCO_HIP_OK) {
             return rc;
@@ -2179,7 +2468,6 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
         problems[t].max_iter = tasks[t].max_iter;
     }
     int rc;
-    if ((rc = prepare(ev, problems, nullptr, score_stats_host)) != ROCCO_HIP_OK) return rc;
     SearchOptions opt;
     opt.force_exact = solver->force_exact != 0;
     opt.spec_depth = solver->spec_depth;
@@ -2214,7 +2502,16 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
         ~LeanOverride() { solver->lean = saved; }
     } lean_override{solver, solver->lean};
     if (const char *e = std::getenv("ROCCO_HIP_LEAN")) solver->lean = std::atoi(e) != 0;
-    if ((rc = calibrate_batch(ev, problems, opt, res)) != ROCCO_HIP_OK) return rc;
+    // the threshold search of every eligible problem as one chain of launches behind the statistics pass (chain.h); what
+    // it leaves open the host-sequenced rounds of calibrate_batch finish
+    std::vector<double> chain_stats;
+    std::vector<Presearch> presearch;
+    bool chained = false;
+    if (score_stats_host == nullptr) {
+        if ((rc = ev.chain_search(problems, opt, chain_stats, presearch, chained)) != ROCCO_HIP_OK) return rc;
+    }
+    if ((rc = prepare(ev, problems, nullptr, score_stats_host, chained ? &chain_stats : nullptr)) != ROCCO_HIP_OK) return rc;
+    if ((rc = calibrate_batch(ev, problems, opt, res, chained ? &presearch : nullptr)) != ROCCO_HIP_OK) return rc;
     if ((rc = ev.scatter_all()) != ROCCO_HIP_OK) return rc;
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));
     if (std::getenv("ROCCO_HIP_DEBUG") != nullptr || std::getenv("ROCCO_HIP_TIMING") != nullptr) {

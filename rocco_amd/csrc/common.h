@@ -78,6 +78,8 @@ struct rocco_hip_solver {
     int lean_look_dirty = 1;             // ... unless a round failed: then the next one initialises it again
     rocco::DeviceBuffer dev_lean_desc;   // its descriptors
     rocco::DeviceBuffer dev_lean_wcap;   // per problem: tolerance cap of the rounding-model evaluation
+    rocco::DeviceBuffer dev_chain;       // state, descriptors and results of the device-sequenced threshold search (chain.hip)
+    rocco::PinnedBuffer host_chain;      // ... its inputs going up and its report coming back
     rocco::PinnedBuffer host_lean_stage; // ... their pinned staging
     rocco::PinnedBuffer host_lean_back;  // ... and the readback of its results
     rocco::PinnedBuffer host_stage;   // pinned staging for uploads

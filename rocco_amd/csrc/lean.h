@@ -71,6 +71,19 @@ struct LeanResult {
     long long flags;      // model tasks: nonzero = the count is not certified equal to the reference's
 };
 
+// Sizes of a round whose shape is decided on the device (chain.hip): its launches are queued before the sizes exist, with
+// fixed grids, and read them here when they run.
+struct LeanRoundCtl {
+    int n_tasks;       // tasks of the evaluation launch
+    int n_units;       // its tickets (workgroups of the fixed grid keep taking tickets until they run out)
+    int n_pairs;       // (task, penalty) pairs of the finish launch
+    int n_pre_tasks;   // compactions in front of the evaluation
+    int n_pre_blocks;  // ... and their workgroup slots
+    unsigned error;    // error words of every round so far (bit 0: a tile gave up waiting, bit 1: a compaction overflowed)
+    int round;         // rounds the director has planned
+    int all_done;      // nothing left to plan: the remaining launches of the chain find every size zero
+};
+
 struct LeanLaunch {
     const LeanTask *tasks;
     int n_tasks;
@@ -86,6 +99,7 @@ struct LeanLaunch {
     unsigned *error_out;        // where the finish kernel copies it for the host (next to the results), or nullptr
     int self_reset;             // the finish kernel restores tickets, granules and the error word for the next round
     int pad;
+    LeanRoundCtl *ctl;          // nullptr: n_tasks / n_units above hold; else the sizes are read from the device (chain.hip)
 };
 
 // compaction of one task at one of its evaluated penalties
@@ -104,6 +118,10 @@ struct LeanCompactTask {
 };
 
 int launch_lean_eval(const LeanLaunch &L, hipStream_t stream);
+// the launches of a chained round (L.ctl != nullptr): fixed grids, sizes read on the device
+int launch_lean_eval_chain(const LeanLaunch &L, int grid, hipStream_t stream);
+int launch_lean_finish_chain(const LeanLaunch &L, int grid, hipStream_t stream);
+int launch_lean_compact_chain(const LeanCompactTask *tasks_dev, LeanRoundCtl *ctl, int grid, hipStream_t stream);
 // the same for rounding-model tasks (kLeanModelBatch penalties per workgroup)
 constexpr int kLeanModelBatch = 4;
 int launch_lean_model(const LeanLaunch &L, hipStream_t stream);

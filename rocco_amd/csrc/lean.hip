@@ -802,14 +802,10 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
 }
 
 // One wavefront per (task, penalty): close the fill across tiles, lay out the compaction.
-__global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pairs)
+__device__ __forceinline__ void finish_pair(const LeanLaunch &L, int n_tasks, int pair)
 {
-    const int pair = blockIdx.x;
-    if (pair >= n_pairs) {
-        return;
-    }
     int ti = 0, acc = 0;
-    while (ti + 1 < L.n_tasks && acc + L.tasks[ti].n_points <= pair) {
+    while (ti + 1 < n_tasks && acc + L.tasks[ti].n_points <= pair) {
         acc += L.tasks[ti].n_points;
         ++ti;
     }
@@ -899,6 +895,9 @@ __global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pai
             if (L.error_out != nullptr) {
                 *L.error_out = e;
             }
+            if (L.ctl != nullptr && e != 0u) {
+                atomicOr(&L.ctl->error, e);
+            }
             *L.error = 0u;
             L.ticket[0] = 0xFFFFFFFFu;
             L.ticket[2] = 0xFFFFFFFFu;
@@ -906,21 +905,45 @@ __global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pai
     }
 }
 
-__global__ __launch_bounds__(kLeanThreads) void lean_compact_kernel(const LeanCompactTask *tasks, int n_tasks,
-                                                                    unsigned *error)
+__global__ __launch_bounds__(64) void lean_finish_kernel(LeanLaunch L, int n_pairs)
 {
-    // one workgroup per tile of the parent level.  Every lane first lists the output cells of its 32-locus
-    // word in LDS (source locus, or -1 for the separator behind a run end) -- no memory access in that loop --,
-    // then the cells are dealt to the threads one by one: independent loads, coalesced stores.
-    __shared__ unsigned wave_sum[4];
-    __shared__ unsigned total_s;
-    __shared__ int src[kLeanTile + kLeanTile / 2 + 8];  // at most one separator per two kept loci
+    const int pair = blockIdx.x;
+    if (pair >= n_pairs) {
+        return;
+    }
+    finish_pair(L, L.n_tasks, pair);
+}
+
+// chained rounds: the number of pairs is on the device, the grid is fixed
+__global__ __launch_bounds__(64) void lean_finish_chain_kernel(LeanLaunch L)
+{
+    const int n_pairs = L.ctl->n_pairs, n_tasks = L.ctl->n_tasks;
+    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        finish_pair(L, n_tasks, pair);
+    }
+}
+
+struct CompactShared {
+    unsigned wave_sum[4];
+    unsigned total_s;
+    int src[kLeanTile + kLeanTile / 2 + 8];  // at most one separator per two kept loci
+};
+
+// one workgroup per tile of the parent level.  Every lane first lists the output cells of its 32-locus
+// word in LDS (source locus, or -1 for the separator behind a run end) -- no memory access in that loop --,
+// then the cells are dealt to the threads one by one: independent loads, coalesced stores.
+__device__ __forceinline__ void compact_block(const LeanCompactTask *tasks, int n_tasks, unsigned *error, int block,
+                                              CompactShared &sh)
+{
+    unsigned(&wave_sum)[4] = sh.wave_sum;
+    unsigned &total_s = sh.total_s;
+    int *src = sh.src;
     int ti = 0;
-    while (ti + 1 < n_tasks && tasks[ti + 1].block_begin <= (int)blockIdx.x) {
+    while (ti + 1 < n_tasks && tasks[ti + 1].block_begin <= block) {
         ++ti;
     }
     const LeanCompactTask task = tasks[ti];
-    const int tile = (int)blockIdx.x - task.block_begin;
+    const int tile = block - task.block_begin;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const unsigned z = task.bits[(long long)tile * kLeanThreads + t];
     unsigned nxt;
@@ -994,6 +1017,24 @@ __global__ __launch_bounds__(kLeanThreads) void lean_compact_kernel(const LeanCo
     }
 }
 
+__global__ __launch_bounds__(kLeanThreads) void lean_compact_kernel(const LeanCompactTask *tasks, int n_tasks,
+                                                                    unsigned *error)
+{
+    __shared__ CompactShared sh;
+    compact_block(tasks, n_tasks, error, (int)blockIdx.x, sh);
+}
+
+// chained rounds: tasks and workgroup slots are counted on the device, the grid is fixed
+__global__ __launch_bounds__(kLeanThreads) void lean_compact_chain_kernel(const LeanCompactTask *tasks, LeanRoundCtl *ctl)
+{
+    __shared__ CompactShared sh;
+    const int n_blocks = ctl->n_pre_blocks, n_tasks = ctl->n_pre_tasks;
+    for (int block = blockIdx.x; block < n_blocks; block += gridDim.x) {
+        compact_block(tasks, n_tasks, &ctl->error, block, sh);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void lean_scatter_kernel(const uint8_t *__restrict__ level, const int *__restrict__ orig,
                                                            long long m, uint8_t *__restrict__ full)
 {
@@ -1042,6 +1083,54 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_eval_kernel(LeanLaunch L
         eval_body<2, false>(L, task, tile, p0, np, lds, sc);
     } else {
         eval_body<1, false>(L, task, tile, p0, np, lds, sc);
+    }
+}
+
+// chained rounds (chain.hip): the launch is queued before the round's tasks exist.  A fixed grid of resident workgroups
+// reads the sizes the director left on the device and keeps taking tickets until they run out; tickets are still taken
+// in tile order, so a tile only ever waits for one that a running workgroup holds.
+__global__ __launch_bounds__(kLeanThreads, 2) void lean_eval_chain_kernel(LeanLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *lds = smem;
+    Scratch *sc = reinterpret_cast<Scratch *>(smem + kTileLds);
+    const int t = threadIdx.x;
+    const int n_units = L.ctl->n_units, n_tasks = L.ctl->n_tasks;
+    if (n_units <= 0) {
+        return;  // (before the ticket is touched: no finish kernel would restore it)
+    }
+    for (;;) {
+        if (t == 0) {
+            sc->ticket = (int)(atomicAdd(L.ticket, 1u) + 1u);
+        }
+        if (t < kLeanBatch * 4) {
+            (&sc->red[0][0])[t] = 0u;
+        }
+        __syncthreads();
+        const int ticket = sc->ticket;
+        if (ticket >= n_units) {
+            return;
+        }
+        int ti = 0;
+        while (ti + 1 < n_tasks && L.tasks[ti + 1].unit_begin <= ticket) {
+            ++ti;
+        }
+        const LeanTask task = L.tasks[ti];
+        const int unit = ticket - task.unit_begin;
+        const int tile = unit / task.n_groups, group = unit % task.n_groups;
+        const int p0 = group * task.batch;
+        const int np = min(task.batch, task.n_points - p0);
+        stage_tile<false>(task.s, task.m, (long long)tile * task.tile_stride * kLeanTile, task.magic, lds);
+        if (np > 4) {
+            eval_body<8, false>(L, task, tile, p0, np, lds, sc);
+        } else if (np > 2) {
+            eval_body<4, false>(L, task, tile, p0, np, lds, sc);
+        } else if (np > 1) {
+            eval_body<2, false>(L, task, tile, p0, np, lds, sc);
+        } else {
+            eval_body<1, false>(L, task, tile, p0, np, lds, sc);
+        }
+        __syncthreads();  // the tile and the scratch are reused
     }
 }
 
@@ -1219,6 +1308,31 @@ int launch_lean_eval(const LeanLaunch &L, hipStream_t stream)
         return rc;
     }
     ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_eval_chain(const LeanLaunch &L, int grid, hipStream_t stream)
+{
+    static bool configured = false;
+    const size_t lds = (size_t)kTileLds * sizeof(double) + sizeof(Scratch);
+    if (!configured) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lean_eval_chain_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(lean_eval_chain_kernel, dim3((unsigned)grid), dim3(kLeanThreads), lds, stream, L);
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_finish_chain(const LeanLaunch &L, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lean_finish_chain_kernel, dim3((unsigned)grid), dim3(64), 0, stream, L);
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_compact_chain(const LeanCompactTask *tasks_dev, LeanRoundCtl *ctl, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lean_compact_chain_kernel, dim3((unsigned)grid), dim3(kLeanThreads), 0, stream, tasks_dev, ctl);
     return ROCCO_HIP_OK;
 }
 

@@ -378,7 +378,8 @@ bool fast_path_applicable(const ChainProblem &p)
 }
 
 int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
-                    const SearchOptions &opt, std::vector<CalibrationResult> &results)
+                    const SearchOptions &opt, std::vector<CalibrationResult> &results,
+                    const std::vector<Presearch> *presearch)
 {
     // (a compaction replaces a problem's arrays: its length and score floor change on the way)
     std::vector<ChainProblem> problems(problems_in);
@@ -406,6 +407,44 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 s.pilot_left = opt.pilot_rounds;
                 s.pg = s.G;
                 s.pl = s.L;
+            }
+            if (presearch != nullptr && b < presearch->size() && !(*presearch)[b].evals.empty()) {
+                // exact-arithmetic counts the evaluator already holds: the thresholds they certify (same rule as for a
+                // bound round of this search, below), no pilot
+                const Presearch &ps = (*presearch)[b];
+                s.pilot_left = 0;
+                for (const auto &e : ps.evals) {
+                    const double x = e.first;
+                    const long long c = e.second;
+                    if (!(x > p.score_min - 1.0 && x < p.score_max + 1.0)) {
+                        continue;  // (outside the interval the grid was sized for: not a fact this search may use)
+                    }
+                    s.evals.emplace_back(x, c);
+                    if (c > s.target) {
+                        if (!s.G_real || x - s.eps > s.G) {
+                            s.G = x - s.eps;
+                            s.cG = c;
+                            s.G_real = true;
+                        }
+                    } else if (!s.L_real || x + s.eps < s.L) {
+                        s.L = x + s.eps;
+                        s.cL = c;
+                        s.L_real = true;
+                    }
+                }
+                s.search_rounds = ps.rounds;
+                s.out.passes += ps.rounds;
+                s.open_before = (s.G_real && s.L_real) ? (s.cG - s.cL) : (long long)p.n;
+                if (std::getenv("ROCCO_SEARCH_DEBUG") != nullptr) {
+                    std::fprintf(stderr, "[search] problem %zu presearch (%zu counts, %d rounds%s): G %.17g (%lld) L %.17g (%lld) width %.3g eps %.3g\n",
+                                 b, ps.evals.size(), ps.rounds, ps.done ? ", ended" : "", s.G, s.cG, s.L, s.cL, s.L - s.G, s.eps);
+                }
+                if (ps.done || s.L - s.G <= 8.0 * s.eps) {
+                    s.searching = false;
+                    s.want_compact = opt.use_compaction && s.G_real && !s.compacted && ev.can_compact(b);
+                    advance_analytic(p, s);
+                    bracket_counts_from_evals(p, s);
+                }
             }
         }
     }

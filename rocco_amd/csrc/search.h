@@ -9,6 +9,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace rocco {
@@ -274,9 +275,20 @@ struct SearchOptions {
     bool align_maps = true;
 };
 
+// What an evaluator found out about a problem before the calibration starts (chain.hip: the threshold search run as one
+// chain of device launches).  Every entry of `evals` is a FACT -- the exact-arithmetic count of the problem at a penalty
+// on the problem's grid, DESIGN.md section 4.4 -- however the penalty was chosen; calibrate_batch derives its certified
+// thresholds from them with its own epsilon, exactly as it does from the evaluations it asks for itself.
+struct Presearch {
+    std::vector<std::pair<double, long long>> evals;  // (penalty, count_q(penalty)), in the order they were evaluated
+    int rounds = 0;     // device rounds behind them (diagnostic: CalibrationResult::passes)
+    bool done = false;  // the evaluator's search ended by the stop rule: nothing more to gain from exact arithmetic
+};
+
 // Calibrate every problem of the batch; solutions are left in the evaluator's solution buffers.
 int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
-                    const SearchOptions &opt, std::vector<CalibrationResult> &results);
+                    const SearchOptions &opt, std::vector<CalibrationResult> &results,
+                    const std::vector<Presearch> *presearch = nullptr);
 
 // Fixed-penalty solve (rocco/dp.py:49-86) with certification, exact fallback.
 int solve_fixed_batch(Evaluator &ev, const std::vector<ChainProblem> &problems,
