@@ -1424,13 +1424,13 @@ public:
         if (opt.pilot_rounds <= 0) {
             tune.pilot_rounds = 0;
         }
-        tune.wgs = std::getenv("ROCCO_HIP_CHAIN_WGS") ? std::max(64, std::atoi(std::getenv("ROCCO_HIP_CHAIN_WGS"))) : 1536;
+        tune.wgs = std::getenv("ROCCO_HIP_CHAIN_WGS") ? std::max(64, std::atoi(std::getenv("ROCCO_HIP_CHAIN_WGS"))) : 512;
         tune.pilot_wgs = std::getenv("ROCCO_HIP_CHAIN_PILOT_WGS") ? std::max(64, std::atoi(std::getenv("ROCCO_HIP_CHAIN_PILOT_WGS"))) : 512;
         tune.pad = 0;
         tune.big_points = std::getenv("ROCCO_HIP_CHAIN_BIG_POINTS") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_BIG_POINTS")) : 2;
         tune.search_gate = opt.search_gate;
         tune.survey_gate = opt.survey_gate;
-        tune.interpolate = std::getenv("ROCCO_HIP_CHAIN_INTERP") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_INTERP")) : 1;
+        tune.interpolate = std::getenv("ROCCO_HIP_CHAIN_INTERP") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_INTERP")) : 0;
         tune.spread = std::getenv("ROCCO_HIP_CHAIN_SPREAD") ? std::atof(std::getenv("ROCCO_HIP_CHAIN_SPREAD")) : 0.005;
         if (!(tune.spread > 0.0 && tune.spread < 0.5)) {
             tune.spread = 0.005;
@@ -1453,7 +1453,7 @@ public:
                 tune.mults[k] = (k < tune.n_mults) ? mults[(size_t)k] : 0.0;
             }
         }
-        const int R = std::getenv("ROCCO_HIP_CHAIN_ROUNDS") ? std::max(1, std::atoi(std::getenv("ROCCO_HIP_CHAIN_ROUNDS"))) : 9;
+        const int R = std::getenv("ROCCO_HIP_CHAIN_ROUNDS") ? std::max(1, std::atoi(std::getenv("ROCCO_HIP_CHAIN_ROUNDS"))) : 12;
 
         // ---- statistics pass: descriptors as in compute_stats ----
         std::vector<int2> blockmap;

@@ -520,16 +520,22 @@ __global__ __launch_bounds__(kDirectorThreads) void chain_director_kernel(ChainA
     }
     __syncthreads();
     if (trace) trace[2] = (long long)wall_clock64();
-    if (threadIdx.x == 0) {
+    if (wave == 0) {
         // penalties per problem: as many groups of eight as keep the round within the workgroups it should fill
         long long tiles = 0;
-        for (int k = 0; k < B; ++k) {
+        for (int k = lane; k < B; k += 64) {
             tiles += (s_flex[k] != 0) ? s_nt[k] : 0;
         }
-        const long long groups = max(1LL, min(8LL, (long long)A.tune.wgs / max(1LL, tiles)));
-        const long long pilot_groups = max(1LL, min(8LL, (long long)A.tune.pilot_wgs / max(1LL, tiles)));
-        s_want = (int)(8 * groups);
-        s_pilot_want = (int)max(2LL, min((long long)kLeanMaxPoints, (long long)A.tune.pilot_points * pilot_groups));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            tiles += __shfl_xor(tiles, off);
+        }
+        if (lane == 0) {
+            const long long groups = max(1LL, min(8LL, (long long)A.tune.wgs / max(1LL, tiles)));
+            const long long pilot_groups = max(1LL, min(8LL, (long long)A.tune.pilot_wgs / max(1LL, tiles)));
+            s_want = (int)(8 * groups);
+            s_pilot_want = (int)max(2LL, min((long long)kLeanMaxPoints, (long long)A.tune.pilot_points * pilot_groups));
+        }
     }
     __syncthreads();
     // ---- the next round's penalties ----
@@ -590,50 +596,86 @@ __global__ __launch_bounds__(kDirectorThreads) void chain_director_kernel(ChainA
     }
     __syncthreads();
     if (trace) trace[3] = (long long)wall_clock64();
-    if (threadIdx.x == 0) {
-        // penalties per workgroup: fewer while the whole round still fits one wave (lean_enqueue: rebatch)
-        int batch = kLeanBatch;
-        for (int cand = 2; cand < kLeanBatch; cand *= 2) {
-            long long u = 0;
-            for (int k = 0; k < B; ++k) {
-                u += (s_np[k] > 0) ? (long long)s_nt[k] * ((s_np[k] + cand - 1) / cand) : 0;
+    if (wave == 0) {
+        // penalties per workgroup: fewer while the whole round still fits one wave (lean_enqueue: rebatch); then every
+        // task's first ticket and first record, every compaction's first workgroup slot: scans over the problems, lane
+        // k taking problems k and k + 64
+        static_assert(kChainMaxProblems <= 128, "two problems per lane");
+        const int k0 = lane, k1 = lane + 64;
+        const int np0 = (k0 < B) ? s_np[k0] : 0, np1 = (k1 < B) ? s_np[k1] : 0;
+        const int nt0 = (k0 < B) ? s_nt[k0] : 0, nt1 = (k1 < B) ? s_nt[k1] : 0;
+        const int pre0 = (k0 < B) ? s_pre[k0] : 0, pre1 = (k1 < B) ? s_pre[k1] : 0;
+        long long u2 = (long long)nt0 * ((max(np0, 0) + 1) / 2) + (long long)nt1 * ((max(np1, 0) + 1) / 2);
+        long long u4 = (long long)nt0 * ((max(np0, 0) + 3) / 4) + (long long)nt1 * ((max(np1, 0) + 3) / 4);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            u2 += __shfl_xor(u2, off);
+            u4 += __shfl_xor(u4, off);
+        }
+        const int batch = (u2 <= 512) ? 2 : ((u4 <= 512) ? 4 : kLeanBatch);
+        // records first: a task whose records would not fit is dropped (its problem is left to the host), which must
+        // not move the others' offsets -- so the scan runs over what fits, decided in problem order
+        long long rec0 = (np0 > 0) ? (long long)nt0 * np0 : 0, rec1 = (np1 > 0) ? (long long)nt1 * np1 : 0;
+        auto scan = [&](long long a, long long b_, long long &ex0, long long &ex1, long long &total) {
+            // exclusive prefix over the order (lane 0's first, ..., lane 63's first, lane 0's second, ...)
+            long long inc = a;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const long long v = __shfl_up(inc, off);
+                inc += (lane >= off) ? v : 0;
             }
-            if (u <= 512) {
-                batch = cand;
-                break;
+            const long long first_total = __shfl(inc, 63);
+            ex0 = inc - a;
+            long long inc2 = b_;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const long long v = __shfl_up(inc2, off);
+                inc2 += (lane >= off) ? v : 0;
+            }
+            ex1 = first_total + inc2 - b_;
+            total = first_total + __shfl(inc2, 63);
+        };
+        long long r_ex0, r_ex1, r_total;
+        scan(rec0, rec1, r_ex0, r_ex1, r_total);
+        const bool fit0 = np0 > 0 && r_ex0 + rec0 <= (long long)A.rec_capacity;
+        const bool fit1 = np1 > 0 && r_ex1 + rec1 <= (long long)A.rec_capacity;
+        // (a dropped task keeps its place in the record scan: the space stays unused, nothing overlaps)
+        long long t_ex0, t_ex1, n_tasks, un_ex0, un_ex1, units, pr_ex0, pr_ex1, pairs, pi_ex0, pi_ex1, n_pre, pb_ex0, pb_ex1, pre_blocks;
+        scan(fit0 ? 1 : 0, fit1 ? 1 : 0, t_ex0, t_ex1, n_tasks);
+        scan(fit0 ? (long long)nt0 * ((np0 + batch - 1) / batch) : 0, fit1 ? (long long)nt1 * ((np1 + batch - 1) / batch) : 0, un_ex0, un_ex1, units);
+        scan(fit0 ? np0 : 0, fit1 ? np1 : 0, pr_ex0, pr_ex1, pairs);
+        scan(pre0 > 0 ? 1 : 0, pre1 > 0 ? 1 : 0, pi_ex0, pi_ex1, n_pre);
+        scan(pre0, pre1, pb_ex0, pb_ex1, pre_blocks);
+        if (k0 < B) {
+            s_task[k0] = fit0 ? (int)t_ex0 : -1;
+            s_unit[k0] = (int)un_ex0;
+            s_rec[k0] = (int)r_ex0;
+            s_pre_idx[k0] = (pre0 > 0) ? (int)pi_ex0 : -1;
+            s_pre_block[k0] = (int)pb_ex0;
+            if (np0 > 0 && !fit0) {
+                s_np[k0] = -1;
             }
         }
-        s_batch = batch;
-        int n_tasks = 0, units = 0, recs = 0, pairs = 0, n_pre = 0, pre_blocks = 0;
-        for (int k = 0; k < B; ++k) {
-            s_task[k] = -1;
-            if (s_np[k] > 0) {
-                const long long r = (long long)s_nt[k] * s_np[k];
-                if ((long long)recs + r > (long long)A.rec_capacity) {
-                    s_np[k] = -1;  // no room for this task's records: the problem is left to the host
-                } else {
-                    s_task[k] = n_tasks++;
-                    s_unit[k] = units;
-                    s_rec[k] = recs;
-                    units += s_nt[k] * ((s_np[k] + batch - 1) / batch);
-                    recs += (int)r;
-                    pairs += s_np[k];
-                }
-            }
-            s_pre_idx[k] = -1;
-            if (s_pre[k] > 0) {
-                s_pre_idx[k] = n_pre++;
-                s_pre_block[k] = pre_blocks;
-                pre_blocks += s_pre[k];
+        if (k1 < B) {
+            s_task[k1] = fit1 ? (int)t_ex1 : -1;
+            s_unit[k1] = (int)un_ex1;
+            s_rec[k1] = (int)r_ex1;
+            s_pre_idx[k1] = (pre1 > 0) ? (int)pi_ex1 : -1;
+            s_pre_block[k1] = (int)pb_ex1;
+            if (np1 > 0 && !fit1) {
+                s_np[k1] = -1;
             }
         }
-        A.ctl->n_tasks = n_tasks;
-        A.ctl->n_units = units;
-        A.ctl->n_pairs = pairs;
-        A.ctl->n_pre_tasks = n_pre;
-        A.ctl->n_pre_blocks = pre_blocks;
-        A.ctl->round = round + 1;
-        A.ctl->all_done = (n_tasks == 0 && n_pre == 0) ? 1 : 0;
+        if (lane == 0) {
+            s_batch = batch;
+            A.ctl->n_tasks = (int)n_tasks;
+            A.ctl->n_units = (int)units;
+            A.ctl->n_pairs = (int)pairs;
+            A.ctl->n_pre_tasks = (int)n_pre;
+            A.ctl->n_pre_blocks = (int)pre_blocks;
+            A.ctl->round = round + 1;
+            A.ctl->all_done = (n_tasks == 0 && n_pre == 0) ? 1 : 0;
+        }
     }
     __syncthreads();
     if (trace) trace[4] = (long long)wall_clock64();

@@ -58,7 +58,9 @@ def test_solve_from_given_statistics_is_the_same_solve(gpu, oracle):
     for s_t, target, a, b in zip(scores, targets, plain, given):
         assert a[0] == b[0] and a[3] == b[3], (a[0], b[0], a[3], b[3])
         assert torch.equal(a[1], b[1])
-        assert a[2] == b[2], (a[2], b[2])
+        # the penalised value is summed over the level the solve ended on (fixed order per level); the two calls search
+        # differently (device-chained / host-sequenced) and may end on different levels: same value to the last few bits
+        assert abs(a[2] - b[2]) <= 1e-12 * max(1.0, abs(a[2])), (a[2], b[2])
         s = s_t.cpu().numpy()
         ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 1.0), target)
         assert b[0] == ref[0] and b[3] == ref[3] and np.array_equal(b[1].cpu().numpy(), ref[1])
