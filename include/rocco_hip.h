@@ -406,6 +406,27 @@ int rocco_hip_multiply_f64(rocco_hip_solver *solver, const double *a_dev, const 
 int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *matrix_dev, const double *row_dev,
                                         size_t K, size_t n, double *out_dev, void *stream);
 
+/* ---- the multipliers of the bootstrap draws on the device (missing item 2) ---------------------
+ * Replaces rocco/inference.py:546-575 `_generate_dependent_wild_weights` (called per row and draw at 654-664 and per
+ * draw at 1206-1213): NumPy's `Generator.standard_normal` over PCG64, SciPy's `fftconvolve(..., "valid")` with the
+ * Bartlett taps (inference.py:534-543), centring and scaling to unit variance.
+ * rocco_hip_pcg64_standard_normal_f64: `count` values of `np.random.Generator(PCG64).standard_normal` continuing from
+ *   the generator state (state, inc: the two 128-bit integers of `bit_generator.state["state"]`, high and low halves);
+ *   *raw_draws_out = the 64-bit draws they consumed (`bit_generator.advance(raw_draws)` puts the host's generator
+ *   where NumPy's would be).  NumPy's values bit for bit except that tail values (|x| > 3.654; 2.6e-4 of them) may
+ *   differ in the last place (NumPy calls the host libm's log1p); positions in the stream never differ.
+ * rocco_hip_bartlett_multipliers_f64: innovations_dev = rows x (n + n_taps - 1) row-major; weights_dev = rows x n:
+ *   every row's "valid" convolution with the taps (direct sum in a fixed order -- SciPy's FFT result to ~1e-16 of the
+ *   scale, not bit for bit), minus its mean, over its standard deviation.  *degenerate_out != 0: a row's deviation is
+ *   <= 1e-8 (the reference then draws signs, inference.py:565-569: left to the caller; that row is returned unscaled).
+ * Opt-in (`multipliers="device"` in rocco_amd.budget): the estimates agree with the host path to ~1e-12, not bit for bit. */
+int rocco_hip_pcg64_standard_normal_f64(rocco_hip_solver *solver, unsigned long long state_hi, unsigned long long state_lo,
+                                        unsigned long long inc_hi, unsigned long long inc_lo, size_t count, double *values_dev,
+                                        unsigned long long *raw_draws_out, void *stream);
+int rocco_hip_bartlett_multipliers_f64(rocco_hip_solver *solver, const double *innovations_dev, size_t rows, size_t n,
+                                       const double *taps_host, size_t n_taps, double *weights_dev, int *degenerate_out,
+                                       void *stream);
+
 /* ---- score-track budget estimate: the n-long pieces (rocco/inference.py:1151-1421, 446-501; rocco/rocco.py:751-789) ----
  * rocco_hip_sort_f64: ascending sorted copy of a float64 vector (-0.0 before +0.0).  Every np.median / MAD / median
  *   of the positive scores of the estimate is an order statistic of it.

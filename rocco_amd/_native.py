@@ -202,6 +202,12 @@ PROTOTYPES = [
     ("rocco_hip_budget_null_draw_stats_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_double,
       c_double_p, ctypes.c_void_p]),
+    ("rocco_hip_pcg64_standard_normal_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_size_t,
+      ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_void_p]),
+    ("rocco_hip_bartlett_multipliers_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, c_double_p, ctypes.c_size_t, ctypes.c_void_p,
+      ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     ("rocco_hip_multiply_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("rocco_hip_subtract_positive_row_f64", ctypes.c_int,

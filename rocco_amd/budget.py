@@ -167,6 +167,78 @@ def _smooth_and_standardise(normals: np.ndarray, taps: np.ndarray):
     return None
 
 
+def device_standard_normal(rng: np.random.Generator, count: int, out_t=None, device_index: Optional[int] = None):
+    """``rng.standard_normal(count)`` made on the device (rocco_hip_pcg64_standard_normal_f64): a float64 CUDA tensor of
+    NumPy's own values -- its ziggurat over PCG64, continued from `rng`'s state -- and `rng` advanced by the raw draws
+    they consumed, so later host draws continue the same stream.  Bit for bit NumPy's except tail values (|x| > 3.654),
+    which may differ in the last place (see include/rocco_hip.h)."""
+    import ctypes
+
+    import torch
+
+    state = rng.bit_generator.state
+    if state.get("bit_generator") != "PCG64":
+        raise ValueError("device multipliers need a PCG64 generator (np.random.default_rng)")
+    count = int(count)
+    index = _dp._device_index() if device_index is None else int(device_index)
+    if out_t is None:
+        out_t = torch.empty(count, dtype=torch.float64, device=f"cuda:{index}")
+    if out_t.dtype != torch.float64 or not out_t.is_contiguous() or out_t.numel() < count:
+        raise ValueError("`out_t` must be a contiguous float64 CUDA tensor of at least `count` elements")
+    if count == 0:
+        return out_t[:0]
+    s128, i128 = int(state["state"]["state"]), int(state["state"]["inc"])
+    mask = (1 << 64) - 1
+    solver = _native.solver_for(out_t.device.index)
+    raws = ctypes.c_ulonglong(0)
+    _native.check(_native.load().rocco_hip_pcg64_standard_normal_f64(
+        solver.handle, s128 >> 64, s128 & mask, i128 >> 64, i128 & mask, count, out_t.data_ptr(), ctypes.byref(raws),
+        _lib_solver_stream(out_t)[2]), "rocco_hip_pcg64_standard_normal_f64")
+    rng.bit_generator.advance(int(raws.value))
+    return out_t.reshape(-1)[:count]
+
+
+def device_multipliers(rng: np.random.Generator, rows: int, n_loci: int, kernel: np.ndarray):
+    """What `rows` successive calls of ``_generate_dependent_wild_weights(n_loci, kernel, rng)`` return, as a [rows,
+    n_loci] float64 CUDA tensor made on the device: the innovations are NumPy's own stream (`device_standard_normal`),
+    the smoothing is a direct sum instead of SciPy's FFT (same values to ~1e-15 of their scale, not bit for bit), centring
+    and scaling per row.  `rng` ends where the host calls would leave it.  None: a row came out degenerate (the reference
+    then draws signs, rocco/inference.py:565-569) -- `rng` is put back and the caller takes the host path for this draw."""
+    import ctypes
+
+    import torch
+
+    rows, n = int(rows), max(1, int(n_loci))
+    taps = np.ascontiguousarray(kernel, dtype=np.float64)
+    if n == 1:
+        return torch.ones((rows, 1), dtype=torch.float64, device=f"cuda:{_dp._device_index()}")
+    before = rng.bit_generator.state
+    width = n + taps.size - 1
+    innovations = device_standard_normal(rng, rows * width)
+    weights = torch.empty((rows, n), dtype=torch.float64, device=innovations.device)
+    solver = _native.solver_for(weights.device.index)
+    degenerate = ctypes.c_int(0)
+    _native.check(_native.load().rocco_hip_bartlett_multipliers_f64(
+        solver.handle, innovations.data_ptr(), rows, n, taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size,
+        weights.data_ptr(), ctypes.byref(degenerate), _lib_solver_stream(weights)[2]), "rocco_hip_bartlett_multipliers_f64")
+    if degenerate.value != 0:
+        rng.bit_generator.state = before
+        return None
+    return weights
+
+
+def _resolve_multipliers(multipliers: Optional[str]) -> str:
+    """"host" (NumPy + SciPy, the reference's own calls: every statistic bit for bit) or "device" (normal.hip: the same
+    generator stream, direct smoothing; estimates equal to ~1e-12).  None: the environment's ROCCO_BUDGET_MULTIPLIERS, else
+    "host"."""
+    import os
+
+    choice = multipliers if multipliers is not None else os.environ.get("ROCCO_BUDGET_MULTIPLIERS", "host")
+    if choice not in ("host", "device"):
+        raise ValueError("`multipliers` must be 'host' or 'device'")
+    return choice
+
+
 class _Running:
     """Welford mean / sum of squared deviations (rocco/inference.py:578-590)."""
 
@@ -240,10 +312,12 @@ def estimate_budget_nonnull_fraction_from_score_track(score_track, dependence_la
                                                       num_null_draws: int = 25, random_seed: int = 0,
                                                       progress_label: Optional[str] = None, num_processes: int = 1,
                                                       return_details: bool = False, min_null_draws: Optional[int] = None,
-                                                      stability_abs_tol: float = 5.0e-3, stability_rel_tol: float = 5.0e-2):
+                                                      stability_abs_tol: float = 5.0e-3, stability_rel_tol: float = 5.0e-2,
+                                                      multipliers: Optional[str] = None):
     """Conservative enriched fraction of a score track (rocco/inference.py:1312-1421): tail occupancy of the observed
     scores above the null's threshold minus that of dependent-wild-bootstrap draws of the one-sided residual track.
-    `score_track`: NumPy array or float64 CUDA tensor.  Same return value and details keys as the reference."""
+    `score_track`: NumPy array or float64 CUDA tensor.  Same return value and details keys as the reference.
+    `multipliers` (not in the reference): see `_resolve_multipliers`."""
     import torch
 
     s_t = _as_score_tensor(score_track)
@@ -290,7 +364,8 @@ def estimate_budget_nonnull_fraction_from_score_track(score_track, dependence_la
     # host threads, up to that many draws ahead of the one being consumed.  A draw whose smoothed series is degenerate
     # takes signs from the generator BEFORE the next draw's normals: the generator is put back to that draw's start and
     # the rest runs in sequence.  (Draws past the stopping rule's verdict are wasted host work, nothing else.)
-    ahead = int(max(1, num_processes)) if n > 1 else 1
+    on_device = _resolve_multipliers(multipliers) == "device" and n > 1
+    ahead = int(max(1, num_processes)) if (n > 1 and not on_device) else 1
     pool, queue = None, []
     if ahead > 1:
         import concurrent.futures
@@ -321,7 +396,11 @@ def estimate_budget_nonnull_fraction_from_score_track(score_track, dependence_la
         return weights
 
     for _draw in range(max_draws):
-        weights_dev.copy_(torch.from_numpy(next_weights()))
+        made = device_multipliers(rng, 1, n, taps) if on_device else None  # (None: degenerate, generator put back)
+        if made is not None:
+            weights_dev = made[0]
+        else:
+            weights_dev.copy_(torch.from_numpy(next_weights()))
         _native.check(lib.rocco_hip_multiply_f64(solver.handle, template_t.data_ptr(), weights_dev.data_ptr(),
                                                  product_t.data_ptr(), n, stream), "rocco_hip_multiply_f64")
         d_mass, d_units, d_fraction, d_tail = _draw_stats(product_t, null_center, soft_scale, null_threshold)
@@ -441,7 +520,7 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
                                         dependence_lag_hint: Optional[int] = None, num_null_draws: int = 25,
                                         random_seed: int = 0, progress_label: Optional[str] = None, num_processes: int = 1,
                                         min_null_draws: Optional[int] = None, stability_abs_tol: float = 5.0e-3,
-                                        stability_rel_tol: float = 5.0e-2) -> Dict[str, Any]:
+                                        stability_rel_tol: float = 5.0e-2, multipliers: Optional[str] = None) -> Dict[str, Any]:
     """Score null of one chromosome by the dependent wild residual bootstrap (rocco/inference.py:719-985).
 
     Same arguments and the same dictionary as the reference's (`observed_scores` comes back as a float64 CUDA tensor).
@@ -494,7 +573,8 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
     look_every = int(max(1, min(max(1, int(num_processes)), max_draws)))  # the reference's pool batch
     draw_min_effect = None if min_effect is None else float(max(min_effect, 0.0))
     mass, units, fraction, tail = _Running(), _Running(), _Running(), _Running()
-    weights_t = torch.empty_like(template_t)
+    on_device = _resolve_multipliers(multipliers) == "device" and n > 1
+    weights_t = None if on_device else torch.empty_like(template_t)  # (device multipliers arrive in their own tensor)
     product_t = torch.empty_like(template_t)
     staging = torch.empty((2, n), dtype=torch.float64).pin_memory()
     copies = [torch.cuda.Event(), torch.cuda.Event()]
@@ -504,7 +584,7 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
     # GIL in their loops), each into a K x n host array, and consumed IN DRAW ORDER, so the running moments see the same
     # sequence.  One worker (`--low_memory`): the rows stream through two pinned rows and no K x n host array exists.
     pool = None
-    if look_every > 1:
+    if look_every > 1 and not on_device:
         import concurrent.futures
 
         pool = concurrent.futures.ThreadPoolExecutor(max_workers=min(look_every, os.cpu_count() or 1), thread_name_prefix="rocco-null")
@@ -529,12 +609,22 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
         batch = list(range(first, min(max_draws, first + look_every)))
         pending, to_submit = {}, list(batch)
         for draw in batch:
-            if pool is not None:
+            made = None
+            if on_device:
+                # the draw's generator is seeded on the host, its stream runs through the rows on the device (normal.hip)
+                made = device_multipliers(np.random.default_rng(int(random_seed) + (104729 * (draw + 1))), K, n, taps)
+            if made is not None:
+                draw_weights = made
+            elif on_device:
+                draw_weights = torch.from_numpy(host_weights(draw)).to(template_t.device)  # (a degenerate row: the reference's own calls)
+            elif pool is not None:
                 while to_submit and len(pending) < inflight:
                     ahead = to_submit.pop(0)
                     pending[ahead] = pool.submit(host_weights, ahead)
                 weights_t.copy_(torch.from_numpy(pending.pop(draw).result()))
+                draw_weights = weights_t
             else:
+                draw_weights = weights_t
                 rng = np.random.default_rng(int(random_seed) + (104729 * (draw + 1)))
                 for row in range(K):  # uploads overlap the next row's generation
                     slot = row & 1
@@ -544,8 +634,9 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
                     weights_t[row].copy_(staging[slot], non_blocking=True)
                     copies[slot].record()
             d_mass, d_units, d_fraction, d_tail = _inf.compute_budget_null_draw_device(
-                template_t, weights_t, lower_bound_z, prior_df, draw_min_effect, floor_ratio, null_center, soft_scale,
+                template_t, draw_weights, lower_bound_z, prior_df, draw_min_effect, floor_ratio, null_center, soft_scale,
                 null_threshold, work_t=product_t)
+            del made, draw_weights
             torch.cuda.current_stream().synchronize()
             mass.add(d_mass)
             units.add(d_units)
@@ -594,7 +685,7 @@ def estimate_budget_nonnull_fraction_from_wild_bootstrap_null(centered_matrix, o
                                                               dependence_lag_hint: Optional[int] = None,
                                                               num_null_draws: int = 25, random_seed: int = 0,
                                                               progress_label: Optional[str] = None, num_processes: int = 1,
-                                                              return_details: bool = False):
+                                                              return_details: bool = False, multipliers: Optional[str] = None):
     """Conservative enriched fraction of a chromosome from its centred K x n matrix (rocco/inference.py:988-1148): the
     tail occupancy of the observed scores above the fitted null's threshold (centre + 2 scale) minus the average of the
     same statistic over dependent-wild-bootstrap draws of the residual template, clipped to [0, 1].
@@ -610,7 +701,7 @@ def estimate_budget_nonnull_fraction_from_wild_bootstrap_null(centered_matrix, o
         centered_t, lower_bound_z=lower_bound_z, prior_df=prior_df, min_effect=min_effect,
         precision_floor_ratio=precision_floor_ratio, observed_scores=observed_scores,
         dependence_lag_hint=dependence_lag_hint, num_null_draws=num_null_draws, random_seed=random_seed,
-        progress_label=progress_label, num_processes=num_processes)
+        progress_label=progress_label, num_processes=num_processes, multipliers=multipliers)
     s_t = null["observed_scores"]
     null_center, null_scale = float(null["null_center"]), float(null["null_scale"])
     soft_scale = float(max(null_scale, 1.0e-6))

@@ -1,0 +1,84 @@
+"""GPU: both budget estimators with the bootstrap multipliers made on the device (`multipliers="device"`,
+rocco_amd/csrc/normal.hip) against the reference-written fixtures.  The innovations are NumPy's own stream (bit for bit
+but for the last place of tail values), the smoothing is a direct sum where the reference calls SciPy's FFT: the
+multipliers agree to ~1e-15 of their scale, so the estimates cannot be the reference's bits.  What must hold: every
+discrete outcome -- draws used, adaptive stop, truncation lag, support sizes, strings -- is the reference's, and every
+statistic is within 1e-9 relative; how many statistics keep their bits is printed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DISCRETE = {"num_null_draws", "max_null_draws", "adaptive_stop", "ess_max_lag", "ess_lags_used", "num_loci",
+            "negative_support_size", "wild_bandwidth", "wild_process", "null_method"}
+
+
+def _against(want, details, name):
+    assert set(details) == set(want), name
+    same, worst = 0, 0.0
+    for key, value in want.items():
+        if isinstance(value, (str, bool)) or key in DISCRETE:
+            assert details[key] == value, (name, key, details[key], value)
+            same += 1
+            continue
+        assert np.isclose(details[key], value, rtol=1e-9, atol=1e-12), (name, key, details[key], value)
+        same += int(details[key] == value)
+        if value != 0.0:
+            worst = max(worst, abs(details[key] - value) / abs(value))
+    return same, len(want), worst
+
+
+def test_count_matrix_estimator_on_the_reference_written_cases(gpu):
+    from rocco_amd.budget import estimate_budget_nonnull_fraction_from_wild_bootstrap_null as estimate
+
+    gold = np.load(os.path.join(HERE, "golden", "wild_bootstrap_vectors.npz"))
+    report = []
+    for name in gold["names"]:
+        kwargs = json.loads(str(gold[f"{name}_kwargs"][0]))
+        observed = gold[f"{name}_observed"] if f"{name}_observed" in gold.files else None
+        fraction, details = estimate(gold[f"{name}_centered"], observed_scores=observed, return_details=True,
+                                     multipliers="device", **kwargs)
+        want = json.loads(str(gold[f"{name}_details"][0]))
+        same, total, worst = _against(want, details, str(name))
+        assert np.isclose(fraction, float(gold[f"{name}_fraction"][0]), rtol=1e-9, atol=1e-12), name
+        report.append((str(name), same, total, worst, fraction == float(gold[f"{name}_fraction"][0])))
+    for row in report:
+        print("wild bootstrap, device multipliers: %-28s %2d / %2d entries keep the reference's bits, worst relative "
+              "difference %.2e, enriched fraction %s" % (row[0], row[1], row[2], row[3], "equal" if row[4] else "differs"))
+
+
+def test_score_track_estimator_on_the_reference_written_tracks(gpu):
+    from rocco_amd.budget import estimate_budget_nonnull_fraction_from_score_track as estimate
+
+    gold = np.load(os.path.join(HERE, "golden", "budget_vectors.npz"))
+    for name in gold["names"]:
+        scores = gold[f"{name}_scores"]
+        draws, hint = (int(v) for v in gold[f"{name}_params"])
+        fraction, details = estimate(scores, dependence_lag_hint=None if hint < 0 else hint, num_null_draws=draws,
+                                     return_details=True, multipliers="device")
+        want = json.loads(str(gold[f"{name}_details"][0]))
+        same, total, worst = _against(want, details, str(name))
+        assert np.isclose(fraction, float(gold[f"{name}_fraction"][0]), rtol=1e-9, atol=1e-12), name
+        print("score track, device multipliers: %-24s %2d / %2d entries keep the reference's bits, worst relative "
+              "difference %.2e" % (str(name), same, total, worst))
+
+
+def test_environment_switch_and_bad_value(gpu, monkeypatch):
+    from rocco_amd import budget
+
+    rng = np.random.default_rng(3)
+    scores = rng.normal(0.0, 1.0, 20000)
+    host = budget.estimate_budget_nonnull_fraction_from_score_track(scores, num_null_draws=6, return_details=True)
+    monkeypatch.setenv("ROCCO_BUDGET_MULTIPLIERS", "device")
+    dev = budget.estimate_budget_nonnull_fraction_from_score_track(scores, num_null_draws=6, return_details=True)
+    assert np.isclose(dev[0], host[0], rtol=1e-9, atol=1e-12) and dev[1]["num_null_draws"] == host[1]["num_null_draws"]
+    # an explicit argument wins over the environment
+    again = budget.estimate_budget_nonnull_fraction_from_score_track(scores, num_null_draws=6, return_details=True,
+                                                                     multipliers="host")
+    assert again[0] == host[0] and again[1] == host[1]
+    with pytest.raises(ValueError):
+        budget.estimate_budget_nonnull_fraction_from_score_track(scores, num_null_draws=6, multipliers="gpu")
