@@ -239,6 +239,62 @@ def _resolve_multipliers(multipliers: Optional[str]) -> str:
     return choice
 
 
+class TrackWeightsAhead:
+    """The multipliers of ONE score track's bootstrap draws, made on host threads ahead of their use.
+
+    The draws of a track share one generator (rocco/inference.py:1195-1213), so their normals are drawn one after the
+    other; what costs -- SciPy's FFT convolution, 2.5 s per draw of a 5 M-locus track against 0.07 s for its normals --
+    does not touch the generator and runs in `ahead` threads, up to that many draws before the one being consumed.  A
+    draw whose smoothed series is degenerate takes signs from the generator BEFORE the next draw's normals: the
+    generator is put back to that draw's start and the rest runs in sequence.  Draws past the stopping rule's verdict
+    are wasted host work, nothing else.  The object starts filling when it is made: the composed driver makes the
+    next chromosomes' objects while the current chromosome's estimate runs (rocco_amd/rocco.py)."""
+
+    def __init__(self, n_loci: int, dependence_lag_hint: Optional[int], max_draws: int, random_seed: int = 0, ahead: int = 1):
+        self.n = int(n_loci)
+        self.taps = _build_budget_bootstrap_kernel(_resolve_budget_bootstrap_bandwidth(self.n, dependence_lag_hint))
+        self.max_draws = int(max(1, max_draws))
+        self.rng = np.random.default_rng(int(random_seed))
+        self.ahead = int(max(1, ahead)) if self.n > 1 else 1
+        self.issued = 0
+        self.queue = []
+        self.pool = None
+        if self.ahead > 1:
+            import concurrent.futures
+            import os
+
+            self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=min(self.ahead, os.cpu_count() or 1),
+                                                              thread_name_prefix="rocco-null")
+            self._fill()
+
+    def _fill(self) -> None:
+        width = self.n + self.taps.size - 1
+        while self.issued < self.max_draws and len(self.queue) < self.ahead:
+            state = self.rng.bit_generator.state
+            self.queue.append((state, self.pool.submit(_smooth_and_standardise, self.rng.standard_normal(width), self.taps)))
+            self.issued += 1
+
+    def next(self) -> np.ndarray:
+        if self.pool is None:
+            return _generate_dependent_wild_weights(self.n, self.taps, self.rng)
+        self._fill()
+        state, future = self.queue.pop(0)
+        weights = future.result()
+        if weights is None:  # degenerate: back to this draw's start, in sequence from here on
+            self.close()
+            self.rng.bit_generator.state = state
+            return _generate_dependent_wild_weights(self.n, self.taps, self.rng)
+        return weights
+
+    def close(self) -> None:
+        if self.pool is not None:
+            for _state, later in self.queue:
+                later.cancel()
+            self.queue.clear()
+            self.pool.shutdown(wait=True)
+            self.pool = None
+
+
 class _Running:
     """Welford mean / sum of squared deviations (rocco/inference.py:578-590)."""
 
@@ -313,11 +369,12 @@ def estimate_budget_nonnull_fraction_from_score_track(score_track, dependence_la
                                                       progress_label: Optional[str] = None, num_processes: int = 1,
                                                       return_details: bool = False, min_null_draws: Optional[int] = None,
                                                       stability_abs_tol: float = 5.0e-3, stability_rel_tol: float = 5.0e-2,
-                                                      multipliers: Optional[str] = None):
+                                                      multipliers: Optional[str] = None, weights_source=None):
     """Conservative enriched fraction of a score track (rocco/inference.py:1312-1421): tail occupancy of the observed
     scores above the null's threshold minus that of dependent-wild-bootstrap draws of the one-sided residual track.
     `score_track`: NumPy array or float64 CUDA tensor.  Same return value and details keys as the reference.
-    `multipliers` (not in the reference): see `_resolve_multipliers`."""
+    `multipliers` (not in the reference): see `_resolve_multipliers`.  `weights_source` (not in the reference): a
+    `TrackWeightsAhead` made for this track earlier, whose host threads have been filling it since."""
     import torch
 
     s_t = _as_score_tensor(score_track)
@@ -356,45 +413,19 @@ def estimate_budget_nonnull_fraction_from_score_track(score_track, dependence_la
     max_draws = int(max(1, num_null_draws))
     min_draws = int(min(max_draws, max(4, 8 if min_null_draws is None else min_null_draws)))
     mass, units, fraction, tail = _Running(), _Running(), _Running(), _Running()
-    rng = np.random.default_rng(int(random_seed))
     product_t = torch.empty_like(s_t)
     weights_dev = torch.empty_like(s_t)
-    # The draws share ONE generator, so their normals come one after the other; what costs (SciPy's FFT convolution: 2.5 s per
-    # draw of a 5 M-locus track against 0.07 s for its normals) does not touch the generator and runs in `num_processes`
-    # host threads, up to that many draws ahead of the one being consumed.  A draw whose smoothed series is degenerate
-    # takes signs from the generator BEFORE the next draw's normals: the generator is put back to that draw's start and
-    # the rest runs in sequence.  (Draws past the stopping rule's verdict are wasted host work, nothing else.)
+    # Host multipliers come from a `TrackWeightsAhead` (made here, or handed in by a caller that started it earlier);
+    # device multipliers (normal.hip) continue the same generator on the device, draw after draw.
     on_device = _resolve_multipliers(multipliers) == "device" and n > 1
-    ahead = int(max(1, num_processes)) if (n > 1 and not on_device) else 1
-    pool, queue = None, []
-    if ahead > 1:
-        import concurrent.futures
-        import os
-
-        pool = concurrent.futures.ThreadPoolExecutor(max_workers=min(ahead, os.cpu_count() or 1), thread_name_prefix="rocco-null")
-    taps64 = np.asarray(taps, dtype=np.float64)
-    issued = 0
-
-    def next_weights():
-        nonlocal pool, issued
-        if pool is None:
-            return _generate_dependent_wild_weights(n, taps, rng)
-        while issued < max_draws and len(queue) < ahead:
-            state = rng.bit_generator.state
-            queue.append((state, pool.submit(_smooth_and_standardise, rng.standard_normal(n + taps64.size - 1), taps64)))
-            issued += 1
-        state, future = queue.pop(0)
-        weights = future.result()
-        if weights is None:  # degenerate: back to this draw's start, in sequence from here on
-            for _state, later in queue:
-                later.cancel()
-            queue.clear()
-            pool.shutdown(wait=True)
-            pool = None
-            rng.bit_generator.state = state
-            return _generate_dependent_wild_weights(n, taps, rng)
-        return weights
-
+    source = weights_source
+    if source is None:
+        source = TrackWeightsAhead(n, dependence_lag_hint, max_draws, random_seed=random_seed,
+                                   ahead=1 if on_device else int(max(1, num_processes)))
+    elif source.n != n or source.max_draws != max_draws or not np.array_equal(source.taps, taps):
+        raise ValueError("`weights_source` was made for another track")
+    rng = source.rng
+    next_weights = source.next
     for _draw in range(max_draws):
         made = device_multipliers(rng, 1, n, taps) if on_device else None  # (None: degenerate, generator put back)
         if made is not None:
@@ -410,10 +441,7 @@ def estimate_budget_nonnull_fraction_from_score_track(score_track, dependence_la
         tail.add(d_tail)
         if _stable_enough(units, min_draws, stability_abs_tol, stability_rel_tol):
             break
-    if pool is not None:
-        for _state, later in queue:
-            later.cancel()
-        pool.shutdown(wait=True)
+    source.close()
     draws_used = units.count
 
     # ---- observed side and the effective sample size (rocco/inference.py:1340-1366) ----

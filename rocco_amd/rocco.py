@@ -558,107 +558,192 @@ def _matrix_to_device(chrom_matrix):
     return torch.from_numpy(np.ascontiguousarray(arr)).to(f"cuda:{_dp._device_index()}")
 
 
-def _median_scores_resident(chrom_matrix, method="quantile", quantile=0.50, power=1.0):
-    """The cache's bigWig scoring call (rocco/rocco.py:983-991) with the result left in HBM."""
-    matrix_t = _matrix_to_device(chrom_matrix)
-    if matrix_t.ndim != 2:
-        raise ValueError("`chrom_matrix` must be a 2D array.")
-    if matrix_t.shape[0] == 1:
-        import torch
+class _CachePlan:
+    """What one cache build reads from `args`, read once (rocco/rocco.py:939-947, 1010-1048)."""
 
-        return matrix_t[0].to(torch.float64).contiguous()  # one track: the row itself (rocco/rocco.py:254-255)
-    return score_central_tendency_chrom_device(matrix_t)
+    def __init__(self, args: dict):
+        self.bigwig = args["input_track_type"] == "bigwig"
+        self.low_memory = bool(args.get("low_memory", False))
+        self.draws = args["budget_null_draws"]
+        workers = 1 if self.low_memory else _resolve_parallel_process_count(int(self.draws), int(args["threads"]))
+        self.null_processes = min(int(self.draws), int(workers))
+        self.wls = dict(lower_bound_z=args["score_lower_bound_z"], prior_df=args["score_prior_df"],
+                        min_effect=args.get("score_min_effect"), precision_floor_ratio=args["score_precision_floor_ratio"])
+        self.multipliers = args.get("budget_null_multipliers")  # None: the estimators' default (host)
+        self.narrow_peak = bool(args.get("narrowPeak", False)) and not self.bigwig
 
 
-def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> dict:
-    """rocco/rocco.py:933-1110 for matrices in memory: per chromosome the scores (bigWig tracks: column median; count
-    matrices: the WLS score), the data-driven budget estimate with its metadata, the switch cost, and the narrowPeak
-    summit track when asked for.  Same keys as the reference's cache; "scores" is a NumPy array that keeps its copy in
-    HBM (`dp.ResidentArray`), so the solve does not upload it again.  `generate_chrom_matrix`, `score_loci_wls` and the
-    two budget estimators are taken from this module's namespace when called, as in the reference."""
-    from . import budget as _budget
-
-    this = globals()
-    chrom_cache = {}
-    low_memory = bool(args.get("low_memory", False))
-    budget_null_processes = 1 if low_memory else _resolve_parallel_process_count(int(args["budget_null_draws"]),
-                                                                                 int(args["threads"]))
-    null_processes = min(int(args["budget_null_draws"]), int(budget_null_processes))
-    for chrom_ in chroms_to_process:
-        logger.info("Generating chromosome matrix: %s", chrom_)
-        chrom_intervals, chrom_matrix = this["generate_chrom_matrix"](
-            chrom_, signal_inputs, args.get("chrom_sizes_file"), args.get("step"),
+def _gather_chromosomes(chroms_to_process: list, signal_inputs, args: dict, plan: _CachePlan, generate):
+    """Every chromosome's (name, locus starts, matrix in HBM), in the caller's order: the reference's call of
+    `generate_chrom_matrix` with the reference's keywords, its skip of chromosomes without data and its finiteness check
+    (rocco/rocco.py:948-974).  A generator: under `--low_memory` the caller holds one matrix at a time."""
+    for name in chroms_to_process:
+        logger.info("Generating chromosome matrix: %s", name)
+        starts, matrix = generate(
+            name, signal_inputs, args.get("chrom_sizes_file"), args.get("step"),
             round_digits=args.get("round_digits"), effective_genome_size=args.get("effective_genome_size"),
             norm_method=args.get("norm_method"), min_mapping_score=args.get("min_mapping_score"),
             flag_include=args.get("flag_include"), flag_exclude=args.get("flag_exclude"),
             extend_reads=args.get("extend_reads"), center_reads=args.get("center_reads"),
             ignore_for_norm=args.get("ignore_for_norm"), scale_factor=args.get("scale_factor"),
-            num_processors=args.get("threads"), low_memory=low_memory)
-        if chrom_intervals is None or chrom_matrix is None:
-            logger.warning("Skipping chromosome %s... no data found.", chrom_)
+            num_processors=args.get("threads"), low_memory=plan.low_memory)
+        if starts is None or matrix is None:
+            logger.warning("Skipping chromosome %s... no data found.", name)
             continue
-        logger.info("Chromosome %s matrix: %s", chrom_, tuple(chrom_matrix.shape))
-        if not _all_finite(chrom_matrix):
-            raise ValueError(f"{chrom_} matrix contains non-finite values")
-        if args["input_track_type"] == "bigwig":
-            if chrom_matrix.shape[0] > 1:
-                logger.warning("Multiple bigwig tracks detected for %s: aggregated by the column-wise median, not WLS.", chrom_)
-            chrom_scores = _median_scores_resident(chrom_matrix, method="quantile", quantile=0.50, power=1.0)
-            if not _all_finite(chrom_scores):
-                raise ValueError(f"{chrom_} direct scores contain non-finite values")
-            score_details = {"mean": chrom_scores}
-            chrom_scores = _host_scores(chrom_scores)
-            budget_fraction_hat, budget_rate_meta = this["estimate_budget_nonnull_fraction_from_score_track"](
-                chrom_scores, num_null_draws=args["budget_null_draws"], progress_label=f"Budget null {chrom_}",
-                num_processes=null_processes, return_details=True)
-        else:
-            chrom_scores, score_details = this["score_loci_wls"](
-                _matrix_to_device(chrom_matrix), lower_bound_z=args["score_lower_bound_z"],
-                prior_df=args["score_prior_df"], min_effect=args.get("score_min_effect"),
-                precision_floor_ratio=args["score_precision_floor_ratio"], low_memory=low_memory, return_details=True,
-                resident=True)
-            if not _all_finite(chrom_scores):
-                raise ValueError(f"{chrom_} scores contain non-finite values")
-            centered_matrix = score_details.pop("centered_matrix")
-            if not _all_finite(centered_matrix):
-                raise ValueError(f"{chrom_} centered matrix contains non-finite values")
-            chrom_scores = _host_scores(chrom_scores)
-            budget_fraction_hat, budget_rate_meta = this["estimate_budget_nonnull_fraction_from_wild_bootstrap_null"](
-                centered_matrix, observed_scores=chrom_scores, lower_bound_z=args["score_lower_bound_z"],
-                prior_df=args["score_prior_df"], min_effect=args.get("score_min_effect"),
-                precision_floor_ratio=args["score_precision_floor_ratio"],
-                dependence_lag_hint=max(25, int(score_details.get("local_baseline_window", 101))),
-                num_null_draws=args["budget_null_draws"], progress_label=f"Budget null {chrom_}",
-                num_processes=null_processes, return_details=True)
-            del centered_matrix
-        del chrom_matrix
-        if not np.isfinite(budget_fraction_hat):
-            raise ValueError(f"{chrom_} budget estimate is not finite")
-        n_loci = int(chrom_scores.shape[0])
-        budget_total_count_hat = float(np.clip(budget_rate_meta.get("effective_total_count", n_loci), 1.0, n_loci))
-        budget_count_hat = float(np.clip(budget_fraction_hat * budget_total_count_hat, 0.0, budget_total_count_hat))
-        logger.info("%s raw budget estimate: %s", chrom_, budget_rate_meta)
-        chrom_gamma, gamma_meta = _budget._resolve_chrom_gamma(chrom_, args, chrom_scores, budget_rate_meta)
-        chrom_cache[chrom_] = {
-            "intervals": chrom_intervals,
-            "scores": chrom_scores,
-            "effect_mean": score_details.get("mean", chrom_scores),
-            "gamma": chrom_gamma,
-            "gamma_meta": gamma_meta,
-            "budget_count_hat": float(budget_count_hat),
-            "budget_fraction_hat": float(budget_fraction_hat),
-            "budget_rate_meta": budget_rate_meta,
-            "total_count": float(budget_total_count_hat),
-            "num_loci": n_loci,
-        }
-    if args.get("narrowPeak", False) and args["input_track_type"] == "bam":
-        for chrom_, chrom_data in chrom_cache.items():
-            effect = chrom_data["effect_mean"]
+        logger.info("Chromosome %s matrix: %s", name, tuple(matrix.shape))
+        if not _all_finite(matrix):
+            raise ValueError(f"{name} matrix contains non-finite values")
+        if plan.bigwig and matrix.shape[0] > 1:
+            logger.warning("Multiple bigwig tracks detected for %s: aggregated by the column-wise median, not WLS.", name)
+        yield name, starts, _matrix_to_device(matrix)
+
+
+def _score_gathered(batch: list, plan: _CachePlan, own_wls: bool, wls):
+    """Scores (and, for count matrices, the details with the centred matrix) of the gathered chromosomes, all of them on
+    the device at once: bigWig tracks -- every column median of the batch in ONE launch (rocco_hip_score_median_batch; a
+    single track is its own score, rocco/rocco.py:254-255); count matrices -- ONE `score_loci_wls_batch_device` call,
+    which shares the baseline and rolling launches between the chromosomes.  `wls` replaced by
+    the caller (the reference's tests do): one call per matrix through it, with the reference's keywords."""
+    import torch
+
+    from . import inference as _inf
+
+    if plan.bigwig:
+        scores = [None] * len(batch)
+        many = [i for i, (_n, _s, m) in enumerate(batch) if m.ndim == 2 and m.shape[0] > 1]
+        for i, (_n, _s, m) in enumerate(batch):
+            if m.ndim != 2:
+                raise ValueError("`chrom_matrix` must be a 2D array.")
+            if m.shape[0] == 1:
+                scores[i] = m[0].to(torch.float64).contiguous()
+        if many:
+            for i, out in zip(many, score_central_tendency_chrom_batch_device([batch[i][2] for i in many])):
+                scores[i] = out
+        return [(s_t, {"mean": s_t}) for s_t in scores]
+    if own_wls and len(batch) > 1 and not plan.low_memory:
+        mats = []
+        for _n, _s, m in batch:
+            if m.ndim != 2:
+                raise ValueError("`chrom_matrix` must be two-dimensional")
+            mats.append(m.to(torch.float64).contiguous())
+        return _inf.score_loci_wls_batch_device(mats, overwrite_input=True, **plan.wls)
+    return [wls(m, low_memory=plan.low_memory, return_details=True, resident=True, **plan.wls) if own_wls else
+            wls(m, low_memory=plan.low_memory, return_details=True, **plan.wls) for _n, _s, m in batch]
+
+
+def _batches_within_memory(items, plan: _CachePlan):
+    """The gathered chromosomes in batches the device can score at once: a count matrix needs about four times its size
+    beside itself while it is scored (log scale, baselines, rank finder, dealing), and its centred matrix stays until its
+    budget estimate is done; a bigWig batch only its scores.  `--low_memory`: one chromosome at a time."""
+    import torch
+
+    batch, held = [], 0
+    for item in items:
+        size = int(item[2].numel()) * 8
+        if batch:
+            free, _total = torch.cuda.mem_get_info(item[2].device)
+            room = free + held  # (what the batch holds so far is counted as held, the rest must fit beside it)
+            if plan.low_memory or (not plan.bigwig and 5 * (held + size) > room) or (plan.bigwig and held + size > room):
+                yield batch
+                batch, held = [], 0
+        batch.append(item)
+        held += size
+    if batch:
+        yield batch
+
+
+def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> dict:
+    """The chromosome cache of rocco/rocco.py:933-1110 for matrices in memory, built the way a GPU wants it built:
+    the matrices are gathered first; ALL chromosomes of a batch are scored by one device call (one median launch, or one
+    batched WLS scoring); then the budget estimates run chromosome after chromosome with the NEXT chromosomes' bootstrap
+    multipliers already being made on host threads (`budget.TrackWeightsAhead`), or with the multipliers made on the
+    device (`args["budget_null_multipliers"] = "device"`, normal.hip); then switch costs and summit tracks.  Same keys
+    and values as the reference's cache ("scores" is a NumPy array that keeps its copy in HBM, `dp.ResidentArray`); the
+    reference's checks, with its messages, in its order within each phase.  `generate_chrom_matrix`, `score_loci_wls`
+    and the two budget estimators are taken from this module's namespace when called, as the reference's tests replace
+    them there; a replaced one is called exactly as the reference calls it."""
+    from . import budget as _budget
+    from . import inference as _inf
+
+    this = globals()
+    plan = _CachePlan(args)
+    wls = this["score_loci_wls"]
+    track_estimate = this["estimate_budget_nonnull_fraction_from_score_track"]
+    count_estimate = this["estimate_budget_nonnull_fraction_from_wild_bootstrap_null"]
+    own_track = track_estimate is _budget.estimate_budget_nonnull_fraction_from_score_track
+    own_count = count_estimate is _budget.estimate_budget_nonnull_fraction_from_wild_bootstrap_null
+    host_multipliers = _budget._resolve_multipliers(plan.multipliers) == "host"
+    cache = {}
+    gathered = _gather_chromosomes(chroms_to_process, signal_inputs, args, plan, this["generate_chrom_matrix"])
+    for batch in _batches_within_memory(gathered, plan):
+        scored = _score_gathered(batch, plan, wls is _inf.score_loci_wls, wls)
+        # the reference's checks on what the scoring returned, chromosome by chromosome (rocco/rocco.py:992, 1019, 1024)
+        ready = []
+        for (name, starts, _matrix), (scores, details) in zip(batch, scored):
+            if not _all_finite(scores):
+                raise ValueError(f"{name} direct scores contain non-finite values" if plan.bigwig
+                                 else f"{name} scores contain non-finite values")
+            centred = None
+            if not plan.bigwig:
+                centred = details.pop("centered_matrix")
+                if not _all_finite(centred):
+                    raise ValueError(f"{name} centered matrix contains non-finite values")
+            ready.append((name, starts, _host_scores(scores), details, centred))
+        del batch, scored
+        # multipliers of the coming score tracks, made ahead on host threads while earlier estimates run
+        ahead = {}
+        depth = max(1, min(8, (os.cpu_count() or 1) // max(1, plan.null_processes)))
+
+        def start_ahead(upto):
+            for j in range(min(upto, len(ready))):
+                if j not in ahead and plan.bigwig and own_track and host_multipliers and plan.null_processes > 1:
+                    ahead[j] = _budget.TrackWeightsAhead(int(ready[j][2].shape[0]), None, int(max(1, plan.draws)),
+                                                         random_seed=0, ahead=plan.null_processes)
+
+        try:
+            for i, (name, starts, scores, details, centred) in enumerate(ready):
+                start_ahead(i + 1 + depth)
+                extra = {} if plan.multipliers is None else {"multipliers": plan.multipliers}
+                if plan.bigwig:
+                    if own_track and i in ahead:
+                        extra["weights_source"] = ahead.pop(i)
+                    fraction, meta = track_estimate(scores, num_null_draws=plan.draws, progress_label=f"Budget null {name}",
+                                                    num_processes=plan.null_processes, return_details=True,
+                                                    **(extra if own_track else {}))
+                else:
+                    fraction, meta = count_estimate(
+                        centred, observed_scores=scores, dependence_lag_hint=max(25, int(details.get("local_baseline_window", 101))),
+                        num_null_draws=plan.draws, progress_label=f"Budget null {name}", num_processes=plan.null_processes,
+                        return_details=True, **plan.wls, **(extra if own_count else {}))
+                    centred = None
+                    ready[i] = (name, starts, scores, details, None)  # the centred matrix goes as soon as its estimate is done
+                if not np.isfinite(fraction):
+                    raise ValueError(f"{name} budget estimate is not finite")
+                n_loci = int(scores.shape[0])
+                total = float(np.clip(meta.get("effective_total_count", n_loci), 1.0, n_loci))
+                logger.info("%s raw budget estimate: %s", name, meta)
+                gamma, gamma_meta = _budget._resolve_chrom_gamma(name, args, scores, meta)
+                cache[name] = {
+                    "intervals": starts,
+                    "scores": scores,
+                    "effect_mean": details.get("mean", scores),
+                    "gamma": gamma,
+                    "gamma_meta": gamma_meta,
+                    "budget_count_hat": float(np.clip(fraction * total, 0.0, total)),
+                    "budget_fraction_hat": float(fraction),
+                    "budget_rate_meta": meta,
+                    "total_count": total,
+                    "num_loci": n_loci,
+                }
+        finally:
+            for source in ahead.values():
+                source.close()
+    for name, entry in cache.items():
+        effect = entry.pop("effect_mean", None)
+        if plan.narrow_peak:
             effect = effect.cpu().numpy() if _dp._is_tensor(effect) else np.asarray(effect, dtype=np.float64)
-            chrom_data["summit_track_file"] = _cpy_narrowpeak_summit_track(chrom_, chrom_data["intervals"], effect)
-    for chrom_data in chrom_cache.values():
-        chrom_data.pop("effect_mean", None)
-    return chrom_cache
+            entry["summit_track_file"] = _cpy_narrowpeak_summit_track(name, entry["intervals"], effect)
+    return cache
 
 
 def _resolve_budgets(chrom_cache: dict, args: dict):
@@ -717,9 +802,8 @@ def _run_chromosomes_sharded(chroms_to_process: list, signal_inputs, args: dict,
     chrom_budgets, _ = this["_resolve_budgets"](pooled_view, args)
     solved = solve_cached_chromosomes(chrom_cache, {c: chrom_budgets[c] for c in chrom_cache},
                                       selection_penalty=args["selection_penalty"], min_length_bp=args["min_length_bp"],
-                                      run_id=run_id, write_files=False)
-    rows = [(unit_of[chrom_], int(start), int(end)) for chrom_, _objective, _details, records in solved for _c, start, end in records]
-    rows_t = torch.tensor(rows, dtype=torch.int64, device=exchange_device).reshape(-1, 3)
+                                      run_id=run_id, write_files=False, rows_for_units=unit_of)
+    rows_t = solved.rows.to(exchange_device)  # (unit, start, end) in base pairs: the decode's own table, never a Python list
     everyone = _shard.gather_interval_rows(rows_t, group=group)
     if rank == 0:
         files = []
@@ -779,14 +863,74 @@ def run_chromosomes(chroms_to_process: list, signal_inputs, args: dict, run_id: 
 # per-rank solve driver
 # --------------------------------------------------------------------------------------------
 
+class _Solved(list):
+    """The list `solve_cached_chromosomes` returns; `rows` (with `rows_for_units`): every chromosome's merged intervals as
+    one int64 CUDA tensor of (unit, start, end) rows in base pairs."""
+    rows = None
+
+
+def _interval_rows_device(chroms, chrom_cache, solutions, unit_of, min_length_bp):
+    """(unit, start bp, end bp) rows of the solved chromosomes, made on the device from the decode's table of (unit, first
+    locus, locus behind the last) rows: a chromosome's locus starts are equally spaced (checked, as
+    chrom_solution_to_bed checks them), so a locus index becomes base pairs by one multiply-add per row.  Chromosomes
+    whose starts are not equally spaced and increasing take the per-chromosome route and are appended."""
+    import torch
+
+    dev = solutions[0].device
+    regular, odd_rows = [], []
+    first_bp, step_bp = {}, {}
+    for chrom, sol_t in zip(chroms, solutions):
+        starts = np.asarray(chrom_cache[chrom]["intervals"])
+        if int(starts.shape[0]) != int(sol_t.shape[0]):
+            raise ValueError("Intervals and solution must have the same length at the pre-merge stage: "
+                             f"{int(starts.shape[0])} != {int(sol_t.shape[0])}")
+        diffs = np.diff(starts) if starts.shape[0] > 1 else np.zeros(0, dtype=np.int64)
+        if diffs.size and np.any(diffs != diffs[0]):
+            raise ValueError(f"Intervals must be contiguous: {set(diffs.tolist())}")
+        if diffs.size and diffs[0] <= 0:
+            records = chrom_solution_records(chrom, starts, sol_t, check_gaps_intervals=True, min_length_bp=min_length_bp)
+            odd_rows.extend((unit_of[chrom], int(a), int(b)) for _c, a, b in records)
+            continue
+        regular.append((chrom, sol_t))
+        first_bp[unit_of[chrom]] = int(starts[0]) if starts.shape[0] else 0
+        step_bp[unit_of[chrom]] = int(diffs[0]) if diffs.size else 0
+    tables = []
+    for at in range(0, len(regular), 48):
+        part = regular[at:at + 48]
+        table_t, _offsets, _host = decode_runs_table_device([sol_t for _c, sol_t in part], units=[unit_of[c] for c, _s in part],
+                                                            to_host=False)
+        tables.append(table_t)
+    if tables:
+        table_t = torch.cat(tables, dim=0) if len(tables) > 1 else tables[0]
+        size = max(unit_of.values()) + 1
+        first_t = torch.zeros(size, dtype=torch.int64, device=dev)
+        step_t = torch.zeros(size, dtype=torch.int64, device=dev)
+        for unit, value in first_bp.items():
+            first_t[unit] = value
+            step_t[unit] = step_bp[unit]
+        unit_col = table_t[:, 0]
+        # the locus behind a run's last one exists (the chain's last locus is never reported selected, rocco/rocco.py:180)
+        rows = torch.stack([unit_col, first_t[unit_col] + table_t[:, 1] * step_t[unit_col],
+                            first_t[unit_col] + table_t[:, 2] * step_t[unit_col]], dim=1)
+        if min_length_bp is not None:
+            rows = rows[(rows[:, 2] - rows[:, 1]) >= int(min_length_bp)]
+    else:
+        rows = torch.zeros((0, 3), dtype=torch.int64, device=dev)
+    if odd_rows:
+        rows = torch.cat([rows, torch.tensor(odd_rows, dtype=torch.int64, device=dev).reshape(-1, 3)], dim=0)
+    return rows
+
+
 def solve_cached_chromosomes(chrom_cache: Dict[str, dict], chrom_budgets: Dict[str, float],
                              selection_penalty: Optional[float] = None,
                              min_length_bp: Optional[int] = None,
-                             run_id: Optional[str] = None, write_files: bool = True):
+                             run_id: Optional[str] = None, write_files: bool = True, rows_for_units: Optional[dict] = None):
     """Solve every chromosome in `chrom_cache` on the current GPU (rocco/rocco.py:890-930 and
     1146-1196).  `chrom_cache[chrom]` holds "scores" (NumPy or CUDA tensor), "intervals" and
     "gamma" as in the reference's cache.  Returns a list of
-    (chrom, objective, details, bed_path_or_records) in cache order.
+    (chrom, objective, details, bed_path_or_records) in cache order.  With `rows_for_units` (chromosome -> unit number;
+    what the sharded driver passes) no per-chromosome records are made: the list's `rows` attribute holds every
+    interval as a (unit, start, end) row of ONE device table, the form the gather takes.
     """
     import torch
 
@@ -816,7 +960,7 @@ def solve_cached_chromosomes(chrom_cache: Dict[str, dict], chrom_budgets: Dict[s
         gammas.append(gamma)
         targets.append(int(np.floor(int(s_t.shape[0]) * budget)))  # rocco/dp.py:197
 
-    results = []
+    results = _Solved()
     if selection_penalty is None:
         solved = _dp.calibrate_batch_device(scores_list, gammas, targets)
     else:
@@ -833,7 +977,9 @@ def solve_cached_chromosomes(chrom_cache: Dict[str, dict], chrom_budgets: Dict[s
             "selection_penalty": float(penalty),
         }
         data = chrom_cache[chrom]
-        if write_files:
+        if rows_for_units is not None:
+            out = None
+        elif write_files:
             out = chrom_solution_to_bed(chrom, data["intervals"], sol_t, run_id,
                                         check_gaps_intervals=True, min_length_bp=min_length_bp)
         else:
@@ -843,4 +989,7 @@ def solve_cached_chromosomes(chrom_cache: Dict[str, dict], chrom_budgets: Dict[s
                     details["selected_count"], details["selected_fraction"],
                     details["selection_penalty"], objective)
         results.append((chrom, float(objective), details, out))
+    if rows_for_units is not None:
+        results.rows = _interval_rows_device(chroms, chrom_cache, [sol_t for (_p, sol_t, _v, _c, _i) in solved], rows_for_units,
+                                             min_length_bp) if chroms else torch.zeros((0, 3), dtype=torch.int64)
     return results

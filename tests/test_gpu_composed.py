@@ -1,15 +1,19 @@
 """GPU: the composed driver -- rocco_amd.rocco._build_chrom_cache -> _resolve_budgets -> _solve_cached_chromosomes ->
 combine_chrom_results (the device form of rocco/rocco.py:933-1196, 194-240) -- against what the REFERENCE's own
 composition wrote for the same in-memory matrices (tests/golden/make_golden_composed.py, part 2: its
-`generate_chrom_matrix` replaced by the matrices, exactly as its own tests replace it), and the reference's own
-cache-builder tests (tests/test_rocco.py:566-689, 838-897) with their fakes.
+`generate_chrom_matrix` replaced by the matrices, exactly as its own tests replace it), and against the caches the
+reference's builder made of stand-in callables (tests/golden/make_golden_seam.py: the seam its own tests use,
+tests/test_rocco.py:566-689, 838-897).
 
 What must be equal: the scores, the switch costs, every statistic of the budget estimate that does not come from the
 autocorrelation time, every chromosome's BED bytes and the combined BED bytes.  The autocorrelation time comes from an
 FFT in the reference and from lagged products here (1e-9), and the effective totals, pooled budgets and therefore the
-calibrated penalties inherit that last-digit freedom: they are compared at 1e-9.  The `counts_general` fixture starts
-from general integer counts, where the device's correctly rounded log2 and NumPy's log2 differ by one ulp on a small
-share of the entries: its scores are compared at 1e-9 and its BED bytes must still be equal."""
+budgets inherit that last-digit freedom (1e-9).  The solve sees a budget only through floor(n * budget): that integer
+must be the reference's -- how far n * budget lies from the next integer is asserted against the 1e-9 freedom -- and on
+the fixtures whose scores and switch costs are the reference's bits the calibrated penalty must then be the reference's
+double.  `counts_general` starts from general integer counts; they stay below 7957, where the device's correctly rounded
+log2 and this image's np.log2 first differ, so its scores are the reference's bits too;
+its budgets come from `args["budget"]` scaled by the pooled estimate, so its penalties are held to 1e-9."""
 import json
 import os
 
@@ -51,10 +55,7 @@ def test_composed_driver_reproduces_the_references_bed(gpu, gold, fixture, tmp_p
         entry = cache[c]
         want_scores = gold[f"{fixture}_{c}_scores"]
         assert isinstance(entry["scores"], np.ndarray) and entry["scores"].dtype == np.float64
-        if exact:
-            assert np.array_equal(entry["scores"], want_scores), c
-        else:
-            assert np.allclose(entry["scores"], want_scores, rtol=1e-9, atol=1e-12), c
+        assert np.array_equal(entry["scores"], want_scores), c  # (counts_general too: every count is below 7957)
         gamma, count_hat, fraction_hat, total, n_loci, budget = gold[f"{fixture}_{c}_numbers"]
         want_rate = json.loads(str(gold[f"{fixture}_{c}_rate_meta"][0]))
         assert set(entry["budget_rate_meta"]) == set(want_rate), c
@@ -81,14 +82,23 @@ def test_composed_driver_reproduces_the_references_bed(gpu, gold, fixture, tmp_p
         assert open(f).read() == str(gold[f"{fixture}_{c}_bed"][0]), c
     final = impl.combine_chrom_results(files, str(tmp_path / "combined.bed"), name_features=False)
     assert open(final).read() == str(gold[f"{fixture}_combined_bed"][0])
-    # the penalties: the reference's bisection ends within ~1e-11 of a level of the TV-regularised scores, which moves
-    # continuously with the budget's last digits; the selected counts must be the reference's
+    # What the solve sees of a budget is floor(n * budget) (rocco/dp.py:197).  The pooled budgets carry the 1e-9 freedom of
+    # the autocorrelation time; the integer must not: n * budget has to lie further from an integer than that freedom.
     solved = impl.solve_cached_chromosomes(cache, budgets, selection_penalty=None, min_length_bp=args["min_length_bp"],
                                            write_files=False)
     for (c, _objective, details, _records) in solved:
         penalty, count, _obj, _pen = gold[f"{fixture}_{c}_solve"]
+        n_loci, want_budget = int(gold[f"{fixture}_{c}_numbers"][4]), float(gold[f"{fixture}_{c}_numbers"][5])
+        product = n_loci * want_budget
+        assert int(np.floor(n_loci * budgets[c])) == int(np.floor(product)), c
+        clearance = min(product - np.floor(product), np.ceil(product) - product) if product != np.floor(product) else 1.0
+        assert clearance > 1.0e3 * (1.0e-9 * product), (c, product, clearance)  # three orders above the tolerance's reach
         assert details["selected_count"] == int(count), c
-        assert np.isclose(details["selection_penalty"], penalty, rtol=1e-6, atol=1e-9), c
+        if exact:
+            # same scores, same switch cost, same target count: the calibration is the reference's, step for step
+            assert details["selection_penalty"] == penalty, (c, details["selection_penalty"], penalty)
+        else:
+            assert np.isclose(details["selection_penalty"], penalty, rtol=1e-9, atol=1e-12), c
 
 
 def test_run_chromosomes_end_to_end_and_cleans_up(gpu, gold, tmp_path, monkeypatch):
@@ -131,97 +141,77 @@ def test_composed_driver_against_the_oracle_on_fresh_matrices(gpu, oracle, tmp_p
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# the reference's own cache-builder tests, with its fakes (tests/test_rocco.py:566-689, 838-897)
+# the seam: stand-in callables in the module namespace (tests/golden/make_golden_seam.py ran the reference on the same)
 # ------------------------------------------------------------------------------------------------------------------
-REFERENCE_TEST_ARGS = {
-    "chrom_sizes_file": None, "step": 50, "round_digits": 5, "effective_genome_size": None, "norm_method": "rpkm",
-    "min_mapping_score": 0, "flag_include": None, "flag_exclude": None, "extend_reads": 0, "center_reads": False,
-    "ignore_for_norm": [], "scale_factor": 1.0, "threads": 1, "input_track_type": "bam", "score_lower_bound_z": 1.0,
-    "score_prior_df": 5.0, "score_precision_floor_ratio": 0.01, "budget_null_draws": 4,
-}
+SEAM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seam_vectors.npz")
 
 
-def test_build_chrom_cache_uses_global_fixed_gamma(gpu, monkeypatch):
+def _stand_ins(seam, name, chroms, seen):
+    """The scenario's three callables, made from its data; every call notes the keyword names it was given."""
+    data = {}
+    for c in chroms:
+        if f"{name}_{c}_starts" in seam.files:
+            fake = json.loads(str(seam[f"{name}_{c}_fake"][0]))
+            data[c] = dict(starts=seam[f"{name}_{c}_starts"], matrix=seam[f"{name}_{c}_matrix"], fraction=fake["fraction"],
+                           meta=fake["meta"], window=fake["window"],
+                           scores=seam[f"{name}_{c}_fake_scores"] if f"{name}_{c}_fake_scores" in seam.files else None,
+                           mean=seam[f"{name}_{c}_fake_mean"] if f"{name}_{c}_fake_mean" in seam.files else None)
+
+    def generate(chrom, *a, **k):
+        seen["generate"].append(sorted(k))
+        entry = data.get(chrom)
+        return (None, None) if entry is None else (entry["starts"].copy(), entry["matrix"].copy())
+
+    def wls(matrix, **k):
+        seen["wls"].append(sorted(k))
+        entry = next(e for e in data.values() if tuple(e["matrix"].shape) == tuple(matrix.shape))
+        return entry["scores"].copy(), {"centered_matrix": np.zeros_like(entry["matrix"]), "local_baseline_window": entry["window"],
+                                        "mean": entry["mean"].copy()}
+
+    def estimate(first, *a, **k):
+        seen["estimate"].append(sorted(k))
+        n = np.asarray(k.get("observed_scores", first)).shape[-1]
+        entry = next(e for e in data.values() if len(e["starts"]) == n)
+        return entry["fraction"], dict(entry["meta"])
+
+    return generate, wls, estimate
+
+
+def test_cache_built_from_stand_ins_is_the_references(gpu, monkeypatch):
     from rocco_amd import rocco as impl
 
-    chrom_lengths = {"chr_small": 120, "chr_big": 240}
-
-    def fake_generate_chrom_matrix(chrom, *args, **kwargs):
-        n = chrom_lengths[chrom]
-        return np.arange(n, dtype=float), np.zeros((n, 2), dtype=float)
-
-    def fake_score_loci_wls(chrom_matrix, **kwargs):
-        n = chrom_matrix.shape[0]
-        return np.linspace(0.0, 3.0, n, dtype=float), {"centered_matrix": np.zeros((n, 2), dtype=float),
-                                                       "local_baseline_window": 101,
-                                                       "mean": np.linspace(10.0, 13.0, n, dtype=float)}
-
-    def fake_budget_estimator(centered_matrix, observed_scores, **kwargs):
-        return 0.05, {"effective_total_count": float(observed_scores.shape[0])}
-
-    monkeypatch.setattr(impl, "generate_chrom_matrix", fake_generate_chrom_matrix)
-    monkeypatch.setattr(impl, "score_loci_wls", fake_score_loci_wls)
-    monkeypatch.setattr(impl, "estimate_budget_nonnull_fraction_from_wild_bootstrap_null", fake_budget_estimator)
-    chrom_cache = impl._build_chrom_cache(["chr_small", "chr_big"], [], dict(REFERENCE_TEST_ARGS, gamma=2.5))
-    assert chrom_cache["chr_small"]["gamma"] == 2.5
-    assert chrom_cache["chr_big"]["gamma"] == 2.5
-    assert chrom_cache["chr_small"]["gamma_meta"] is None
-    assert chrom_cache["chr_big"]["gamma_meta"] is None
-
-
-def test_build_chrom_cache_derives_auto_gamma_from_scores_and_autocorrelation(gpu, monkeypatch):
-    from rocco_amd import rocco as impl
-
-    def fake_generate_chrom_matrix(chrom, *args, **kwargs):
-        return np.arange(5, dtype=float), np.zeros((2, 5), dtype=float)
-
-    def fake_score_loci_wls(chrom_matrix, **kwargs):
-        scores = np.array([-1.0, 0.5, 1.5, 2.5, 0.0], dtype=float)
-        return scores, {"centered_matrix": np.zeros((2, 5), dtype=float), "local_baseline_window": 101, "mean": scores.copy()}
-
-    def fake_budget_estimator(centered_matrix, observed_scores, **kwargs):
-        return 0.05, {"effective_total_count": float(observed_scores.shape[0]), "autocorrelation_time": 3.2}
-
-    monkeypatch.setattr(impl, "generate_chrom_matrix", fake_generate_chrom_matrix)
-    monkeypatch.setattr(impl, "score_loci_wls", fake_score_loci_wls)
-    monkeypatch.setattr(impl, "estimate_budget_nonnull_fraction_from_wild_bootstrap_null", fake_budget_estimator)
-    chrom_cache = impl._build_chrom_cache(["chr1"], [], dict(REFERENCE_TEST_ARGS, gamma=None))
-    assert chrom_cache["chr1"]["gamma"] == pytest.approx(3.0)
-    assert chrom_cache["chr1"]["gamma_meta"]["method"] == "auto_score_autocorr"
-    assert chrom_cache["chr1"]["gamma_meta"]["characteristic_run_length"] == 4
-    assert chrom_cache["chr1"]["gamma_meta"]["positive_score_median"] == pytest.approx(1.5)
-
-
-def test_build_chrom_cache_uses_bigwig_scores_directly(gpu, monkeypatch):
-    from rocco_amd import rocco as impl
-
-    direct_budget_calls = []
-
-    def fake_generate_chrom_matrix(chrom, *args, **kwargs):
-        return np.array([0, 50, 100, 150], dtype=int), np.array([[0.0, 2.0, 1.0, 0.0], [0.0, 3.0, 2.0, 0.0]], dtype=float)
-
-    def fail_score_loci_wls(*args, **kwargs):
-        raise AssertionError("bigWig inputs should bypass WLS scoring")
-
-    def fake_budget_estimator(scores, **kwargs):
-        direct_budget_calls.append(np.asarray(scores, dtype=float))
-        return 0.05, {"effective_total_count": float(len(scores))}
-
-    monkeypatch.setattr(impl, "generate_chrom_matrix", fake_generate_chrom_matrix)
-    monkeypatch.setattr(impl, "score_loci_wls", fail_score_loci_wls)
-    monkeypatch.setattr(impl, "estimate_budget_nonnull_fraction_from_score_track", fake_budget_estimator)
-    args = dict(REFERENCE_TEST_ARGS, norm_method="RPGC", input_track_type="bigwig", score_min_effect=None, gamma=3.0)
-    chrom_cache = impl._build_chrom_cache(["chr1"], ["track1.bw", "track2.bw"], args)
-    assert len(direct_budget_calls) == 1
-    assert np.allclose(direct_budget_calls[0], np.array([0.0, 2.5, 1.5, 0.0]))
-    assert np.allclose(chrom_cache["chr1"]["scores"], np.array([0.0, 2.5, 1.5, 0.0]))
-    assert chrom_cache["chr1"]["gamma"] == 3.0
+    seam = np.load(SEAM)
+    assert len(seam["names"]) >= 5
+    for name in (str(v) for v in seam["names"]):
+        args = json.loads(str(seam[f"{name}_args"][0]))
+        chroms = [str(c) for c in seam[f"{name}_chroms"]]
+        seen = {"generate": [], "wls": [], "estimate": []}
+        generate, wls, estimate = _stand_ins(seam, name, chroms, seen)
+        monkeypatch.setattr(impl, "generate_chrom_matrix", generate)
+        monkeypatch.setattr(impl, "score_loci_wls", wls)
+        monkeypatch.setattr(impl, "estimate_budget_nonnull_fraction_from_wild_bootstrap_null", estimate)
+        monkeypatch.setattr(impl, "estimate_budget_nonnull_fraction_from_score_track", estimate)
+        cache = impl._build_chrom_cache(chroms, [], args)
+        assert list(cache) == [str(c) for c in seam[f"{name}_cached"]], name
+        # the stand-ins were called as the reference calls them: as often, with the same keywords
+        assert seen == json.loads(str(seam[f"{name}_seen"][0])), name
+        for c, entry in cache.items():
+            assert sorted(entry) == [str(k) for k in seam[f"{name}_{c}_cache_keys"]], (name, c)
+            assert np.array_equal(np.asarray(entry["scores"]), seam[f"{name}_{c}_cache_scores"]), (name, c)
+            gamma, count_hat, fraction_hat, total, n_loci = seam[f"{name}_{c}_cache_numbers"]
+            assert (entry["gamma"], entry["budget_count_hat"], entry["budget_fraction_hat"], entry["total_count"],
+                    float(entry["num_loci"])) == (gamma, count_hat, fraction_hat, total, n_loci), (name, c)
+            want_meta = json.loads(str(seam[f"{name}_{c}_cache_gamma_meta"][0]))
+            assert (entry["gamma_meta"] is None) == (want_meta is None), (name, c)
+            for key, value in (want_meta or {}).items():
+                assert entry["gamma_meta"][key] == value, (name, c, key)
 
 
 def test_cache_builder_errors(gpu):
     from rocco_amd import rocco as impl
 
-    args = dict(REFERENCE_TEST_ARGS, input_track_type="bigwig", gamma=1.0)
+    args = {"input_track_type": "bigwig", "gamma": 1.0, "threads": 1, "budget_null_draws": 4, "score_lower_bound_z": 1.0,
+            "score_prior_df": 5.0, "score_precision_floor_ratio": 0.01}
     bad = np.ones((2, 50))
     bad[1, 7] = np.nan
     with pytest.raises(ValueError, match="chrQ matrix contains non-finite values"):
