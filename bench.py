@@ -47,6 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--chroms", type=str, default="", help="comma list (default: whole genome)")
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-composed", action="store_true", help="skip the composed-driver leg (next_rows.composed_driver)")
     ap.add_argument("--headline-only", action="store_true",
                     help="the timed steps and their roofline block only (for profiler runs: the kernel statistics then "
                          "hold the steps' launches and nothing else)")
@@ -174,6 +175,105 @@ def rehearse(args, rank, world):
             "shard_loci": [int(sum(sizes[i] for i in part)) for part in owned]}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _composed_driver_leg(args, genome, device, works, mine, po):
+    """`rocco_amd.rocco.run_chromosomes` -- cache (scores, budget estimates, switch costs), pooled budgets, solve, BED text --
+    on the whole genome: K = 10 bigWig-style tracks with the bootstrap multipliers made on the host (the reference's own
+    NumPy / SciPy calls: every statistic bit for bit) and on the device (normal.hip), and K = 100 count matrices with
+    device multipliers; host multipliers of the count branch on one short chromosome only (they take hours on the genome);
+    the oracle's composition (CPU, one chromosome) beside them."""
+    import torch
+
+    from rocco_amd import budget, synth
+    from rocco_amd import inference
+    from rocco_amd import rocco as rr
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import budget_oracle as bo
+
+    base = {"budget_null_draws": 25, "threads": -1, "gamma": None, "budget": None, "scale_chrom_budgets": 1.0,
+            "budget_posterior_quantile": 0.01, "selection_penalty": None, "min_length_bp": None, "score_lower_bound_z": 1.0,
+            "score_prior_df": 5.0, "score_min_effect": None, "score_precision_floor_ratio": 0.01, "low_memory": False,
+            "narrowPeak": False}
+    names = [n for n, _ in genome]
+    total = sum(n for _, n in genome)
+
+    def run(inputs, chroms, track_type, multipliers, tmp):
+        phases, mult = {}, {}
+        budget.collect_timings(mult)
+        run_args = dict(base, input_track_type=track_type, budget_null_multipliers=multipliers, _phase_seconds=phases,
+                        output=os.path.join(tmp, f"{track_type}_{multipliers}.bed"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = rr.run_chromosomes(chroms, inputs, run_args, run_id="b")
+        seconds = time.perf_counter() - t0
+        budget.collect_timings(None)
+        loci = sum(int(inputs[c][1].shape[1]) for c in chroms)
+        cache_s = phases.get("cache_s", 0.0)
+        estimates = phases.get("budget_estimates_s", 0.0)
+        made = mult.get("multipliers_host_s", 0.0) + mult.get("multipliers_device_s", 0.0)
+        return {"seconds": round(seconds, 3), "loci_per_s": round(loci / seconds, 1), "chromosomes": len(chroms), "loci": loci,
+                "multipliers": multipliers, "intervals": sum(1 for _ in open(out)),
+                "split_s": {"matrices_to_device": round(phases.get("gather_s", 0.0), 3), "scoring": round(phases.get("scoring_s", 0.0), 3),
+                            "budget_null_multipliers_" + multipliers: round(made, 3),
+                            "budget_null_device_rest": round(max(0.0, estimates - made), 3),
+                            "switch_costs_and_cache_rest": round(max(0.0, cache_s - phases.get("gather_s", 0.0) - phases.get("scoring_s", 0.0) - estimates), 3),
+                            "pooled_budgets": round(phases.get("pooled_budgets_s", 0.0), 3),
+                            "solve_and_chromosome_bed_text": round(phases.get("solve_and_chromosome_files_s", 0.0), 3),
+                            "combined_bed_text": round(phases.get("combine_s", 0.0), 3)}}, out
+
+    leg = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory(prefix="rocco_composed_") as tmp:
+        os.chdir(tmp)
+        try:
+            # (a) bigWig-style tracks, K = 10, whole genome
+            tracks = {}
+            for idx, (name, n) in enumerate(genome):
+                tracks[name] = (np.arange(n, dtype=np.int64) * args.step_bp,
+                                synth.hash_matrix_device(10, n, synth.chrom_seed(args.seed, idx), device=device))
+            run({names[-1]: tracks[names[-1]]}, [names[-1]], "bigwig", "device", tmp)  # (first-call allocations)
+            on_device, bed_dev = run(tracks, names, "bigwig", "device", tmp)
+            on_host, bed_host = run(tracks, names, "bigwig", "host", tmp)
+            on_device["bed_equal_to_host_multipliers_run"] = open(bed_dev).read() == open(bed_host).read()
+            # the oracle's composition (CPU restatement of the reference's driver) on one chromosome
+            small = min(genome, key=lambda g: g[1])[0]
+            inputs_h = {small: (tracks[small][0], tracks[small][1].cpu().numpy())}
+            t0 = time.perf_counter()
+            _c, _b, _s, o_combined = bo.run_chromosomes([small], inputs_h, dict(base, input_track_type="bigwig"))
+            t_cpu = time.perf_counter() - t0
+            one, bed_one = run({small: tracks[small]}, [small], "bigwig", "host", tmp)
+            leg["bigwig_K10_whole_genome"] = {
+                "device_multipliers": on_device, "host_multipliers": on_host,
+                "cpu_oracle_one_chromosome": {"chromosome": small, "seconds": round(t_cpu, 3),
+                                              "loci_per_s": round(inputs_h[small][1].shape[1] / t_cpu, 1),
+                                              "gpu_seconds_same_chromosome_host_multipliers": one["seconds"],
+                                              "bed_identical": open(bed_one).read() == po.bed_text(o_combined)}}
+            del tracks
+            # (b) count matrices, K = 100, whole genome: the benchmark's matrices turned into counts
+            counts = {}
+            for idx, w in enumerate(works):
+                synth.hash_matrix_device(args.samples, w.n, synth.chrom_seed(args.seed, mine[idx]), out=w.matrix_t)
+                w.matrix_t.mul_(20.0).round_()
+                counts[w.name] = (np.arange(w.n, dtype=np.int64) * args.step_bp, w.matrix_t)
+            order = [w.name for w in works]
+            small = min(works, key=lambda w: w.n).name
+            torch.cuda.reset_peak_memory_stats()
+            genome_counts, _bed = run(counts, order, "bam", "device", tmp)
+            genome_counts["peak_torch_memory_GB"] = round(torch.cuda.max_memory_allocated() / 1e9, 1)
+            one_dev, bed_dev = run({small: counts[small]}, [small], "bam", "device", tmp)
+            one_host, bed_host = run({small: counts[small]}, [small], "bam", "host", tmp)
+            one_dev["bed_equal_to_host_multipliers_run"] = open(bed_dev).read() == open(bed_host).read()
+            leg[f"counts_K{args.samples}_whole_genome"] = {
+                "device_multipliers": genome_counts,
+                "one_chromosome": {"chromosome": small, "device_multipliers": one_dev, "host_multipliers": one_host,
+                                   "note": "host multipliers (NumPy normals + SciPy FFT for K rows per draw) on the whole genome take "
+                                           "hours; their cost is shown on the shortest chromosome"}}
+            inference.release_batch_workers()
+        finally:
+            os.chdir(cwd)
+    return leg
 
 
 def main():
@@ -513,6 +613,11 @@ def main():
                                       "sweeps, rolling sums: bit-exactness pins their order) run at the latency of their longest "
                                       "row, not at bandwidth, and take ~60 % of the time"},
                 "scores_finite": finite}
+
+    # ---- the composed driver (rocco/rocco.py:933-1196, 1269-1300: matrices -> scores -> data-driven budgets and switch costs ->
+    # solve -> combined BED) on the BASELINE configurations, reported beside the headline, not part of it ----
+    if next_rows is not None and names is None and not args.no_composed:
+        next_rows["composed_driver"] = _composed_driver_leg(args, genome, device, works, mine, po)
 
     if rank == 0:
         line = {

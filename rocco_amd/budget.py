@@ -167,6 +167,21 @@ def _smooth_and_standardise(normals: np.ndarray, taps: np.ndarray):
     return None
 
 
+# Where a composed run's time goes (bench.py's composed-driver leg): a dict handed to `collect_timings` receives the
+# seconds the estimators spend obtaining multipliers (host: waiting for the threads that make them; device: making them).
+_TIMINGS = None
+
+
+def collect_timings(store: Optional[dict]) -> None:
+    global _TIMINGS
+    _TIMINGS = store
+
+
+def _note(key: str, seconds: float) -> None:
+    if _TIMINGS is not None:
+        _TIMINGS[key] = _TIMINGS.get(key, 0.0) + float(seconds)
+
+
 def device_standard_normal(rng: np.random.Generator, count: int, out_t=None, device_index: Optional[int] = None):
     """``rng.standard_normal(count)`` made on the device (rocco_hip_pcg64_standard_normal_f64): a float64 CUDA tensor of
     NumPy's own values -- its ziggurat over PCG64, continued from `rng`'s state -- and `rng` advanced by the raw draws
@@ -426,12 +441,16 @@ def estimate_budget_nonnull_fraction_from_score_track(score_track, dependence_la
         raise ValueError("`weights_source` was made for another track")
     rng = source.rng
     next_weights = source.next
+    import time as _time
+
     for _draw in range(max_draws):
+        t_mult = _time.perf_counter()
         made = device_multipliers(rng, 1, n, taps) if on_device else None  # (None: degenerate, generator put back)
         if made is not None:
             weights_dev = made[0]
         else:
             weights_dev.copy_(torch.from_numpy(next_weights()))
+        _note("multipliers_device_s" if made is not None else "multipliers_host_s", _time.perf_counter() - t_mult)
         _native.check(lib.rocco_hip_multiply_f64(solver.handle, template_t.data_ptr(), weights_dev.data_ptr(),
                                                  product_t.data_ptr(), n, stream), "rocco_hip_multiply_f64")
         d_mass, d_units, d_fraction, d_tail = _draw_stats(product_t, null_center, soft_scale, null_threshold)
@@ -560,6 +579,7 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
     stopping rule; that batching is kept, the draws themselves run one after another on the GPU."""
     import os
     import sys
+    import time as _time
 
     import torch
 
@@ -638,6 +658,7 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
         pending, to_submit = {}, list(batch)
         for draw in batch:
             made = None
+            t_mult = _time.perf_counter()
             if on_device:
                 # the draw's generator is seeded on the host, its stream runs through the rows on the device (normal.hip)
                 made = device_multipliers(np.random.default_rng(int(random_seed) + (104729 * (draw + 1))), K, n, taps)
@@ -661,6 +682,7 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
                     staging[slot].numpy()[:] = _generate_dependent_wild_weights(n, taps, rng)
                     weights_t[row].copy_(staging[slot], non_blocking=True)
                     copies[slot].record()
+            _note("multipliers_device_s" if made is not None else "multipliers_host_s", _time.perf_counter() - t_mult)
             d_mass, d_units, d_fraction, d_tail = _inf.compute_budget_null_draw_device(
                 template_t, draw_weights, lower_bound_z, prior_df, draw_min_effect, floor_ratio, null_center, soft_scale,
                 null_threshold, work_t=product_t)

@@ -414,6 +414,10 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         if int(c.shape[0]) == 0 or int(c.shape[1]) == 0:
             raise ValueError("`chrom_matrix` must be non-empty")
     device = counts_list[0].device
+    # (`overwrite_input`: one flag, or one per matrix -- a caller that owns only some of them)
+    overwrite = [bool(v) for v in overwrite_input] if isinstance(overwrite_input, (list, tuple)) else [bool(overwrite_input)] * len(counts_list)
+    if len(overwrite) != len(counts_list):
+        raise ValueError("`overwrite_input` must be one flag or one per matrix")
     workers = max(1, min(int(workers), len(counts_list), _native.max_side_streams()))  # never more streams than hardware queues
     caller_stream = torch.cuda.current_stream(device)
     sizes = [int(c.shape[0]) * int(c.shape[1]) for c in counts_list]
@@ -451,7 +455,7 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
             stream.wait_event(start)
             # phase 1: log scale, pilot offset (rocco/inference.py:325, 333-334)
-            centred = {i: log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite_input else None,
+            centred = {i: log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite[i] else None,
                                                        apply_log2=(input_scale == "counts"))[0] for i in idx}
             stamp("baselines start")
             # phase 2: local baselines (335), the group's matrices of one penalty together, and their subtraction (338)

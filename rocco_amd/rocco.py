@@ -595,7 +595,8 @@ def _gather_chromosomes(chroms_to_process: list, signal_inputs, args: dict, plan
             raise ValueError(f"{name} matrix contains non-finite values")
         if plan.bigwig and matrix.shape[0] > 1:
             logger.warning("Multiple bigwig tracks detected for %s: aggregated by the column-wise median, not WLS.", name)
-        yield name, starts, _matrix_to_device(matrix)
+        matrix_t = _matrix_to_device(matrix)
+        yield name, starts, matrix_t, matrix_t is not matrix  # (a matrix that came in as a CUDA tensor is the caller's: never written to)
 
 
 def _score_gathered(batch: list, plan: _CachePlan, own_wls: bool, wls):
@@ -610,8 +611,8 @@ def _score_gathered(batch: list, plan: _CachePlan, own_wls: bool, wls):
 
     if plan.bigwig:
         scores = [None] * len(batch)
-        many = [i for i, (_n, _s, m) in enumerate(batch) if m.ndim == 2 and m.shape[0] > 1]
-        for i, (_n, _s, m) in enumerate(batch):
+        many = [i for i, (_n, _s, m, _o) in enumerate(batch) if m.ndim == 2 and m.shape[0] > 1]
+        for i, (_n, _s, m, _o) in enumerate(batch):
             if m.ndim != 2:
                 raise ValueError("`chrom_matrix` must be a 2D array.")
             if m.shape[0] == 1:
@@ -621,14 +622,16 @@ def _score_gathered(batch: list, plan: _CachePlan, own_wls: bool, wls):
                 scores[i] = out
         return [(s_t, {"mean": s_t}) for s_t in scores]
     if own_wls and len(batch) > 1 and not plan.low_memory:
-        mats = []
-        for _n, _s, m in batch:
+        mats, ours = [], []
+        for _n, _s, m, owned in batch:
             if m.ndim != 2:
                 raise ValueError("`chrom_matrix` must be two-dimensional")
-            mats.append(m.to(torch.float64).contiguous())
-        return _inf.score_loci_wls_batch_device(mats, overwrite_input=True, **plan.wls)
+            m64 = m.to(torch.float64).contiguous()
+            mats.append(m64)
+            ours.append(owned or m64 is not m)  # centred in place where the matrix is a copy this call made
+        return _inf.score_loci_wls_batch_device(mats, overwrite_input=ours, **plan.wls)
     return [wls(m, low_memory=plan.low_memory, return_details=True, resident=True, **plan.wls) if own_wls else
-            wls(m, low_memory=plan.low_memory, return_details=True, **plan.wls) for _n, _s, m in batch]
+            wls(m, low_memory=plan.low_memory, return_details=True, **plan.wls) for _n, _s, m, _o in batch]
 
 
 def _batches_within_memory(items, plan: _CachePlan):
@@ -665,8 +668,21 @@ def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> di
     from . import budget as _budget
     from . import inference as _inf
 
+    import time as _time
+
     this = globals()
     plan = _CachePlan(args)
+    phases = args.get("_phase_seconds")  # (bench.py: a dict that receives where the time goes; the device is waited for
+                                         # at phase ends only when it is given)
+
+    def lap(key, since):
+        if phases is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            phases[key] = phases.get(key, 0.0) + (_time.perf_counter() - since)
+        return _time.perf_counter()
+
     wls = this["score_loci_wls"]
     track_estimate = this["estimate_budget_nonnull_fraction_from_score_track"]
     count_estimate = this["estimate_budget_nonnull_fraction_from_wild_bootstrap_null"]
@@ -675,11 +691,14 @@ def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> di
     host_multipliers = _budget._resolve_multipliers(plan.multipliers) == "host"
     cache = {}
     gathered = _gather_chromosomes(chroms_to_process, signal_inputs, args, plan, this["generate_chrom_matrix"])
+    clock = _time.perf_counter()
     for batch in _batches_within_memory(gathered, plan):
+        clock = lap("gather_s", clock)
         scored = _score_gathered(batch, plan, wls is _inf.score_loci_wls, wls)
+        clock = lap("scoring_s", clock)
         # the reference's checks on what the scoring returned, chromosome by chromosome (rocco/rocco.py:992, 1019, 1024)
         ready = []
-        for (name, starts, _matrix), (scores, details) in zip(batch, scored):
+        for (name, starts, _matrix, _owned), (scores, details) in zip(batch, scored):
             if not _all_finite(scores):
                 raise ValueError(f"{name} direct scores contain non-finite values" if plan.bigwig
                                  else f"{name} scores contain non-finite values")
@@ -738,6 +757,7 @@ def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> di
         finally:
             for source in ahead.values():
                 source.close()
+        clock = lap("budget_estimates_s", clock)
     for name, entry in cache.items():
         effect = entry.pop("effect_mean", None)
         if plan.narrow_peak:
@@ -840,10 +860,20 @@ def run_chromosomes(chroms_to_process: list, signal_inputs, args: dict, run_id: 
     this = globals()
     if _world_size(group) > 1:
         return _run_chromosomes_sharded(chroms_to_process, signal_inputs, args, run_id, group)
+    import time as _time
+
+    phases = args.get("_phase_seconds")
+    t0 = _time.perf_counter()
     chrom_cache = this["_build_chrom_cache"](chroms_to_process, signal_inputs, args)
+    t1 = _time.perf_counter()
     chrom_budgets, _ = this["_resolve_budgets"](chrom_cache, args)
+    t2 = _time.perf_counter()
     tmp_chrom_bed_files = this["_solve_cached_chromosomes"](chrom_cache, chrom_budgets, args, run_id)
+    t3 = _time.perf_counter()
     final_output = combine_chrom_results(tmp_chrom_bed_files, args["output"], name_features=False)
+    if phases is not None:
+        phases.update(cache_s=t1 - t0, pooled_budgets_s=t2 - t1, solve_and_chromosome_files_s=t3 - t2,
+                      combine_s=_time.perf_counter() - t3)
     for tmp_file in tmp_chrom_bed_files:
         try:
             os.remove(tmp_file)
