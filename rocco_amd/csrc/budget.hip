@@ -1398,6 +1398,7 @@ public:
                      std::vector<Presearch> &pre, bool &ran)
     {
         ran = false;
+        const double tc0 = now_us();
         const size_t B = probs.size();
         const char *flag = std::getenv("ROCCO_HIP_CHAIN");
         if ((flag != nullptr && std::atoi(flag) == 0) || solver_->lean == 0 || B == 0 || B > (size_t)kChainMaxProblems ||
@@ -1416,10 +1417,18 @@ public:
         if (!any) {
             return ROCCO_HIP_OK;
         }
+        // A chained round costs its director and three launch boundaries (~45 us), about what a host-sequenced round costs
+        // in turn-around; what the chain gains is in the rounds' shape (three short pilot rounds of eight penalties, two
+        // penalties on the pass over every locus), which pays on a genome (7 555 tiles: 2.80 -> 2.60 ms per calibration) and not
+        // on a rank's shard of one (973 tiles at N = 8: 0.94 -> 1.07 ms).  Below `min_tiles` the host sequences the rounds.
+        const long long min_tiles = std::getenv("ROCCO_HIP_CHAIN_MIN_TILES") ? std::atoll(std::getenv("ROCCO_HIP_CHAIN_MIN_TILES")) : 4096;
+        if (tiles0 < min_tiles && flag == nullptr) {
+            return ROCCO_HIP_OK;
+        }
         int rc;
         if ((rc = lean_prepare()) != ROCCO_HIP_OK) return rc;
         ChainTuning tune;
-        tune.pilot_rounds = std::getenv("ROCCO_HIP_CHAIN_PILOT_ROUNDS") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_PILOT_ROUNDS")) : 3;
+        tune.pilot_rounds = std::getenv("ROCCO_HIP_CHAIN_PILOT_ROUNDS") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_PILOT_ROUNDS")) : 6;
         tune.pilot_points = std::getenv("ROCCO_HIP_CHAIN_PILOT_POINTS") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_PILOT_POINTS")) : 8;
         if (opt.pilot_rounds <= 0) {
             tune.pilot_rounds = 0;
@@ -1482,6 +1491,7 @@ public:
         const size_t down_bytes = off - o_probs;
         const size_t o_hot = carve(B * sizeof(ChainHot));
         const size_t o_pilot = carve(B * sizeof(ChainPilot));
+        const size_t o_evals = carve(B * sizeof(ChainEvals));
         const size_t o_tasks = carve(B * sizeof(LeanTask));
         const size_t o_points = carve(B * kLeanMaxPoints * sizeof(double));
         const size_t o_results = carve(B * kLeanMaxPoints * sizeof(LeanResult));
@@ -1540,6 +1550,7 @@ public:
         A.probs = (ChainProb *)(dv + o_probs);
         A.hot = (ChainHot *)(dv + o_hot);
         A.pilot = (ChainPilot *)(dv + o_pilot);
+        A.evals = (ChainEvals *)(dv + o_evals);
         A.stats = (const double *)(dv + o_stats);
         A.ctl = (LeanRoundCtl *)(dv + o_ctl);
         A.tasks = (LeanTask *)(dv + o_tasks);
@@ -1582,7 +1593,15 @@ public:
         ROCCO_HIP_TRY(hipMemcpyAsync(h, dv + o_probs, down_bytes, hipMemcpyDeviceToHost, stream_));
         const double ts0 = now_us();
         ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
-        t_wait_ += now_us() - ts0;
+        const double ts1 = now_us();
+        t_wait_ += ts1 - ts0;
+        t_chain_submit_ = ts0 - tc0;
+        t_chain_wait_ = ts1 - ts0;
+        struct Parse {
+            double &acc;
+            double t0;
+            ~Parse() { acc = now_us() - t0; }
+        } parse{t_chain_parse_, ts1};
         solver_->lean_look_dirty = 0;
         const ChainProb *rep = (const ChainProb *)h;
         const double *hstats = (const double *)(h + (o_stats - o_probs));
@@ -1608,6 +1627,7 @@ public:
         stats_out.assign(hstats, hstats + 5 * B);
         pre.assign(B, Presearch());
         const bool debug = std::getenv("ROCCO_HIP_DEBUG") != nullptr;
+        const bool chain_debug = std::getenv("ROCCO_HIP_CHAIN_DEBUG") != nullptr;
         bool grid_ok = true;
         for (size_t b = 0; b < B; ++b) {
             const ChainProb &r = rep[b];
@@ -1635,8 +1655,11 @@ public:
                 continue;
             }
             Presearch &ps = pre[b];
-            for (int i = 0; i < r.n_evals; ++i) {
-                ps.evals.emplace_back(r.eval_x[i], r.eval_c[i]);
+            for (int i = 0; i < r.n_above; ++i) {
+                ps.evals.emplace_back(r.above_x[i], r.above_c[i]);
+            }
+            for (int i = 0; i < r.n_below; ++i) {
+                ps.evals.emplace_back(r.below_x[i], r.below_c[i]);
             }
             ps.rounds = r.rounds + r.pilots;
             ps.done = (r.done == 1);
@@ -1657,10 +1680,12 @@ public:
                 ls.levels.push_back(lv);
             }
             ls.pool_at = (size_t)r.pool_at;
-            if (std::getenv("ROCCO_HIP_CHAIN_DEBUG") != nullptr) {
+            if (chain_debug) {
+                std::vector<ChainEvals> all(1);
+                ROCCO_HIP_TRY(hipMemcpy(all.data(), dv + o_evals + b * sizeof(ChainEvals), sizeof(ChainEvals), hipMemcpyDeviceToHost));
                 for (int i = 0; i < r.n_evals; ++i) {
-                    std::fprintf(stderr, "[chain] problem %zu count(%.17g) = %lld%s\n", b, r.eval_x[i], r.eval_c[i],
-                                 r.eval_c[i] > std::max(0LL, std::min(problems[b].target_count, (long long)probs[b].n)) ? "  >" : "");
+                    std::fprintf(stderr, "[chain] problem %zu count(%.17g) = %lld%s\n", b, all[0].x[i], all[0].c[i],
+                                 all[0].c[i] > std::max(0LL, std::min(problems[b].target_count, (long long)probs[b].n)) ? "  >" : "");
                 }
             }
             if (debug) {
@@ -1680,6 +1705,7 @@ private:
 public:
     double t_prep_ = 0.0, t_launch_ = 0.0, t_wait_ = 0.0, t_consume_ = 0.0, t_round_ = 0.0;
     double t_lean_cpu_ = 0.0, t_lean_h2d_ = 0.0, t_lean_launch_ = 0.0;
+    double t_chain_submit_ = 0.0, t_chain_wait_ = 0.0, t_chain_parse_ = 0.0;
     int rounds_all = 0;
     static double now_us()
     {
@@ -2510,10 +2536,14 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (score_stats_host == nullptr) {
         if ((rc = ev.chain_search(problems, opt, chain_stats, presearch, chained)) != ROCCO_HIP_OK) return rc;
     }
+    const double tp0 = HipEvaluator::now_us();
     if ((rc = prepare(ev, problems, nullptr, score_stats_host, chained ? &chain_stats : nullptr)) != ROCCO_HIP_OK) return rc;
+    const double tp1 = HipEvaluator::now_us();
     if ((rc = calibrate_batch(ev, problems, opt, res, chained ? &presearch : nullptr)) != ROCCO_HIP_OK) return rc;
+    const double tp2 = HipEvaluator::now_us();
     if ((rc = ev.scatter_all()) != ROCCO_HIP_OK) return rc;
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+    const double t_prepare = tp1 - tp0, t_calibrate = tp2 - tp1, t_scatter = HipEvaluator::now_us() - tp2;
     if (std::getenv("ROCCO_HIP_DEBUG") != nullptr || std::getenv("ROCCO_HIP_TIMING") != nullptr) {
         const double total = HipEvaluator::now_us() - t_solve0;
         std::fprintf(stderr, "[host] solve %.0f us: %d rounds (%d with rounding-model kernels): in the rounds %.0f us = waiting for the device %.0f "
@@ -2523,6 +2553,9 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
         std::fprintf(stderr, "[host] lean rounds: building the descriptors %.0f us, their upload call %.0f, the launch calls %.0f; general rounds: "
                              "preparing %.0f, launching %.0f\n",
                      ev.t_lean_cpu_, ev.t_lean_h2d_, ev.t_lean_launch_, ev.t_prep_, ev.t_launch_);
+        std::fprintf(stderr, "[host] chained search: queued in %.0f us, waited for %.0f, report read in %.0f; statistics -> problems %.0f; "
+                             "calibration after it %.0f; scatter and the last wait %.0f\n",
+                     ev.t_chain_submit_, ev.t_chain_wait_, ev.t_chain_parse_, t_prepare, t_calibrate, t_scatter);
     }
     for (size_t t = 0; t < n_tasks; ++t) {
         results[t].selection_penalty = res[t].selection_penalty;

@@ -27,6 +27,7 @@ constexpr int kChainMaxLevels = 8;
 constexpr int kChainMaxEvals = 384;     // certified (penalty, count) records kept per problem
 constexpr int kChainMaxPilot = 192;     // sampled estimates kept per problem
 constexpr int kChainMaxMults = 4;
+constexpr int kChainKeep = 4;           // certified counts reported per side of the target
 
 // what the host knows of a problem before the chain starts (uploaded)
 struct ChainInput {
@@ -65,8 +66,18 @@ struct ChainProb {
     int pad;
     unsigned long long pool_at;
     ChainLevelReport levels[kChainMaxLevels];
-    double eval_x[kChainMaxEvals];
-    long long eval_c[kChainMaxEvals];
+    // The certified counts the host needs: the tightest ones on either side of the target.  Every round's penalties lie
+    // between the thresholds of the round before, so the counts above the target arrive with ascending penalties and the
+    // others with descending ones: the last few recorded on each side are the tightest.  (All of them, in order of
+    // evaluation: ChainEvals, read back for diagnostics only.)
+    int n_above, n_below;
+    double above_x[kChainKeep], below_x[kChainKeep];
+    long long above_c[kChainKeep], below_c[kChainKeep];
+};
+
+struct ChainEvals {
+    double x[kChainMaxEvals];
+    long long c[kChainMaxEvals];
 };
 
 // The director's working state of a problem: a block of scalars that travels global memory -> LDS -> global memory as a
@@ -81,6 +92,7 @@ struct ChainHot {
     double smin, smax, sabs_sum, eps;
     // pilot
     double pg, pl, pilot_scale;
+    double est_pg, est_pl;  // the pilot's estimated counts at pg and pl
     // thresholds
     double G, L;
     long long cG, cL;
@@ -134,6 +146,7 @@ struct ChainArgs {
     ChainProb *probs;
     ChainHot *hot;
     ChainPilot *pilot;
+    ChainEvals *evals;
     const double *stats;    // [n_problems][5] smin, smax, cmin, cmax, sum |s| (stats_final_kernel)
     LeanRoundCtl *ctl;
     LeanTask *tasks;        // [n_problems]

@@ -86,6 +86,8 @@ __device__ void init_problem(const ChainArgs &A, int b, ChainHot &H)
     H.eps = 0.0;
     H.pg = H.pl = 0.0;
     H.pilot_scale = 1.0;
+    H.est_pg = (double)in.n;
+    H.est_pl = 0.0;
     H.G = H.L = 0.0;
     H.cG = H.cL = 0;
     H.open_before = 0x7FFFFFFFFFFFFFFFLL;
@@ -159,6 +161,8 @@ __device__ void init_problem(const ChainArgs &A, int b, ChainHot &H)
     l0.cap_points = 0;
     l0.pad = 0;
     A.probs[b].levels[0] = l0;
+    A.probs[b].n_above = 0;
+    A.probs[b].n_below = 0;
     H.phase = 2;
     if (A.tune.pilot_rounds > 0 && in.target > 0 && in.can_pilot != 0 && (H.pl - H.pg > 64.0 * H.eps)) {
         H.phase = 1;
@@ -213,23 +217,33 @@ __device__ int consume(const ChainArgs &A, int b, ChainHot &H, double x, long lo
             W.c[at + lane] = est;
         }
         const bool more = on && est > (double)target;
-        double up = more ? x : -INFINITY, down = (on && !more) ? x : INFINITY;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            up = fmax(up, __shfl_xor(up, off));
-            down = fmin(down, __shfl_xor(down, off));
-        }
+        // the interval's ends: the highest penalty whose estimate exceeds the target, the lowest whose does not, and the
+        // estimates there (penalties ascend with the lanes, estimates do not rise)
+        const unsigned long long more_b = __ballot(more), less_b = __ballot(on && !more);
+        const int i_up = more_b ? 63 - __builtin_clzll(more_b) : 0, i_down = less_b ? __builtin_ctzll(less_b) : 0;
+        const double up = more_b ? __shfl(x, i_up) : -INFINITY, down = less_b ? __shfl(x, i_down) : INFINITY;
+        const double est_up = __shfl(est, i_up), est_down = __shfl(est, i_down);
         if (lane == 0) {
             ++H.pilots;
             H.n_pilot = n_old + room;
-            const double pg = fmax(H.pg, up), pl = fmin(H.pl, down);
-            H.pg = pg;
-            H.pl = pl;
+            if (up > H.pg) {
+                H.pg = up;
+                H.est_pg = est_up;
+            }
+            if (down < H.pl) {
+                H.pl = down;
+                H.est_pl = est_down;
+            }
+            const double pg = H.pg, pl = H.pl;
             const int left = H.pilot_left - 1;
             H.pilot_left = left;
-            // enough: the estimated interval is a fraction of a percent of the range, or as narrow as epsilon allows
-            const double range = (H.smax + 1.0) - (H.smin - 1.0);
-            if (left <= 0 || !(pl - pg > 64.0 * eps) || (pl - pg) * 500.0 <= range) {
+            // Enough when the estimates at the two ends are within a factor of 2.5 of each other: the first certified
+            // round takes its penalties from a log-linear interpolation between neighbouring samples, which is only as good
+            // as the estimate is smooth between them (on tracks with a noise floor the count falls by orders of magnitude
+            // within a hundredth of the range).  Or when the interval is as narrow as epsilon allows, or the rounds are
+            // used up.
+            const bool smooth = H.est_pg <= 2.5 * fmax(H.est_pl, 1.0);
+            if (left <= 0 || !(pl - pg > 64.0 * eps) || smooth) {
                 H.pilot_left = 0;
                 H.pilot_hint = 1;
                 H.phase = 2;
@@ -240,8 +254,8 @@ __device__ int consume(const ChainArgs &A, int b, ChainHot &H, double x, long lo
     // certified counts on the deepest level: records, thresholds (search.cpp, "bound_round"), stop rule
     const int n_evals = H.n_evals;
     if (on && n_evals + lane < kChainMaxEvals) {
-        P.eval_x[n_evals + lane] = x;
-        P.eval_c[n_evals + lane] = count;
+        A.evals[b].x[n_evals + lane] = x;
+        A.evals[b].c[n_evals + lane] = count;
     }
     // penalties ascend and counts do not rise: the thresholds move to the last "more than the target" and the first
     // "at most the target" of the round
@@ -250,6 +264,51 @@ __device__ int consume(const ChainArgs &A, int b, ChainHot &H, double x, long lo
     const double x_more = __shfl(x, i_more), x_less = __shfl(x, i_less);
     const long long c_more = __shfl(count, i_more), c_less = __shfl(count, i_less);
     const long long child_more = __shfl(child, i_more);
+    // the report keeps the last kChainKeep counts on each side (see ChainProb): this round's highest penalties above
+    // the target behind what is there, its lowest ones at or below it likewise
+    {
+        const int n_more = __builtin_popcountll(more), n_less = __builtin_popcountll(less);
+        const int take_more = min(n_more, kChainKeep), take_less = min(n_less, kChainKeep);
+        const int old_above = P.n_above, old_below = P.n_below;
+        const int keep_above = min(old_above, kChainKeep - take_more), keep_below = min(old_below, kChainKeep - take_less);
+        // survivors of the old entries move to the front (the newest are at the end)
+        double ax = 0.0, bx = 0.0;
+        long long ac = 0, bc = 0;
+        if (lane < keep_above) {
+            ax = P.above_x[old_above - keep_above + lane];
+            ac = P.above_c[old_above - keep_above + lane];
+        }
+        if (lane < keep_below) {
+            bx = P.below_x[old_below - keep_below + lane];
+            bc = P.below_c[old_below - keep_below + lane];
+        }
+        if (lane < keep_above) {
+            P.above_x[lane] = ax;
+            P.above_c[lane] = ac;
+        }
+        if (lane < keep_below) {
+            P.below_x[lane] = bx;
+            P.below_c[lane] = bc;
+        }
+        // above the target: the round's last take_more such lanes, ascending; at or below: its first take_less lanes,
+        // stored so that the tightest (lowest penalty) comes last
+        const int rank_more = __builtin_popcountll(more & ((1ull << lane) - 1ull));  // my index among the lanes above
+        if (((more >> lane) & 1ull) && rank_more >= n_more - take_more) {
+            const int slot = keep_above + (rank_more - (n_more - take_more));
+            P.above_x[slot] = x;
+            P.above_c[slot] = count;
+        }
+        const int rank_less = __builtin_popcountll(less & ((1ull << lane) - 1ull));
+        if (((less >> lane) & 1ull) && rank_less < take_less) {
+            const int slot = keep_below + (take_less - 1 - rank_less);
+            P.below_x[slot] = x;
+            P.below_c[slot] = count;
+        }
+        if (lane == 0) {
+            P.n_above = keep_above + take_more;
+            P.n_below = keep_below + take_less;
+        }
+    }
     int pre_tiles = 0;
     if (lane == 0) {
         ++H.rounds;
@@ -265,6 +324,14 @@ __device__ int consume(const ChainArgs &A, int b, ChainHot &H, double x, long lo
             H.L = x_less + eps;
             H.cL = c_less;
             H.L_real = 1;
+        }
+        if (!H.G_real && H.n_pilot > 0 && H.n_levels == 1 && H.rounds <= 2 && H.can_pilot != 0 && x_less > H.pg + 64.0 * eps) {
+            // the pilot's hints all fell at or below the target (its estimate was too coarse where the count falls
+            // steeply): two more pilot rounds below the lowest certified penalty, then new hints
+            H.pl = fmin(H.pl, x_less);
+            H.est_pl = fmin(H.est_pl, (double)c_less);
+            H.phase = 1;
+            H.pilot_left = 2;
         }
         if (n_evals + np + kLeanMaxPoints > kChainMaxEvals) {
             give_up(H);  // (no room for another round's records: the host goes on)
