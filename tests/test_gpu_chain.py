@@ -1,0 +1,81 @@
+"""GPU: the threshold search sequenced by the device (rocco_amd/csrc/chain.hip: director kernel + chained lean launches)
+against the oracle's calibration (rocco/dp.py:89-164 restated) and against the host-sequenced search.  By default only
+genome-sized batches take the chain; ROCCO_HIP_CHAIN=1 forces it, =0 forbids it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(scores_list, gammas, targets, chain, monkeypatch):
+    import torch
+
+    from rocco_amd import dp
+
+    monkeypatch.setenv("ROCCO_HIP_CHAIN", "1" if chain else "0")
+    tensors = [torch.from_numpy(np.ascontiguousarray(s)).cuda() for s in scores_list]
+    return dp.calibrate_batch_device(tensors, gammas, targets)
+
+
+def _tracks(rng, n, kind):
+    if kind == "peaks":  # a noise floor with enriched stretches: the shape of the benchmark's tracks
+        s = np.round(rng.gamma(1.0, 0.3, n), 5)
+        for p in range(50, max(51, n - 50), 1500):
+            s[p:p + int(rng.integers(4, 40))] += rng.gamma(6.0, 1.0)
+        return s
+    if kind == "normal":
+        return rng.normal(0.0, 1.0, n)
+    if kind == "integers":  # ties everywhere
+        return rng.integers(-3, 9, n).astype(np.float64)
+    if kind == "offset":  # far from zero: the rounding model's magnitudes
+        return 1000.0 + rng.gamma(1.0, 1.0, n)
+    return np.round(rng.normal(0.2, 0.05, n), 3)  # "flat": a steep cliff in the count
+
+
+@pytest.mark.parametrize("kind", ["peaks", "normal", "integers", "offset", "flat"])
+def test_chained_search_gives_the_oracles_calibration(gpu, oracle, monkeypatch, kind):
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    sizes = [8191, 8192, 8193, 70000, 3, 2, 262145]
+    scores = [_tracks(rng, n, kind) for n in sizes]
+    gammas = [1.0, 0.5, 2.0, 1.0, 1.0, 1.0, 3.0]
+    targets = [int(np.floor(n * b)) for n, b in zip(sizes, (0.02, 0.1, 0.005, 0.03, 0.5, 0.0, 0.02))]
+    chained = _solve(scores, gammas, targets, True, monkeypatch)
+    plain = _solve(scores, gammas, targets, False, monkeypatch)
+    for s, gamma, target, a, b in zip(scores, gammas, targets, chained, plain):
+        ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, gamma), target)
+        assert a[0] == ref[0] and a[3] == ref[3], (kind, len(s), a[0], ref[0])
+        assert np.array_equal(a[1].cpu().numpy(), ref[1])
+        assert b[0] == ref[0] and b[3] == ref[3]
+
+
+def test_chained_search_with_pilot_on_a_long_chromosome(gpu, oracle, monkeypatch):
+    """Long enough for the sampled pilot (128 tiles and more), beside short ones that search without it; the chain must
+    finish the search itself (passes: chain rounds + binade map + rounding-model rounds + window)."""
+    rng = np.random.default_rng(77)
+    sizes = [1_300_000, 40_000, 1_100_000]
+    scores = [_tracks(rng, n, "peaks") for n in sizes]
+    targets = [int(np.floor(n * 0.02)) for n in sizes]
+    chained = _solve(scores, [1.0] * 3, targets, True, monkeypatch)
+    for s, target, a in zip(scores, targets, chained):
+        ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 1.0), target)
+        assert a[0] == ref[0] and a[3] == ref[3]
+        assert np.array_equal(a[1].cpu().numpy(), ref[1])
+        assert a[4]["path"] == 1 and a[4]["passes"] <= 24
+
+
+def test_chain_leaves_cost_vectors_and_tiny_problems_to_the_host(gpu, oracle, monkeypatch):
+    """A batch in which nothing is eligible (switch-cost vectors, single loci) and a mixed one."""
+    import torch
+
+    from rocco_amd import dp
+
+    monkeypatch.setenv("ROCCO_HIP_CHAIN", "1")
+    rng = np.random.default_rng(5)
+    s = rng.normal(0.0, 1.0, 30000)
+    costs = rng.uniform(0.5, 2.0, s.size - 1)
+    out = dp.calibrate_batch_device([torch.from_numpy(s).cuda(), torch.from_numpy(s[:1].copy()).cuda(), torch.from_numpy(s).cuda()],
+                                    [torch.from_numpy(costs).cuda(), 1.0, 1.5], [600, 0, 900])
+    ref0 = oracle.calibrate_selection_penalty(s, costs, 600)
+    ref2 = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 1.5), 900)
+    assert out[0][0] == ref0[0] and out[0][3] == ref0[3] and np.array_equal(out[0][1].cpu().numpy(), ref0[1])
+    assert out[2][0] == ref2[0] and out[2][3] == ref2[3] and np.array_equal(out[2][1].cpu().numpy(), ref2[1])
