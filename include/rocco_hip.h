@@ -406,6 +406,16 @@ int rocco_hip_multiply_f64(rocco_hip_solver *solver, const double *a_dev, const 
 int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *matrix_dev, const double *row_dev,
                                         size_t K, size_t n, double *out_dev, void *stream);
 
+/* ---- sizing a solver's buffers ahead of a count-path batch ------------------------------------------------------
+ * The count-path entries grow the solver's scratch on demand (hipMalloc + hipFree: device-wide synchronisations).  A
+ * caller that runs several solver handles side by side on streams of their own (rocco_amd.inference.score_loci_wls_batch_device)
+ * sizes each handle for the matrices it will see BEFORE the threads start: rows[i] x cols[i], i < count; penalty_lambda > 0
+ * also builds (or extends) the device's Whittaker factor for the longest row.  rocco_hip_buffer_growths(): how many times
+ * any solver buffer of the process has grown so far (diagnostic). */
+int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const size_t *rows, const size_t *cols,
+                                 double penalty_lambda, void *stream);
+long long rocco_hip_buffer_growths(void);
+
 /* ---- the multipliers of the bootstrap draws on the device (missing item 2) ---------------------
  * Replaces rocco/inference.py:546-575 `_generate_dependent_wild_weights` (called per row and draw at 654-664 and per
  * draw at 1206-1213): NumPy's `Generator.standard_normal` over PCG64, SciPy's `fftconvolve(..., "valid")` with the

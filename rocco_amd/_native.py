@@ -202,6 +202,10 @@ PROTOTYPES = [
     ("rocco_hip_budget_null_draw_stats_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_double,
       c_double_p, ctypes.c_void_p]),
+    ("rocco_hip_count_path_reserve", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.c_double,
+      ctypes.c_void_p]),
+    ("rocco_hip_buffer_growths", ctypes.c_longlong, []),
     ("rocco_hip_pcg64_standard_normal_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_size_t,
       ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_void_p]),
@@ -316,6 +320,11 @@ def max_side_streams() -> int:
     the workers' streams stop for good (their host threads never return from hipStreamSynchronize; the process has to
     be killed), and the same run with GPU_MAX_HW_QUEUES=8 completes.  So the side streams are capped at the number of
     hardware queues minus the caller's."""
+    if os.environ.get("ROCCO_MAX_SIDE_STREAMS"):  # (experiments: lift or lower the cap)
+        try:
+            return max(1, int(os.environ["ROCCO_MAX_SIDE_STREAMS"]))
+        except ValueError:
+            pass
     try:
         queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
     except ValueError:

@@ -3,6 +3,8 @@
 #include <memory>
 #include <mutex>
 #include "kernels.h"
+#include <atomic>
+
 #include "budget.h"
 
 #include <algorithm>
@@ -15,11 +17,17 @@ static thread_local std::string g_last_error;
 
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 
+// How often a solver buffer had to grow (hipMalloc + hipFree, or the pinned twins): the count path's batch sizes every
+// buffer of a pipeline before its worker threads start, so that no thread allocates or frees device memory -- both
+// device-wide synchronisations -- while the others' streams are in flight (tests/test_gpu_count_path_batch.py reads this).
+static std::atomic<long long> g_buffer_growths{0};
+
 int DeviceBuffer::reserve(size_t want)
 {
     if (want <= bytes) {
         return ROCCO_HIP_OK;
     }
+    g_buffer_growths.fetch_add(1, std::memory_order_relaxed);
     size_t grow = bytes ? bytes * 2 : (size_t)1 << 16;
     if (grow < want) {
         grow = want;
@@ -50,6 +58,7 @@ int PinnedBuffer::reserve(size_t want)
     if (want <= bytes) {
         return ROCCO_HIP_OK;
     }
+    g_buffer_growths.fetch_add(1, std::memory_order_relaxed);
     size_t grow = bytes ? bytes * 2 : (size_t)1 << 14;
     if (grow < want) {
         grow = want;
@@ -111,6 +120,9 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
         return;
     }
     (void)hipSetDevice(solver->device);
+    // whatever was queued with this handle's buffers has to be over before they go (a kernel that outlives its scratch
+    // faults: "Memory access fault by GPU" at teardown)
+    (void)hipDeviceSynchronize();
     solver->dev_tasks.release();
     solver->dev_params.release();
     solver->dev_results.release();
@@ -831,6 +843,39 @@ int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t c
     ROCCO_HIP_TRY(hipMemcpyAsync(solver->dev_tasks.ptr, host, t * sizeof(WlsRollingTask), hipMemcpyHostToDevice, (hipStream_t)stream));
     if ((rc = launch_wls_rolling_batch((const WlsRollingTask *)solver->dev_tasks.ptr, t, (int)group, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
     ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the task table is the solver's
+    return ROCCO_HIP_OK;
+}
+
+long long rocco_hip_buffer_growths(void) { return g_buffer_growths.load(std::memory_order_relaxed); }
+
+int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const size_t *rows, const size_t *cols, double penalty_lambda,
+                                 void *stream)
+{
+    if (solver == nullptr || (count > 0 && (rows == nullptr || cols == nullptr))) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    size_t misc = whittaker_batch_scratch_bytes(rows, cols, count), groups = 0, total_rows = 0, most_rows = 0, longest = 0;
+    for (size_t i = 0; i < count; ++i) {
+        if (rows[i] == 0 || cols[i] == 0) {
+            continue;
+        }
+        misc = std::max(misc, wls_scratch_bytes(rows[i], cols[i], 31, true));
+        misc = std::max(misc, wls_scratch_bytes(rows[i], cols[i], 31, false));
+        misc = std::max(misc, log_scale_scratch_bytes(rows[i], cols[i]));
+        misc = std::max(misc, whittaker_batch_scratch_bytes(&rows[i], &cols[i], 1));
+        groups += (rows[i] + (size_t)whittaker_group_rows() - 1) / (size_t)whittaker_group_rows();
+        total_rows += rows[i];
+        most_rows = std::max(most_rows, rows[i]);
+        longest = std::max(longest, cols[i]);
+    }
+    int rc;
+    if ((rc = solver->dev_misc.reserve(misc)) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->dev_tasks.reserve(total_rows * sizeof(WlsRollingTask) + 256)) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->host_stage.reserve(std::max(2 * groups * sizeof(WhittakerRowTask) + 64, total_rows * sizeof(WlsRollingTask) + 256))) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->host_back.reserve(256 + most_rows * sizeof(int))) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->dev_results.reserve(256)) != ROCCO_HIP_OK) return rc;
+    if (penalty_lambda > 0.0 && (rc = ensure_whittaker_factor(solver, longest, penalty_lambda, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
     return ROCCO_HIP_OK;
 }
 

@@ -13,6 +13,7 @@ every host.  There is no CPU fallback: without the library or a GPU these raise.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import threading
 from typing import Tuple
@@ -361,6 +362,7 @@ def score_loci_wls_device(counts_t, lower_bound_z: float = 1.0, prior_df: float 
 _batch_lock = threading.Lock()  # one batch at a time per process: the pipelines and their scratch are shared
 _batch_pool = None
 _batch_workers = {}
+last_batch_growths_in_flight = 0  # solver buffers that grew while the last batch's pipelines were running (must be 0)
 
 
 def _batch_worker(device_index: int, slot: int):
@@ -503,10 +505,25 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
 
     with _batch_lock:
         if _batch_pool is None:
-            _batch_pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-count")
+            _batch_pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(4, _native.max_side_streams()),
+                                                                thread_name_prefix="rocco-count")
+        # Every pipeline's solver is sized HERE, on the calling thread, for the matrices it is about to see (scratch of the
+        # baseline sweeps, the rolling task table, the trend fit's scratch, the Whittaker factor of its longest row): no
+        # worker thread allocates or frees device memory -- both synchronise the whole device -- while the others are in flight.
+        for slot, idx in enumerate(groups):
+            solver, _stream = _batch_worker(device.index, slot)
+            rows_a = (ctypes.c_size_t * len(idx))(*[int(counts_list[i].shape[0]) for i in idx])
+            cols_a = (ctypes.c_size_t * len(idx))(*[int(counts_list[i].shape[1]) for i in idx])
+            lams = {_consenrich_whittaker_lambda(w) for w in (_resolve_local_baseline_window(int(counts_list[i].shape[1]), target_window=101)
+                                                                for i in idx) if w != 0}
+            _native.check(_native.load().rocco_hip_count_path_reserve(solver.handle, len(idx), rows_a, cols_a,
+                                                                      max(lams) if len(lams) == 1 else 0.0,
+                                                                      caller_stream.cuda_stream), "rocco_hip_count_path_reserve")
         start = torch.cuda.Event()
         start.record(caller_stream)
         t_start = _time.perf_counter()
+        global last_batch_growths_in_flight
+        grown_before = int(_native.load().rocco_hip_buffer_growths())
         futures = [_batch_pool.submit(run_group, slot, idx, start, t_start) for slot, idx in enumerate(groups)]
         first_error = None
         for f in futures:
@@ -514,6 +531,7 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
                 f.result()
             except BaseException as exc:  # noqa: BLE001
                 first_error = first_error or exc
+        last_batch_growths_in_flight = int(_native.load().rocco_hip_buffer_growths()) - grown_before
         if first_error is not None:
             raise first_error
         return result

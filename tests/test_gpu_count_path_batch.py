@@ -83,3 +83,24 @@ def test_release_batch_workers_then_batch_again(gpu):
     assert inference._batch_workers == {}
     second = [s for s, _ in inference.score_loci_wls_batch_device(mats)]
     assert all(torch.equal(a, b) for a, b in zip(first, second))
+
+
+def test_no_solver_buffer_grows_while_the_pipelines_run(gpu):
+    """Growing a solver buffer is a hipMalloc + hipFree, each a device-wide synchronisation; the batch sizes every
+    pipeline's buffers on the calling thread before its worker threads start (rocco_hip_count_path_reserve), also on the
+    very first call of fresh pipelines."""
+    import torch
+
+    from rocco_amd import inference
+
+    inference.release_batch_workers()
+    rng = np.random.default_rng(12)
+    mats = [torch.from_numpy(rng.poisson(6.0, size=(K, n)).astype(np.float64)).cuda()
+            for K, n in ((5, 30000), (3, 9000), (6, 51000), (4, 4096), (5, 12345))]
+    first = inference.score_loci_wls_batch_device([m.clone() for m in mats], workers=3)
+    assert inference.last_batch_growths_in_flight == 0
+    again = inference.score_loci_wls_batch_device([m.clone() for m in mats], workers=3)
+    assert inference.last_batch_growths_in_flight == 0
+    for (a, _da), (b, _db), m in zip(first, again, mats):
+        single = inference.score_loci_wls_device(m.clone())[0]
+        assert torch.equal(a, b) and torch.equal(a, single)
