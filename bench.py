@@ -516,10 +516,10 @@ def main():
             import multiprocessing as mp
 
             ctx = mp.get_context("spawn")
-            # (a one-GPU box's CPU share is 16 cores; there are only as many jobs as chromosomes)
-            share = max(1, min(16, usable, len(jobs)))
-            for label, procs in (("one_process", 1), ("four_processes_reference_policy", min(4, usable)), ("cpu_share_one_chromosome_per_core", share)):
-                if procs <= 4 and label.startswith("cpu_share"):
+            # every usable core, one chromosome per core -- there are only as many jobs as chromosomes
+            share = max(1, min(usable, len(jobs)))
+            for label, procs in (("one_process", 1), ("four_processes_reference_policy", min(4, usable)), ("all_cores_one_chromosome_per_core", share)):
+                if procs <= 4 and label.startswith("all_cores"):
                     continue
                 t0 = time.perf_counter()
                 if procs == 1:

@@ -227,7 +227,9 @@ def solve_rank(chroms: Sequence[ChromWork], scores_out: Optional[list] = None, g
 
             with _group_lock:
                 if _pool is None:
-                    _pool = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix="rocco-solve")
+                    # (one thread per group stream, never more than the side streams allowed)
+                    _pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, _native.max_side_streams()),
+                                                                  thread_name_prefix="rocco-solve")
                 futures = []
                 if SCORE_FIRST:
                     every, stats_all = score_all([chroms[i] for i in order])
