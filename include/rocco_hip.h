@@ -415,6 +415,8 @@ int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *
 int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const size_t *rows, const size_t *cols,
                                  double penalty_lambda, void *stream);
 long long rocco_hip_buffer_growths(void);
+/* device memory the solver's scratch buffers hold now (they are kept between calls) */
+long long rocco_hip_solver_device_bytes(const rocco_hip_solver *solver);
 
 /* ---- the multipliers of the bootstrap draws on the device (missing item 2) ---------------------
  * Replaces rocco/inference.py:546-575 `_generate_dependent_wild_weights` (called per row and draw at 654-664 and per

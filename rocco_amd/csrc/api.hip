@@ -848,6 +848,22 @@ int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t c
 
 long long rocco_hip_buffer_growths(void) { return g_buffer_growths.load(std::memory_order_relaxed); }
 
+long long rocco_hip_solver_device_bytes(const rocco_hip_solver *solver)
+{
+    if (solver == nullptr) {
+        return 0;
+    }
+    const rocco::DeviceBuffer *all[] = {&solver->dev_tasks, &solver->dev_params, &solver->dev_results, &solver->dev_bits, &solver->dev_misc,
+                                        &solver->dev_median_partials, &solver->dev_solution, &solver->dev_maps, &solver->dev_frozen,
+                                        &solver->dev_lean_pool, &solver->dev_lean_round, &solver->dev_lean_look, &solver->dev_lean_desc,
+                                        &solver->dev_lean_wcap, &solver->dev_chain};
+    long long total = 0;
+    for (const rocco::DeviceBuffer *b : all) {
+        total += (long long)b->bytes;
+    }
+    return total;
+}
+
 int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const size_t *rows, const size_t *cols, double penalty_lambda,
                                  void *stream)
 {

@@ -16,7 +16,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -387,7 +387,7 @@ def release_batch_workers() -> None:
 
 def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
                                 precision_floor_ratio: float = 0.01, overwrite_input: bool = False,
-                                input_scale: str = "counts", workers: int = 3):
+                                input_scale: str = "counts", workers: int = 3, memory_budget_bytes: Optional[int] = None):
     """`score_loci_wls_device` for several [K_i, n_i] float64 CUDA count matrices -- the chromosomes a rank owns
     (the loop of rocco/rocco.py:948-1018 around rocco/inference.py:302-379).  Returns one (scores, details) pair per
     matrix, bit for bit what the single-matrix call returns.  What is shared: the matrices are dealt to `workers`
@@ -399,7 +399,14 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
     medians; rank finding, dealing, selects and accumulation of the trend fit) are launches over whole matrices.
     Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values): 0.70 s with one pipeline, 0.60 s with two, 0.58 s with three
     (the default; the baselines of the longest rows -- 5 M loci x 27 ns x 2 sweeps -- are 0.27-0.30 s of it whatever
-    runs beside them)."""
+    runs beside them).
+
+    Memory: beside its matrices a pipeline holds, while it works on a set of them of S bytes, their baselines (S), the
+    sweeps' scratch (2 S) and then their rolling variances (S) -- four times the set.  A pipeline therefore walks its
+    matrices in CHUNKS whose size the device's free memory allows (`memory_budget_bytes`: what the whole call may hold
+    beside the inputs; default 92 % of what is free or reusable when it starts): everything at once when that fits (the K = 100
+    genome: 49 GB of matrices, ~200 GB in all), several chunks one after the other when it does not (K = 50 at 10 bp,
+    123 GB of matrices, centred in place: chunks of ~40 GB, each paying its longest row's chains again)."""
     import concurrent.futures
 
     import torch
@@ -456,52 +463,57 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
 
         with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
             stream.wait_event(start)
-            # phase 1: log scale, pilot offset (rocco/inference.py:325, 333-334)
-            centred = {i: log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite[i] else None,
-                                                       apply_log2=(input_scale == "counts"))[0] for i in idx}
-            stamp("baselines start")
-            # phase 2: local baselines (335), the group's matrices of one penalty together, and their subtraction (338)
-            windows = {i: _resolve_local_baseline_window(int(centred[i].shape[1]), target_window=101) for i in idx}
-            penalties = {i: (0.0 if windows[i] == 0 else _consenrich_whittaker_lambda(windows[i])) for i in idx}
-            for lam in sorted({penalties[i] for i in idx if windows[i] != 0}):
-                same = [i for i in idx if windows[i] != 0 and penalties[i] == lam]
-                baselines = crossfit_whittaker_baseline_batch_device([centred[i] for i in same], lam)
-                for i, b in zip(same, baselines):
-                    c = centred[i]
-                    rc = _native.load().rocco_hip_subtract_finite_f64(solver.handle, c.data_ptr(), b.data_ptr(), c.data_ptr(),
-                                                                      int(c.shape[0]) * int(c.shape[1]), stream.cuda_stream)
-                    if rc == _native.EINVAL:
-                        raise ValueError("Local baseline fit produced non-finite values")
-                    _native.check(rc, "rocco_hip_subtract_finite_f64")
-                del baselines
-            stamp("rolling variances start")
-            # phase 3: the centred WLS (342-348): the rolling variances of every row of the group in one launch (one
-            # workgroup per row), then rank finding, trend fits and accumulation matrix by matrix
-            variances = dict(zip(idx, wls_rolling_variances_batch_device([centred[i] for i in idx], spatial_window=31)))
-            stamp("trend fits and accumulation start")
-            for i in idx:
-                c = centred[i]
-                n = int(c.shape[1])
-                floor_ratio = float(max(precision_floor_ratio, 0.0))
-                scores, mean, raw, prior, mod, se, total_df, resolved_window = score_centered_wls_device(
-                    c, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df), min_effect=min_effect, spatial_window=31,
-                    precision_floor_ratio=floor_ratio, variances_t=variances.pop(i))
-                z_scores = mean / torch.clamp_min(se, 1.0e-8)
-                if not bool(torch.isfinite(torch.stack([scores, mean, raw, prior, mod, se, z_scores])).all()):
-                    raise ValueError("EB scoring produced non-finite values")
-                details = {
-                    "input_scale": "log2p1", "local_baseline_window": int(windows[i]), "local_baseline_lambda": float(penalties[i]),
-                    "mean": mean, "raw_variance": raw, "prior_variance": prior, "moderated_variance": mod, "standard_error": se,
-                    "z_scores": z_scores, "min_effect": float(0.0 if min_effect is None else max(min_effect, 0.0)),
-                    "precision_floor_ratio": floor_ratio, "prior_spatial_window": int(resolved_window),
-                    "degrees_of_freedom": torch.full((n,), float(total_df), dtype=torch.float64, device=c.device),
-                    "centered_matrix": c,
-                }
-                for t in (scores, mean, raw, prior, mod, se, z_scores, details["degrees_of_freedom"], c):
-                    t.record_stream(caller_stream)
-                result[i] = (scores, details)
+            for part in chunks_of[slot]:
+                run_chunk(solver, stream, part, stamp)
             stream.synchronize()
             stamp("done")
+
+    def run_chunk(solver, stream, idx, stamp):
+        # phase 1: log scale, pilot offset (rocco/inference.py:325, 333-334)
+        centred = {i: log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite[i] else None,
+                                                   apply_log2=(input_scale == "counts"))[0] for i in idx}
+        stamp("baselines start")
+        # phase 2: local baselines (335), the group's matrices of one penalty together, and their subtraction (338)
+        windows = {i: _resolve_local_baseline_window(int(centred[i].shape[1]), target_window=101) for i in idx}
+        penalties = {i: (0.0 if windows[i] == 0 else _consenrich_whittaker_lambda(windows[i])) for i in idx}
+        for lam in sorted({penalties[i] for i in idx if windows[i] != 0}):
+            same = [i for i in idx if windows[i] != 0 and penalties[i] == lam]
+            baselines = crossfit_whittaker_baseline_batch_device([centred[i] for i in same], lam)
+            for i, b in zip(same, baselines):
+                c = centred[i]
+                rc = _native.load().rocco_hip_subtract_finite_f64(solver.handle, c.data_ptr(), b.data_ptr(), c.data_ptr(),
+                                                                  int(c.shape[0]) * int(c.shape[1]), stream.cuda_stream)
+                if rc == _native.EINVAL:
+                    raise ValueError("Local baseline fit produced non-finite values")
+                _native.check(rc, "rocco_hip_subtract_finite_f64")
+            del baselines
+        stamp("rolling variances start")
+        # phase 3: the centred WLS (342-348): the rolling variances of every row of the group in one launch (one
+        # workgroup per row), then rank finding, trend fits and accumulation matrix by matrix
+        variances = dict(zip(idx, wls_rolling_variances_batch_device([centred[i] for i in idx], spatial_window=31)))
+        stamp("trend fits and accumulation start")
+        for i in idx:
+            c = centred[i]
+            n = int(c.shape[1])
+            floor_ratio = float(max(precision_floor_ratio, 0.0))
+            scores, mean, raw, prior, mod, se, total_df, resolved_window = score_centered_wls_device(
+                c, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df), min_effect=min_effect, spatial_window=31,
+                precision_floor_ratio=floor_ratio, variances_t=variances.pop(i))
+            z_scores = mean / torch.clamp_min(se, 1.0e-8)
+            if not bool(torch.isfinite(torch.stack([scores, mean, raw, prior, mod, se, z_scores])).all()):
+                raise ValueError("EB scoring produced non-finite values")
+            details = {
+                "input_scale": "log2p1", "local_baseline_window": int(windows[i]), "local_baseline_lambda": float(penalties[i]),
+                "mean": mean, "raw_variance": raw, "prior_variance": prior, "moderated_variance": mod, "standard_error": se,
+                "z_scores": z_scores, "min_effect": float(0.0 if min_effect is None else max(min_effect, 0.0)),
+                "precision_floor_ratio": floor_ratio, "prior_spatial_window": int(resolved_window),
+                "degrees_of_freedom": torch.full((n,), float(total_df), dtype=torch.float64, device=c.device),
+                "centered_matrix": c,
+            }
+            for t in (scores, mean, raw, prior, mod, se, z_scores, details["degrees_of_freedom"], c):
+                t.record_stream(caller_stream)
+            result[i] = (scores, details)
+        del centred, variances
 
     with _batch_lock:
         if _batch_pool is None:
@@ -510,15 +522,43 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         # Every pipeline's solver is sized HERE, on the calling thread, for the matrices it is about to see (scratch of the
         # baseline sweeps, the rolling task table, the trend fit's scratch, the Whittaker factor of its longest row): no
         # worker thread allocates or frees device memory -- both synchronise the whole device -- while the others are in flight.
-        for slot, idx in enumerate(groups):
+        # chunks: what a pipeline holds beside the inputs is ~4x the chunk it works on (+ a copy of every matrix that
+        # may not be centred in place, which stays as the result's centred matrix)
+        torch.cuda.synchronize(device)
+        free_now, _total = torch.cuda.mem_get_info(device)
+        # what the call may take: free memory, what PyTorch's allocator caches without using, and what the pipelines'
+        # solvers already hold from earlier calls (their scratch is reused, not allocated again)
+        cached = max(0, int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device)))
+        held = sum(int(_native.load().rocco_hip_solver_device_bytes(_batch_worker(device.index, slot)[0].handle))
+                   for slot in range(len(groups)))
+        budget = int(0.92 * (free_now + cached + held)) if memory_budget_bytes is None else int(memory_budget_bytes)
+        copies = sum(8 * sizes[i] for i in range(len(counts_list)) if not overwrite[i])
+        everything = max(1, sum(8 * sizes[i] for idx in groups for i in idx))
+        chunks_of = []
+        for idx in groups:
+            # (a pipeline's share of the budget is its share of the values)
+            per_group = max(0, budget - copies) * sum(8 * sizes[i] for i in idx) // everything
+            parts, part, held = [], [], 0
+            for i in idx:  # (longest first: a chunk's first matrix holds its longest rows)
+                if part and 4 * (held + 8 * sizes[i]) > per_group:
+                    parts.append(part)
+                    part, held = [], 0
+                part.append(i)
+                held += 8 * sizes[i]
+            parts.append(part)
+            chunks_of.append(parts)
+        if trace:
+            print(f"[batch] {len(groups)} pipelines, chunks per pipeline {[len(p) for p in chunks_of]}, budget {budget / 1e9:.1f} GB", flush=True)
+        for slot, parts in enumerate(chunks_of):
             solver, _stream = _batch_worker(device.index, slot)
-            rows_a = (ctypes.c_size_t * len(idx))(*[int(counts_list[i].shape[0]) for i in idx])
-            cols_a = (ctypes.c_size_t * len(idx))(*[int(counts_list[i].shape[1]) for i in idx])
-            lams = {_consenrich_whittaker_lambda(w) for w in (_resolve_local_baseline_window(int(counts_list[i].shape[1]), target_window=101)
-                                                                for i in idx) if w != 0}
-            _native.check(_native.load().rocco_hip_count_path_reserve(solver.handle, len(idx), rows_a, cols_a,
-                                                                      max(lams) if len(lams) == 1 else 0.0,
-                                                                      caller_stream.cuda_stream), "rocco_hip_count_path_reserve")
+            for idx in parts:
+                rows_a = (ctypes.c_size_t * len(idx))(*[int(counts_list[i].shape[0]) for i in idx])
+                cols_a = (ctypes.c_size_t * len(idx))(*[int(counts_list[i].shape[1]) for i in idx])
+                lams = {_consenrich_whittaker_lambda(w) for w in (_resolve_local_baseline_window(int(counts_list[i].shape[1]), target_window=101)
+                                                                    for i in idx) if w != 0}
+                _native.check(_native.load().rocco_hip_count_path_reserve(solver.handle, len(idx), rows_a, cols_a,
+                                                                          max(lams) if len(lams) == 1 else 0.0,
+                                                                          caller_stream.cuda_stream), "rocco_hip_count_path_reserve")
         start = torch.cuda.Event()
         start.record(caller_stream)
         t_start = _time.perf_counter()

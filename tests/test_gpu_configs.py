@@ -123,6 +123,42 @@ def test_config5_whole_genome_k50_10bp(gpu, oracle):
         assert res["path"] in (1, 4), name  # certified or exact spine: never the sequential last resort
 
 
+def test_config5_count_matrices_scored_on_one_gpu(gpu):
+    """BASELINE config 5 as count matrices: K = 50, 10 bp bins, 308.8 M loci = 123.5 GB of counts -- the count-path scoring
+    (rocco/inference.py:302-379 for every chromosome) in ONE call on one GPU: the matrices are centred in place and every
+    pipeline walks its chromosomes in chunks that the free memory allows (rocco_amd.inference.score_loci_wls_batch_device).
+    Every track finite; the chunked call's tracks for three chromosomes bit for bit the single-matrix call's."""
+    import torch
+
+    from rocco_amd import inference, synth
+
+    K, step = 50, 10
+    genome = synth.chrom_loci(step)
+    free, _total = torch.cuda.mem_get_info()
+    if free < 250e9:
+        pytest.skip("needs 250 GB of free HBM")
+    mats = []
+    for i, (_name, n) in enumerate(genome):
+        m = synth.hash_matrix_device(K, n, synth.chrom_seed(20240, i))
+        m.mul_(20.0).round_()
+        mats.append(m)
+    check = [len(genome) - 1, len(genome) - 3, 12]  # chr21, chrY and one of middle length: kept to compare
+    kept = {i: mats[i].clone() for i in check}
+    out = inference.score_loci_wls_batch_device(mats, overwrite_input=True)
+    assert inference.last_batch_growths_in_flight == 0
+    for (scores, details), (_name, n) in zip(out, genome):
+        assert tuple(scores.shape) == (n,) and bool(torch.isfinite(scores).all())
+        assert details["centered_matrix"].shape == (K, n)
+    tracks = {i: (out[i][0].clone(), out[i][1]["standard_error"].clone(), out[i][1]["centered_matrix"][:, :4096].clone()) for i in check}
+    del out, mats
+    inference.release_batch_workers()
+    torch.cuda.empty_cache()
+    for i in check:
+        scores, details = inference.score_loci_wls_device(kept[i], overwrite_input=True)
+        assert torch.equal(scores, tracks[i][0]) and torch.equal(details["standard_error"], tracks[i][1])
+        assert torch.equal(details["centered_matrix"][:, :4096], tracks[i][2])
+
+
 # ---- entry points ------------------------------------------------------------------------------------------
 
 def _cache(rng, sizes, gamma=1.0):

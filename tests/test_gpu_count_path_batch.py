@@ -104,3 +104,23 @@ def test_no_solver_buffer_grows_while_the_pipelines_run(gpu):
     for (a, _da), (b, _db), m in zip(first, again, mats):
         single = inference.score_loci_wls_device(m.clone())[0]
         assert torch.equal(a, b) and torch.equal(a, single)
+
+
+def test_chunks_within_a_memory_budget_give_the_same_tracks(gpu):
+    """A budget that forces every pipeline to walk its matrices in several chunks (each paying its baseline and rolling
+    launches again): bit for bit the results of the call that holds everything at once."""
+    import torch
+
+    from rocco_amd import inference
+
+    rng = np.random.default_rng(21)
+    shapes = ((4, 20000), (4, 18000), (3, 9000), (5, 30000), (4, 4096), (4, 15000), (2, 7000))
+    mats = [torch.from_numpy(rng.poisson(5.0, size=s).astype(np.float64)).cuda() for s in shapes]
+    whole = inference.score_loci_wls_batch_device([m.clone() for m in mats], workers=2, overwrite_input=True)
+    largest = max(8 * k * n for k, n in shapes)
+    tight = inference.score_loci_wls_batch_device([m.clone() for m in mats], workers=2, overwrite_input=True,
+                                                  memory_budget_bytes=2 * 4 * largest)  # one or two matrices per chunk
+    assert inference.last_batch_growths_in_flight == 0
+    for (a, da), (b, db) in zip(whole, tight):
+        assert torch.equal(a, b) and torch.equal(da["centered_matrix"], db["centered_matrix"])
+        assert torch.equal(da["standard_error"], db["standard_error"])
