@@ -608,7 +608,30 @@ public:
     bool force_full_ = false;  // (set while penalties the model kernel could not certify are repeated by the full kernels)
     bool model_any_ = false;   // test entry: any problem with a map, and the flags are reported instead of settled
 
-    int probe_depth(size_t problem) const override { return model_eligible(problem) ? 5 : 0; }
+    // Levels of the bisection tree a rounding-model round evaluates (2^depth - 1 penalties, four per workgroup): as deep
+    // as keeps the round of ALL compacted problems within one wave of workgroups -- a round costs its latency (one
+    // wave: ~40 us, plus ~45 us of turn-around) until it spills into further waves, and fourteen open levels take
+    // five rounds of three levels (the genome's 214 tiles: 2.55 ms per calibration) against three of five (2.68 ms).
+    int probe_depth(size_t problem) const override
+    {
+        if (!model_eligible(problem)) {
+            return 0;
+        }
+        if (const char *e = std::getenv("ROCCO_HIP_MODEL_DEPTH")) {
+            return std::max(1, std::min(6, std::atoi(e)));
+        }
+        long long tiles = 0;
+        for (size_t b = 0; b < probs.size(); ++b) {
+            if (probs[b].compacted && probs[b].costs == nullptr) {
+                tiles += (long long)((probs[b].n + kLeanTile - 1) / kLeanTile);
+            }
+        }
+        int depth = 3;
+        while (depth < 6 && tiles * ((((1LL << (depth + 1)) - 1) + kLeanModelBatch - 1) / kLeanModelBatch) <= 512) {
+            ++depth;
+        }
+        return depth;
+    }
 
     static constexpr long long kPilotMinTiles = 128;
 
