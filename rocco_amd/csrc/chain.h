@@ -116,6 +116,8 @@ struct ChainHot {
     int np;    // its penalties
     int have_soft;
     int can_pilot;
+    int pilot_ready;  // the pilot's estimate is smooth enough (or its rounds are used up): waits for the batch's other pilots
+    int pad;
 };
 static_assert(sizeof(ChainHot) % 8 == 0, "ChainHot is moved as 8-byte words");
 

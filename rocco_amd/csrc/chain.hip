@@ -114,6 +114,8 @@ __device__ void init_problem(const ChainArgs &A, int b, ChainHot &H)
     H.np = 0;
     H.have_soft = 0;
     H.can_pilot = in.can_pilot;
+    H.pilot_ready = 0;
+    H.pad = 0;
     if (in.allowed == 0 || in.n < 2 || !(in.target < in.n) || in.target < 0) {
         return;
     }
@@ -243,11 +245,9 @@ __device__ int consume(const ChainArgs &A, int b, ChainHot &H, double x, long lo
             // within a hundredth of the range).  Or when the interval is as narrow as epsilon allows, or the rounds are
             // used up.
             const bool smooth = H.est_pg <= 2.5 * fmax(H.est_pl, 1.0);
-            if (left <= 0 || !(pl - pg > 64.0 * eps) || smooth) {
-                H.pilot_left = 0;
-                H.pilot_hint = 1;
-                H.phase = 2;
-            }
+            // (the pilots of a batch end together -- see the director: the pass over every locus that follows is one launch
+            // for all of them, not one per group of stragglers)
+            H.pilot_ready = (left <= 0 || !(pl - pg > 64.0 * eps) || smooth) ? 1 : 0;
         }
         return 0;
     }
@@ -332,6 +332,7 @@ __device__ int consume(const ChainArgs &A, int b, ChainHot &H, double x, long lo
             H.est_pl = fmin(H.est_pl, (double)c_less);
             H.phase = 1;
             H.pilot_left = 2;
+            H.pilot_ready = 0;
         }
         if (n_evals + np + kLeanMaxPoints > kChainMaxEvals) {
             give_up(H);  // (no room for another round's records: the host goes on)
@@ -586,6 +587,36 @@ __global__ __launch_bounds__(kDirectorThreads) void chain_director_kernel(ChainA
         }
     }
     __syncthreads();
+    {
+        // The pilots of a batch end together: while one of them still needs a round the others refine theirs (a round
+        // costs the same with them in it), and the pass over every locus that follows is ONE launch.
+        __shared__ int s_waiting;
+        if (threadIdx.x == 0) {
+            s_waiting = 0;
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < B; b += kDirectorThreads) {
+            if (s_flex[b] == 2 && sh[b].pilot_ready == 0) {
+                atomicOr(&s_waiting, 1);
+            }
+        }
+        __syncthreads();
+        if (s_waiting == 0) {
+            for (int b = threadIdx.x; b < B; b += kDirectorThreads) {
+                if (s_flex[b] == 2) {
+                    ChainHot &H = sh[b];
+                    H.pilot_left = 0;
+                    H.pilot_hint = 1;
+                    H.pilot_ready = 0;
+                    H.phase = 2;
+                    s_nt[b] = (int)((H.lv_m + kLeanTile - 1) / kLeanTile);
+                    s_stride[b] = 1;
+                    s_flex[b] = (H.n_levels == 1 && s_nt[b] >= 128) ? 0 : 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (trace) trace[2] = (long long)wall_clock64();
     if (wave == 0) {
         // penalties per problem: as many groups of eight as keep the round within the workgroups it should fill
@@ -624,8 +655,8 @@ __global__ __launch_bounds__(kDirectorThreads) void chain_director_kernel(ChainA
                 pts[__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = x;
             }
             np = __builtin_popcountll(mask);
-            if (np == 0 && lane == 0) {
-                give_up(H);
+            if (np == 0 && lane == 0 && H.pilot_ready == 0) {
+                give_up(H);  // (a pilot that is ready and has no room left for samples sits the round out)
             }
         } else {
             const int want = (s_flex[b] == 1) ? s_want : max(1, min(8, A.tune.big_points));
