@@ -620,10 +620,13 @@ public:
         if (const char *e = std::getenv("ROCCO_HIP_MODEL_DEPTH")) {
             return std::max(1, std::min(6, std::atoi(e)));
         }
-        long long tiles = 0;
-        for (size_t b = 0; b < probs.size(); ++b) {
-            if (probs[b].compacted && probs[b].costs == nullptr) {
-                tiles += (long long)((probs[b].n + kLeanTile - 1) / kLeanTile);
+        // (the problems still asking: those of the last rounding-model round; before the first one, every compacted problem)
+        long long tiles = model_tiles_last_round_;
+        if (tiles <= 0) {
+            for (size_t b = 0; b < probs.size(); ++b) {
+                if (probs[b].compacted && probs[b].costs == nullptr) {
+                    tiles += (long long)((probs[b].n + kLeanTile - 1) / kLeanTile);
+                }
             }
         }
         int depth = 3;
@@ -632,6 +635,8 @@ public:
         }
         return depth;
     }
+
+    long long model_tiles_last_round_ = 0;
 
     static constexpr long long kPilotMinTiles = 128;
 
@@ -724,6 +729,7 @@ public:
         ++lean_rounds;
         std::vector<LeanCompactTask> pre, post;
         std::vector<LeanTask> tasks, model_tasks;
+        long long model_tiles = 0;
         std::vector<LeanWcapTask> wcap_tasks;
         int model_units = 0, wcap_blocks = 0;
         std::vector<double> points;
@@ -754,6 +760,7 @@ public:
                 }
                 const int np = (int)r.lambdas.size();
                 const int nt = (int)((p.n + kLeanTile - 1) / kLeanTile);
+                model_tiles += nt;
                 LeanTask t;
                 t.s = p.scores;
                 t.m = (long long)p.n;
@@ -990,6 +997,9 @@ public:
             rebatch(model_tasks, kLeanModelBatch, model_units);
         }
         lean_units += units + model_units;
+        if (model_tiles > 0) {
+            model_tiles_last_round_ = model_tiles;
+        }
         const int n_bound_tasks = (int)tasks.size();
         tasks.insert(tasks.end(), model_tasks.begin(), model_tasks.end());
 
@@ -2535,6 +2545,7 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_ROUNDS")) opt.pilot_rounds = std::atoi(e);
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_POINTS")) opt.pilot_points = std::atoi(e);
     if (const char *e = std::getenv("ROCCO_HIP_ALIGN_MAPS")) opt.align_maps = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ROCCO_HIP_ALIGN_WINDOWS")) opt.align_windows = std::atoi(e) != 0;
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_LEVELS")) {  // comma list, e.g. "2.2" or "2.2,1.0"
         opt.pilot_levels.clear();
         for (const char *q = e; *q != '\0';) {

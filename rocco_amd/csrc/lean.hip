@@ -85,6 +85,33 @@ __device__ __forceinline__ double granule_wait(const unsigned long long *p, unsi
     return __longlong_as_double((long long)v);
 }
 
+// ---- which task a ticket (workgroup slot, pair) belongs to ---------------------------------------------------
+// The tasks of a launch are a short table in memory (one per chromosome and level); a workgroup finds its own from
+// the first ticket of every task.  Walking the table costs one DEPENDENT memory round trip per task -- up to two
+// dozen before a workgroup's first useful load, and in a round of a single wave of workgroups every workgroup is the
+// first on its CU, with cold caches: that walk was most of the ~25 us such a round took beyond its work.  Here the
+// lanes of a wavefront fetch the tasks' first tickets side by side (one round trip per 64 tasks) and a ballot picks
+// the last one that does not exceed the key.  Every lane of the wavefront must call it with the same key.
+template <typename First>
+__device__ __forceinline__ int find_task(int n_tasks, int key, First first_of)
+{
+    const int lane = threadIdx.x & 63;
+    int ti = 0;
+    for (int base = 0; base < n_tasks; base += 64) {
+        const int i = base + lane;
+        const int v = (i < n_tasks) ? first_of(i) : 0x7FFFFFFF;
+        const unsigned long long le = __ballot(v <= key);
+        if (le == 0ull) {
+            break;
+        }
+        ti = base + 63 - __builtin_clzll(le);
+        if (le != ~0ull) {
+            break;
+        }
+    }
+    return ti;
+}
+
 // ---- tile staging: rn_q(score) into LDS --------------------------------------------------------
 template <bool RAW>
 __device__ __forceinline__ void stage_tile(const double *__restrict__ s, long long m, long long base, double magic,
@@ -457,10 +484,7 @@ constexpr int kZeroBytes = 16384;  // per workgroup of the zero launch
 
 __global__ __launch_bounds__(256) void lean_zero_batch_kernel(const LeanScatterTask *__restrict__ tasks, int n_tasks)
 {
-    int ti = 0;
-    while (ti + 1 < n_tasks && tasks[ti + 1].zero_begin <= (int)blockIdx.x) {
-        ++ti;
-    }
+    const int ti = find_task(n_tasks, (int)blockIdx.x, [&](int i) { return tasks[i].zero_begin; });
     const LeanScatterTask task = tasks[ti];
     const long long at = (long long)((int)blockIdx.x - task.zero_begin) * kZeroBytes;
     uint8_t *p = task.full + at;
@@ -481,10 +505,7 @@ __global__ __launch_bounds__(256) void lean_zero_batch_kernel(const LeanScatterT
 
 __global__ __launch_bounds__(256) void lean_scatter_batch_kernel(const LeanScatterTask *__restrict__ tasks, int n_tasks)
 {
-    int ti = 0;
-    while (ti + 1 < n_tasks && tasks[ti + 1].scatter_begin <= (int)blockIdx.x) {
-        ++ti;
-    }
+    const int ti = find_task(n_tasks, (int)blockIdx.x, [&](int i) { return tasks[i].scatter_begin; });
     const LeanScatterTask task = tasks[ti];
     const long long i = (long long)((int)blockIdx.x - task.scatter_begin) * 256 + threadIdx.x;
     if (i < task.m) {
@@ -804,14 +825,30 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
 // One wavefront per (task, penalty): close the fill across tiles, lay out the compaction.
 __device__ __forceinline__ void finish_pair(const LeanLaunch &L, int n_tasks, int pair)
 {
+    // the task whose penalties hold this pair: the tasks' penalty counts summed side by side (see find_task)
+    const int lane = threadIdx.x;
     int ti = 0, acc = 0;
-    while (ti + 1 < n_tasks && acc + L.tasks[ti].n_points <= pair) {
-        acc += L.tasks[ti].n_points;
-        ++ti;
+    for (int base = 0; base < n_tasks; base += 64) {
+        const int i = base + lane;
+        const int np_i = (i < n_tasks) ? L.tasks[i].n_points : 0;
+        int incl = np_i;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            incl += (lane >= off) ? v : 0;
+        }
+        const unsigned long long beyond = __ballot(i < n_tasks && acc + incl > pair);  // first task whose end passes the pair
+        if (beyond != 0ull) {
+            const int at = __builtin_ctzll(beyond);
+            ti = base + at;
+            acc += __shfl(incl - np_i, at);
+            break;
+        }
+        acc += __shfl(incl, 63);
+        ti = min(n_tasks - 1, base + 63);
     }
     const LeanTask task = L.tasks[ti];
     const int p = pair - acc;
-    const int lane = threadIdx.x;
     const LeanTileRec *recs = L.recs + (long long)task.rec_begin + (long long)p * task.n_tiles;
     const int nt = task.n_tiles;
 
@@ -938,10 +975,7 @@ __device__ __forceinline__ void compact_block(const LeanCompactTask *tasks, int 
     unsigned(&wave_sum)[4] = sh.wave_sum;
     unsigned &total_s = sh.total_s;
     int *src = sh.src;
-    int ti = 0;
-    while (ti + 1 < n_tasks && tasks[ti + 1].block_begin <= block) {
-        ++ti;
-    }
+    const int ti = find_task(n_tasks, block, [&](int i) { return tasks[i].block_begin; });
     const LeanCompactTask task = tasks[ti];
     const int tile = block - task.block_begin;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1064,10 +1098,7 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_eval_kernel(LeanLaunch L
     if (ticket >= L.n_units) {
         return;
     }
-    int ti = 0;
-    while (ti + 1 < L.n_tasks && L.tasks[ti + 1].unit_begin <= ticket) {
-        ++ti;
-    }
+    const int ti = find_task(L.n_tasks, ticket, [&](int i) { return L.tasks[i].unit_begin; });
     const LeanTask task = L.tasks[ti];
     const int unit = ticket - task.unit_begin;
     const int tile = unit / task.n_groups, group = unit % task.n_groups;
@@ -1111,10 +1142,7 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_eval_chain_kernel(LeanLa
         if (ticket >= n_units) {
             return;
         }
-        int ti = 0;
-        while (ti + 1 < n_tasks && L.tasks[ti + 1].unit_begin <= ticket) {
-            ++ti;
-        }
+        const int ti = find_task(n_tasks, ticket, [&](int i) { return L.tasks[i].unit_begin; });
         const LeanTask task = L.tasks[ti];
         const int unit = ticket - task.unit_begin;
         const int tile = unit / task.n_groups, group = unit % task.n_groups;
@@ -1155,10 +1183,7 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_model_kernel(LeanLaunch 
     if (ticket >= L.n_units) {
         return;
     }
-    int ti = 0;
-    while (ti + 1 < L.n_tasks && L.tasks[ti + 1].unit_begin <= ticket) {
-        ++ti;
-    }
+    const int ti = find_task(L.n_tasks, ticket, [&](int i) { return L.tasks[i].unit_begin; });
     const LeanTask task = L.tasks[ti];
     const int unit = ticket - task.unit_begin;
     const int tile = unit / task.n_groups, group = unit % task.n_groups;
@@ -1181,10 +1206,7 @@ __global__ __launch_bounds__(kLeanThreads) void lean_wcap_count_kernel(const Lea
 {
     __shared__ unsigned steps[128], ties[128], clean[128];
     __shared__ double magic_u[kLeanThreads], half_u[kLeanThreads];  // per chunk of the tile (0: hazard, no tie test)
-    int ti = 0;
-    while (ti + 1 < n_tasks && tasks[ti + 1].block_begin <= (int)blockIdx.x) {
-        ++ti;
-    }
+    const int ti = find_task(n_tasks, (int)blockIdx.x, [&](int i) { return tasks[i].block_begin; });
     const LeanWcapTask task = tasks[ti];
     const int t = threadIdx.x;
     if (t < 128) {

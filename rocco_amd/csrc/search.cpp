@@ -459,6 +459,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
         std::vector<WindowRequest> surveys;
         std::vector<CompactRequest> compacts;
         std::vector<size_t> first_maps;  // positions in `maps` of maps asked for right after a threshold search
+        std::vector<size_t> final_windows;  // positions in `windows` of windows that only certify and write a decided penalty
 
         // speculation depth of this iteration's probe rounds, from the loci they will cover
         double round_loci = 0.0;
@@ -791,6 +792,9 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 r.problem = b;
                 r.lambda_lo = std::min(eff_lower(s), s.upper);  // below it every outcome is known already
                 r.lambda_hi = s.upper;
+                if (s.iters_left <= 0 && !s.use_exact) {
+                    final_windows.push_back(windows.size());
+                }
                 windows.push_back(r);
                 window_owner.push_back(b);
                 break;
@@ -830,6 +834,15 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     maps.erase(maps.begin() + (long)first_maps[k]);
                     map_owner.erase(map_owner.begin() + (long)first_maps[k]);
                 }
+            }
+        }
+        if (opt.align_windows && !final_windows.empty() && final_windows.size() < B &&
+            (!probes.empty() || !maps.empty() || !compacts.empty() || !spines.empty() || windows.size() > final_windows.size())) {
+            // other problems of the batch are still at work: the finished ones' last windows sit this round out (their
+            // state does not change; they ask again in the next one)
+            for (size_t k = final_windows.size(); k-- > 0;) {
+                windows.erase(windows.begin() + (long)final_windows[k]);
+                window_owner.erase(window_owner.begin() + (long)final_windows[k]);
             }
         }
         if (probes.empty() && windows.empty() && exacts.empty() && maps.empty() && spines.empty() && compacts.empty()) {

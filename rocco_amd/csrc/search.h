@@ -273,6 +273,10 @@ struct SearchOptions {
     // kernels, so a problem that waits for the others loses nothing -- the batch ends with its slowest member either
     // way -- and the maps of all of them take ONE set of launches instead of one per straggler.
     bool align_maps = true;
+    // The same for the window that ends a calibration whose every bisection step is decided (it certifies the final
+    // penalty's solution and writes it): while another problem of the batch still asks for probes or a map, it waits --
+    // one set of window launches for the batch instead of one per group of finishers.
+    bool align_windows = true;
 };
 
 // What an evaluator found out about a problem before the calibration starts (chain.hip: the threshold search run as one
