@@ -417,6 +417,11 @@ int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const s
 long long rocco_hip_buffer_growths(void);
 /* device memory the solver's scratch buffers hold now (they are kept between calls) */
 long long rocco_hip_solver_device_bytes(const rocco_hip_solver *solver);
+/* Diagnostic, process-wide since load: how the last bisection steps of the calibrations (rocco/dp.py:141-162) were
+ * sequenced -- out[0] chains of rounding-model rounds queued by the device-side director (csrc/model_chain.h), out[1]
+ * certified counts the host took over from them, out[2] counts its replay of the reference's steps was answered from
+ * them without device work, out[3] counts it asked for that the chain had not evaluated (answered by regular rounds). */
+void rocco_hip_model_chain_counters(long long out[4]);
 
 /* ---- the multipliers of the bootstrap draws on the device (missing item 2) ---------------------
  * Replaces rocco/inference.py:546-575 `_generate_dependent_wild_weights` (called per row and draw at 654-664 and per

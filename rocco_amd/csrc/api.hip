@@ -64,7 +64,7 @@ int PinnedBuffer::reserve(size_t want)
         grow = want;
     }
     void *p = nullptr;
-    ROCCO_HIP_TRY(hipHostMalloc(&p, grow, hipHostMallocDefault));
+    ROCCO_HIP_TRY(hipHostMalloc(&p, grow, coherent ? (hipHostMallocCoherent | hipHostMallocMapped) : hipHostMallocDefault));
     if (ptr != nullptr) {
         (void)hipHostFree(ptr);
     }
@@ -139,6 +139,7 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->dev_lean_wcap.release();
     solver->dev_chain.release();
     solver->host_chain.release();
+    solver->host_follow.release();
     solver->dev_median_partials.release();
     solver->host_lean_stage.release();
     solver->host_lean_back.release();
@@ -847,6 +848,13 @@ int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t c
 }
 
 long long rocco_hip_buffer_growths(void) { return g_buffer_growths.load(std::memory_order_relaxed); }
+
+void rocco_hip_model_chain_counters(long long out[4])
+{
+    if (out != nullptr) {
+        rocco::model_chain_counters(out);
+    }
+}
 
 long long rocco_hip_solver_device_bytes(const rocco_hip_solver *solver)
 {

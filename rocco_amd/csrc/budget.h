@@ -44,4 +44,7 @@ int delta_window(rocco_hip_solver *solver, const double *scores_dev, const doubl
 int delta_model_lean(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n, const uint8_t *emap_dev,
                      const double *lambdas, size_t n_lambdas, long long *counts_out, long long *open_out, hipStream_t stream);
 
+// process-wide diagnostic (include/rocco_hip.h: rocco_hip_model_chain_counters)
+void model_chain_counters(long long out[4]);
+
 }  // namespace rocco

@@ -9,12 +9,14 @@
 #include "budget.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
 #include "chain.h"
+#include "model_chain.h"
 #include "chain_fast.h"
 #include "lean.h"
 #include "search.h"
@@ -117,6 +119,8 @@ int grid_exponent(double cmax, double lo, double hi)
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+std::atomic<long long> g_model_chain_counters[4];
+
 class HipEvaluator : public Evaluator {
 public:
     HipEvaluator(rocco_hip_solver *solver, hipStream_t stream) : solver_(solver), stream_(stream) {}
@@ -170,7 +174,9 @@ public:
         std::vector<RoundTask> tasks;
         add_probe_tasks(reqs, tasks);
         if (tasks.empty()) {
-            ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+            if (lean_wait_needed()) {
+                ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+            }
         } else if ((rc = run_round(tasks)) != ROCCO_HIP_OK) {
             return rc;
         }
@@ -714,6 +720,393 @@ public:
 
     static double separator_score(double base, double gamma) { return std::floor(base - 2.0 * gamma - 2.0); }
 
+    // ---- chained rounding-model rounds (model_chain.h) ----
+    // certified counts the evaluator holds per problem: (penalty, the reference's count there)
+    std::vector<std::vector<std::pair<double, long long>>> facts_;
+    std::vector<std::pair<size_t, double>> open_facts_;  // (problem, penalty) the chains evaluated without certifying the count
+    bool model_chain_inflight_ = false;  // the requests of lean_inflight_ started a chain (lean_consume answers them from its facts)
+    bool model_chain_running_ = false;   // a chain is on the stream and may still publish rounds
+    int model_chain_ingested_ = 0;       // rounds of it whose facts are in facts_
+    std::vector<size_t> model_chain_problems_;
+    const ModelChainReport *model_chain_report_ = nullptr;
+    const int *model_chain_np_ = nullptr;
+    const ModelChainFact *model_chain_facts_ = nullptr;
+    long long model_chains = 0, model_chain_facts = 0, model_chain_hits = 0, model_chain_misses = 0, model_chain_stopped = 0;
+    long long model_tiles_answered_ = 0;
+    double t_mchain_submit_ = 0.0, t_mchain_wait_ = 0.0;
+
+    // host-side event log (ROCCO_HIP_TIMING=2): label, microseconds
+    std::vector<std::pair<const char *, double>> marks_;
+    bool marks_on_ = false;
+    void mark(const char *label)
+    {
+        if (marks_on_) {
+            marks_.emplace_back(label, now_us());
+        }
+    }
+
+    // Does the iteration's lean work need the stream to drain before it is read?  Not when nothing was queued (every
+    // request was answered from the facts), and not for a chain: its rounds are followed through pinned memory.
+    bool lean_wait_needed() const { return !lean_inflight_.empty() && !model_chain_inflight_; }
+
+    bool fact_lookup(size_t problem, double lambda, long long *count) const
+    {
+        if (problem >= facts_.size()) {
+            return false;
+        }
+        for (const auto &f : facts_[problem]) {
+            if (f.first == lambda) {
+                *count = f.second;
+                return true;
+            }
+        }
+        return false;
+    }
+
+    bool facts_answer(const ProbeRequest &q, std::vector<ProbeResult> &res) const
+    {
+        res.assign(q.lambdas.size(), ProbeResult());
+        for (size_t i = 0; i < q.lambdas.size(); ++i) {
+            if (!fact_lookup(q.problem, q.lambdas[i], &res[i].count)) {
+                return false;
+            }
+        }
+        return true;
+    }
+
+    bool in_running_chain(size_t problem) const
+    {
+        return model_chain_running_ &&
+               std::find(model_chain_problems_.begin(), model_chain_problems_.end(), problem) != model_chain_problems_.end();
+    }
+
+    // Take over the rounds the running chain has published since the last call; `wait`: until at least one more round is
+    // there or the chain has ended.  The facts sit in host-coherent pinned memory, written by the director kernels.
+    int model_chain_ingest(bool wait, bool *got)
+    {
+        *got = false;
+        if (!model_chain_running_) {
+            return ROCCO_HIP_OK;
+        }
+        const double t0 = now_us();
+        const size_t B = model_chain_problems_.size();
+        const ModelChainReport *rep = model_chain_report_;
+        long long spins = 0;
+        for (;;) {
+            const int finished = __atomic_load_n(&rep->finished, __ATOMIC_ACQUIRE);
+            const int published = __atomic_load_n(&rep->published, __ATOMIC_ACQUIRE);
+            if (published > model_chain_ingested_) {
+                for (int r = model_chain_ingested_; r < published; ++r) {
+                    for (size_t i = 0; i < B; ++i) {
+                        const int np = model_chain_np_[(size_t)r * B + i];
+                        const ModelChainFact *f = model_chain_facts_ + ((size_t)r * B + i) * kLeanMaxPoints;
+                        for (int k = 0; k < np && k < kLeanMaxPoints; ++k) {
+                            if (f[k].flags == 0) {
+                                facts_[model_chain_problems_[i]].emplace_back(f[k].penalty, f[k].count);
+                                ++model_chain_facts;
+                            } else {
+                                open_facts_.emplace_back(model_chain_problems_[i], f[k].penalty);  // evaluated, not certified
+                            }
+                        }
+                    }
+                }
+                model_chain_ingested_ = published;
+                *got = true;
+                mark("chain round ingested");
+            }
+            if (finished != 0 && model_chain_ingested_ >= __atomic_load_n(&rep->published, __ATOMIC_ACQUIRE)) {
+                model_chain_running_ = false;
+                model_chain_stopped += rep->stopped;
+                if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                    std::fprintf(stderr, "[model chain] ended: %d rounds asked something, %d problems stopped at an open outcome\n",
+                                 rep->rounds_run, rep->stopped);
+                }
+                if (rep->error & 1u) {
+                    solver_->lean_look_dirty = 1;
+                    set_last_error("lean evaluation: a tile waited for its predecessor beyond the spin limit");
+                    return ROCCO_HIP_EHIP;
+                }
+                break;
+            }
+            if (*got || !wait) {
+                break;
+            }
+            if ((++spins & 1023) == 0 && hipStreamQuery(stream_) == hipSuccess) {
+                // the stream has drained: whatever was going to be published is there
+                if (__atomic_load_n(&rep->finished, __ATOMIC_ACQUIRE) == 0) {
+                    model_chain_running_ = false;
+                    set_last_error("model chain: the stream ended without the chain's report");
+                    return ROCCO_HIP_EHIP;
+                }
+            }
+        }
+        t_mchain_wait_ += now_us() - t0;
+        return ROCCO_HIP_OK;
+    }
+
+    int model_chain_drain()
+    {
+        int rc = ROCCO_HIP_OK;
+        bool got = false;
+        while (model_chain_running_ && rc == ROCCO_HIP_OK) {
+            rc = model_chain_ingest(true, &got);
+        }
+        return rc;
+    }
+
+    // every request of the round is a rounding-model probe that says how the bisection goes on: run the rounds ahead
+    bool model_chain_wanted(const std::vector<LeanReq> &reqs) const
+    {
+        const char *flag = std::getenv("ROCCO_HIP_MODEL_CHAIN");
+        if ((flag != nullptr && std::atoi(flag) == 0) || model_any_ || reqs.empty() || reqs.size() > (size_t)kModelChainMaxProblems) {
+            return false;
+        }
+        int rounds = 0;
+        for (const LeanReq &r : reqs) {
+            if (!r.model || r.probe == nullptr || !r.probe->ahead.valid || r.probe->ahead.open_depth < 1) {
+                return false;
+            }
+            const BisectionAhead &a = r.probe->ahead;
+            rounds = std::max(rounds, (a.iters_left + a.open_depth - 1) / a.open_depth);
+        }
+        return rounds >= 2;
+    }
+
+    int model_chain_enqueue(std::vector<LeanReq> &reqs)
+    {
+        int rc;
+        if ((rc = model_chain_drain()) != ROCCO_HIP_OK) return rc;
+        const double t0 = now_us();
+        mark("model chain: enqueue begins");
+        const size_t B = reqs.size();
+        ++lean_rounds;
+        ++model_chains;
+        std::vector<ModelChainWalk> walk(B);
+        std::vector<LeanTask> tasks(B);
+        std::vector<LeanWcapTask> wcap_tasks;
+        int wcap_blocks = 0;
+        long long tiles = 0;
+        int rounds = 0, depth0 = 0, depth_floor = 0;
+        model_chain_problems_.assign(B, 0);
+        for (size_t i = 0; i < B; ++i) {
+            LeanReq &r = reqs[i];
+            DevProblem &p = probs[r.problem];
+            const BisectionAhead &a = r.probe->ahead;
+            model_chain_problems_[i] = r.problem;
+            double *wcap = (double *)solver_->dev_lean_wcap.ptr + r.problem;
+            unsigned *counters = (unsigned *)((char *)solver_->dev_lean_wcap.ptr + align_up(probs.size() * sizeof(double), 256)) + 512 * r.problem;
+            if (p.wcap_version != p.map_version) {
+                LeanWcapTask wt;
+                wt.emap = p.emap;
+                wt.s = p.scores;
+                wt.m = (long long)p.n;
+                wt.qexp = p.qexp;
+                wt.e_floor = std::ilogb(2.0 * p.cmax + 2.0 * p.sabs + (p.sabs + 2.0) + 2.0);  // (|penalty| <= sabs + 2)
+                wt.counters = counters;
+                wt.clean_chunks = counters + 384;
+                wt.wcap = wcap;
+                wt.block_begin = wcap_blocks;
+                wt.pad = 0;
+                wcap_blocks += (int)((p.n + kLeanTile - 1) / kLeanTile);
+                wcap_tasks.push_back(wt);
+                p.wcap_version = p.map_version;
+            }
+            LeanTask &t = tasks[i];
+            t.s = p.scores;
+            t.m = (long long)p.n;
+            t.c_raw = p.gamma;
+            t.magic = std::ldexp(1.5, 52 + p.qexp);
+            t.big = std::ldexp(1.0, 50 + p.qexp);
+            t.n_tiles = (int)((p.n + kLeanTile - 1) / kLeanTile);
+            t.n_points = 0;
+            t.n_groups = 0;
+            t.unit_begin = 0;
+            t.point_begin = (int)i * kLeanMaxPoints;
+            t.rec_begin = 0;
+            t.bits_begin = 0;
+            t.off_begin = 0;
+            t.result_begin = (int)i * kLeanMaxPoints;
+            t.tile_stride = 1;
+            t.independent = 0;
+            t.store = 0;
+            t.emap = p.emap;
+            t.wcap = wcap;
+            t.clean_chunks = counters + 384;
+            t.cmax = p.cmax;
+            t.sabs = p.sabs;
+            t.qexp = p.qexp;
+            t.batch = kLeanModelBatch;
+            tiles += t.n_tiles;
+            ModelChainWalk &w = walk[i];
+            w.lower = a.lower;
+            w.upper = a.upper;
+            w.G = a.G;
+            w.L = a.L;
+            w.sabs = a.sabs;
+            w.cost_max = a.cost_max;
+            w.none_from = a.none_from;
+            w.all_upto = a.all_upto;
+            w.target = a.target;
+            w.cG = a.cG;
+            w.cL = a.cL;
+            w.n = a.n;
+            w.iters_left = a.iters_left;
+            w.G_real = a.G_real ? 1 : 0;
+            w.L_real = a.L_real ? 1 : 0;
+            w.cost_ok = a.cost_ok ? 1 : 0;
+            w.n_tiles = t.n_tiles;
+            w.pad[0] = w.pad[1] = w.pad[2] = 0;
+            depth0 = std::max(depth0, a.open_depth);
+            depth_floor = std::max(depth_floor, a.depth_floor);
+            rounds = std::max(rounds, (a.iters_left + a.open_depth - 1) / a.open_depth);
+        }
+        if (const char *e = std::getenv("ROCCO_HIP_MODEL_CHAIN_ROUNDS")) {
+            rounds = std::atoi(e);
+        }
+        rounds = std::max(1, std::min(kModelChainMaxRounds, rounds));
+        model_tiles_last_round_ = tiles + model_tiles_answered_;
+
+        // device: [tasks][walk][wcap tasks] (uploaded) [state][points][results][ctl][globals]
+        const size_t b_tasks = align_up(B * sizeof(LeanTask), 256);
+        const size_t b_walk = align_up(B * sizeof(ModelChainWalk), 256);
+        const size_t b_wcap = align_up(wcap_tasks.size() * sizeof(LeanWcapTask), 256);
+        const size_t up_bytes = b_tasks + b_walk + b_wcap;
+        const size_t b_state = align_up(B * sizeof(ModelChainState), 256);
+        const size_t b_points = align_up(B * kLeanMaxPoints * sizeof(double), 256);
+        const size_t b_results = align_up(B * kLeanMaxPoints * sizeof(LeanResult), 256);
+        const size_t dev_bytes = up_bytes + b_state + b_points + b_results + 512;
+        // host-coherent: [report][n_points per round and problem][facts]
+        const size_t b_np = align_up((size_t)rounds * B * sizeof(int), 256);
+        const size_t follow_bytes = 256 + b_np + (size_t)rounds * B * kLeanMaxPoints * sizeof(ModelChainFact);
+        if ((rc = solver_->dev_chain.reserve(dev_bytes + 256)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_chain.reserve(up_bytes + 256)) != ROCCO_HIP_OK) return rc;
+        solver_->host_follow.coherent = true;
+        if ((rc = solver_->host_follow.reserve(follow_bytes + 256)) != ROCCO_HIP_OK) return rc;
+        char *dv = (char *)solver_->dev_chain.ptr;
+        char *h = (char *)solver_->host_chain.ptr;
+        char *f = (char *)solver_->host_follow.ptr;
+        std::memcpy(h, tasks.data(), B * sizeof(LeanTask));
+        std::memcpy(h + b_tasks, walk.data(), B * sizeof(ModelChainWalk));
+        if (!wcap_tasks.empty()) std::memcpy(h + b_tasks + b_walk, wcap_tasks.data(), wcap_tasks.size() * sizeof(LeanWcapTask));
+        mark("model chain: tables built");
+        ROCCO_HIP_TRY(hipMemcpyAsync(dv, h, up_bytes, hipMemcpyHostToDevice, stream_));
+        if (!wcap_tasks.empty()) {
+            if ((rc = launch_lean_wcap((const LeanWcapTask *)(dv + b_tasks + b_walk), (int)wcap_tasks.size(), wcap_blocks, stream_)) != ROCCO_HIP_OK) return rc;
+        }
+        ModelChainArgs A;
+        A.n_problems = (int)B;
+        A.depth0 = depth0;
+        A.depth_floor = depth_floor;
+        A.depth_fixed = std::getenv("ROCCO_HIP_MODEL_DEPTH") ? std::max(1, std::min(6, std::atoi(std::getenv("ROCCO_HIP_MODEL_DEPTH")))) : 0;
+        A.adapt_batch = (std::getenv("ROCCO_HIP_LEAN_BATCH") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_BATCH")) != 0) ? 1 : 0;
+        A.pad = 0;
+        A.tasks = (LeanTask *)dv;
+        A.walk = (const ModelChainWalk *)(dv + b_tasks);
+        A.state = (ModelChainState *)(dv + up_bytes);
+        A.points = (double *)(dv + up_bytes + b_state);
+        A.results = (LeanResult *)(dv + up_bytes + b_state + b_points);
+        A.ctl = (LeanRoundCtl *)(dv + up_bytes + b_state + b_points + b_results);
+        A.globals = (int *)(dv + up_bytes + b_state + b_points + b_results + 256);
+        A.report = (ModelChainReport *)f;
+        A.n_points_out = (int *)(f + 256);
+        A.facts = (ModelChainFact *)(f + 256 + b_np);
+        std::memset(f, 0, 256);
+        model_chain_report_ = A.report;
+        model_chain_np_ = A.n_points_out;
+        model_chain_facts_ = A.facts;
+        if (facts_.size() < probs.size()) {
+            facts_.resize(probs.size());
+        }
+
+        // round scratch as the regular rounds keep it (lean_enqueue): sized for the deepest round a chain may plan
+        const long long max_recs = tiles * (long long)(kLeanMaxPoints - 1);
+        const size_t b_look = align_up(256 + (size_t)max_recs * 4 * sizeof(unsigned long long), 256);
+        {
+            const void *old_ptr = solver_->dev_lean_look.ptr;
+            const size_t old_bytes = solver_->dev_lean_look.bytes;
+            if ((rc = solver_->dev_lean_look.reserve(b_look)) != ROCCO_HIP_OK) return rc;
+            if (solver_->lean_look_dirty != 0 || solver_->dev_lean_look.ptr != old_ptr || solver_->dev_lean_look.bytes != old_bytes) {
+                ROCCO_HIP_TRY(hipMemsetAsync(solver_->dev_lean_look.ptr, 0xFF, solver_->dev_lean_look.bytes, stream_));
+                ROCCO_HIP_TRY(hipMemsetAsync((char *)solver_->dev_lean_look.ptr + 128, 0, 4, stream_));
+                solver_->lean_look_dirty = 0;
+            }
+        }
+        if ((rc = solver_->dev_lean_round.reserve(align_up((size_t)max_recs * sizeof(LeanTileRec), 256) + 256)) != ROCCO_HIP_OK) return rc;
+        char *look = (char *)solver_->dev_lean_look.ptr;
+        LeanLaunch L;
+        L.tasks = A.tasks;
+        L.n_tasks = 0;
+        L.n_units = 0;
+        L.points = A.points;
+        L.ticket = (unsigned *)look;
+        L.look = (unsigned long long *)(look + 256);
+        L.recs = (LeanTileRec *)solver_->dev_lean_round.ptr;
+        L.bits = (unsigned *)solver_->dev_lean_pool.ptr;
+        L.tile_off = (unsigned *)solver_->dev_lean_pool.ptr;
+        L.results = A.results;
+        L.error = (unsigned *)(look + 128);
+        L.error_out = nullptr;
+        L.self_reset = 1;
+        L.pad = 0;
+        L.ctl = A.ctl;
+        LeanLaunch M = L;
+        M.ticket = (unsigned *)look + 2;
+        const int grid_eval = (int)std::max(1LL, std::min(512LL, tiles * 16));
+        const int grid_finish = (int)std::max(1LL, std::min(1536LL, (long long)B * (kLeanMaxPoints - 1)));
+        solver_->lean_look_dirty = 1;
+        for (int r = 0; r < rounds; ++r) {
+            if ((rc = launch_model_chain_director(A, r, 0, stream_)) != ROCCO_HIP_OK) return rc;
+            if ((rc = launch_lean_model_chain(M, grid_eval, stream_)) != ROCCO_HIP_OK) return rc;
+            if ((rc = launch_lean_finish_chain(L, grid_finish, stream_)) != ROCCO_HIP_OK) return rc;
+        }
+        if ((rc = launch_model_chain_director(A, rounds, 1, stream_)) != ROCCO_HIP_OK) return rc;
+        ROCCO_HIP_TRY(hipGetLastError());
+        solver_->lean_look_dirty = 0;
+        lean_inflight_ = reqs;
+        model_chain_inflight_ = true;
+        model_chain_running_ = true;
+        model_chain_ingested_ = 0;
+        t_mchain_submit_ += now_us() - t0;
+        mark("model chain: queued");
+        if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+            std::fprintf(stderr, "[model chain] %zu problems, %lld tiles, %d rounds queued (depth %d, floor %d)\n", B, tiles, rounds, depth0,
+                         depth_floor);
+        }
+        return ROCCO_HIP_OK;
+    }
+
+    // the requests that started the chain: answered as soon as its first round is published
+    int model_chain_consume()
+    {
+        model_chain_inflight_ = false;
+        int rc;
+        bool got = false;
+        while (model_chain_running_ && model_chain_ingested_ < 1) {
+            if ((rc = model_chain_ingest(true, &got)) != ROCCO_HIP_OK) return rc;
+        }
+        for (LeanReq &r : lean_inflight_) {
+            DevProblem &p = probs[r.problem];
+            r.probe->results.assign(r.lambdas.size(), ProbeResult());
+            for (size_t i = 0; i < r.lambdas.size(); ++i) {
+                long long c = 0;
+                if (fact_lookup(r.problem, r.lambdas[i], &c)) {
+                    r.probe->results[i].count = c;
+                    ++model_chain_hits;
+                } else {
+                    // not among the facts (the model left it open, or the director asked something else): the full kernels decide
+                    r.probe->results[i].uncertain = 1;
+                    r.probe->results[i].effect = (long long)p.n + 1;
+                    model_open_.emplace_back(r.probe, i);
+                    const bool evaluated = std::find(open_facts_.begin(), open_facts_.end(), std::make_pair(r.problem, r.lambdas[i])) != open_facts_.end();
+                    model_chain_misses += evaluated ? 0 : 1;
+                }
+            }
+            lean_model_points += (long long)r.lambdas.size();
+        }
+        lean_inflight_.clear();
+        return ROCCO_HIP_OK;
+    }
+
     // Queue one round of lean work on the stream: compactions decided by the previous round, the evaluation of
     // every request, the layout of its compactions, the final compactions.  lean_consume() after the stream
     // has been synchronised.
@@ -726,6 +1119,9 @@ public:
         }
         int rc;
         if ((rc = lean_prepare()) != ROCCO_HIP_OK) return rc;
+        if (model_chain_wanted(reqs)) {
+            return model_chain_enqueue(reqs);
+        }
         ++lean_rounds;
         std::vector<LeanCompactTask> pre, post;
         std::vector<LeanTask> tasks, model_tasks;
@@ -997,8 +1393,8 @@ public:
             rebatch(model_tasks, kLeanModelBatch, model_units);
         }
         lean_units += units + model_units;
-        if (model_tiles > 0) {
-            model_tiles_last_round_ = model_tiles;
+        if (model_tiles + model_tiles_answered_ > 0) {
+            model_tiles_last_round_ = model_tiles + model_tiles_answered_;
         }
         const int n_bound_tasks = (int)tasks.size();
         tasks.insert(tasks.end(), model_tasks.begin(), model_tasks.end());
@@ -1116,6 +1512,9 @@ public:
     {
         if (lean_inflight_.empty()) {
             return ROCCO_HIP_OK;
+        }
+        if (model_chain_inflight_) {
+            return model_chain_consume();
         }
         const LeanResult *res = (const LeanResult *)solver_->host_lean_back.ptr;
         const unsigned *error_words = (const unsigned *)((const char *)solver_->host_lean_back.ptr + (size_t)lean_result_count_ * sizeof(LeanResult));
@@ -1319,8 +1718,28 @@ public:
             r.comp = &c;
             reqs.push_back(r);
         }
+        model_tiles_answered_ = 0;
         for (ProbeRequest &q : probes) {
             if (lean_takes(*this, q)) {
+                if (!q.bound && !model_any_ && q.problem < facts_.size() && (!facts_[q.problem].empty() || in_running_chain(q.problem))) {
+                    // rounding-model counts the evaluator already holds, or that the running chain is about to publish
+                    // (model_chain.h): no device work
+                    std::vector<ProbeResult> res;
+                    bool all = facts_answer(q, res);
+                    while (!all && in_running_chain(q.problem)) {
+                        bool got = false;
+                        const int rc = model_chain_ingest(true, &got);
+                        if (rc != ROCCO_HIP_OK) return rc;
+                        all = facts_answer(q, res);
+                    }
+                    if (all) {
+                        q.results = res;
+                        model_chain_hits += (long long)q.lambdas.size();
+                        lean_model_points += (long long)q.lambdas.size();
+                        model_tiles_answered_ += (long long)((probs[q.problem].n + kLeanTile - 1) / kLeanTile);
+                        continue;
+                    }
+                }
                 LeanReq r;
                 r.problem = q.problem;
                 r.lambdas = q.lambdas;
@@ -1329,6 +1748,9 @@ public:
                 r.pilot = q.bound && q.pilot && can_pilot(q.problem);
                 reqs.push_back(r);
             }
+        }
+        if (reqs.empty() && model_tiles_answered_ > 0) {
+            model_tiles_last_round_ = model_tiles_answered_;
         }
         return lean_enqueue(reqs);
     }
@@ -1352,7 +1774,9 @@ public:
             double t0;
             ~Total() { acc += now_us() - t0; }
         } total{t_round_, tr0};
+        mark("round begins");
         if ((rc = lean_submit(compacts, probes)) != ROCCO_HIP_OK) return rc;
+        mark("round: lean part submitted");
         std::vector<RoundTask> tasks;
         if ((rc = add_map_tasks(maps, tasks)) != ROCCO_HIP_OK) return rc;
         if ((rc = add_survey_tasks(surveys, tasks)) != ROCCO_HIP_OK) return rc;
@@ -1360,17 +1784,21 @@ public:
         add_window_tasks(windows, tasks);
         if ((rc = add_spine_tasks(spines, tasks)) != ROCCO_HIP_OK) return rc;
         if (tasks.empty()) {
-            const double ts0 = now_us();
-            ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
-            t_wait_ += now_us() - ts0;
+            if (lean_wait_needed()) {
+                const double ts0 = now_us();
+                ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+                t_wait_ += now_us() - ts0;
+            }
         } else if ((rc = run_round(tasks)) != ROCCO_HIP_OK) {
             return rc;
         }
         const double tc0 = now_us();
+        mark("round: device work waited for");
         if ((rc = lean_consume()) != ROCCO_HIP_OK) return rc;
         if ((rc = model_fallback()) != ROCCO_HIP_OK) return rc;
         adopt_maps(maps);
         t_consume_ += now_us() - tc0;
+        mark("round ends");
         ++rounds_all;
         return ROCCO_HIP_OK;
     }
@@ -1593,6 +2021,18 @@ public:
         A.pool = (char *)solver_->dev_lean_pool.ptr;
         A.trace = want_trace ? (long long *)(dv + o_trace) : nullptr;
         A.tune = tune;
+        // the report comes through host-coherent memory as soon as the searches have ended (chain.h: ChainArgs::follow);
+        // ROCCO_HIP_CHAIN_FOLLOW=0: through a copy at the end of the stream
+        const bool follow = std::getenv("ROCCO_HIP_CHAIN_FOLLOW") == nullptr || std::atoi(std::getenv("ROCCO_HIP_CHAIN_FOLLOW")) != 0;
+        A.follow = nullptr;
+        A.follow_words = (int)((o_ctl_back - o_probs) / 8);
+        A.follow_ctl_word = A.follow_words;
+        if (follow) {
+            solver_->host_follow.coherent = true;
+            if ((rc = solver_->host_follow.reserve(256 + down_bytes + 256)) != ROCCO_HIP_OK) return rc;
+            A.follow = (unsigned long long *)solver_->host_follow.ptr;
+            std::memset(solver_->host_follow.ptr, 0, 256);
+        }
 
         LeanLaunch L;
         L.tasks = A.tasks;
@@ -1622,11 +2062,29 @@ public:
         }
         if ((rc = launch_chain_director(A, R, 1, stream_)) != ROCCO_HIP_OK) return rc;
         ROCCO_HIP_TRY(hipGetLastError());
-        ROCCO_HIP_TRY(hipMemcpyAsync(dv + o_ctl_back, dv + o_ctl, sizeof(LeanRoundCtl), hipMemcpyDeviceToDevice, stream_));
-        ROCCO_HIP_TRY(hipMemcpyAsync(h, dv + o_probs, down_bytes, hipMemcpyDeviceToHost, stream_));
         const double ts0 = now_us();
-        ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        if (follow) {
+            const unsigned long long *flag = A.follow;
+            for (long long spins = 1;; ++spins) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0ull) {
+                    break;
+                }
+                if ((spins & 1023) == 0 && hipStreamQuery(stream_) == hipSuccess) {
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0ull) {
+                        break;
+                    }
+                    set_last_error("chained search: the stream ended without the chain's report");
+                    return ROCCO_HIP_EHIP;
+                }
+            }
+            h = (char *)solver_->host_follow.ptr + 256;
+        } else {
+            ROCCO_HIP_TRY(hipMemcpyAsync(dv + o_ctl_back, dv + o_ctl, sizeof(LeanRoundCtl), hipMemcpyDeviceToDevice, stream_));
+            ROCCO_HIP_TRY(hipMemcpyAsync(h, dv + o_probs, down_bytes, hipMemcpyDeviceToHost, stream_));
+            ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+        }
         const double ts1 = now_us();
+        mark("threshold chain waited for");
         t_wait_ += ts1 - ts0;
         t_chain_submit_ = ts0 - tc0;
         t_chain_wait_ = ts1 - ts0;
@@ -2256,6 +2714,13 @@ int prepare(HipEvaluator &ev, std::vector<ChainProblem> &problems, const std::ve
 
 }  // namespace
 
+void model_chain_counters(long long out[4])
+{
+    for (int k = 0; k < 4; ++k) {
+        out[k] = g_model_chain_counters[k].load(std::memory_order_relaxed);
+    }
+}
+
 int solve_fixed_penalty(rocco_hip_solver *solver, const double *scores_dev,
                         const double *switch_costs_dev, double gamma, size_t n, double lambda,
                         uint8_t *solution_dev, double *value_out, long long *count_out, int *path_out,
@@ -2541,6 +3006,8 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     if (const char *e = std::getenv("ROCCO_HIP_SEARCH_INTERP")) opt.search_interpolate = std::atoi(e) != 0;
     std::vector<CalibrationResult> res;
     const double t_solve0 = HipEvaluator::now_us();
+    ev.marks_on_ = std::getenv("ROCCO_HIP_TIMING") != nullptr && std::atoi(std::getenv("ROCCO_HIP_TIMING")) >= 2;
+    ev.mark("solve begins");
     if (const char *e = std::getenv("ROCCO_HIP_COMPACT")) opt.use_compaction = std::atoi(e) != 0;
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_ROUNDS")) opt.pilot_rounds = std::atoi(e);
     if (const char *e = std::getenv("ROCCO_HIP_PILOT_POINTS")) opt.pilot_points = std::atoi(e);
@@ -2571,13 +3038,19 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
         if ((rc = ev.chain_search(problems, opt, chain_stats, presearch, chained)) != ROCCO_HIP_OK) return rc;
     }
     const double tp0 = HipEvaluator::now_us();
+    ev.mark("threshold chain parsed");
     if ((rc = prepare(ev, problems, nullptr, score_stats_host, chained ? &chain_stats : nullptr)) != ROCCO_HIP_OK) return rc;
     const double tp1 = HipEvaluator::now_us();
     if ((rc = calibrate_batch(ev, problems, opt, res, chained ? &presearch : nullptr)) != ROCCO_HIP_OK) return rc;
     const double tp2 = HipEvaluator::now_us();
+    ev.mark("calibration ends");
     if ((rc = ev.scatter_all()) != ROCCO_HIP_OK) return rc;
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));
     const double t_prepare = tp1 - tp0, t_calibrate = tp2 - tp1, t_scatter = HipEvaluator::now_us() - tp2;
+    g_model_chain_counters[0].fetch_add(ev.model_chains, std::memory_order_relaxed);
+    g_model_chain_counters[1].fetch_add(ev.model_chain_facts, std::memory_order_relaxed);
+    g_model_chain_counters[2].fetch_add(ev.model_chain_hits, std::memory_order_relaxed);
+    g_model_chain_counters[3].fetch_add(ev.model_chain_misses, std::memory_order_relaxed);
     if (std::getenv("ROCCO_HIP_DEBUG") != nullptr || std::getenv("ROCCO_HIP_TIMING") != nullptr) {
         const double total = HipEvaluator::now_us() - t_solve0;
         std::fprintf(stderr, "[host] solve %.0f us: %d rounds (%d with rounding-model kernels): in the rounds %.0f us = waiting for the device %.0f "
@@ -2590,6 +3063,14 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
         std::fprintf(stderr, "[host] chained search: queued in %.0f us, waited for %.0f, report read in %.0f; statistics -> problems %.0f; "
                              "calibration after it %.0f; scatter and the last wait %.0f\n",
                      ev.t_chain_submit_, ev.t_chain_wait_, ev.t_chain_parse_, t_prepare, t_calibrate, t_scatter);
+        std::fprintf(stderr, "[host] chained rounding-model rounds: %lld chains queued in %.0f us, their rounds waited for %.0f us; %lld counts taken "
+                             "over, %lld requests answered from them, %lld not\n",
+                     ev.model_chains, ev.t_mchain_submit_, ev.t_mchain_wait_, ev.model_chain_facts, ev.model_chain_hits, ev.model_chain_misses);
+        ev.mark("solve ends");
+        for (size_t k = 0; k < ev.marks_.size(); ++k) {
+            std::fprintf(stderr, "[mark] %8.1f  +%6.1f  %s\n", ev.marks_[k].second - t_solve0,
+                         k ? ev.marks_[k].second - ev.marks_[k - 1].second : 0.0, ev.marks_[k].first);
+        }
     }
     for (size_t t = 0; t < n_tasks; ++t) {
         results[t].selection_penalty = res[t].selection_penalty;

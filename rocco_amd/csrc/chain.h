@@ -157,6 +157,12 @@ struct ChainArgs {
     LeanCompactTask *pre;   // [n_problems]
     char *pool;             // the solver's level pool
     long long *trace;       // nullptr, or [rounds + 1][8] timestamps of the director's phases (100 MHz clock; diagnostics)
+    // Host-coherent pinned memory (or nullptr): the director that finds every search ended -- or the last one -- copies the
+    // report there ([32 words: word 0 = 1 when complete][follow_words words from `probs` on, the statistics behind them]
+    // [the round sizes at follow_ctl_word]) so that the host need not wait for the launches still queued behind it.
+    unsigned long long *follow;
+    int follow_words;
+    int follow_ctl_word;
     ChainTuning tune;
 };
 

@@ -848,6 +848,23 @@ __global__ __launch_bounds__(kDirectorThreads) void chain_director_kernel(ChainA
         }
     }
     if (trace) trace[5] = (long long)wall_clock64();
+    // ---- the host follows the chain: hand it the report as soon as nothing is left to run ----
+    if (A.follow != nullptr && (last != 0 || A.ctl->all_done != 0)) {
+        __syncthreads();  // the report is complete in device memory (this workgroup wrote the last of it)
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(A.probs);
+        unsigned long long *dst = A.follow + 32;
+        for (int i = threadIdx.x; i < A.follow_words; i += kDirectorThreads) {
+            dst[i] = src[i];
+        }
+        if (threadIdx.x < (int)(sizeof(LeanRoundCtl) / 8)) {
+            dst[A.follow_ctl_word + threadIdx.x] = reinterpret_cast<const unsigned long long *>(A.ctl)[threadIdx.x];
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(A.follow, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 }  // namespace

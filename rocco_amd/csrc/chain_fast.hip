@@ -1927,6 +1927,35 @@ __global__ __launch_bounds__(kFastThreads) void stats_partial_kernel(const Stats
     const StatsTask t = tasks[bm.x];
     const long long base = (long long)bm.y * kFastBlockLoci;
     double v[kStat] = {INFINITY, -INFINITY, INFINITY, -INFINITY, 0.0};
+    if (t.switch_costs == nullptr && base + kFastBlockLoci <= t.n && ((reinterpret_cast<uintptr_t>(t.scores + base) & 15U) == 0)) {
+        // a whole tile of scores only: sixteen unconditional 16-byte loads per lane, all in flight together (a load under
+        // a per-element condition is waited for before the next one is issued), four independent accumulations
+        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(t.scores + base) + threadIdx.x;
+        double2 x[kChunk / 2];
+#pragma unroll
+        for (int r = 0; r < kChunk / 2; ++r) {
+            x[r] = src[r * kFastThreads];
+        }
+        double lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        double sum[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < kChunk / 2; ++r) {
+            const int k = r & 3;
+            lo[k] = fmin(lo[k], fmin(x[r].x, x[r].y));
+            hi[k] = fmax(hi[k], fmax(x[r].x, x[r].y));
+            sum[k] += fabs(x[r].x) + fabs(x[r].y);
+        }
+        v[0] = fmin(fmin(lo[0], lo[1]), fmin(lo[2], lo[3]));
+        v[1] = fmax(fmax(hi[0], hi[1]), fmax(hi[2], hi[3]));
+        v[4] = (sum[0] + sum[1]) + (sum[2] + sum[3]);
+        stats_reduce(v, red);
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < kStat; ++k) {
+                partials[(long long)kStat * blockIdx.x + k] = red[0][k];
+            }
+        }
+        return;
+    }
     for (int r = 0; r < kChunk; ++r) {
         const long long j = base + r * kFastThreads + threadIdx.x;
         if (j < t.n) {

@@ -22,6 +22,7 @@
 // All of it is integer / exact FP64 min-max-add work bound by HBM reads of 8 B per locus and round (level
 // 0) or by launch latency (deeper levels); no MFMA -- the path is BLAS-1.
 #include "lean.h"
+#include "model_chain.h"
 
 #include <cmath>
 
@@ -1199,6 +1200,51 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_model_kernel(LeanLaunch 
     }
 }
 
+// the same for a chained round (model_chain.hip): sizes on the device, a fixed grid of workgroups that take tickets
+// until they run out
+__global__ __launch_bounds__(kLeanThreads, 2) void lean_model_chain_kernel(LeanLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *lds = smem;
+    Scratch *sc = reinterpret_cast<Scratch *>(smem + kTileLds);
+    const int t = threadIdx.x;
+    const int n_units = L.ctl->n_units, n_tasks = L.ctl->n_tasks;
+    if (n_units <= 0) {
+        return;  // (before the ticket is touched: no finish kernel would restore it)
+    }
+    for (;;) {
+        if (t == 0) {
+            sc->ticket = (int)(atomicAdd(L.ticket, 1u) + 1u);
+        }
+        if (t < kLeanBatch * 4) {
+            (&sc->red[0][0])[t] = 0u;
+        }
+        if (t < kLeanBatch) {
+            sc->uncertain[t] = 0u;
+        }
+        __syncthreads();
+        const int ticket = sc->ticket;
+        if (ticket >= n_units) {
+            return;
+        }
+        const int ti = find_task(n_tasks, ticket, [&](int i) { return L.tasks[i].unit_begin; });
+        const LeanTask task = L.tasks[ti];
+        const int unit = ticket - task.unit_begin;
+        const int tile = unit / task.n_groups, group = unit % task.n_groups;
+        const int p0 = group * task.batch;
+        const int np = min(task.batch, task.n_points - p0);
+        stage_tile<true>(task.s, task.m, (long long)tile * kLeanTile, task.magic, lds);
+        if (np > 2) {
+            eval_body<4, true>(L, task, tile, p0, np, lds, sc);
+        } else if (np > 1) {
+            eval_body<2, true>(L, task, tile, p0, np, lds, sc);
+        } else {
+            eval_body<1, true>(L, task, tile, p0, np, lds, sc);
+        }
+        __syncthreads();  // the tile and the scratch are reused
+    }
+}
+
 // What a locus can inherit at most (see lean_model_kernel): the weights of every hazard chunk's steps and of every
 // exact half-way tie rn_u(s) in a clean chunk, plus the largest hazard base.  Counted per exponent (integers: no
 // order dependence) by one workgroup per tile, summed by one thread per task, which also clears the counters.
@@ -1372,6 +1418,19 @@ int launch_lean_model(const LeanLaunch &L, hipStream_t stream)
     }
     hipLaunchKernelGGL(lean_model_kernel, dim3((unsigned)L.n_units), dim3(kLeanThreads), lds, stream, L);
     ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_model_chain(const LeanLaunch &L, int grid, hipStream_t stream)
+{
+    static bool configured = false;
+    const size_t lds = (size_t)kTileLds * sizeof(double) + sizeof(Scratch);
+    if (!configured) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lean_model_chain_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(lean_model_chain_kernel, dim3((unsigned)grid), dim3(kLeanThreads), lds, stream, L);
     return ROCCO_HIP_OK;
 }
 

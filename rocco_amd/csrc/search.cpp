@@ -473,6 +473,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
         // rounds over compacted problems are launch-bound (about 110 us whatever they evaluate) until their
         // (workgroup, penalty) pairs fill the device a few times over: speculate as deep as that allows
         int deep = opt.spec_depth;
+        int deep_floor = opt.spec_depth;  // (what the rule below asks for before the evaluator's own wish)
         if (all_compacted) {
             double blocks = 0.0;
             for (size_t b = 0; b < B; ++b) {
@@ -484,6 +485,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
             while (deep > opt.spec_depth && blocks * (double)((1 << deep) - 1) > 1600.0) {
                 --deep;
             }
+            deep_floor = deep;
             // (an evaluator with cheap probes says how deep it wants them)
             int wanted = 64;
             for (size_t b = 0; b < B; ++b) {
@@ -773,6 +775,28 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     ProbeRequest r;
                     r.problem = b;
                     build_open_tree(p, s, s.tree_depth, s.iters_left, s.nodes, r.lambdas);
+                    if (all_compacted && s.has_map && !s.point_pending) {
+                        BisectionAhead &a = r.ahead;
+                        a.valid = true;
+                        a.lower = s.lower;
+                        a.upper = s.upper;
+                        a.iters_left = s.iters_left;
+                        a.target = s.target;
+                        a.G_real = s.G_real;
+                        a.L_real = s.L_real;
+                        a.G = s.G;
+                        a.L = s.L;
+                        a.cG = s.cG;
+                        a.cL = s.cL;
+                        a.cost_ok = (p.cost_min >= 0.0);
+                        a.n = (long long)p.n;
+                        a.sabs = std::max(std::fabs(p.score_min), std::fabs(p.score_max));
+                        a.cost_max = p.cost_max;
+                        a.none_from = p.score_max + 1.0;
+                        a.all_upto = p.score_min - 1.0;
+                        a.open_depth = spec_depth;
+                        a.depth_floor = deep_floor;
+                    }
                     probes.push_back(r);
                     probe_owner.push_back(b);
                 }

@@ -55,6 +55,28 @@ struct ExactResult {
     long long count = 0;
 };
 
+// With the rounding-model probes of a bisection: how the search goes on from them while every outcome is certain (the
+// reference's steps, rocco/dp.py:141-162, with the outcomes that need no evaluation).  An evaluator that sequences its
+// own launches may evaluate the following rounds' penalties ahead and answer the later requests from what it holds:
+// a certified count is a fact about the reference at that penalty, whoever chose the penalty.
+struct BisectionAhead {
+    bool valid = false;
+    double lower = 0.0, upper = 0.0;  // the bracket the request's tree starts from
+    int iters_left = 0;
+    long long target = 0;
+    // outcomes known without evaluation (search.cpp: known_count): at or below G more than the target, at or above L at most
+    bool G_real = false, L_real = false;
+    double G = 0.0, L = 0.0;
+    long long cG = 0, cL = 0;
+    // analytic_count's terms: n (|lambda| + sabs + cost_max + 1) < 1e15 and cost_min >= 0;  lambda >= none_from selects
+    // nothing, lambda <= all_upto everything
+    bool cost_ok = false;
+    long long n = 0;
+    double sabs = 0.0, cost_max = 0.0, none_from = 0.0, all_upto = 0.0;
+    int open_depth = 0;   // open levels per round of this request (before the cut at iters_left)
+    int depth_floor = 0;  // what the search's own rule asks for at least in the rounds that follow
+};
+
 // One batch round of device work.  Indices refer to the problems of the batch.
 struct ProbeRequest {
     size_t problem = 0;
@@ -67,6 +89,7 @@ struct ProbeRequest {
     bool pilot = false;
     std::vector<double> lambdas;
     std::vector<ProbeResult> results;  // filled by the evaluator
+    BisectionAhead ahead;              // (optional)
 };
 
 struct WindowRequest {

@@ -7,6 +7,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _model_chain_counters():
+    import ctypes
+
+    from rocco_amd import _native
+
+    out = (ctypes.c_longlong * 4)()
+    _native.load().rocco_hip_model_chain_counters(out)
+    return list(out)  # chains, counts taken over, counts answered from them, counts asked for that a chain had not evaluated
+
+
 def _solve(scores_list, gammas, targets, chain, monkeypatch):
     import torch
 
@@ -79,3 +89,64 @@ def test_chain_leaves_cost_vectors_and_tiny_problems_to_the_host(gpu, oracle, mo
     ref2 = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 1.5), 900)
     assert out[0][0] == ref0[0] and out[0][3] == ref0[3] and np.array_equal(out[0][1].cpu().numpy(), ref0[1])
     assert out[2][0] == ref2[0] and out[2][3] == ref2[3] and np.array_equal(out[2][1].cpu().numpy(), ref2[1])
+
+
+@pytest.mark.parametrize("kind", ["peaks", "normal", "integers", "offset", "flat"])
+@pytest.mark.parametrize("model_chain,follow", [("1", "1"), ("0", "1"), ("1", "0")])
+def test_chained_rounding_model_rounds_give_the_oracles_calibration(gpu, oracle, monkeypatch, kind, model_chain, follow):
+    """The last bisection steps walked by the device (model_chain.hip: the host follows its facts through host-coherent
+    memory and replays the reference's steps from them) against the oracle, with the threshold search chained or
+    sequenced by the host, the report followed or copied at the end of the stream."""
+    monkeypatch.setenv("ROCCO_HIP_MODEL_CHAIN", model_chain)
+    monkeypatch.setenv("ROCCO_HIP_CHAIN_FOLLOW", follow)
+    rng = np.random.default_rng(1000 + sum(map(ord, kind)))
+    sizes = [8191, 8193, 70000, 3, 262145, 500000]
+    scores = [_tracks(rng, n, kind) for n in sizes]
+    gammas = [1.0, 0.5, 2.0, 1.0, 3.0, 1.0]
+    targets = [int(np.floor(n * b)) for n, b in zip(sizes, (0.02, 0.1, 0.005, 0.5, 0.02, 0.03))]
+    before = _model_chain_counters()
+    for chain in (True, False):
+        out = _solve(scores, gammas, targets, chain, monkeypatch)
+        for s, gamma, target, a in zip(scores, gammas, targets, out):
+            ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, gamma), target)
+            assert a[0] == ref[0] and a[3] == ref[3], (kind, chain, len(s), a[0], ref[0])
+            assert np.array_equal(a[1].cpu().numpy(), ref[1])
+    if model_chain == "0":
+        assert _model_chain_counters() == before
+
+
+@pytest.mark.parametrize("kind", ["peaks", "normal", "offset"])
+def test_the_director_asks_what_the_hosts_replay_asks(gpu, oracle, monkeypatch, kind):
+    """A batch whose every problem ends on a compacted level: the rounding-model rounds run as a chain, and every count the
+    host's replay of the reference's bisection asks for is among the counts the chain evaluated (the director mirrors
+    search.cpp's walk; a divergence would still be correct -- regular rounds answer -- but slow, and show here)."""
+    rng = np.random.default_rng(2000 + sum(map(ord, kind)))
+    sizes = [300_000, 120_000, 90_000, 500_000]
+    scores = [_tracks(rng, n, kind) for n in sizes]
+    targets = [int(np.floor(n * 0.02)) for n in sizes]
+    for chain in (True, False):
+        before = _model_chain_counters()
+        out = _solve(scores, [1.0] * len(sizes), targets, chain, monkeypatch)
+        after = _model_chain_counters()
+        for s, target, a in zip(scores, targets, out):
+            ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 1.0), target)
+            assert a[0] == ref[0] and a[3] == ref[3]
+            assert np.array_equal(a[1].cpu().numpy(), ref[1])
+        assert after[0] > before[0] and after[2] > before[2], (kind, chain, before, after)
+        assert after[3] == before[3], (kind, chain, before, after)
+
+
+def test_model_chain_depth_override_and_single_problem(gpu, oracle, monkeypatch):
+    """One compacted problem alone (deep trees: up to 63 penalties a round) and a forced depth."""
+    rng = np.random.default_rng(4242)
+    s = _tracks(rng, 300_000, "peaks")
+    ref = oracle.calibrate_selection_penalty(s, oracle.build_switch_costs(s, 1.0), 6000)
+    for depth in (None, "2", "5", "6"):
+        if depth is None:
+            monkeypatch.delenv("ROCCO_HIP_MODEL_DEPTH", raising=False)
+        else:
+            monkeypatch.setenv("ROCCO_HIP_MODEL_DEPTH", depth)
+        for chain in (True, False):
+            a = _solve([s], [1.0], [6000], chain, monkeypatch)[0]
+            assert a[0] == ref[0] and a[3] == ref[3], (depth, chain)
+            assert np.array_equal(a[1].cpu().numpy(), ref[1])
