@@ -398,6 +398,7 @@ public:
         if ((rc = solver_->dev_params.reserve(R * 64 * sizeof(double))) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->dev_results.reserve(R * 64 * (sizeof(double) + sizeof(long long)))) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->dev_bits.reserve(words_total * sizeof(unsigned long long) + 8)) != ROCCO_HIP_OK) return rc;
+        if ((rc = stage_wait()) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_stage.reserve(R * sizeof(ExactTask) + R * 64 * sizeof(double))) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_back.reserve(R * 64 * (sizeof(double) + sizeof(long long)))) != ROCCO_HIP_OK) return rc;
 
@@ -569,6 +570,7 @@ public:
         const size_t b_part = align_up((size_t)(2 * tiles + 2) * sizeof(double), 256);
         const size_t b_out = align_up(W * sizeof(double), 256);
         if ((rc = solver_->dev_misc.reserve(b_tasks + b_part + b_out)) != ROCCO_HIP_OK) return rc;
+        if ((rc = stage_wait()) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_stage.reserve(b_tasks)) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_back.reserve(b_out)) != ROCCO_HIP_OK) return rc;
         char *dv = (char *)solver_->dev_misc.ptr;
@@ -743,6 +745,35 @@ public:
         if (marks_on_) {
             marks_.emplace_back(label, now_us());
         }
+    }
+
+    // A round that builds binade maps hands nothing back to the host: it is queued and NOT waited for -- whatever the
+    // search asks next (the rounding-model rounds) queues behind it while it runs.  Only the pinned staging buffer its
+    // descriptors were copied from must not be written again before that copy has happened: an event marks it.
+    hipEvent_t staged_event_ = nullptr;
+    bool staged_pending_ = false;
+    ~HipEvaluator() override
+    {
+        if (staged_event_ != nullptr) {
+            (void)hipEventDestroy(staged_event_);
+        }
+    }
+    int stage_wait()
+    {
+        if (staged_pending_) {
+            staged_pending_ = false;
+            ROCCO_HIP_TRY(hipEventSynchronize(staged_event_));
+        }
+        return ROCCO_HIP_OK;
+    }
+    int stage_mark()
+    {
+        if (staged_event_ == nullptr) {
+            ROCCO_HIP_TRY(hipEventCreateWithFlags(&staged_event_, hipEventDisableTiming));
+        }
+        ROCCO_HIP_TRY(hipEventRecord(staged_event_, stream_));
+        staged_pending_ = true;
+        return ROCCO_HIP_OK;
     }
 
     // Does the iteration's lean work need the stream to drain before it is read?  Not when nothing was queued (every
@@ -1789,8 +1820,8 @@ public:
                 ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
                 t_wait_ += now_us() - ts0;
             }
-        } else if ((rc = run_round(tasks)) != ROCCO_HIP_OK) {
-            return rc;
+        } else if ((rc = run_round(tasks, !lean_wait_needed())) != ROCCO_HIP_OK) {
+            return rc;  // (a round of maps alone is not waited for unless lean results of this iteration are read below)
         }
         const double tc0 = now_us();
         mark("round: device work waited for");
@@ -1825,6 +1856,7 @@ public:
         const size_t bytes_out = align_up(B * 5 * sizeof(double), 256);
         int rc;
         if ((rc = solver_->dev_misc.reserve(bytes_tasks + bytes_map + bytes_part + bytes_out)) != ROCCO_HIP_OK) return rc;
+        if ((rc = stage_wait()) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_stage.reserve(bytes_tasks + bytes_map)) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_back.reserve(bytes_out)) != ROCCO_HIP_OK) return rc;
         char *h = (char *)solver_->host_stage.ptr;
@@ -2204,13 +2236,18 @@ public:
     }
 
 private:
-    int run_round(std::vector<RoundTask> &rt)
+    // `may_defer`: the caller reads nothing behind this round that needs the stream drained (see stage_mark)
+    int run_round(std::vector<RoundTask> &rt, bool may_defer = false)
     {
         const size_t T = rt.size();
         if (T == 0) {
             return ROCCO_HIP_OK;
         }
         ++rounds;
+        {
+            const int rcw = stage_wait();
+            if (rcw != ROCCO_HIP_OK) return rcw;
+        }
         const double tt0 = now_us();
         std::vector<FastTask> tasks(T);
         std::vector<FastChain> chains;
@@ -2496,6 +2533,18 @@ private:
         ROCCO_HIP_TRY(hipMemsetAsync(L.buf.results, 0, S * sizeof(FastSlotResult), stream_));
         if ((rc = launch_fast_round(L, stream_)) != ROCCO_HIP_OK) {
             return rc;
+        }
+        {
+            bool only_maps = true;
+            for (size_t t = 0; t < T; ++t) {
+                only_maps = only_maps && rt[t].map;
+            }
+            const char *defer = std::getenv("ROCCO_HIP_DEFER_MAPS");
+            if (may_defer && only_maps && (defer == nullptr || std::atoi(defer) != 0)) {
+                // nothing of a map round is read on the host (adopt_maps only takes the pointers over)
+                t_launch_ += now_us() - tt1;
+                return stage_mark();
+            }
         }
         if (any_record) {
             if ((rc = solver_->host_back.reserve(T * sizeof(int) + S * sizeof(FastSlotResult))) != ROCCO_HIP_OK) return rc;
