@@ -709,8 +709,10 @@ int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev,
 namespace {
 
 // The LDL^T factor depends on the penalty and (at its last two entries only) on the length: the solver keeps the one of
-// the longest row seen with this penalty (the recurrence is sequential: ~0.19 s per million loci).  A longer row with the
-// same penalty extends the factor instead of starting over; a new penalty starts a new one.
+// the longest row seen with this penalty.  The recurrence is sequential and data-independent: two host threads walk it
+// (whittaker_host.cpp, ~10 ns per step against ~190 ns for a GPU lane: 0.1 s instead of 1.05 s for chr1 at 50 bp) and the
+// table is copied up.  A longer row with the same penalty extends the factor instead of starting over; a new penalty
+// starts a new one.
 std::mutex g_factor_mutex;
 // per device; on the heap and never destroyed: at process exit the HIP runtime may be gone before static destructors run
 std::map<int, std::shared_ptr<rocco::SharedFactor>> &g_factors = *new std::map<int, std::shared_ptr<rocco::SharedFactor>>();
@@ -734,8 +736,13 @@ int ensure_whittaker_factor(rocco_hip_solver *solver, size_t cols, double penalt
         return rc;
     }
     const bool extend = current && current->cap > 0 && current->lambda == penalty_lambda;
-    rc = launch_whittaker_factor(cols, penalty_lambda, (double *)grown->buf.ptr, stream,
-                                 extend ? (const double *)current->buf.ptr : nullptr, extend ? current->cap : 0);
+    // (ROCCO_HIP_FACTOR_ON_DEVICE=1: the recurrence walked by one GPU lane per parity instead of two host threads)
+    const char *on_device = std::getenv("ROCCO_HIP_FACTOR_ON_DEVICE");
+    rc = (on_device != nullptr && std::atoi(on_device) != 0)
+             ? launch_whittaker_factor(cols, penalty_lambda, (double *)grown->buf.ptr, stream,
+                                       extend ? (const double *)current->buf.ptr : nullptr, extend ? current->cap : 0)
+             : build_whittaker_factor_on_host(cols, penalty_lambda, (double *)grown->buf.ptr, stream,
+                                              extend ? (const double *)current->buf.ptr : nullptr, extend ? current->cap : 0);
     if (rc == ROCCO_HIP_OK && hipStreamSynchronize(stream) != hipSuccess) {
         rc = ROCCO_HIP_EHIP;
     }

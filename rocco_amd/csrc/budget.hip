@@ -1928,7 +1928,7 @@ public:
         }
         tune.wgs = std::getenv("ROCCO_HIP_CHAIN_WGS") ? std::max(64, std::atoi(std::getenv("ROCCO_HIP_CHAIN_WGS"))) : 512;
         tune.pilot_wgs = std::getenv("ROCCO_HIP_CHAIN_PILOT_WGS") ? std::max(64, std::atoi(std::getenv("ROCCO_HIP_CHAIN_PILOT_WGS"))) : 512;
-        tune.pad = 0;
+        tune.pilot_tiles = std::getenv("ROCCO_HIP_CHAIN_PILOT_TILES") ? std::max(2, std::atoi(std::getenv("ROCCO_HIP_CHAIN_PILOT_TILES"))) : 16;
         tune.big_points = std::getenv("ROCCO_HIP_CHAIN_BIG_POINTS") ? std::atoi(std::getenv("ROCCO_HIP_CHAIN_BIG_POINTS")) : 2;
         tune.search_gate = opt.search_gate;
         tune.survey_gate = opt.survey_gate;

@@ -131,7 +131,7 @@ struct ChainTuning {
     int pilot_points;
     int n_mults;
     int pilot_wgs;      // workgroups a pilot round should fill
-    int pad;
+    int pilot_tiles;    // tiles of a chromosome a pilot round samples (about: every (tiles / pilot_tiles)-th one, at least every 4th)
     int wgs;            // workgroups a round on compacted levels should fill
     double mults[kChainMaxMults];  // multiples of the target at which the first certified round evaluates
     double search_gate, survey_gate;

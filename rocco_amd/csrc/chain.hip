@@ -569,7 +569,7 @@ __global__ __launch_bounds__(kDirectorThreads) void chain_director_kernel(ChainA
                     // every stride-th tile of the caller's array, each a chain of its own (lean_enqueue: pilot)
                     const long long n = H.n;
                     const long long all_tiles = (n + kLeanTile - 1) / kLeanTile;
-                    const int stride = (int)max(4LL, all_tiles / 16);
+                    const int stride = (int)max(4LL, all_tiles / max(2, A.tune.pilot_tiles));
                     const int nt = (int)((all_tiles + stride - 1) / stride);
                     const long long last_at = (long long)(nt - 1) * stride * kLeanTile;
                     const long long sampled = (long long)(nt - 1) * kLeanTile + min((long long)kLeanTile, n - last_at);

@@ -124,6 +124,10 @@ int launch_objective_batch(const ObjectiveTask *tasks_dev, int n_tasks, long lon
 size_t whittaker_scratch_bytes(size_t rows, size_t cols);
 int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_dev, hipStream_t stream,
                             const double *old_factor_dev = nullptr, size_t old_cap = 0);
+// the same table walked by two host threads and copied up (whittaker_host.cpp): same bits, a tenth of the time; returns
+// with the stream drained
+int build_whittaker_factor_on_host(size_t cap, double penalty_lambda, double *factor_dev, hipStream_t stream,
+                                   const double *old_factor_dev = nullptr, size_t old_cap = 0);
 // one group of up to 32 rows of one matrix: a workgroup of the row-parallel sweeps (whittaker.hip)
 struct WhittakerRowTask {
     const double *src0, *src1;

@@ -13,8 +13,11 @@ for item in sys.argv[1].split(";"):
     configs[name] = dict(kv.split("=", 1) for kv in envs.split(",") if "=" in kv)
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 genome = synth.chrom_loci(50, None)
+only = os.environ.get("AB_CHROMS")  # e.g. "chr1,chr9,chr17" (a rank's shard); default: the whole genome
 scores = []
 for idx, (name, n) in enumerate(genome):
+    if only and name not in only.split(","):
+        continue
     m = synth.hash_matrix_device(100, n, synth.chrom_seed(20240, idx), device=device)
     scores.append(rr.score_central_tendency_chrom_batch_device([m])[0])
     del m

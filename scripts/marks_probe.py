@@ -12,7 +12,10 @@ from rocco_amd import rocco as rr
 device = torch.device("cuda:0")
 genome = synth.chrom_loci(50, None)
 scores = []
+only = os.environ.get("AB_CHROMS")
 for idx, (name, n) in enumerate(genome):
+    if only and name not in only.split(","):
+        continue
     m = synth.hash_matrix_device(100, n, synth.chrom_seed(20240, idx), device=device)
     scores.append(rr.score_central_tendency_chrom_batch_device([m])[0])
     del m

@@ -60,3 +60,18 @@ def test_factor_is_extended_for_longer_rows(gpu, oracle):
     for cols in (25, 26, 31, 600, 599, 40000, 8, 40001, 1000, 250000, 30):
         m = rng.normal(size=(3, cols))
         assert crossfit_whittaker_baseline(m, lam).tobytes() == oracle.crossfit_whittaker_baseline(m, lam).tobytes(), cols
+
+
+def test_factor_walked_on_the_device_gives_the_same_baselines(gpu, oracle, monkeypatch):
+    """The factor table is walked by two host threads by default (whittaker_host.cpp) and by one GPU lane per parity with
+    ROCCO_HIP_FACTOR_ON_DEVICE=1: the same IEEE operations in the same order, so the same baselines, here against the
+    oracle for both, from scratch and extended (penalties no other test uses)."""
+    from rocco_amd.inference import _consenrich_whittaker_lambda, crossfit_whittaker_baseline
+
+    rng = np.random.default_rng(13)
+    for where, window in (("1", 61), ("0", 63)):
+        monkeypatch.setenv("ROCCO_HIP_FACTOR_ON_DEVICE", where)
+        lam = _consenrich_whittaker_lambda(window)
+        for cols in (27, 5000, 4999, 120001, 300):
+            m = rng.normal(size=(2, cols))
+            assert crossfit_whittaker_baseline(m, lam).tobytes() == oracle.crossfit_whittaker_baseline(m, lam).tobytes(), (where, cols)
