@@ -862,12 +862,15 @@ public:
             if (*got || !wait) {
                 break;
             }
-            if ((++spins & 1023) == 0 && hipStreamQuery(stream_) == hipSuccess) {
-                // the stream has drained: whatever was going to be published is there
-                if (__atomic_load_n(&rep->finished, __ATOMIC_ACQUIRE) == 0) {
-                    model_chain_running_ = false;
-                    set_last_error("model chain: the stream ended without the chain's report");
-                    return ROCCO_HIP_EHIP;
+            if ((++spins & 1023) == 0) {
+                const hipError_t q = hipStreamQuery(stream_);
+                if (q != hipErrorNotReady) {
+                    // the stream has drained (whatever was going to be published is there) or failed
+                    if (q != hipSuccess || __atomic_load_n(&rep->finished, __ATOMIC_ACQUIRE) == 0) {
+                        model_chain_running_ = false;
+                        set_last_error(q != hipSuccess ? "model chain: the stream reports an error" : "model chain: the stream ended without the chain's report");
+                        return ROCCO_HIP_EHIP;
+                    }
                 }
             }
         }
@@ -2101,12 +2104,15 @@ public:
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0ull) {
                     break;
                 }
-                if ((spins & 1023) == 0 && hipStreamQuery(stream_) == hipSuccess) {
-                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0ull) {
-                        break;
+                if ((spins & 1023) == 0) {
+                    const hipError_t q = hipStreamQuery(stream_);
+                    if (q != hipErrorNotReady) {
+                        if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0ull) {
+                            break;
+                        }
+                        set_last_error(q != hipSuccess ? "chained search: the stream reports an error" : "chained search: the stream ended without the chain's report");
+                        return ROCCO_HIP_EHIP;
                     }
-                    set_last_error("chained search: the stream ended without the chain's report");
-                    return ROCCO_HIP_EHIP;
                 }
             }
             h = (char *)solver_->host_follow.ptr + 256;
