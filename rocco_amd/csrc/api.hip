@@ -140,6 +140,7 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->dev_chain.release();
     solver->host_chain.release();
     solver->host_follow.release();
+    solver->host_objective.release();
     solver->dev_median_partials.release();
     solver->host_lean_stage.release();
     solver->host_lean_back.release();

@@ -478,12 +478,17 @@ public:
     }
 
     // every compacted problem of the batch in two launches (zero the callers' buffers, scatter the kept loci)
-    int scatter_all()
+    // `only`: just these problems (nullptr: every compacted problem not scattered yet)
+    int scatter_all(const std::vector<size_t> *only = nullptr)
     {
         std::vector<LeanScatterTask> tasks;
         int zero_blocks = 0, scatter_blocks = 0;
-        for (DevProblem &p : probs) {
+        for (size_t b = 0; b < probs.size(); ++b) {
+            DevProblem &p = probs[b];
             if (!p.compacted || p.solution_in_orig || p.scattered) {
+                continue;
+            }
+            if (only != nullptr && std::find(only->begin(), only->end(), b) == only->end()) {
                 continue;
             }
             LeanScatterTask t;
@@ -540,9 +545,108 @@ public:
         return ROCCO_HIP_OK;
     }
 
+    // Objective sums fetched ahead (prefetch_objectives): problem -> sum of the solution that a window wrote, valid until
+    // another round touches the problem's solution.
+    std::vector<char> objective_ready_;
+    std::vector<double> objective_sum_;
+    std::vector<size_t> objective_pending_;  // problems whose sums are on their way to pinned memory
+    long long objective_prefetches = 0, objective_prefetch_hits = 0;
+
+    void objective_invalidate(size_t problem)
+    {
+        if (problem < objective_ready_.size() && objective_ready_[problem]) {
+            objective_ready_[problem] = 0;
+        }
+        probs[problem].scattered = false;  // (a solution scattered ahead is scattered again once it is final)
+    }
+
+    // Behind a round of windows that each write the solution of ONE penalty (the calibration's last step when every
+    // bisection step was decided), before that round is waited for: scatter those solutions and reduce their objectives,
+    // so that the one wait brings both.  Undone per problem by objective_collect when its window did not certify.
+    int prefetch_objectives(const std::vector<size_t> &which)
+    {
+        objective_pending_.clear();
+        const size_t W = which.size();
+        if (W == 0) {
+            return ROCCO_HIP_OK;
+        }
+        int rc;
+        if ((rc = scatter_all(&which)) != ROCCO_HIP_OK) return rc;
+        std::vector<ObjectiveTask> tasks(W);
+        long long tiles = 0;
+        for (size_t i = 0; i < W; ++i) {
+            const DevProblem &p = probs[which[i]];
+            const bool on_level = p.compacted && !p.solution_in_orig;
+            tasks[i].solution = on_level ? p.solution : (p.compacted ? p.orig_solution : p.solution);
+            tasks[i].scores = on_level ? p.scores : (p.compacted ? p.orig_scores : p.scores);
+            tasks[i].switch_costs = p.costs;
+            tasks[i].gamma = p.gamma;
+            tasks[i].n = (long long)(on_level ? p.n : (p.compacted ? p.orig_n : p.n));
+            tasks[i].tile_begin = tiles;
+            tiles += objective_tiles((size_t)tasks[i].n);
+        }
+        const size_t b_tasks = align_up(W * sizeof(ObjectiveTask), 256);
+        const size_t b_part = align_up((size_t)(2 * tiles + 2) * sizeof(double), 256);
+        const size_t b_out = align_up(W * sizeof(double), 256);
+        if ((rc = solver_->dev_misc.reserve(b_tasks + b_part + b_out)) != ROCCO_HIP_OK) return rc;
+        // (a pinned buffer of their own: descriptors up from its head, sums back behind them)
+        if ((rc = solver_->host_objective.reserve(b_tasks + b_out)) != ROCCO_HIP_OK) return rc;
+        char *dv = (char *)solver_->dev_misc.ptr;
+        char *ho = (char *)solver_->host_objective.ptr;
+        std::memcpy(ho, tasks.data(), W * sizeof(ObjectiveTask));
+        ROCCO_HIP_TRY(hipMemcpyAsync(dv, ho, W * sizeof(ObjectiveTask), hipMemcpyHostToDevice, stream_));
+        if ((rc = launch_objective_batch((const ObjectiveTask *)dv, (int)W, tiles, (double *)(dv + b_tasks),
+                                         (double *)(dv + b_tasks + b_part), stream_)) != ROCCO_HIP_OK) {
+            return rc;
+        }
+        ROCCO_HIP_TRY(hipMemcpyAsync(ho + b_tasks, dv + b_tasks + b_part, W * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        objective_back_ = (const double *)(ho + b_tasks);
+        objective_pending_ = which;
+        ++objective_prefetches;
+        return ROCCO_HIP_OK;
+    }
+    const double *objective_back_ = nullptr;
+
+    // after the wait: keep the sums of the problems whose window certified its solution; the others are scattered again later
+    void objective_collect(const std::vector<char> &certified)
+    {
+        if (objective_ready_.size() < probs.size()) {
+            objective_ready_.resize(probs.size(), 0);
+            objective_sum_.resize(probs.size(), 0.0);
+        }
+        const double *back = objective_back_;
+        for (size_t i = 0; i < objective_pending_.size(); ++i) {
+            const size_t b = objective_pending_[i];
+            if (certified[i]) {
+                objective_ready_[b] = 1;
+                objective_sum_[b] = back[i];
+            } else {
+                probs[b].scattered = false;
+            }
+        }
+        objective_pending_.clear();
+    }
+
     int penalized_values(const std::vector<size_t> &which, const std::vector<double> &lambdas,
                          const std::vector<long long> &counts, std::vector<double> &values) override
     {
+        {
+            // every sum fetched ahead behind the final windows: nothing left to do on the device
+            bool all = !which.empty();
+            for (size_t b : which) {
+                all = all && b < objective_ready_.size() && objective_ready_[b] != 0;
+            }
+            if (all) {
+                int rc0;
+                if ((rc0 = scatter_all()) != ROCCO_HIP_OK) return rc0;  // (problems that are not in `which`, if any)
+                values.assign(which.size(), 0.0);
+                for (size_t i = 0; i < which.size(); ++i) {
+                    values[i] = -objective_sum_[which[i]] - lambdas[i] * (double)counts[i];
+                }
+                objective_prefetch_hits += (long long)which.size();
+                return ROCCO_HIP_OK;
+            }
+        }
         // every objective in two launches, on the arrays the solution lives in (a compacted problem's kept loci
         // carry the same scores and the same transitions as the caller's array), one synchronisation; the
         // compacted solutions are scattered to the callers' buffers on the way
@@ -1823,8 +1927,32 @@ public:
                 ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
                 t_wait_ += now_us() - ts0;
             }
-        } else if ((rc = run_round(tasks, !lean_wait_needed())) != ROCCO_HIP_OK) {
-            return rc;  // (a round of maps alone is not waited for unless lean results of this iteration are read below)
+        } else {
+            // windows that each write the solution of one penalty and nothing else: the calibration's last round when every
+            // step was decided -- their objectives ride behind them
+            std::vector<size_t> final_problems;
+            const char *pf = std::getenv("ROCCO_HIP_PREFETCH_OBJECTIVE");
+            if ((pf == nullptr || std::atoi(pf) != 0) && !windows.empty() && tasks.size() == windows.size() && lean_inflight_.empty()) {
+                for (const WindowRequest &w : windows) {
+                    if (w.lambda_lo == w.lambda_hi) {
+                        final_problems.push_back(w.problem);
+                    }
+                }
+                if (final_problems.size() != windows.size()) {
+                    final_problems.clear();
+                }
+            }
+            // (a round of maps alone is not waited for unless lean results of this iteration are read below)
+            if ((rc = run_round(tasks, !lean_wait_needed(), final_problems.empty() ? nullptr : &final_problems)) != ROCCO_HIP_OK) {
+                return rc;
+            }
+            if (!final_problems.empty()) {
+                std::vector<char> certified(windows.size(), 0);
+                for (size_t i = 0; i < windows.size(); ++i) {
+                    certified[i] = (!windows[i].result.overflow && windows[i].result.n_diff == 0) ? 1 : 0;
+                }
+                objective_collect(certified);
+            }
         }
         const double tc0 = now_us();
         mark("round: device work waited for");
@@ -2242,14 +2370,18 @@ public:
     }
 
 private:
-    // `may_defer`: the caller reads nothing behind this round that needs the stream drained (see stage_mark)
-    int run_round(std::vector<RoundTask> &rt, bool may_defer = false)
+    // `may_defer`: the caller reads nothing behind this round that needs the stream drained (see stage_mark);
+    // `prefetch`: problems whose objective sums are queued behind the round's kernels, before the wait (prefetch_objectives)
+    int run_round(std::vector<RoundTask> &rt, bool may_defer = false, const std::vector<size_t> *prefetch = nullptr)
     {
         const size_t T = rt.size();
         if (T == 0) {
             return ROCCO_HIP_OK;
         }
         ++rounds;
+        for (size_t t = 0; t < T; ++t) {
+            objective_invalidate(rt[t].problem);  // (the round may rewrite the problem's solution)
+        }
         {
             const int rcw = stage_wait();
             if (rcw != ROCCO_HIP_OK) return rcw;
@@ -2579,6 +2711,9 @@ private:
                     hf += align_up((size_t)tasks[t].n_blocks, 64);
                 }
             }
+        }
+        if (prefetch != nullptr && (rc = prefetch_objectives(*prefetch)) != ROCCO_HIP_OK) {
+            return rc;
         }
         const double tt2 = now_us();
         t_launch_ += tt2 - tt1;
@@ -3121,6 +3256,8 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
         std::fprintf(stderr, "[host] chained rounding-model rounds: %lld chains queued in %.0f us, their rounds waited for %.0f us; %lld counts taken "
                              "over, %lld requests answered from them, %lld not\n",
                      ev.model_chains, ev.t_mchain_submit_, ev.t_mchain_wait_, ev.model_chain_facts, ev.model_chain_hits, ev.model_chain_misses);
+        std::fprintf(stderr, "[host] objectives fetched behind final windows: %lld rounds, %lld sums used\n", ev.objective_prefetches,
+                     ev.objective_prefetch_hits);
         ev.mark("solve ends");
         for (size_t k = 0; k < ev.marks_.size(); ++k) {
             std::fprintf(stderr, "[mark] %8.1f  +%6.1f  %s\n", ev.marks_[k].second - t_solve0,
