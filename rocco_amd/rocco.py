@@ -655,6 +655,61 @@ def _batches_within_memory(items, plan: _CachePlan):
         yield batch
 
 
+def _native_side_streams() -> int:
+    from . import _native
+
+    return int(_native.max_side_streams())
+
+
+def _count_estimates_side_by_side(ready: list, plan, count_estimate, streams: int) -> list:
+    """The count branch's budget estimates (rocco/rocco.py:1027-1048, one call per chromosome) of a batch with the
+    chromosomes' draws running side by side: one estimate is a sequence of 8-25 draws, each a K x n product and a WLS
+    rescoring whose rolling and trend-fit launches occupy a fraction of the device (one workgroup per row), so `streams`
+    host threads, each with a stream and a solver handle of its own (the count-path batch's), work through the
+    chromosomes longest first.  Every estimate is what the loop computes: its generators are seeded per draw, nothing
+    is shared.  Returns [(fraction, meta)] in the order of `ready`; the centred matrices are released as they are done."""
+    import concurrent.futures
+    import threading
+
+    import torch
+
+    from . import _native
+    from . import inference as _inf
+
+    device = ready[0][4].device
+    caller = torch.cuda.current_stream(device)
+    start = torch.cuda.Event()
+    start.record(caller)
+    order = iter(sorted(range(len(ready)), key=lambda i: -int(ready[i][4].shape[1])))
+    lock = threading.Lock()
+    out = [None] * len(ready)
+
+    def work(slot):
+        solver, stream = _inf._batch_worker(device.index, slot)
+        with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
+            stream.wait_event(start)
+            while True:
+                with lock:
+                    i = next(order, None)
+                if i is None:
+                    break
+                name, starts, scores, details, centred = ready[i]
+                centred.record_stream(stream)
+                out[i] = count_estimate(
+                    centred, observed_scores=scores, dependence_lag_hint=max(25, int(details.get("local_baseline_window", 101))),
+                    num_null_draws=plan.draws, progress_label=None, num_processes=plan.null_processes, return_details=True,
+                    **plan.wls, **({} if plan.multipliers is None else {"multipliers": plan.multipliers}))
+                del centred
+                ready[i] = (name, starts, scores, details, None)
+                logger.info("Budget null %s: %s draws", name, out[i][1].get("num_null_draws"))
+            stream.synchronize()
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=streams, thread_name_prefix="rocco-budget") as pool:
+        for future in [pool.submit(work, slot) for slot in range(streams)]:
+            future.result()
+    return out
+
+
 def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> dict:
     """The chromosome cache of rocco/rocco.py:933-1110 for matrices in memory, built the way a GPU wants it built:
     the matrices are gathered first; ALL chromosomes of a batch are scored by one device call (one median launch, or one
@@ -719,11 +774,18 @@ def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> di
                     ahead[j] = _budget.TrackWeightsAhead(int(ready[j][2].shape[0]), None, int(max(1, plan.draws)),
                                                          random_seed=0, ahead=plan.null_processes)
 
+        # the count branch with the multipliers made on the device: the chromosomes' estimates side by side
+        side_streams = min(len(ready), _native_side_streams(), int(os.environ.get("ROCCO_BUDGET_NULL_STREAMS", "3")))
+        together = None
+        if not plan.bigwig and own_count and not host_multipliers and side_streams > 1:
+            together = _count_estimates_side_by_side(ready, plan, count_estimate, side_streams)
         try:
             for i, (name, starts, scores, details, centred) in enumerate(ready):
                 start_ahead(i + 1 + depth)
                 extra = {} if plan.multipliers is None else {"multipliers": plan.multipliers}
-                if plan.bigwig:
+                if together is not None:
+                    fraction, meta = together[i]
+                elif plan.bigwig:
                     if own_track and i in ahead:
                         extra["weights_source"] = ahead.pop(i)
                     fraction, meta = track_estimate(scores, num_null_draws=plan.draws, progress_label=f"Budget null {name}",
