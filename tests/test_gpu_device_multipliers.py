@@ -82,3 +82,38 @@ def test_environment_switch_and_bad_value(gpu, monkeypatch):
     assert again[0] == host[0] and again[1] == host[1]
     with pytest.raises(ValueError):
         budget.estimate_budget_nonnull_fraction_from_score_track(scores, num_null_draws=6, multipliers="gpu")
+
+
+def test_count_branch_budget_estimates_side_by_side_give_the_same_bed(gpu, tmp_path, monkeypatch):
+    """The composed driver's count branch with device multipliers runs the chromosomes' budget estimates on worker streams
+    side by side (rocco_amd.rocco._count_estimates_side_by_side); ROCCO_BUDGET_NULL_STREAMS=1 runs them one after another
+    as the reference's loop does (rocco/rocco.py:1027-1048): same cache entries, same combined BED."""
+    import torch
+
+    from rocco_amd import rocco as impl
+
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(2718)
+    inputs = {}
+    for chrom, n in (("chr5", 30011), ("chr11", 8200), ("chr2", 45001), ("chr20", 12000)):
+        m = rng.poisson(3.0, size=(6, n)).astype(np.float64)
+        for p in range(200, n - 100, 900):
+            m[:, p:p + int(rng.integers(5, 40))] += rng.poisson(25.0, size=(6, 1))
+        inputs[chrom] = (np.arange(n, dtype=np.int64) * 50, torch.from_numpy(m).cuda())
+    args = {"input_track_type": "bam", "budget_null_draws": 12, "threads": -1, "gamma": None, "budget": None,
+            "scale_chrom_budgets": 1.0, "budget_posterior_quantile": 0.01, "selection_penalty": None, "min_length_bp": None,
+            "score_lower_bound_z": 1.0, "score_prior_df": 5.0, "score_min_effect": None, "score_precision_floor_ratio": 0.01,
+            "low_memory": False, "narrowPeak": False, "budget_null_multipliers": "device"}
+    beds, caches = {}, {}
+    for streams in ("1", "3"):
+        monkeypatch.setenv("ROCCO_BUDGET_NULL_STREAMS", streams)
+        a = dict(args)
+        a["output"] = str(tmp_path / f"out{streams}.bed")
+        beds[streams] = open(impl.run_chromosomes(list(inputs), inputs, a, run_id=streams), "rb").read()
+        caches[streams] = impl._build_chrom_cache(list(inputs), inputs, dict(args))
+    assert beds["1"] == beds["3"] and len(beds["1"]) > 0
+    assert list(caches["1"]) == list(caches["3"]) == list(inputs)
+    for c in inputs:
+        for key in ("budget_count_hat", "budget_fraction_hat", "gamma", "total_count"):
+            assert caches["1"][c][key] == caches["3"][c][key], (c, key)
+        assert caches["1"][c]["budget_rate_meta"] == caches["3"][c]["budget_rate_meta"], c
