@@ -661,13 +661,14 @@ def _native_side_streams() -> int:
     return int(_native.max_side_streams())
 
 
-def _count_estimates_side_by_side(ready: list, plan, count_estimate, streams: int) -> list:
-    """The count branch's budget estimates (rocco/rocco.py:1027-1048, one call per chromosome) of a batch with the
-    chromosomes' draws running side by side: one estimate is a sequence of 8-25 draws, each a K x n product and a WLS
-    rescoring whose rolling and trend-fit launches occupy a fraction of the device (one workgroup per row), so `streams`
-    host threads, each with a stream and a solver handle of its own (the count-path batch's), work through the
-    chromosomes longest first.  Every estimate is what the loop computes: its generators are seeded per draw, nothing
-    is shared.  Returns [(fraction, meta)] in the order of `ready`; the centred matrices are released as they are done."""
+def _estimates_side_by_side(ready: list, plan, estimate, streams: int) -> list:
+    """The budget estimates of a batch (rocco/rocco.py:994-1008 for tracks, 1027-1048 for count matrices: one call per
+    chromosome) with the chromosomes' draws running side by side.  One estimate is a sequence of 8-25 draws -- for a
+    count matrix each a K x n product and a WLS rescoring whose rolling and trend-fit launches occupy a fraction of the
+    device (one workgroup per row), for a score track a handful of short reductions -- so `streams` host threads, each
+    with a stream and a solver handle of its own (the count-path batch's), work through the chromosomes longest first.
+    Every estimate is what the loop computes: its generators are seeded per draw, nothing is shared.  Returns
+    [(fraction, meta)] in the order of `ready`; the centred matrices are released as they are done."""
     import concurrent.futures
     import threading
 
@@ -676,11 +677,16 @@ def _count_estimates_side_by_side(ready: list, plan, count_estimate, streams: in
     from . import _native
     from . import inference as _inf
 
-    device = ready[0][4].device
+    device = torch.device(f"cuda:{_dp._device_index()}")
+    for entry in ready:
+        twin = entry[4] if entry[4] is not None else _dp._resident_tensor(entry[2])
+        if twin is not None:
+            device = twin.device
+            break
     caller = torch.cuda.current_stream(device)
     start = torch.cuda.Event()
     start.record(caller)
-    order = iter(sorted(range(len(ready)), key=lambda i: -int(ready[i][4].shape[1])))
+    order = iter(sorted(range(len(ready)), key=lambda i: -int(ready[i][2].shape[0])))
     lock = threading.Lock()
     out = [None] * len(ready)
 
@@ -694,11 +700,10 @@ def _count_estimates_side_by_side(ready: list, plan, count_estimate, streams: in
                 if i is None:
                     break
                 name, starts, scores, details, centred = ready[i]
-                centred.record_stream(stream)
-                out[i] = count_estimate(
-                    centred, observed_scores=scores, dependence_lag_hint=max(25, int(details.get("local_baseline_window", 101))),
-                    num_null_draws=plan.draws, progress_label=None, num_processes=plan.null_processes, return_details=True,
-                    **plan.wls, **({} if plan.multipliers is None else {"multipliers": plan.multipliers}))
+                for t in (centred, _dp._resident_tensor(scores)):
+                    if t is not None:
+                        t.record_stream(stream)
+                out[i] = estimate(scores, details, centred)
                 del centred
                 ready[i] = (name, starts, scores, details, None)
                 logger.info("Budget null %s: %s draws", name, out[i][1].get("num_null_draws"))
@@ -774,11 +779,22 @@ def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> di
                     ahead[j] = _budget.TrackWeightsAhead(int(ready[j][2].shape[0]), None, int(max(1, plan.draws)),
                                                          random_seed=0, ahead=plan.null_processes)
 
-        # the count branch with the multipliers made on the device: the chromosomes' estimates side by side
+        # the multipliers made on the device: nothing of an estimate waits for the host, the chromosomes' estimates run side by side
         side_streams = min(len(ready), _native_side_streams(), int(os.environ.get("ROCCO_BUDGET_NULL_STREAMS", "3")))
         together = None
-        if not plan.bigwig and own_count and not host_multipliers and side_streams > 1:
-            together = _count_estimates_side_by_side(ready, plan, count_estimate, side_streams)
+        if not host_multipliers and side_streams > 1 and (own_track if plan.bigwig else own_count):
+            shared = {} if plan.multipliers is None else {"multipliers": plan.multipliers}
+            if plan.bigwig:
+                def one(scores, details, centred):
+                    return track_estimate(scores, num_null_draws=plan.draws, progress_label=None, num_processes=plan.null_processes,
+                                          return_details=True, **shared)
+            else:
+                def one(scores, details, centred):
+                    return count_estimate(centred, observed_scores=scores,
+                                          dependence_lag_hint=max(25, int(details.get("local_baseline_window", 101))),
+                                          num_null_draws=plan.draws, progress_label=None, num_processes=plan.null_processes,
+                                          return_details=True, **plan.wls, **shared)
+            together = _estimates_side_by_side(ready, plan, one, side_streams)
         try:
             for i, (name, starts, scores, details, centred) in enumerate(ready):
                 start_ahead(i + 1 + depth)

@@ -86,7 +86,7 @@ def test_environment_switch_and_bad_value(gpu, monkeypatch):
 
 def test_count_branch_budget_estimates_side_by_side_give_the_same_bed(gpu, tmp_path, monkeypatch):
     """The composed driver's count branch with device multipliers runs the chromosomes' budget estimates on worker streams
-    side by side (rocco_amd.rocco._count_estimates_side_by_side); ROCCO_BUDGET_NULL_STREAMS=1 runs them one after another
+    side by side (rocco_amd.rocco._estimates_side_by_side); ROCCO_BUDGET_NULL_STREAMS=1 runs them one after another
     as the reference's loop does (rocco/rocco.py:1027-1048): same cache entries, same combined BED."""
     import torch
 
@@ -113,6 +113,36 @@ def test_count_branch_budget_estimates_side_by_side_give_the_same_bed(gpu, tmp_p
         caches[streams] = impl._build_chrom_cache(list(inputs), inputs, dict(args))
     assert beds["1"] == beds["3"] and len(beds["1"]) > 0
     assert list(caches["1"]) == list(caches["3"]) == list(inputs)
+    for c in inputs:
+        for key in ("budget_count_hat", "budget_fraction_hat", "gamma", "total_count"):
+            assert caches["1"][c][key] == caches["3"][c][key], (c, key)
+        assert caches["1"][c]["budget_rate_meta"] == caches["3"][c]["budget_rate_meta"], c
+
+
+def test_track_branch_budget_estimates_side_by_side_give_the_same_bed(gpu, tmp_path, monkeypatch):
+    """The same for score tracks (rocco/rocco.py:994-1008)."""
+    from rocco_amd import rocco as impl
+
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(31415)
+    inputs = {}
+    for chrom, n in (("chr4", 40003), ("chr9", 9000), ("chr1", 65000), ("chr21", 12001), ("chrX", 20000)):
+        m = np.round(rng.gamma(1.0, 0.3, size=(4, n)), 5)
+        for p in range(300, n - 100, 800):
+            m[:, p:p + int(rng.integers(5, 40))] += rng.gamma(6.0, 0.8, size=(4, 1))
+        inputs[chrom] = (np.arange(n, dtype=np.int64) * 50, m)
+    args = {"input_track_type": "bigwig", "budget_null_draws": 12, "threads": -1, "gamma": None, "budget": None,
+            "scale_chrom_budgets": 1.0, "budget_posterior_quantile": 0.01, "selection_penalty": None, "min_length_bp": None,
+            "score_lower_bound_z": 1.0, "score_prior_df": 5.0, "score_precision_floor_ratio": 0.01, "low_memory": False,
+            "narrowPeak": False, "budget_null_multipliers": "device"}
+    beds, caches = {}, {}
+    for streams in ("1", "3"):
+        monkeypatch.setenv("ROCCO_BUDGET_NULL_STREAMS", streams)
+        a = dict(args)
+        a["output"] = str(tmp_path / f"out{streams}.bed")
+        beds[streams] = open(impl.run_chromosomes(list(inputs), inputs, a, run_id=streams), "rb").read()
+        caches[streams] = impl._build_chrom_cache(list(inputs), inputs, dict(args))
+    assert beds["1"] == beds["3"] and len(beds["1"]) > 0
     for c in inputs:
         for key in ("budget_count_hat", "budget_fraction_hat", "gamma", "total_count"):
             assert caches["1"][c][key] == caches["3"][c][key], (c, key)
