@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 #include "chain.h"
 #include "model_chain.h"
@@ -965,6 +966,9 @@ public:
             }
             if (*got || !wait) {
                 break;
+            }
+            if (spins > 200000) {
+                std::this_thread::yield();  // (a chain queued behind long work of another kind: do not burn the core)
             }
             if ((++spins & 1023) == 0) {
                 const hipError_t q = hipStreamQuery(stream_);
@@ -2231,6 +2235,9 @@ public:
             for (long long spins = 1;; ++spins) {
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0ull) {
                     break;
+                }
+                if (spins > 200000) {
+                    std::this_thread::yield();
                 }
                 if ((spins & 1023) == 0) {
                     const hipError_t q = hipStreamQuery(stream_);
