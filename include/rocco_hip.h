@@ -422,6 +422,11 @@ long long rocco_hip_solver_device_bytes(const rocco_hip_solver *solver);
  * certified counts the host took over from them, out[2] counts its replay of the reference's steps was answered from
  * them without device work, out[3] counts it asked for that the chain had not evaluated (answered by regular rounds). */
 void rocco_hip_model_chain_counters(long long out[4]);
+/* ... and how their last step -- the window that certifies and writes the solution of the final penalty (rocco/dp.py:164, the
+ * solve at `upper`) -- was served: out[0] solutions a chain wrote itself at the penalty its bisection ended at
+ * (lean_write_solutions_kernel from the class words of that penalty's certified evaluation), out[1] final windows answered
+ * from them without device work. */
+void rocco_hip_model_chain_written_counters(long long out[2]);
 
 /* ---- the multipliers of the bootstrap draws on the device (missing item 2) ---------------------
  * Replaces rocco/inference.py:546-575 `_generate_dependent_wild_weights` (called per row and draw at 654-664 and per

@@ -207,6 +207,7 @@ PROTOTYPES = [
       ctypes.c_void_p]),
     ("rocco_hip_buffer_growths", ctypes.c_longlong, []),
     ("rocco_hip_model_chain_counters", None, [ctypes.POINTER(ctypes.c_longlong)]),
+    ("rocco_hip_model_chain_written_counters", None, [ctypes.POINTER(ctypes.c_longlong)]),
     ("rocco_hip_solver_device_bytes", ctypes.c_longlong, [ctypes.c_void_p]),
     ("rocco_hip_pcg64_standard_normal_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_size_t,

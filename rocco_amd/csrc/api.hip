@@ -141,6 +141,7 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->host_chain.release();
     solver->host_follow.release();
     solver->host_objective.release();
+    solver->dev_objective.release();
     solver->dev_median_partials.release();
     solver->host_lean_stage.release();
     solver->host_lean_back.release();
@@ -861,6 +862,13 @@ void rocco_hip_model_chain_counters(long long out[4])
 {
     if (out != nullptr) {
         rocco::model_chain_counters(out);
+    }
+}
+
+void rocco_hip_model_chain_written_counters(long long out[2])
+{
+    if (out != nullptr) {
+        rocco::model_chain_written_counters(out);
     }
 }
 

@@ -46,5 +46,6 @@ int delta_model_lean(rocco_hip_solver *solver, const double *scores_dev, double 
 
 // process-wide diagnostic (include/rocco_hip.h: rocco_hip_model_chain_counters)
 void model_chain_counters(long long out[4]);
+void model_chain_written_counters(long long out[2]);
 
 }  // namespace rocco

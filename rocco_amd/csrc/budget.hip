@@ -120,7 +120,7 @@ int grid_exponent(double cmax, double lo, double hi)
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-std::atomic<long long> g_model_chain_counters[4];
+std::atomic<long long> g_model_chain_counters[6];
 
 class HipEvaluator : public Evaluator {
 public:
@@ -185,9 +185,15 @@ public:
         return model_fallback();
     }
 
+    std::vector<char> window_answered_;  // (round_all: windows answered from a solution a chain wrote -- no task for them)
+
     void add_window_tasks(std::vector<WindowRequest> &reqs, std::vector<RoundTask> &tasks)
     {
-        for (WindowRequest &r : reqs) {
+        for (size_t i = 0; i < reqs.size(); ++i) {
+            WindowRequest &r = reqs[i];
+            if (i < window_answered_.size() && window_answered_[i]) {
+                continue;
+            }
             RoundTask t;
             t.problem = r.problem;
             t.window = true;
@@ -199,6 +205,7 @@ public:
 
     int window(std::vector<WindowRequest> &reqs) override
     {
+        window_answered_.clear();
         std::vector<RoundTask> tasks;
         add_window_tasks(reqs, tasks);
         return run_round(tasks);
@@ -559,6 +566,9 @@ public:
             objective_ready_[problem] = 0;
         }
         probs[problem].scattered = false;  // (a solution scattered ahead is scattered again once it is final)
+        if (problem < written_.size()) {
+            written_[problem].valid = false;  // (a solution a chain wrote is about to be rewritten)
+        }
     }
 
     // Behind a round of windows that each write the solution of ONE penalty (the calibration's last step when every
@@ -566,13 +576,38 @@ public:
     // so that the one wait brings both.  Undone per problem by objective_collect when its window did not certify.
     int prefetch_objectives(const std::vector<size_t> &which)
     {
+        for (size_t b : objective_pending_) {
+            probs[b].scattered = false;  // (sums queued earlier and never collected: their scatter does not count either)
+        }
         objective_pending_.clear();
+        objective_behind_chain_ = false;
         const size_t W = which.size();
         if (W == 0) {
             return ROCCO_HIP_OK;
         }
         int rc;
-        if ((rc = scatter_all(&which)) != ROCCO_HIP_OK) return rc;
+        // Everything here goes through buffers of its own (dev_objective, host_objective): behind a chain these launches sit
+        // in the stream for a while, and the rounds' staging buffers may be written again meanwhile.
+        std::vector<LeanScatterTask> scatters;
+        int zero_blocks = 0, scatter_blocks = 0;
+        for (size_t b : which) {
+            DevProblem &p = probs[b];
+            if (!p.compacted || p.solution_in_orig || p.scattered) {
+                continue;
+            }
+            LeanScatterTask t;
+            t.level_solution = p.solution;
+            t.orig = p.lean_orig;
+            t.m = (long long)p.n;
+            t.full = p.orig_solution;
+            t.n = (long long)p.orig_n;
+            t.zero_begin = zero_blocks;
+            t.scatter_begin = scatter_blocks;
+            zero_blocks += (int)((p.orig_n + 16383) / 16384);
+            scatter_blocks += (int)((p.n + 255) / 256);
+            scatters.push_back(t);
+            p.scattered = true;
+        }
         std::vector<ObjectiveTask> tasks(W);
         long long tiles = 0;
         for (size_t i = 0; i < W; ++i) {
@@ -586,27 +621,32 @@ public:
             tasks[i].tile_begin = tiles;
             tiles += objective_tiles((size_t)tasks[i].n);
         }
+        const size_t b_scatter = align_up(scatters.size() * sizeof(LeanScatterTask), 256);
         const size_t b_tasks = align_up(W * sizeof(ObjectiveTask), 256);
         const size_t b_part = align_up((size_t)(2 * tiles + 2) * sizeof(double), 256);
         const size_t b_out = align_up(W * sizeof(double), 256);
-        if ((rc = solver_->dev_misc.reserve(b_tasks + b_part + b_out)) != ROCCO_HIP_OK) return rc;
-        // (a pinned buffer of their own: descriptors up from its head, sums back behind them)
-        if ((rc = solver_->host_objective.reserve(b_tasks + b_out)) != ROCCO_HIP_OK) return rc;
-        char *dv = (char *)solver_->dev_misc.ptr;
+        if ((rc = solver_->dev_objective.reserve(b_scatter + b_tasks + b_part + b_out)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_objective.reserve(b_scatter + b_tasks + b_out)) != ROCCO_HIP_OK) return rc;
+        char *dv = (char *)solver_->dev_objective.ptr;
         char *ho = (char *)solver_->host_objective.ptr;
-        std::memcpy(ho, tasks.data(), W * sizeof(ObjectiveTask));
-        ROCCO_HIP_TRY(hipMemcpyAsync(dv, ho, W * sizeof(ObjectiveTask), hipMemcpyHostToDevice, stream_));
-        if ((rc = launch_objective_batch((const ObjectiveTask *)dv, (int)W, tiles, (double *)(dv + b_tasks),
-                                         (double *)(dv + b_tasks + b_part), stream_)) != ROCCO_HIP_OK) {
+        if (!scatters.empty()) std::memcpy(ho, scatters.data(), scatters.size() * sizeof(LeanScatterTask));
+        std::memcpy(ho + b_scatter, tasks.data(), W * sizeof(ObjectiveTask));
+        ROCCO_HIP_TRY(hipMemcpyAsync(dv, ho, b_scatter + b_tasks, hipMemcpyHostToDevice, stream_));
+        if (!scatters.empty()) {
+            if ((rc = launch_lean_scatter_batch((const LeanScatterTask *)dv, (int)scatters.size(), zero_blocks, scatter_blocks, stream_)) != ROCCO_HIP_OK) return rc;
+        }
+        if ((rc = launch_objective_batch((const ObjectiveTask *)(dv + b_scatter), (int)W, tiles, (double *)(dv + b_scatter + b_tasks),
+                                         (double *)(dv + b_scatter + b_tasks + b_part), stream_)) != ROCCO_HIP_OK) {
             return rc;
         }
-        ROCCO_HIP_TRY(hipMemcpyAsync(ho + b_tasks, dv + b_tasks + b_part, W * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        objective_back_ = (const double *)(ho + b_tasks);
+        ROCCO_HIP_TRY(hipMemcpyAsync(ho + b_scatter + b_tasks, dv + b_scatter + b_tasks + b_part, W * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        objective_back_ = (const double *)(ho + b_scatter + b_tasks);
         objective_pending_ = which;
         ++objective_prefetches;
         return ROCCO_HIP_OK;
     }
     const double *objective_back_ = nullptr;
+    bool objective_behind_chain_ = false;  // the pending sums were queued behind a chain: valid for the problems it wrote
 
     // after the wait: keep the sums of the problems whose window certified its solution; the others are scattered again later
     void objective_collect(const std::vector<char> &certified)
@@ -631,6 +671,20 @@ public:
     int penalized_values(const std::vector<size_t> &which, const std::vector<double> &lambdas,
                          const std::vector<long long> &counts, std::vector<double> &values) override
     {
+        if (objective_behind_chain_ && !objective_pending_.empty()) {
+            // sums queued behind a chain of rounding-model rounds: they are there once the stream has drained, and they
+            // count for the problems whose solution the chain wrote and nothing has touched since
+            int rcw;
+            if ((rcw = model_chain_drain()) != ROCCO_HIP_OK) return rcw;
+            ROCCO_HIP_TRY(hipStreamSynchronize(stream_));
+            std::vector<char> good(objective_pending_.size(), 0);
+            for (size_t i = 0; i < objective_pending_.size(); ++i) {
+                const size_t b = objective_pending_[i];
+                good[i] = (b < written_.size() && written_[b].valid && probs[b].scattered) ? 1 : 0;
+            }
+            objective_collect(good);
+            objective_behind_chain_ = false;
+        }
         {
             // every sum fetched ahead behind the final windows: nothing left to do on the device
             bool all = !which.empty();
@@ -838,6 +892,15 @@ public:
     const ModelChainReport *model_chain_report_ = nullptr;
     const int *model_chain_np_ = nullptr;
     const ModelChainFact *model_chain_facts_ = nullptr;
+    const ModelChainFinal *model_chain_finals_ = nullptr;
+    // solutions a chain wrote at its end: problem -> (penalty, selected loci); valid until a round touches the problem
+    struct Written {
+        bool valid = false;
+        double penalty = 0.0;
+        long long count = 0;
+    };
+    std::vector<Written> written_;
+    long long model_chain_written = 0, model_chain_windows_answered = 0;
     long long model_chains = 0, model_chain_facts = 0, model_chain_hits = 0, model_chain_misses = 0, model_chain_stopped = 0;
     long long model_tiles_answered_ = 0;
     double t_mchain_submit_ = 0.0, t_mchain_wait_ = 0.0;
@@ -953,6 +1016,22 @@ public:
             if (finished != 0 && model_chain_ingested_ >= __atomic_load_n(&rep->published, __ATOMIC_ACQUIRE)) {
                 model_chain_running_ = false;
                 model_chain_stopped += rep->stopped;
+                if (written_.size() < probs.size()) {
+                    written_.resize(probs.size());
+                }
+                for (size_t i = 0; i < B; ++i) {
+                    const ModelChainFinal &fin = model_chain_finals_[i];
+                    Written &w = written_[model_chain_problems_[i]];
+                    w.valid = fin.written != 0 && fin.iters_left == 0;
+                    w.penalty = fin.upper;
+                    w.count = fin.count;
+                    if (w.valid) {
+                        ++model_chain_written;
+                        if (!objective_behind_chain_) {
+                            probs[model_chain_problems_[i]].scattered = false;  // (no scatter queued behind the write: it is due)
+                        }
+                    }
+                }
                 if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
                     std::fprintf(stderr, "[model chain] ended: %d rounds asked something, %d problems stopped at an open outcome\n",
                                  rep->rounds_run, rep->stopped);
@@ -1098,6 +1177,8 @@ public:
             w.cost_ok = a.cost_ok ? 1 : 0;
             w.n_tiles = t.n_tiles;
             w.pad[0] = w.pad[1] = w.pad[2] = 0;
+            w.solution = p.solution;
+            w.m = (long long)p.n;
             depth0 = std::max(depth0, a.open_depth);
             depth_floor = std::max(depth_floor, a.depth_floor);
             rounds = std::max(rounds, (a.iters_left + a.open_depth - 1) / a.open_depth);
@@ -1116,10 +1197,19 @@ public:
         const size_t b_state = align_up(B * sizeof(ModelChainState), 256);
         const size_t b_points = align_up(B * kLeanMaxPoints * sizeof(double), 256);
         const size_t b_results = align_up(B * kLeanMaxPoints * sizeof(LeanResult), 256);
-        const size_t dev_bytes = up_bytes + b_state + b_points + b_results + 512;
-        // host-coherent: [report][n_points per round and problem][facts]
+        // what writes the final solutions at the chain's end (lean.h: LeanTask::store == 2): two 256-word planes and one
+        // entering value per (tile, penalty) pair of every round; ROCCO_HIP_CHAIN_WRITE=0: nothing is kept, the final windows
+        // run as before
+        const char *write_env = std::getenv("ROCCO_HIP_CHAIN_WRITE");
+        const long long cap_pairs = (write_env != nullptr && std::atoi(write_env) == 0) ? 0 : std::max<long long>(tiles * 7, 2048);
+        const size_t b_bits = align_up((size_t)rounds * (size_t)cap_pairs * 2 * 256 * sizeof(unsigned), 256);
+        const size_t b_enter = align_up((size_t)rounds * (size_t)cap_pairs * sizeof(unsigned), 256);
+        const size_t b_writes = align_up(B * sizeof(LeanWriteTask), 256);
+        const size_t dev_bytes = up_bytes + b_state + b_points + b_results + 512 + b_writes + 256 + b_enter + b_bits;
+        // host-coherent: [report][n_points per round and problem][finals][facts]
         const size_t b_np = align_up((size_t)rounds * B * sizeof(int), 256);
-        const size_t follow_bytes = 256 + b_np + (size_t)rounds * B * kLeanMaxPoints * sizeof(ModelChainFact);
+        const size_t b_finals = align_up(B * sizeof(ModelChainFinal), 256);
+        const size_t follow_bytes = 256 + b_np + b_finals + (size_t)rounds * B * kLeanMaxPoints * sizeof(ModelChainFact);
         if ((rc = solver_->dev_chain.reserve(dev_bytes + 256)) != ROCCO_HIP_OK) return rc;
         if ((rc = solver_->host_chain.reserve(up_bytes + 256)) != ROCCO_HIP_OK) return rc;
         solver_->host_follow.coherent = true;
@@ -1141,7 +1231,7 @@ public:
         A.depth_floor = depth_floor;
         A.depth_fixed = std::getenv("ROCCO_HIP_MODEL_DEPTH") ? std::max(1, std::min(6, std::atoi(std::getenv("ROCCO_HIP_MODEL_DEPTH")))) : 0;
         A.adapt_batch = (std::getenv("ROCCO_HIP_LEAN_BATCH") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_BATCH")) != 0) ? 1 : 0;
-        A.pad = 0;
+        A.cap_pairs = (int)cap_pairs;
         A.tasks = (LeanTask *)dv;
         A.walk = (const ModelChainWalk *)(dv + b_tasks);
         A.state = (ModelChainState *)(dv + up_bytes);
@@ -1151,7 +1241,16 @@ public:
         A.globals = (int *)(dv + up_bytes + b_state + b_points + b_results + 256);
         A.report = (ModelChainReport *)f;
         A.n_points_out = (int *)(f + 256);
-        A.facts = (ModelChainFact *)(f + 256 + b_np);
+        A.finals = (ModelChainFinal *)(f + 256 + b_np);
+        A.facts = (ModelChainFact *)(f + 256 + b_np + b_finals);
+        {
+            char *tail = dv + up_bytes + b_state + b_points + b_results + 512;
+            A.writes = (LeanWriteTask *)tail;
+            A.n_writes = (int *)(tail + b_writes);
+            A.entering = (unsigned *)(tail + b_writes + 256);
+            A.bits = (unsigned *)(tail + b_writes + 256 + b_enter);
+        }
+        model_chain_finals_ = A.finals;
         std::memset(f, 0, 256);
         model_chain_report_ = A.report;
         model_chain_np_ = A.n_points_out;
@@ -1183,8 +1282,8 @@ public:
         L.ticket = (unsigned *)look;
         L.look = (unsigned long long *)(look + 256);
         L.recs = (LeanTileRec *)solver_->dev_lean_round.ptr;
-        L.bits = (unsigned *)solver_->dev_lean_pool.ptr;
-        L.tile_off = (unsigned *)solver_->dev_lean_pool.ptr;
+        L.bits = A.bits;          // (rounding-model tasks keep nothing in the level pool: the chain's own word arrays)
+        L.tile_off = A.entering;
         L.results = A.results;
         L.error = (unsigned *)(look + 128);
         L.error_out = nullptr;
@@ -1202,6 +1301,17 @@ public:
             if ((rc = launch_lean_finish_chain(L, grid_finish, stream_)) != ROCCO_HIP_OK) return rc;
         }
         if ((rc = launch_model_chain_director(A, rounds, 1, stream_)) != ROCCO_HIP_OK) return rc;
+        if (cap_pairs > 0) {
+            // the solutions of the bisections that ended, at the penalties they ended at (the last director names them)
+            if ((rc = launch_lean_write_solutions(A.writes, A.n_writes, (int)std::max(1LL, std::min(256LL, tiles)), stream_)) != ROCCO_HIP_OK) return rc;
+            // ... and, behind them, their scatter into the callers' buffers and their objective sums (for every problem of the
+            // chain: what was not written is scattered and summed again when its window has run)
+            const char *pf = std::getenv("ROCCO_HIP_PREFETCH_OBJECTIVE");
+            if (pf == nullptr || std::atoi(pf) != 0) {
+                if ((rc = prefetch_objectives(model_chain_problems_)) != ROCCO_HIP_OK) return rc;
+                objective_behind_chain_ = true;
+            }
+        }
         ROCCO_HIP_TRY(hipGetLastError());
         solver_->lean_look_dirty = 0;
         lean_inflight_ = reqs;
@@ -1919,6 +2029,30 @@ public:
         mark("round begins");
         if ((rc = lean_submit(compacts, probes)) != ROCCO_HIP_OK) return rc;
         mark("round: lean part submitted");
+        // a window that only certifies and writes the solution of ONE penalty, asked of a problem whose chain of
+        // rounding-model rounds ended at that very penalty: the chain's last evaluation there was certified class by class
+        // and lean_write_solutions_kernel has turned it into the solution bytes (model_chain.h) -- nothing left to run
+        window_answered_.assign(windows.size(), 0);
+        std::vector<size_t> answered_problems;
+        if (!windows.empty()) {
+            bool any_in_chain = false;
+            for (const WindowRequest &w : windows) {
+                any_in_chain = any_in_chain || in_running_chain(w.problem);
+            }
+            if (any_in_chain && (rc = model_chain_drain()) != ROCCO_HIP_OK) return rc;
+            for (size_t i = 0; i < windows.size(); ++i) {
+                WindowRequest &w = windows[i];
+                if (w.problem < written_.size() && written_[w.problem].valid && w.lambda_lo == w.lambda_hi &&
+                    w.lambda_lo == written_[w.problem].penalty) {
+                    w.result = WindowResult();
+                    w.result.count_lo = w.result.count_hi = written_[w.problem].count;
+                    w.result.n_diff = 0;
+                    window_answered_[i] = 1;
+                    answered_problems.push_back(w.problem);
+                    ++model_chain_windows_answered;
+                }
+            }
+        }
         std::vector<RoundTask> tasks;
         if ((rc = add_map_tasks(maps, tasks)) != ROCCO_HIP_OK) return rc;
         if ((rc = add_survey_tasks(surveys, tasks)) != ROCCO_HIP_OK) return rc;
@@ -1936,13 +2070,14 @@ public:
             // step was decided -- their objectives ride behind them
             std::vector<size_t> final_problems;
             const char *pf = std::getenv("ROCCO_HIP_PREFETCH_OBJECTIVE");
-            if ((pf == nullptr || std::atoi(pf) != 0) && !windows.empty() && tasks.size() == windows.size() && lean_inflight_.empty()) {
-                for (const WindowRequest &w : windows) {
-                    if (w.lambda_lo == w.lambda_hi) {
-                        final_problems.push_back(w.problem);
+            const size_t open_windows = windows.size() - answered_problems.size();
+            if ((pf == nullptr || std::atoi(pf) != 0) && open_windows > 0 && tasks.size() == open_windows && lean_inflight_.empty()) {
+                for (size_t i = 0; i < windows.size(); ++i) {
+                    if (!window_answered_[i] && windows[i].lambda_lo == windows[i].lambda_hi) {
+                        final_problems.push_back(windows[i].problem);
                     }
                 }
-                if (final_problems.size() != windows.size()) {
+                if (final_problems.size() != open_windows) {
                     final_problems.clear();
                 }
             }
@@ -1951,9 +2086,11 @@ public:
                 return rc;
             }
             if (!final_problems.empty()) {
-                std::vector<char> certified(windows.size(), 0);
+                std::vector<char> certified;
                 for (size_t i = 0; i < windows.size(); ++i) {
-                    certified[i] = (!windows[i].result.overflow && windows[i].result.n_diff == 0) ? 1 : 0;
+                    if (!window_answered_[i]) {
+                        certified.push_back((!windows[i].result.overflow && windows[i].result.n_diff == 0) ? 1 : 0);
+                    }
                 }
                 objective_collect(certified);
             }
@@ -2918,6 +3055,12 @@ void model_chain_counters(long long out[4])
     }
 }
 
+void model_chain_written_counters(long long out[2])
+{
+    out[0] = g_model_chain_counters[4].load(std::memory_order_relaxed);
+    out[1] = g_model_chain_counters[5].load(std::memory_order_relaxed);
+}
+
 int solve_fixed_penalty(rocco_hip_solver *solver, const double *scores_dev,
                         const double *switch_costs_dev, double gamma, size_t n, double lambda,
                         uint8_t *solution_dev, double *value_out, long long *count_out, int *path_out,
@@ -3248,6 +3391,8 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
     g_model_chain_counters[1].fetch_add(ev.model_chain_facts, std::memory_order_relaxed);
     g_model_chain_counters[2].fetch_add(ev.model_chain_hits, std::memory_order_relaxed);
     g_model_chain_counters[3].fetch_add(ev.model_chain_misses, std::memory_order_relaxed);
+    g_model_chain_counters[4].fetch_add(ev.model_chain_written, std::memory_order_relaxed);
+    g_model_chain_counters[5].fetch_add(ev.model_chain_windows_answered, std::memory_order_relaxed);
     if (std::getenv("ROCCO_HIP_DEBUG") != nullptr || std::getenv("ROCCO_HIP_TIMING") != nullptr) {
         const double total = HipEvaluator::now_us() - t_solve0;
         std::fprintf(stderr, "[host] solve %.0f us: %d rounds (%d with rounding-model kernels): in the rounds %.0f us = waiting for the device %.0f "
@@ -3263,8 +3408,9 @@ int solve_budget_batch(rocco_hip_solver *solver, size_t n_tasks, const rocco_hip
         std::fprintf(stderr, "[host] chained rounding-model rounds: %lld chains queued in %.0f us, their rounds waited for %.0f us; %lld counts taken "
                              "over, %lld requests answered from them, %lld not\n",
                      ev.model_chains, ev.t_mchain_submit_, ev.t_mchain_wait_, ev.model_chain_facts, ev.model_chain_hits, ev.model_chain_misses);
-        std::fprintf(stderr, "[host] objectives fetched behind final windows: %lld rounds, %lld sums used\n", ev.objective_prefetches,
-                     ev.objective_prefetch_hits);
+        std::fprintf(stderr, "[host] objectives fetched behind final windows: %lld rounds, %lld sums used; solutions written by the chains: %lld, "
+                             "final windows answered from them: %lld\n",
+                     ev.objective_prefetches, ev.objective_prefetch_hits, ev.model_chain_written, ev.model_chain_windows_answered);
         ev.mark("solve ends");
         for (size_t k = 0; k < ev.marks_.size(); ++k) {
             std::fprintf(stderr, "[mark] %8.1f  +%6.1f  %s\n", ev.marks_[k].second - t_solve0,

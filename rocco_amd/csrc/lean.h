@@ -53,7 +53,10 @@ struct LeanTask {
     int result_begin;     // offset of the task's results: [point]
     int tile_stride;      // 1; a pilot task evaluates every tile_stride-th tile of the array ...
     int independent;      // ... each as a chain of its own (estimates from a sample; nothing is stored)
-    int store;            // 1: keep the kept-locus words and tile offsets of every penalty (compaction candidates)
+    int store;            // 1: keep the kept-locus words and tile offsets of every penalty (compaction candidates);
+                          // 2: keep what writes a SOLUTION later (lean_write_solutions_kernel): per lane the selected-locus word
+                          //    for either value the fill may carry into the tile from the right ([which][penalty][tile][lane],
+                          //    which = 1 first), and per tile that value itself in place of the offset (finish kernel)
     // rounding-model tasks (lean_model_kernel): the reference's own arithmetic per chunk of 32 loci, as
     // oracle/delta_oracle.c defines it from the binade map; penalties are arbitrary doubles
     const uint8_t *emap;  // binade code of every chunk (nullptr: a bound task)
@@ -116,6 +119,19 @@ struct LeanCompactTask {
     int *out_orig;
     long long capacity;       // cells available at out_s / out_orig
 };
+
+// one evaluated penalty of a task turned into the level's 0/1 solution (model_chain.hip names them when a bisection ends)
+struct LeanWriteTask {
+    const unsigned *word1;   // [tile][lane] selected-locus words if the value entering the tile is 1 ...
+    const unsigned *word0;   // ... and if it is 0
+    const unsigned *entering;  // [tile] the value that does enter (finish kernel)
+    uint8_t *solution;       // the level's solution bytes
+    long long m;
+    int n_tiles;
+    int block_begin;         // first workgroup of this task in the launch (one per tile)
+};
+// tasks_dev[0 .. *n_tasks_dev): fixed grid, the workgroups take the tiles of every task in turn
+int launch_lean_write_solutions(const LeanWriteTask *tasks_dev, const int *n_tasks_dev, int grid, hipStream_t stream);
 
 int launch_lean_eval(const LeanLaunch &L, hipStream_t stream);
 // the launches of a chained round (L.ctl != nullptr): fixed grids, sizes read on the device

@@ -753,6 +753,16 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
         const unsigned zeff = d ? 1u : zin;
         const unsigned long long sum = (unsigned long long)nz[p] + (unsigned long long)one[p] + zeff;
         zw[p] = (unsigned)((sum ^ nz[p] ^ one[p]) >> 1);
+        if (MODEL && task.store == 2 && p < np) {
+            // solution words: the lane's selected loci for either value entering the tile (lanes whose fill does not
+            // come from the tile's right edge: the same word twice)
+            const unsigned long long sum0 = (unsigned long long)nz[p] + (unsigned long long)one[p] + (d ? 0u : zin);
+            const unsigned z_if0 = (unsigned)((sum0 ^ nz[p] ^ one[p]) >> 1);
+            const long long plane = (long long)task.n_points * task.n_tiles * kLeanThreads;
+            const long long at = task.bits_begin + ((long long)(p0 + p) * task.n_tiles + tile) * kLeanThreads + t;
+            L.bits[at] = zw[p];
+            L.bits[at + plane] = z_if0;
+        }
         if (!d) {
             cnt0[p] += tail[p] * zin;
             tail[p] = 0u;
@@ -796,7 +806,7 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
             atomicAdd(&sc->red[p][1], tl);
             atomicAdd(&sc->red[p][2], ce);
         }
-        if (p < np && task.store != 0) {
+        if (p < np && task.store == 1) {
             L.bits[task.bits_begin + ((long long)(p0 + p) * task.n_tiles + tile) * kLeanThreads + t] = zw[p];
         }
     }
@@ -876,6 +886,9 @@ __device__ __forceinline__ void finish_pair(const LeanLaunch &L, int n_tasks, in
         const unsigned long long pass_b = __ballot(pass), v_b = __ballot(v);
         const unsigned long long right = (lane == 63) ? 0ull : (~pass_b & (~0ull << (lane + 1)));
         const unsigned zin = right ? (unsigned)((v_b >> __builtin_ctzll(right)) & 1ull) : carry;
+        if (task.store == 2 && k >= 0) {
+            L.tile_off[task.off_begin + (long long)p * nt + k] = zin;  // (what lean_write_solutions_kernel needs of this pair)
+        }
         unsigned long long part = (k >= 0) ? ((unsigned long long)r.base + (unsigned long long)r.tail * zin) : 0ull;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -910,7 +923,7 @@ __device__ __forceinline__ void finish_pair(const LeanLaunch &L, int n_tasks, in
                 incl += u;
             }
         }
-        if (k < nt && task.store != 0) {
+        if (k < nt && task.store == 1) {
             off_out[k] = (unsigned)(running + incl - cells);
         }
         running += __shfl(incl, 63);
@@ -1067,6 +1080,56 @@ __global__ __launch_bounds__(kLeanThreads) void lean_compact_chain_kernel(const 
     for (int block = blockIdx.x; block < n_blocks; block += gridDim.x) {
         compact_block(tasks, n_tasks, &ctl->error, block, sh);
         __syncthreads();
+    }
+}
+
+// The 0/1 solution of a level from the words a store == 2 evaluation left: lane word -> 32 bytes (bit 31 = the lane's
+// first locus).  One workgroup per tile.
+__global__ __launch_bounds__(kLeanThreads) void lean_write_solutions_kernel(const LeanWriteTask *__restrict__ tasks,
+                                                                            const int *__restrict__ n_tasks_dev)
+{
+    const int n_tasks = *n_tasks_dev;
+    if (n_tasks <= 0) {
+        return;
+    }
+    const int total = tasks[n_tasks - 1].block_begin + tasks[n_tasks - 1].n_tiles;
+    for (int block = blockIdx.x; block < total; block += gridDim.x) {
+        const int ti = find_task(n_tasks, block, [&](int i) { return tasks[i].block_begin; });
+        const LeanWriteTask task = tasks[ti];
+        const int tile = block - task.block_begin;
+        const int t = threadIdx.x;
+        const unsigned entering = task.entering[tile];
+        const unsigned z = (entering != 0u ? task.word1 : task.word0)[(long long)tile * kLeanThreads + t];
+        const long long j0 = (long long)tile * kLeanTile + (long long)t * kLeanChunk;
+        if (j0 + kLeanChunk <= task.m && ((reinterpret_cast<uintptr_t>(task.solution + j0) & 15u) == 0u)) {
+            uint4 lo, hi;
+            unsigned *w = reinterpret_cast<unsigned *>(&lo);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned v = 0u;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    v |= ((z >> (31 - (4 * q + b))) & 1u) << (8 * b);
+                }
+                w[q] = v;
+            }
+            w = reinterpret_cast<unsigned *>(&hi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned v = 0u;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    v |= ((z >> (31 - (16 + 4 * q + b))) & 1u) << (8 * b);
+                }
+                w[q] = v;
+            }
+            *reinterpret_cast<uint4 *>(task.solution + j0) = lo;
+            *reinterpret_cast<uint4 *>(task.solution + j0 + 16) = hi;
+        } else {
+            for (int b = 0; b < kLeanChunk && j0 + b < task.m; ++b) {
+                task.solution[j0 + b] = (uint8_t)((z >> (31 - b)) & 1u);
+            }
+        }
     }
 }
 
@@ -1431,6 +1494,12 @@ int launch_lean_model_chain(const LeanLaunch &L, int grid, hipStream_t stream)
         configured = true;
     }
     hipLaunchKernelGGL(lean_model_chain_kernel, dim3((unsigned)grid), dim3(kLeanThreads), lds, stream, L);
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_write_solutions(const LeanWriteTask *tasks_dev, const int *n_tasks_dev, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lean_write_solutions_kernel, dim3((unsigned)grid), dim3(kLeanThreads), 0, stream, tasks_dev, n_tasks_dev);
     return ROCCO_HIP_OK;
 }
 

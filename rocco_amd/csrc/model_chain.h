@@ -35,6 +35,8 @@ struct ModelChainWalk {
     int G_real, L_real, cost_ok;
     int n_tiles;
     int pad[3];
+    uint8_t *solution;   // the problem's (level's) solution bytes: written at the chain's end when the bisection has ended
+    long long m;         // its loci
 };
 
 // per problem, on the device between the rounds
@@ -44,7 +46,24 @@ struct ModelChainState {
     int iters_left;
     int active;                // 0: ended (no step left, or an outcome that was not certified)
     int n_points;
+    int stopped;               // ended at an outcome the model did not certify
+    // where the evaluation that set `upper` left what writes its solution (lean.h: LeanTask::store == 2): word offsets of
+    // its [tile][lane] planes for either entering value, offset of its per-tile entering values; upper_known = 0: `upper`
+    // was not set by an evaluation of this chain (or that round kept nothing)
+    long long upper_w1, upper_w0, upper_zin;
+    long long upper_count;
+    int upper_known;
+    int rec_begin;             // of the round in flight (the director's own prefix of tiles x penalties)
+    int stored;                // the round in flight keeps solution words
     int pad;
+};
+
+// per problem, when the chain has ended (host-coherent memory, behind the report)
+struct ModelChainFinal {
+    double lower, upper;
+    long long count;     // selected loci at `upper` (certified equal to the reference's)
+    int iters_left;
+    int written;         // 1: the solution of `upper` is in the problem's solution bytes (lean_write_solutions_kernel behind the chain)
 };
 
 // one evaluated penalty, written straight into pinned host memory by the director: slot [(round * problems + problem) * 64 + k]
@@ -71,7 +90,7 @@ struct ModelChainArgs {
     int depth_floor;     // from the second round on: max(depth_floor, the evaluator's rule over the tiles of the round before)
     int depth_fixed;     // > 0: the evaluator's rule is overridden (ROCCO_HIP_MODEL_DEPTH)
     int adapt_batch;     // two penalties per workgroup while the round fits 512 workgroups that way
-    int pad;
+    int cap_pairs;       // (tile, penalty) pairs per round whose solution words fit the scratch (0: none are kept)
     const ModelChainWalk *walk;
     ModelChainState *state;
     LeanTask *tasks;       // [n_problems], uploaded complete; the director sets n_points, n_groups, unit_begin, rec_begin, batch
@@ -82,6 +101,13 @@ struct ModelChainArgs {
     ModelChainReport *report;  // pinned
     int *n_points_out;         // pinned [round * n_problems + problem]
     ModelChainFact *facts;     // pinned
+    ModelChainFinal *finals;   // pinned [n_problems]
+    // solution words: `bits` [round][cap_pairs][2][256] words, `entering` [round][cap_pairs] (the launches' LeanLaunch::bits /
+    // tile_off point at them); the write tasks of the chain's end and their number
+    unsigned *bits;
+    unsigned *entering;
+    LeanWriteTask *writes;
+    int *n_writes;
 };
 
 // round: 0 .. n_rounds; the call with last = 1 only reads the last round's results

@@ -58,8 +58,8 @@ __device__ __forceinline__ int next_depth(const ModelChainArgs &A, long long til
 }
 
 struct DirectorShared {
-    double lower[kModelChainMaxProblems], upper[kModelChainMaxProblems];
-    int left[kModelChainMaxProblems], active[kModelChainMaxProblems], np[kModelChainMaxProblems], nt[kModelChainMaxProblems];
+    ModelChainState st[kModelChainMaxProblems];  // every problem's state, global -> LDS -> global once per call
+    int np[kModelChainMaxProblems];
     long long count[kDirectorThreads];  // the round's results of the problems of one pass, lane by lane
     int open[kDirectorThreads];
     unsigned long long tiles_before;
@@ -77,13 +77,9 @@ __device__ __forceinline__ void consume_round(const ModelChainArgs &A, int round
     for (int i0 = 0; i0 < B; i0 += kGroups) {
         const int i = i0 + g;
         const bool have = i < B;
-        ModelChainState st = {0.0, 0.0, 0ull, 0, 0, 0, 0};
-        if (have) {
-            st = A.state[i];
-        }
-        const bool asked = have && st.active != 0 && st.n_points > 0;
+        const bool asked = have && sh.st[i].active != 0 && sh.st[i].n_points > 0;
         LeanResult res = {0, 0, 1};
-        if (asked && j < st.n_points) {
+        if (asked && j < sh.st[i].n_points) {
             res = A.results[i * kLeanMaxPoints + j];
             ModelChainFact f;
             f.penalty = A.points[i * kLeanMaxPoints + j];
@@ -95,6 +91,7 @@ __device__ __forceinline__ void consume_round(const ModelChainArgs &A, int round
         sh.open[threadIdx.x] = (res.flags != 0) ? 1 : 0;
         __syncthreads();
         if (have && j == 0) {
+            ModelChainState st = sh.st[i];
             A.n_points_out[(size_t)(round - 1) * B + i] = asked ? st.n_points : 0;
             if (asked) {
                 const ModelChainWalk in = A.walk[i];
@@ -102,22 +99,26 @@ __device__ __forceinline__ void consume_round(const ModelChainArgs &A, int round
                 atomicAdd(&sh.tiles_before, (unsigned long long)in.n_tiles);
                 // open steps read their count, known steps cost nothing (search.cpp: the probe walk, then advance_analytic)
                 const int depth = A.globals[0];
+                const long long nt = in.n_tiles, np = st.n_points;
+                const long long pairs_at = (long long)(round - 1) * A.cap_pairs + st.rec_begin;
                 double lo = st.lower, hi = st.upper;
                 int left = st.iters_left, open = 0, h = 0;
                 while (left > 0) {
                     const double mid = (lo + hi) / 2.0;  // rocco/dp.py:143
                     bool greater = false;
+                    int slot = -1;
                     if (!known_outcome(in, mid, &greater)) {
                         if (open >= depth || ((st.mask >> h) & 1ull) == 0ull) {
                             break;
                         }
-                        const int slot = g * G + __popcll(st.mask & ((1ull << h) - 1ull));
-                        if (sh.open[slot] != 0) {
+                        slot = __popcll(st.mask & ((1ull << h) - 1ull));
+                        if (sh.open[g * G + slot] != 0) {
                             st.active = 0;  // not certified: the host's own machinery takes this problem from here
+                            st.stopped = 1;
                             atomicAdd(&sh.stopped, 1);
                             break;
                         }
-                        greater = sh.count[slot] > in.target;
+                        greater = sh.count[g * G + slot] > in.target;
                         ++open;
                         h = 2 * h + 1 + (greater ? 1 : 0);
                     }
@@ -125,6 +126,14 @@ __device__ __forceinline__ void consume_round(const ModelChainArgs &A, int round
                         lo = mid;
                     } else {
                         hi = mid;
+                        // the evaluation behind the new upper end, if it kept what writes a solution
+                        st.upper_known = (slot >= 0 && st.stored != 0) ? 1 : 0;
+                        if (st.upper_known != 0) {
+                            st.upper_w1 = pairs_at * (2 * 256) + ((long long)slot * nt) * 256;
+                            st.upper_w0 = st.upper_w1 + np * nt * 256;
+                            st.upper_zin = pairs_at + (long long)slot * nt;
+                            st.upper_count = sh.count[g * G + slot];
+                        }
                     }
                     --left;
                 }
@@ -132,10 +141,9 @@ __device__ __forceinline__ void consume_round(const ModelChainArgs &A, int round
                 st.upper = hi;
                 st.iters_left = left;
             }
-            sh.lower[i] = st.lower;
-            sh.upper[i] = st.upper;
-            sh.left[i] = st.iters_left;
-            sh.active[i] = st.active;
+            st.n_points = 0;
+            st.mask = 0ull;
+            sh.st[i] = st;
         }
         __syncthreads();
     }
@@ -152,15 +160,15 @@ __device__ __forceinline__ void plan_round(const ModelChainArgs &A, int depth, D
     const int B = A.n_problems;
     for (int i0 = 0; i0 < B; i0 += kGroups) {
         const int i = i0 + g;
-        const bool have = i < B && sh.active[i] != 0;
+        const bool have = i < B && sh.st[i].active != 0;
         bool exists = false;
         double mid_out = 0.0;
         const int idx = j + 1;          // heap index, one-based
         const int k = 31 - __clz(idx);  // open steps above this node
         if (have && k < depth) {
             const ModelChainWalk in = A.walk[i];
-            double lo = sh.lower[i], hi = sh.upper[i];
-            int left = sh.left[i];
+            double lo = sh.st[i].lower, hi = sh.st[i].upper;
+            int left = sh.st[i].iters_left;
             for (int level = 0; level <= k; ++level) {
                 bool open_here = false;
                 double mid = 0.0;
@@ -200,16 +208,11 @@ __device__ __forceinline__ void plan_round(const ModelChainArgs &A, int depth, D
         if (exists) {
             A.points[i * kLeanMaxPoints + __popcll(mask & ((1ull << j) - 1ull))] = mid_out;
         }
+        __syncthreads();  // (the state above was read by every lane of the group)
         if (i < B && j == 0) {
-            ModelChainState st;
-            st.lower = sh.lower[i];
-            st.upper = sh.upper[i];
-            st.mask = mask;
-            st.iters_left = sh.left[i];
-            st.active = (have && np > 0) ? 1 : 0;  // (np == 0: every step left is known, nothing more to ask)
-            st.n_points = np;
-            st.pad = 0;
-            A.state[i] = st;
+            sh.st[i].mask = mask;
+            sh.st[i].active = (have && np > 0) ? 1 : 0;  // (np == 0: every step left is known, nothing more to ask)
+            sh.st[i].n_points = np;
             sh.np[i] = np;
         }
     }
@@ -239,19 +242,37 @@ __global__ __launch_bounds__(kDirectorThreads) void model_chain_director_kernel(
         sh.asked = 0;
         sh.stopped = 0;
     }
-    __syncthreads();
-
-    // ---- 1. the round that ended ----
+    // ---- the problems' state ----
+    constexpr int kStateWords = (int)(sizeof(ModelChainState) / 8);
     if (round == 0) {
         for (int i = t; i < B; i += kDirectorThreads) {
             const ModelChainWalk in = A.walk[i];
-            sh.lower[i] = in.lower;
-            sh.upper[i] = in.upper;
-            sh.left[i] = in.iters_left;
-            sh.active[i] = 1;
+            ModelChainState st;
+            st.lower = in.lower;
+            st.upper = in.upper;
+            st.mask = 0ull;
+            st.iters_left = in.iters_left;
+            st.active = 1;
+            st.n_points = 0;
+            st.stopped = 0;
+            st.upper_w1 = st.upper_w0 = st.upper_zin = st.upper_count = 0;
+            st.upper_known = 0;  // (the host's upper end: no evaluation of this chain behind it)
+            st.rec_begin = 0;
+            st.stored = 0;
+            st.pad = 0;
+            sh.st[i] = st;
         }
-        __syncthreads();
     } else {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(A.state);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(sh.st);
+        for (int i = t; i < B * kStateWords; i += kDirectorThreads) {
+            dst[i] = src[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- 1. the round that ended ----
+    if (round > 0) {
         switch (lanes_for(A.globals[0])) {
         case 8: consume_round<8>(A, round, sh); break;
         case 16: consume_round<16>(A, round, sh); break;
@@ -276,17 +297,70 @@ __global__ __launch_bounds__(kDirectorThreads) void model_chain_director_kernel(
         A.globals[1] = asked_rounds;
         A.globals[2] = stopped_all;
         sh.depth = (round == 0) ? min(kModelChainMaxDepth, A.depth0) : next_depth(A, (long long)sh.tiles_before);
-        if (last != 0) {
-            A.report->error = atomicOr(&A.ctl->error, 0u);
-            A.report->stopped = stopped_all;
-            A.report->rounds_run = asked_rounds;
-            __hip_atomic_store(&A.report->finished, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else {
+        if (last == 0) {
             A.globals[0] = sh.depth;
         }
     }
     __syncthreads();
     if (last != 0) {
+        // ---- the chain's end: what every problem's bisection came to, and the solutions that can be written ----
+        __shared__ int cand_s[kModelChainMaxProblems], tiles_s[kModelChainMaxProblems], rank_s[kModelChainMaxProblems],
+            block_s[kModelChainMaxProblems];
+        if (t < kModelChainMaxProblems) {
+            int cand = 0, tiles = 0;
+            if (t < B) {
+                const ModelChainState &st = sh.st[t];
+                cand = (st.iters_left == 0 && st.stopped == 0 && st.upper_known != 0 && A.walk[t].solution != nullptr) ? 1 : 0;
+                tiles = cand ? A.walk[t].n_tiles : 0;
+            }
+            cand_s[t] = cand;
+            tiles_s[t] = tiles;
+        }
+        __syncthreads();
+        if (t < 64) {
+            int ca, cb, ta, tb;
+            const int xa = wave_exclusive(cand_s[t], t, &ca), xb = wave_exclusive(cand_s[t + 64], t, &cb);
+            const int ya = wave_exclusive(tiles_s[t], t, &ta), yb = wave_exclusive(tiles_s[t + 64], t, &tb);
+            rank_s[t] = xa;
+            rank_s[t + 64] = ca + xb;
+            block_s[t] = ya;
+            block_s[t + 64] = ta + yb;
+            if (t == 0) {
+                *A.n_writes = ca + cb;
+            }
+        }
+        __syncthreads();
+        if (t < B) {
+            const ModelChainState &st = sh.st[t];
+            ModelChainFinal f;
+            f.lower = st.lower;
+            f.upper = st.upper;
+            f.count = st.upper_count;
+            f.iters_left = st.iters_left;
+            f.written = cand_s[t];
+            if (cand_s[t] != 0) {
+                const ModelChainWalk in = A.walk[t];
+                LeanWriteTask w;
+                w.word1 = A.bits + st.upper_w1;
+                w.word0 = A.bits + st.upper_w0;
+                w.entering = A.entering + st.upper_zin;
+                w.solution = in.solution;
+                w.m = in.m;
+                w.n_tiles = in.n_tiles;
+                w.block_begin = block_s[t];
+                A.writes[rank_s[t]] = w;
+            }
+            A.finals[t] = f;
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (t == 0) {
+            A.report->error = atomicOr(&A.ctl->error, 0u);
+            A.report->stopped = A.globals[2];
+            A.report->rounds_run = A.globals[1];
+            __threadfence_system();
+            __hip_atomic_store(&A.report->finished, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
 
@@ -314,6 +388,9 @@ __global__ __launch_bounds__(kDirectorThreads) void model_chain_director_kernel(
         (void)wave_exclusive(np_b, t, &pair_b);
         const bool by_two = A.adapt_batch != 0 && two_a + two_b <= 512;
         const int batch = by_two ? 2 : kLeanModelBatch;
+        // solution words are kept while the round's (tile, penalty) pairs fit their scratch
+        const bool keep = A.cap_pairs > 0 && rec_a + rec_b <= A.cap_pairs;
+        const long long round_pairs = (long long)round * A.cap_pairs;
         if (a < B) {
             LeanTask &task = A.tasks[a];
             task.n_points = np_a;
@@ -321,6 +398,11 @@ __global__ __launch_bounds__(kDirectorThreads) void model_chain_director_kernel(
             task.unit_begin = by_two ? x2a : x4a;
             task.rec_begin = xra;
             task.batch = batch;
+            task.store = keep ? 2 : 0;
+            task.bits_begin = (round_pairs + xra) * (2 * 256);
+            task.off_begin = round_pairs + xra;
+            sh.st[a].rec_begin = xra;
+            sh.st[a].stored = keep ? 1 : 0;
         }
         if (b < B) {
             LeanTask &task = A.tasks[b];
@@ -329,6 +411,11 @@ __global__ __launch_bounds__(kDirectorThreads) void model_chain_director_kernel(
             task.unit_begin = (by_two ? two_a + x2b : four_a + x4b);
             task.rec_begin = rec_a + xrb;
             task.batch = batch;
+            task.store = keep ? 2 : 0;
+            task.bits_begin = (round_pairs + rec_a + xrb) * (2 * 256);
+            task.off_begin = round_pairs + rec_a + xrb;
+            sh.st[b].rec_begin = rec_a + xrb;
+            sh.st[b].stored = keep ? 1 : 0;
         }
         if (t == 0) {
             LeanRoundCtl c;
@@ -341,6 +428,14 @@ __global__ __launch_bounds__(kDirectorThreads) void model_chain_director_kernel(
             c.round = round + 1;
             c.all_done = (pair_a + pair_b == 0) ? 1 : 0;
             *A.ctl = c;
+        }
+    }
+    __syncthreads();
+    {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(A.state);
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(sh.st);
+        for (int i = t; i < B * kStateWords; i += kDirectorThreads) {
+            dst[i] = src[i];
         }
     }
 }

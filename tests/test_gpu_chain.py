@@ -17,6 +17,16 @@ def _model_chain_counters():
     return list(out)  # chains, counts taken over, counts answered from them, counts asked for that a chain had not evaluated
 
 
+def _written_counters():
+    import ctypes
+
+    from rocco_amd import _native
+
+    out = (ctypes.c_longlong * 2)()
+    _native.load().rocco_hip_model_chain_written_counters(out)
+    return list(out)  # solutions the chains wrote themselves, final windows answered from them
+
+
 def _solve(scores_list, gammas, targets, chain, monkeypatch):
     import torch
 
@@ -134,6 +144,33 @@ def test_the_director_asks_what_the_hosts_replay_asks(gpu, oracle, monkeypatch, 
             assert np.array_equal(a[1].cpu().numpy(), ref[1])
         assert after[0] > before[0] and after[2] > before[2], (kind, chain, before, after)
         assert after[3] == before[3], (kind, chain, before, after)
+
+
+@pytest.mark.parametrize("write", ["1", "0"])
+def test_solutions_written_by_the_chain_are_the_oracles(gpu, oracle, monkeypatch, write):
+    """The window that ends a calibration (certify + write the solution of the final penalty) is answered from what the
+    chain of rounding-model rounds left: the class words of its certified evaluation at that penalty, turned into bytes by
+    lean_write_solutions_kernel.  ROCCO_HIP_CHAIN_WRITE=0: the windows run.  Solutions, penalties, counts and objective
+    values against the oracle either way."""
+    monkeypatch.setenv("ROCCO_HIP_CHAIN_WRITE", write)
+    rng = np.random.default_rng(777)
+    sizes = [310_000, 95_000, 140_000]
+    scores = [_tracks(rng, n, "peaks") for n in sizes]
+    targets = [int(np.floor(n * 0.02)) for n in sizes]
+    before = _written_counters()
+    out = _solve(scores, [1.0] * 3, targets, False, monkeypatch)
+    after = _written_counters()
+    for s, target, a in zip(scores, targets, out):
+        costs = oracle.build_switch_costs(s, 1.0)
+        ref = oracle.calibrate_selection_penalty(s, costs, target)
+        assert a[0] == ref[0] and a[3] == ref[3]
+        assert np.array_equal(a[1].cpu().numpy(), ref[1])
+        assert np.isclose(a[2], ref[2], rtol=1e-12, atol=1e-9)  # penalised value (summation order differs)
+    if write == "1":
+        # (a bisection whose final upper end was decided without an evaluation of the chain keeps its window)
+        assert after[0] - before[0] >= 1 and after[1] - before[1] == after[0] - before[0], (before, after)
+    else:
+        assert after == before
 
 
 def test_model_chain_depth_override_and_single_problem(gpu, oracle, monkeypatch):
