@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 
 #include "../../include/rocco_hip.h"
 
@@ -382,6 +383,17 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     const std::vector<Presearch> *presearch)
 {
     // (a compaction replaces a problem's arrays: its length and score floor change on the way)
+    struct Tick {
+        static double now()
+        {
+            timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            return 1e6 * (double)ts.tv_sec + 1e-3 * (double)ts.tv_nsec;
+        }
+    };
+    const bool timing = std::getenv("ROCCO_SEARCH_TIMING") != nullptr;
+    const double tick0 = Tick::now();
+    int tick_iter = 0;
     std::vector<ChainProblem> problems(problems_in);
     const size_t B = problems.size();
     std::vector<State> st(B);
@@ -449,7 +461,9 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
         }
     }
 
+    if (timing) std::fprintf(stderr, "[search timing] setup %.1f us\n", Tick::now() - tick0);
     for (;;) {
+        const double tick_a = Tick::now();
         std::vector<ProbeRequest> probes;
         std::vector<WindowRequest> windows;
         std::vector<ExactRequest> exacts;
@@ -873,9 +887,11 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
             break;
         }
         int rc;
+        const double tick_b = Tick::now();
         if ((rc = ev.round_all(compacts, maps, surveys, probes, windows, spines)) != ROCCO_HIP_OK) {
             return rc;
         }
+        if (timing) std::fprintf(stderr, "[search timing] iteration %d: planning %.1f us, round %.1f us\n", tick_iter++, tick_b - tick_a, Tick::now() - tick_b);
         for (size_t q = 0; q < compacts.size(); ++q) {
             const size_t b = compact_owner[q];
             State &s = st[b];
