@@ -1201,7 +1201,10 @@ public:
         // entering value per (tile, penalty) pair of every round; ROCCO_HIP_CHAIN_WRITE=0: nothing is kept, the final windows
         // run as before
         const char *write_env = std::getenv("ROCCO_HIP_CHAIN_WRITE");
-        const long long cap_pairs = (write_env != nullptr && std::atoi(write_env) == 0) ? 0 : std::max<long long>(tiles * 7, 2048);
+        long long cap_pairs = (write_env != nullptr && std::atoi(write_env) == 0) ? 0 : std::max<long long>(tiles * 7, 2048);
+        if ((size_t)rounds * (size_t)cap_pairs * 2 * 256 * sizeof(unsigned) > ((size_t)1 << 30)) {
+            cap_pairs = 0;  // (more than 1 GiB of class words: not worth it, the windows run)
+        }
         const size_t b_bits = align_up((size_t)rounds * (size_t)cap_pairs * 2 * 256 * sizeof(unsigned), 256);
         const size_t b_enter = align_up((size_t)rounds * (size_t)cap_pairs * sizeof(unsigned), 256);
         const size_t b_writes = align_up(B * sizeof(LeanWriteTask), 256);
