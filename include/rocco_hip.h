@@ -177,6 +177,12 @@ int rocco_hip_delta_build_map_f64(rocco_hip_solver *solver, const double *scores
                                   const double *switch_costs_dev, double gamma, size_t n,
                                   double lambda_ref, double margin, uint8_t *emap_dev, void *stream);
 
+/* The same codes from the lean kernels the budgeted solve uses for the first map of its compacted problems (lean.hip:
+ * lean_map_kernel, lean_mapcode_kernel: one tile kernel + one code kernel instead of six launches); scalar switch cost,
+ * n >= 2.  Exported so that the two builders can be compared byte for byte. */
+int rocco_hip_delta_build_map_lean_f64(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n,
+                                       double lambda_ref, double margin, uint8_t *emap_dev, void *stream);
+
 typedef struct {
     long long count_lo, count_hi; /* selected loci of fill(LO) / fill(HI)                 */
     long long n_diff;             /* loci whose class differs between LO and HI           */

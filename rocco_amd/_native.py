@@ -123,6 +123,9 @@ PROTOTYPES = [
     ("rocco_hip_delta_build_map_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t,
       ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_delta_build_map_lean_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+      ctypes.c_void_p]),
     ("rocco_hip_delta_bound_rounds_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t, c_double_p, c_int_p, ctypes.c_int,
       c_double_p, c_ll_p, c_ll_p, ctypes.c_void_p]),

@@ -142,6 +142,8 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->host_follow.release();
     solver->host_objective.release();
     solver->dev_objective.release();
+    solver->dev_map.release();
+    solver->host_map_stage.release();
     solver->dev_median_partials.release();
     solver->host_lean_stage.release();
     solver->host_lean_back.release();
@@ -387,6 +389,16 @@ int rocco_hip_delta_build_map_f64(rocco_hip_solver *solver, const double *scores
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
     return delta_build_map(solver, scores_dev, switch_costs_dev, gamma, n, lambda_ref, margin, emap_dev,
                            (hipStream_t)stream);
+}
+
+int rocco_hip_delta_build_map_lean_f64(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n,
+                                       double lambda_ref, double margin, uint8_t *emap_dev, void *stream)
+{
+    if (solver == nullptr || scores_dev == nullptr || n < 2 || n >= ((size_t)1 << 31) || emap_dev == nullptr || !(margin >= 0.0)) {
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    return delta_build_map_lean(solver, scores_dev, gamma, n, lambda_ref, margin, emap_dev, (hipStream_t)stream);
 }
 
 int rocco_hip_delta_window_f64(rocco_hip_solver *solver, const double *scores_dev,

@@ -44,6 +44,11 @@ int delta_window(rocco_hip_solver *solver, const double *scores_dev, const doubl
 int delta_model_lean(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n, const uint8_t *emap_dev,
                      const double *lambdas, size_t n_lambdas, long long *counts_out, long long *open_out, hipStream_t stream);
 
+// Test entry of the binade map built by the lean kernels (lean.h: lean_map_kernel): the codes delta_build_map gives for a
+// scalar switch cost, bit for bit.
+int delta_build_map_lean(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n, double lambda_ref,
+                         double margin, uint8_t *emap_dev, hipStream_t stream);
+
 // process-wide diagnostic (include/rocco_hip.h: rocco_hip_model_chain_counters)
 void model_chain_counters(long long out[4]);
 void model_chain_written_counters(long long out[2]);

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 
 #include "chain.h"
@@ -125,6 +126,21 @@ std::atomic<long long> g_model_chain_counters[6];
 class HipEvaluator : public Evaluator {
 public:
     HipEvaluator(rocco_hip_solver *solver, hipStream_t stream) : solver_(solver), stream_(stream) {}
+
+    // Environment switches are read once per evaluator (= per solve call: tests and A/B scripts change them between calls);
+    // getenv walks the whole environment, and the search asks some of these per chromosome and round.
+    mutable std::vector<std::pair<const char *, const char *>> env_cache_;
+    const char *env(const char *name) const
+    {
+        for (const auto &e : env_cache_) {
+            if (e.first == name || std::strcmp(e.first, name) == 0) {
+                return e.second;
+            }
+        }
+        const char *value = std::getenv(name);
+        env_cache_.emplace_back(name, value);
+        return value;
+    }
 
     std::vector<DevProblem> probs;
 
@@ -305,13 +321,159 @@ public:
             }
             maps_allocated_ = true;
         }
+        // the first map of a compacted problem: by the lean kernels (lean.h: lean_map_kernel), queued here and not waited for
+        std::vector<MapRequest *> lean_maps;
         for (MapRequest &r : reqs) {
+            if (lean_map_takes(r.problem)) {
+                lean_maps.push_back(&r);
+                continue;
+            }
             RoundTask t;
             t.problem = r.problem;
             t.map = true;
             t.margin = r.margin;
             t.lambdas = {r.lambda_ref};
             tasks.push_back(t);
+        }
+        return lean_map_enqueue(lean_maps);
+    }
+
+    bool force_lean_map_ = false;  // test entry: any array without switch-cost vector and without a map
+    long long lean_maps_built = 0;
+    const unsigned *lean_map_error_ = nullptr;  // pinned word a lean map round reports to (checked at the next waits)
+
+    bool lean_map_takes(size_t problem) const
+    {
+        const char *flag = env("ROCCO_HIP_LEAN_MAP");
+        const bool enabled = (flag != nullptr) ? std::atoi(flag) != 0 : true;
+        const DevProblem &p = probs[problem];
+        return enabled && solver_->lean != 0 && p.costs == nullptr && p.emap == nullptr && p.n >= 2 &&
+               (force_lean_map_ || (lean_ready_ && p.compacted && p.lean_orig != nullptr));
+    }
+
+    int lean_map_check()
+    {
+        if (lean_map_error_ != nullptr && *lean_map_error_ != 0u) {
+            solver_->lean_look_dirty = 1;
+            set_last_error("lean map: a tile waited for its predecessor beyond the spin limit");
+            return ROCCO_HIP_EHIP;
+        }
+        return ROCCO_HIP_OK;
+    }
+
+    int lean_map_enqueue(const std::vector<MapRequest *> &reqs)
+    {
+        if (reqs.empty()) {
+            return ROCCO_HIP_OK;
+        }
+        int rc;
+        if ((rc = lean_prepare()) != ROCCO_HIP_OK) return rc;
+        const size_t T = reqs.size();
+        std::vector<LeanTask> tasks(T);
+        std::vector<double> points(T);
+        std::vector<LeanMapCodeTask> codes(T);
+        int units = 0;
+        for (size_t i = 0; i < T; ++i) {
+            const MapRequest &r = *reqs[i];
+            const DevProblem &p = probs[r.problem];
+            LeanTask &t = tasks[i];
+            t.s = p.scores;
+            t.m = (long long)p.n;
+            t.c_raw = p.gamma;
+            t.magic = std::ldexp(1.5, 52 + p.qexp);
+            t.big = std::ldexp(1.0, 50 + p.qexp);
+            t.n_tiles = (int)((p.n + kLeanTile - 1) / kLeanTile);
+            t.n_points = 1;
+            t.n_groups = 1;
+            t.unit_begin = units;
+            t.point_begin = (int)i;
+            t.rec_begin = units;
+            t.bits_begin = 0;
+            t.off_begin = 0;
+            t.result_begin = (int)i;
+            t.tile_stride = 1;
+            t.independent = 0;
+            t.store = 0;
+            t.emap = nullptr;
+            t.wcap = nullptr;
+            t.clean_chunks = nullptr;
+            t.cmax = t.sabs = 0.0;
+            t.qexp = p.qexp;
+            t.batch = 1;
+            points[i] = r.lambda_ref;
+            units += t.n_tiles;
+        }
+        const size_t b_tasks = align_up(T * sizeof(LeanTask), 256);
+        const size_t b_points = align_up(T * sizeof(double), 256);
+        const size_t b_codes = align_up(T * sizeof(LeanMapCodeTask), 256);
+        const size_t up_bytes = b_tasks + b_points + b_codes;
+        const size_t b_results = align_up(T * sizeof(LeanResult), 256);
+        const size_t b_gc = align_up((size_t)units * kLeanThreads * sizeof(double), 256);
+        const size_t b_gb = align_up((size_t)units * sizeof(double), 256);
+        if ((rc = solver_->dev_map.reserve(up_bytes + b_results + b_gc + b_gb + 256)) != ROCCO_HIP_OK) return rc;
+        if ((rc = solver_->host_map_stage.reserve(up_bytes + 256)) != ROCCO_HIP_OK) return rc;
+        char *dv = (char *)solver_->dev_map.ptr;
+        char *h = (char *)solver_->host_map_stage.ptr;
+        double *gain_chunk = (double *)(dv + up_bytes + b_results);
+        double *gain_block = (double *)(dv + up_bytes + b_results + b_gc);
+        for (size_t i = 0; i < T; ++i) {
+            LeanMapCodeTask &c = codes[i];
+            c.gain_chunk = gain_chunk + (size_t)tasks[i].rec_begin * kLeanThreads;
+            c.gain_block = gain_block + tasks[i].rec_begin;
+            c.emap = map_ptrs_[reqs[i]->problem];
+            c.m = tasks[i].m;
+            c.margin = reqs[i]->margin;
+            c.n_tiles = tasks[i].n_tiles;
+            c.block_begin = tasks[i].unit_begin;
+        }
+        std::memcpy(h, tasks.data(), T * sizeof(LeanTask));
+        std::memcpy(h + b_tasks, points.data(), T * sizeof(double));
+        std::memcpy(h + b_tasks + b_points, codes.data(), T * sizeof(LeanMapCodeTask));
+        unsigned *error_host = (unsigned *)(h + up_bytes);
+        *error_host = 0u;
+        lean_map_error_ = error_host;
+        ROCCO_HIP_TRY(hipMemcpyAsync(dv, h, up_bytes, hipMemcpyHostToDevice, stream_));
+        // round scratch as the lean rounds keep it (lean_enqueue)
+        const size_t b_look = align_up(256 + (size_t)units * 4 * sizeof(unsigned long long), 256);
+        {
+            const void *old_ptr = solver_->dev_lean_look.ptr;
+            const size_t old_bytes = solver_->dev_lean_look.bytes;
+            if ((rc = solver_->dev_lean_look.reserve(b_look)) != ROCCO_HIP_OK) return rc;
+            if (solver_->lean_look_dirty != 0 || solver_->dev_lean_look.ptr != old_ptr || solver_->dev_lean_look.bytes != old_bytes) {
+                ROCCO_HIP_TRY(hipMemsetAsync(solver_->dev_lean_look.ptr, 0xFF, solver_->dev_lean_look.bytes, stream_));
+                ROCCO_HIP_TRY(hipMemsetAsync((char *)solver_->dev_lean_look.ptr + 128, 0, 4, stream_));
+                solver_->lean_look_dirty = 0;
+            }
+        }
+        if ((rc = solver_->dev_lean_round.reserve(align_up((size_t)units * sizeof(LeanTileRec), 256) + 256)) != ROCCO_HIP_OK) return rc;
+        char *look = (char *)solver_->dev_lean_look.ptr;
+        LeanLaunch L;
+        L.tasks = (const LeanTask *)dv;
+        L.n_tasks = (int)T;
+        L.n_units = units;
+        L.points = (const double *)(dv + b_tasks);
+        L.ticket = (unsigned *)look;
+        L.look = (unsigned long long *)(look + 256);
+        L.recs = (LeanTileRec *)solver_->dev_lean_round.ptr;
+        L.bits = (unsigned *)solver_->dev_lean_pool.ptr;
+        L.tile_off = (unsigned *)solver_->dev_lean_pool.ptr;
+        L.results = (LeanResult *)(dv + up_bytes);
+        L.error = (unsigned *)(look + 128);
+        L.error_out = error_host;
+        L.self_reset = 1;
+        L.pad = 0;
+        L.ctl = nullptr;
+        LeanMapOut out;
+        out.gain_chunk = gain_chunk;
+        out.gain_block = gain_block;
+        solver_->lean_look_dirty = 1;
+        if ((rc = launch_lean_map(L, out, stream_)) != ROCCO_HIP_OK) return rc;
+        if ((rc = launch_lean_finish(L, (int)T, stream_)) != ROCCO_HIP_OK) return rc;
+        solver_->lean_look_dirty = 0;
+        if ((rc = launch_lean_mapcode((const LeanMapCodeTask *)(dv + b_tasks + b_points), (int)T, units, stream_)) != ROCCO_HIP_OK) return rc;
+        lean_maps_built += (long long)T;
+        if (env("ROCCO_HIP_DEBUG") != nullptr) {
+            std::fprintf(stderr, "[lean map] %zu problems, %d tiles\n", T, units);
         }
         return ROCCO_HIP_OK;
     }
@@ -766,7 +928,7 @@ public:
     // rounding-model probes of a compacted problem with a map in place go through lean_model_kernel
     bool model_eligible(size_t problem) const
     {
-        const char *flag = std::getenv("ROCCO_HIP_LEAN_MODEL");  // (read per call: tests switch it within one process)
+        const char *flag = env("ROCCO_HIP_LEAN_MODEL");  // (read per call: tests switch it within one process)
         const bool enabled = flag == nullptr || std::atoi(flag) != 0;
         const DevProblem &p = probs[problem];
         return enabled && !force_full_ && solver_->lean != 0 && lean_ready_ && ((p.compacted && p.lean_orig != nullptr) || model_any_) &&
@@ -784,7 +946,7 @@ public:
         if (!model_eligible(problem)) {
             return 0;
         }
-        if (const char *e = std::getenv("ROCCO_HIP_MODEL_DEPTH")) {
+        if (const char *e = env("ROCCO_HIP_MODEL_DEPTH")) {
             return std::max(1, std::min(6, std::atoi(e)));
         }
         // (the problems still asking: those of the last rounding-model round; before the first one, every compacted problem)
@@ -837,7 +999,7 @@ public:
         }
         // a round on a small level costs its launch latency whatever it evaluates (one tile and 8 penalties per
         // workgroup: up to 256 of them run at once), a pass over a long one its evaluations
-        const long long small = std::getenv("ROCCO_HIP_POINTS_SMALL") ? std::atoll(std::getenv("ROCCO_HIP_POINTS_SMALL")) : 256000;
+        const long long small = env("ROCCO_HIP_POINTS_SMALL") ? std::atoll(env("ROCCO_HIP_POINTS_SMALL")) : 256000;
         int pts = (m > 8000000) ? 3 : ((m > 2000000) ? 4 : ((m > 4 * small) ? 8 : ((m > 2 * small) ? 16 : ((m > small) ? 32 : 64))));
         if (!deep) {
             pts = std::min(pts, 8);
@@ -1032,7 +1194,7 @@ public:
                         }
                     }
                 }
-                if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                if (env("ROCCO_HIP_DEBUG") != nullptr) {
                     std::fprintf(stderr, "[model chain] ended: %d rounds asked something, %d problems stopped at an open outcome\n",
                                  rep->rounds_run, rep->stopped);
                 }
@@ -1078,7 +1240,7 @@ public:
     // every request of the round is a rounding-model probe that says how the bisection goes on: run the rounds ahead
     bool model_chain_wanted(const std::vector<LeanReq> &reqs) const
     {
-        const char *flag = std::getenv("ROCCO_HIP_MODEL_CHAIN");
+        const char *flag = env("ROCCO_HIP_MODEL_CHAIN");
         if ((flag != nullptr && std::atoi(flag) == 0) || model_any_ || reqs.empty() || reqs.size() > (size_t)kModelChainMaxProblems) {
             return false;
         }
@@ -1232,8 +1394,8 @@ public:
         A.n_problems = (int)B;
         A.depth0 = depth0;
         A.depth_floor = depth_floor;
-        A.depth_fixed = std::getenv("ROCCO_HIP_MODEL_DEPTH") ? std::max(1, std::min(6, std::atoi(std::getenv("ROCCO_HIP_MODEL_DEPTH")))) : 0;
-        A.adapt_batch = (std::getenv("ROCCO_HIP_LEAN_BATCH") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_BATCH")) != 0) ? 1 : 0;
+        A.depth_fixed = env("ROCCO_HIP_MODEL_DEPTH") ? std::max(1, std::min(6, std::atoi(env("ROCCO_HIP_MODEL_DEPTH")))) : 0;
+        A.adapt_batch = (env("ROCCO_HIP_LEAN_BATCH") == nullptr || std::atoi(env("ROCCO_HIP_LEAN_BATCH")) != 0) ? 1 : 0;
         A.cap_pairs = (int)cap_pairs;
         A.tasks = (LeanTask *)dv;
         A.walk = (const ModelChainWalk *)(dv + b_tasks);
@@ -1309,7 +1471,7 @@ public:
             if ((rc = launch_lean_write_solutions(A.writes, A.n_writes, (int)std::max(1LL, std::min(256LL, tiles)), stream_)) != ROCCO_HIP_OK) return rc;
             // ... and, behind them, their scatter into the callers' buffers and their objective sums (for every problem of the
             // chain: what was not written is scattered and summed again when its window has run)
-            const char *pf = std::getenv("ROCCO_HIP_PREFETCH_OBJECTIVE");
+            const char *pf = env("ROCCO_HIP_PREFETCH_OBJECTIVE");
             if (pf == nullptr || std::atoi(pf) != 0) {
                 if ((rc = prefetch_objectives(model_chain_problems_)) != ROCCO_HIP_OK) return rc;
                 objective_behind_chain_ = true;
@@ -1323,7 +1485,7 @@ public:
         model_chain_ingested_ = 0;
         t_mchain_submit_ += now_us() - t0;
         mark("model chain: queued");
-        if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+        if (env("ROCCO_HIP_DEBUG") != nullptr) {
             std::fprintf(stderr, "[model chain] %zu problems, %lld tiles, %d rounds queued (depth %d, floor %d)\n", B, tiles, rounds, depth0,
                          depth_floor);
         }
@@ -1455,7 +1617,7 @@ public:
             if (r.pilot) {
                 // every stride-th tile of the caller's array, each as a chain of its own; nothing is kept
                 const long long all_tiles = (long long)((p.n + kLeanTile - 1) / kLeanTile);
-                const long long pilot_tiles = std::getenv("ROCCO_HIP_PILOT_TILES") ? std::max(2, std::atoi(std::getenv("ROCCO_HIP_PILOT_TILES"))) : 16;
+                const long long pilot_tiles = env("ROCCO_HIP_PILOT_TILES") ? std::max(2, std::atoi(env("ROCCO_HIP_PILOT_TILES"))) : 16;
                 const int stride = (int)std::max(4LL, all_tiles / pilot_tiles);  // about 16 tiles per chromosome
                 const int nt = (int)((all_tiles + stride - 1) / stride);
                 long long sampled = 0;
@@ -1623,7 +1785,7 @@ public:
         // Penalties per workgroup: a workgroup's time grows with what it carries (about 6 us + 4 us per penalty), a
         // round's with the number of waves of workgroups the device needs (512 at a time).  While the whole round fits
         // at once, carry less per workgroup.
-        const bool adapt = std::getenv("ROCCO_HIP_LEAN_BATCH") == nullptr || std::atoi(std::getenv("ROCCO_HIP_LEAN_BATCH")) != 0;
+        const bool adapt = env("ROCCO_HIP_LEAN_BATCH") == nullptr || std::atoi(env("ROCCO_HIP_LEAN_BATCH")) != 0;
         auto rebatch = [](std::vector<LeanTask> &ts, int full, int &total_units) {
             for (int b = 2; b < full; b *= 2) {
                 long long u = 0;
@@ -1690,7 +1852,7 @@ public:
         // error zero), so no fill is issued per round; it is initialised when it grows or after a failed round.  The
         // records are plain scratch.  Results and the error word are written straight into pinned host memory by the
         // finish kernel.
-        const char *fills = std::getenv("ROCCO_HIP_LEAN_FILLS");
+        const char *fills = env("ROCCO_HIP_LEAN_FILLS");
         const bool self_reset = fills == nullptr || std::atoi(fills) == 0;
         const size_t b_look = align_up(256 + (size_t)recs * 4 * sizeof(unsigned long long), 256);
         const size_t b_recs = align_up((size_t)recs * sizeof(LeanTileRec), 256);
@@ -1756,7 +1918,7 @@ public:
         }
         lean_result_count_ = results;
         lean_inflight_ = reqs;
-        if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+        if (env("ROCCO_HIP_DEBUG") != nullptr) {
             std::fprintf(stderr, "[lean round %d] %zu tasks (%zu rounding-model), %d + %d workgroups, %zu compactions before, %zu after\n",
                          lean_rounds, tasks.size(), model_tasks.size(), units, model_units, pre.size(), post.size());
         }
@@ -1767,6 +1929,10 @@ public:
     {
         if (lean_inflight_.empty()) {
             return ROCCO_HIP_OK;
+        }
+        {
+            const int rcm = lean_map_check();
+            if (rcm != ROCCO_HIP_OK) return rcm;
         }
         if (model_chain_inflight_) {
             return model_chain_consume();
@@ -1807,7 +1973,7 @@ public:
                 }
                 lean_model_points += (long long)r.lambdas.size();
                 lean_model_open += (long long)open;
-                if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                if (env("ROCCO_HIP_DEBUG") != nullptr) {
                     std::fprintf(stderr, "[lean model] problem %zu (n=%zu): %zu penalties, first %.17g -> count %lld, %zu not certified (reasons %lld)\n",
                                  r.problem, p.n, r.lambdas.size(), r.lambdas[0], res[r.result_begin].count, open, why);
                 }
@@ -1827,7 +1993,7 @@ public:
                     r.probe->results[i].count = res[r.result_begin + (int)i].count;
                 }
             }
-            if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+            if (env("ROCCO_HIP_DEBUG") != nullptr) {
                 std::fprintf(stderr, "[lean] problem %zu level %zu (m=%lld, base %.17g): %zu penalties, first %.17g -> count %lld, child %lld\n",
                              r.problem, ls.levels.size() - 1, lv.m, lv.base, np, r.lambdas[0], res[r.result_begin].count,
                              res[r.result_begin].child_len);
@@ -1841,7 +2007,7 @@ public:
                     r.comp->n_new = (size_t)cl;
                     r.comp->score_floor = r.sep;
                 }
-                if (!r.comp->done && std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                if (!r.comp->done && env("ROCCO_HIP_DEBUG") != nullptr) {
                     std::fprintf(stderr, "[lean] problem %zu: final compaction declined (child %lld of %zu)\n", r.problem, cl, p.n);
                 }
             }
@@ -1939,7 +2105,7 @@ public:
                 req.done = true;
                 req.n_new = (size_t)lv.m;
                 req.score_floor = lv.sep;
-                if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                if (env("ROCCO_HIP_DEBUG") != nullptr) {
                     std::fprintf(stderr, "[lean] problem %zu: level %zu (m=%lld, base %.17g) adopted for penalties >= %.17g\n",
                                  req.problem, k, lv.m, lv.base, req.lambda_base);
                 }
@@ -2072,7 +2238,7 @@ public:
             // windows that each write the solution of one penalty and nothing else: the calibration's last round when every
             // step was decided -- their objectives ride behind them
             std::vector<size_t> final_problems;
-            const char *pf = std::getenv("ROCCO_HIP_PREFETCH_OBJECTIVE");
+            const char *pf = env("ROCCO_HIP_PREFETCH_OBJECTIVE");
             const size_t open_windows = windows.size() - answered_problems.size();
             if ((pf == nullptr || std::atoi(pf) != 0) && open_windows > 0 && tasks.size() == open_windows && lean_inflight_.empty()) {
                 for (size_t i = 0; i < windows.size(); ++i) {
@@ -2430,7 +2596,7 @@ public:
         }
         stats_out.assign(hstats, hstats + 5 * B);
         pre.assign(B, Presearch());
-        const bool debug = std::getenv("ROCCO_HIP_DEBUG") != nullptr;
+        const bool debug = env("ROCCO_HIP_DEBUG") != nullptr;
         const bool chain_debug = std::getenv("ROCCO_HIP_CHAIN_DEBUG") != nullptr;
         bool grid_ok = true;
         for (size_t b = 0; b < B; ++b) {
@@ -2609,7 +2775,7 @@ private:
             if (rt[t].survey) {
                 ft.frz_out = p.frz;
             }
-            if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+            if (env("ROCCO_HIP_DEBUG") != nullptr) {
                 const char *kind = rt[t].record ? "spine" : (rt[t].survey ? "survey" : (rt[t].window ? "window" : (rt[t].map ? "map" : "probe")));
                 std::fprintf(stderr, "[round %d] %s problem %zu: %zu lambdas (first %.17g, margin %.3g), %zu / %d blocks%s\n",
                              rounds, kind, rt[t].problem, rt[t].lambdas.size(), rt[t].lambdas[0], rt[t].margin,
@@ -2824,7 +2990,7 @@ private:
             for (size_t t = 0; t < T; ++t) {
                 only_maps = only_maps && rt[t].map;
             }
-            const char *defer = std::getenv("ROCCO_HIP_DEFER_MAPS");
+            const char *defer = env("ROCCO_HIP_DEFER_MAPS");
             if (may_defer && only_maps && (defer == nullptr || std::atoi(defer) != 0)) {
                 // nothing of a map round is read on the host (adopt_maps only takes the pointers over)
                 t_launch_ += now_us() - tt1;
@@ -2875,7 +3041,7 @@ private:
             for (int k = 0; k < tasks[t].slot_count; ++k) {
                 if (hr[tasks[t].slot_begin + k].overflow) {
                     // a lane was still stepping when it reached a block that was not evaluated
-                    if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                    if (env("ROCCO_HIP_DEBUG") != nullptr) {
                         std::fprintf(stderr, "[spine] problem %zu: repeated in full\n", rt[t].problem);
                     }
                     no_frozen_ = true;
@@ -2914,7 +3080,7 @@ private:
                     }
                 }
                 p.active_blocks.swap(active);
-                if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                if (env("ROCCO_HIP_DEBUG") != nullptr) {
                     std::fprintf(stderr, "[survey] problem %zu: bracket [%.17g, %.17g] width %.3g active %zu / %d blocks\n",
                                  rt[t].problem, rt[t].lambdas[0], rt[t].lambdas[1],
                                  rt[t].lambdas[1] - rt[t].lambdas[0], p.active_blocks.size(), nb);
@@ -2940,7 +3106,7 @@ private:
                     rt[t].spine->stepped[k] = hr[ft.slot_begin + k].uncertain;
                 }
                 rt[t].spine->selected = (ft.sel_depth > 0) ? hr[ft.slot_begin].e_global : -1;
-                if (std::getenv("ROCCO_HIP_DEBUG") != nullptr) {
+                if (env("ROCCO_HIP_DEBUG") != nullptr) {
                     std::fprintf(stderr, "[spine] problem %zu: lane 0 stepped %lld chunks of %lld\n", rt[t].problem,
                                  (long long)hr[ft.slot_begin].uncertain, (long long)((p.n + kChunk - 1) / kChunk));
                     std::fprintf(stderr, "[spine] prof (100 MHz ticks): fetch %lld loop %lld (steps %lld) slow groups %lld\n",
@@ -3122,6 +3288,36 @@ int delta_build_map(rocco_hip_solver *solver, const double *scores_dev, const do
     ROCCO_HIP_TRY(hipMemcpyAsync(emap_dev, ev.probs[0].emap, (n + kChunk - 1) / kChunk, hipMemcpyDeviceToDevice, stream));
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));
     return ROCCO_HIP_OK;
+}
+
+int delta_build_map_lean(rocco_hip_solver *solver, const double *scores_dev, double gamma, size_t n, double lambda_ref,
+                         double margin, uint8_t *emap_dev, hipStream_t stream)
+{
+    HipEvaluator ev(solver, stream);
+    DevProblem d;
+    d.scores = scores_dev;
+    d.costs = nullptr;
+    d.gamma = gamma;
+    d.n = n;
+    ev.probs.push_back(d);
+    std::vector<ChainProblem> problems(1);
+    problems[0].n = n;
+    problems[0].gamma = gamma;
+    int rc;
+    if ((rc = prepare(ev, problems, nullptr)) != ROCCO_HIP_OK) return rc;
+    ev.force_lean_map_ = true;
+    if (!ev.lean_map_takes(0)) {
+        set_last_error("lean map: not available for this array (lean evaluation off, or fewer than two loci)");
+        return ROCCO_HIP_EINVAL;
+    }
+    std::vector<MapRequest> reqs(1);
+    reqs[0].problem = 0;
+    reqs[0].lambda_ref = lambda_ref;
+    reqs[0].margin = margin;
+    if ((rc = ev.build_map(reqs)) != ROCCO_HIP_OK) return rc;
+    ROCCO_HIP_TRY(hipMemcpyAsync(emap_dev, ev.probs[0].emap, (n + kChunk - 1) / kChunk, hipMemcpyDeviceToDevice, stream));
+    ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+    return ev.lean_map_check();
 }
 
 int delta_spine(rocco_hip_solver *solver, const double *scores_dev, const double *switch_costs_dev,

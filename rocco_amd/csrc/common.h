@@ -81,6 +81,8 @@ struct rocco_hip_solver {
     rocco::DeviceBuffer dev_lean_wcap;   // per problem: tolerance cap of the rounding-model evaluation
     rocco::DeviceBuffer dev_chain;       // state, descriptors and results of the device-sequenced threshold search (chain.hip)
     rocco::PinnedBuffer host_chain;      // ... its inputs going up and its report coming back
+    rocco::DeviceBuffer dev_map;         // binade maps built by the lean kernels: descriptors, gains
+    rocco::PinnedBuffer host_map_stage;  // ... their descriptors going up, their error word coming back
     rocco::DeviceBuffer dev_objective;   // ... their descriptors, partial sums and sums on the device
     rocco::PinnedBuffer host_objective;  // objective sums fetched behind the final windows: descriptors up, sums back
     rocco::PinnedBuffer host_follow;     // host-coherent: what the chained rounding-model rounds publish round by round (model_chain.h)

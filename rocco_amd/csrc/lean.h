@@ -133,6 +133,29 @@ struct LeanWriteTask {
 // tasks_dev[0 .. *n_tasks_dev): fixed grid, the workgroups take the tiles of every task in turn
 int launch_lean_write_solutions(const LeanWriteTask *tasks_dev, const int *n_tasks_dev, int grid, hipStream_t stream);
 
+// ---- the binade map of a level by lean kernels -------------------------------------------------
+// What chain_fast.hip's map round computes (K1 ... K6: the running stay-off value p0 at both ends of every chunk of 32
+// loci at one penalty, in exact arithmetic on the grid q, and its binade code) with the lean evaluation's tile kernel: the
+// same per-locus operations in the same order and the same reduction trees, so the same codes bit for bit
+// (tests/test_gpu_lean_map.py compares the bytes).  Tasks are LeanTasks with one penalty each (any double);
+// lean_map_kernel leaves per-chunk and per-tile gains, lean_finish_kernel restores the round scratch, lean_mapcode_kernel
+// writes the codes.
+struct LeanMapOut {
+    double *gain_chunk;  // [(task.rec_begin + tile) * 256 + lane]
+    double *gain_block;  // [task.rec_begin + tile]
+};
+struct LeanMapCodeTask {
+    const double *gain_chunk;  // the task's own [tile * 256 + lane]
+    const double *gain_block;  // ... [tile]
+    uint8_t *emap;
+    long long m;
+    double margin;
+    int n_tiles;
+    int block_begin;
+};
+int launch_lean_map(const LeanLaunch &L, const LeanMapOut &out, hipStream_t stream);
+int launch_lean_mapcode(const LeanMapCodeTask *tasks_dev, int n_tasks, int n_blocks, hipStream_t stream);
+
 int launch_lean_eval(const LeanLaunch &L, hipStream_t stream);
 // the launches of a chained round (L.ctl != nullptr): fixed grids, sizes read on the device
 int launch_lean_eval_chain(const LeanLaunch &L, int grid, hipStream_t stream);

@@ -1083,6 +1083,226 @@ __global__ __launch_bounds__(kLeanThreads) void lean_compact_chain_kernel(const 
     }
 }
 
+// ---- binade map by lean kernels (lean.h) ---------------------------------------------------------------------------
+// One tile, one penalty: a = rn_q(s - lambda) on raw scores (chain_fast.hip: lean_apply_steps<false, ...>, step_a of an
+// unmapped chunk), the chunk functions composed and handed from tile to tile exactly as eval_body does, then the
+// recursion from the true incoming delta with the gain of chain_fast.hip's K3: sum over the chunk's loci j (0 < j < m) of
+// max(0, delta_{j-1} - c).  Loci past the array's end take no step (K3's edge loop skips them).
+__device__ __forceinline__ void map_body(const LeanLaunch &L, const LeanTask &task, int tile, double *lds, Scratch *sc,
+                                         const LeanMapOut &out)
+{
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const long long base = (long long)tile * kLeanTile;
+    const double magic = task.magic;
+    const double c = (task.c_raw + magic) - magic;
+    const double big = task.big;
+    const double lam = L.points[task.point_begin];
+    const long long j0 = base + (long long)t * kLeanChunk;
+    const int valid = (int)max(0LL, min((long long)kLeanChunk, task.m - j0));
+    const double *row = lds + t * kStride;
+
+    // chunk function (identity for a lane past the array)
+    Fn f;
+    f.a = 0.0;
+    f.lo = -big;
+    f.hi = big;
+    for (int i = 0; i < valid; ++i) {
+        const double cc = (j0 + i == 0) ? big : c;
+        const double a = ((row[i] - lam) + magic) - magic;
+        f.a += a;
+        f.lo = fmin(fmax(f.lo, -cc), cc) + a;
+        f.hi = fmin(fmax(f.hi, -cc), cc) + a;
+    }
+    Fn inc = f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Fn prev = shfl_up_fn(inc, off);
+        if (lane >= off) {
+            inc = compose(prev, inc);
+        }
+    }
+    if (lane == 63) {
+        sc->wave_fn[wave][0][0] = inc.a;
+        sc->wave_fn[wave][0][1] = inc.lo;
+        sc->wave_fn[wave][0][2] = inc.hi;
+    }
+    __syncthreads();
+    if (t == 0) {
+        Fn agg;
+        agg.a = sc->wave_fn[0][0][0];
+        agg.lo = sc->wave_fn[0][0][1];
+        agg.hi = sc->wave_fn[0][0][2];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            Fn g;
+            g.a = sc->wave_fn[w][0][0];
+            g.lo = sc->wave_fn[w][0][1];
+            g.hi = sc->wave_fn[w][0][2];
+            agg = compose(agg, g);
+        }
+        const long long rec = (long long)task.rec_begin + tile;
+        unsigned long long *mine = L.look + rec * 4;
+        const bool more = (tile + 1 < task.n_tiles);
+        if (more) {
+            granule_store(mine + 0, agg.lo);
+            granule_store(mine + 1, agg.hi);
+            if (agg.lo == agg.hi) {
+                granule_store(mine + 3, agg.lo);
+            }
+        }
+        double din = 0.0;
+        if (tile > 0) {
+            const unsigned long long *prev = L.look + (rec - 1) * 4;
+            const double plo = granule_wait(prev + 0, L.error);
+            const double phi = granule_wait(prev + 1, L.error);
+            din = (plo == phi) ? plo : granule_wait(prev + 3, L.error);
+        }
+        sc->tile_in[0] = din;
+        if (more && agg.lo != agg.hi) {
+            granule_store(mine + 3, clampd(din + agg.a, agg.lo, agg.hi));
+        }
+        // what the finish kernel reads of this tile (it only restores the round scratch here: nothing is counted)
+        LeanTileRec r;
+        r.base = 0u;
+        r.tail = 0u;
+        r.cells = 0u;
+        r.flags = 1u;
+        L.recs[rec] = r;
+    }
+    __syncthreads();
+    // true incoming delta of this lane: wavefronts before mine, then the lanes before mine
+    Fn e = shfl_up_fn(inc, 1);
+    if (lane == 0) {
+        e.a = 0.0;
+        e.lo = -big;
+        e.hi = big;
+    }
+    double v = sc->tile_in[0];
+    for (int w = 0; w < wave; ++w) {
+        v = clampd(v + sc->wave_fn[w][0][0], sc->wave_fn[w][0][1], sc->wave_fn[w][0][2]);
+    }
+    double d = clampd(v + e.a, e.lo, e.hi);
+    double g = 0.0;
+    for (int i = 0; i < valid; ++i) {
+        const double a = ((row[i] - lam) + magic) - magic;
+        if (j0 + i > 0) {
+            g += fmax(0.0, d - c);
+            d = fmin(fmax(d, -c), c) + a;
+        } else {
+            d = a;
+        }
+    }
+    const long long rec = (long long)task.rec_begin + tile;
+    out.gain_chunk[rec * kLeanThreads + t] = g;
+    // the tile's gain: chain_fast.hip's reduction order (K3: shfl_down tree per wavefront, then ((w0 + w1) + w2) + w3)
+    double gs = g;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        gs += __shfl_down(gs, off);
+    }
+    __syncthreads();  // (wave_fn is read above by every lane)
+    if (lane == 0) {
+        sc->wave_fn[wave][1][0] = gs;
+    }
+    __syncthreads();
+    if (t == 0) {
+        out.gain_block[rec] = ((sc->wave_fn[0][1][0] + sc->wave_fn[1][1][0]) + sc->wave_fn[2][1][0]) + sc->wave_fn[3][1][0];
+    }
+}
+
+__global__ __launch_bounds__(kLeanThreads, 2) void lean_map_kernel(LeanLaunch L, LeanMapOut out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *lds = smem;
+    Scratch *sc = reinterpret_cast<Scratch *>(smem + kTileLds);
+    const int t = threadIdx.x;
+    if (t == 0) {
+        sc->ticket = (int)(atomicAdd(L.ticket, 1u) + 1u);
+    }
+    __syncthreads();
+    const int ticket = sc->ticket;
+    if (ticket >= L.n_units) {
+        return;
+    }
+    const int ti = find_task(L.n_tasks, ticket, [&](int i) { return L.tasks[i].unit_begin; });
+    const LeanTask task = L.tasks[ti];
+    const int tile = ticket - task.unit_begin;
+    stage_tile<true>(task.s, task.m, (long long)tile * kLeanTile, task.magic, lds);
+    map_body(L, task, tile, lds, sc, out);
+}
+
+// chain_fast.hip: binade_code (K6) -- the code of a chunk from the stay-off value at its two ends
+__device__ __forceinline__ uint8_t lean_binade_code(double p0_lo, double p0_hi, double margin)
+{
+    const double top = fmax(p0_hi, 1.0);
+    int e = ilogb(top);
+    if (e > 60) {
+        e = 60;
+    }
+    bool clean = false;
+    if (p0_lo > 0.0) {
+        const double lo_edge = ldexp(1.0, e), hi_edge = ldexp(1.0, e + 1);
+        clean = (p0_lo - lo_edge > margin) && (hi_edge - p0_hi > margin);
+    }
+    return (uint8_t)((clean ? 0 : 0x80) | (e + kModelMapBias));
+}
+
+// One workgroup per tile: the gain before the tile in chain_fast.hip's K4 order (tiles in groups of 64: inclusive scan by
+// shuffles, running carry), then K6: the chunks' inclusive scan inside the tile, the codes.
+__global__ __launch_bounds__(kLeanThreads) void lean_mapcode_kernel(const LeanMapCodeTask *__restrict__ tasks, int n_tasks)
+{
+    __shared__ double wsum[4];
+    __shared__ double pre_s;
+    const int ti = find_task(n_tasks, (int)blockIdx.x, [&](int i) { return tasks[i].block_begin; });
+    const LeanMapCodeTask task = tasks[ti];
+    const int tile = (int)blockIdx.x - task.block_begin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        double carry = 0.0;
+        for (int base = 0; base <= tile; base += 64) {
+            const int b = base + lane;
+            const double g = (b < task.n_tiles) ? task.gain_block[b] : 0.0;
+            double inc = g;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double p = __shfl_up(inc, off);
+                if (lane >= off) {
+                    inc += p;
+                }
+            }
+            if (b == tile) {
+                pre_s = carry + (inc - g);
+            }
+            carry += __shfl(inc, 63);
+        }
+    }
+    const long long chunk = (long long)tile * kLeanThreads + threadIdx.x;
+    const bool valid = chunk * kLeanChunk < task.m;
+    const double g = valid ? task.gain_chunk[chunk] : 0.0;
+    double inc = g;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double p = __shfl_up(inc, off);
+        if (lane >= off) {
+            inc += p;
+        }
+    }
+    if (lane == 63) {
+        wsum[wave] = inc;
+    }
+    __syncthreads();
+    double pre = pre_s;
+    for (int w = 0; w < wave; ++w) {
+        pre += wsum[w];
+    }
+    const double p0_end = pre + inc;
+    const double p0_start = p0_end - g;
+    if (valid) {
+        task.emap[chunk] = lean_binade_code(p0_start, p0_end, task.margin);
+    }
+}
+
 // The 0/1 solution of a level from the words a store == 2 evaluation left: lane word -> 32 bytes (bit 31 = the lane's
 // first locus).  One workgroup per tile.
 __global__ __launch_bounds__(kLeanThreads) void lean_write_solutions_kernel(const LeanWriteTask *__restrict__ tasks,
@@ -1494,6 +1714,33 @@ int launch_lean_model_chain(const LeanLaunch &L, int grid, hipStream_t stream)
         configured = true;
     }
     hipLaunchKernelGGL(lean_model_chain_kernel, dim3((unsigned)grid), dim3(kLeanThreads), lds, stream, L);
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_map(const LeanLaunch &L, const LeanMapOut &out, hipStream_t stream)
+{
+    if (L.n_units <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    static bool configured = false;
+    const size_t lds = (size_t)kTileLds * sizeof(double) + sizeof(Scratch);
+    if (!configured) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lean_map_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(lean_map_kernel, dim3((unsigned)L.n_units), dim3(kLeanThreads), lds, stream, L, out);
+    ROCCO_HIP_TRY(hipGetLastError());
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_mapcode(const LeanMapCodeTask *tasks_dev, int n_tasks, int n_blocks, hipStream_t stream)
+{
+    if (n_tasks <= 0 || n_blocks <= 0) {
+        return ROCCO_HIP_OK;
+    }
+    hipLaunchKernelGGL(lean_mapcode_kernel, dim3((unsigned)n_blocks), dim3(kLeanThreads), 0, stream, tasks_dev, n_tasks);
+    ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }
 

@@ -114,6 +114,12 @@ struct State {
         int le, gt;  // next node after "count <= target" / "count > target" (-1: the round ends there)
     };
     std::vector<TreeNode> nodes;
+    struct TreeItem {
+        double lo, hi;
+        int open, steps, parent;
+        bool gt;
+    };
+    std::vector<TreeItem> queue;  // build_open_tree's work list
 };
 
 // Outcome of the reference at `lambda` known without device work: analytic, or outside the certified
@@ -137,16 +143,13 @@ bool known_count(const ChainProblem &p, const State &s, double lambda, long long
 // The reference's next bisection steps as a tree: a step whose outcome is known (analytically or from the certified
 // thresholds) costs nothing and has one successor; an open one is evaluated and has two.  `open_depth` open steps per
 // path at most, `max_steps` steps in all (the iterations the reference has left).
-void build_open_tree(const ChainProblem &p, const State &s, int open_depth, int max_steps, std::vector<State::TreeNode> &nodes,
+void build_open_tree(const ChainProblem &p, State &s, int open_depth, int max_steps, std::vector<State::TreeNode> &nodes,
                      std::vector<double> &lambdas)
 {
-    struct Item {
-        double lo, hi;
-        int open, steps, parent;
-        bool gt;
-    };
+    using Item = State::TreeItem;
     nodes.clear();
-    std::vector<Item> queue;
+    std::vector<Item> &queue = s.queue;  // (kept between rounds: no allocation on the way)
+    queue.clear();
     queue.push_back({s.lower, s.upper, 0, 0, -1, false});
     for (size_t at = 0; at < queue.size() && nodes.size() < 8192; ++at) {
         const Item it = queue[at];
@@ -392,6 +395,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
         }
     };
     const bool timing = std::getenv("ROCCO_SEARCH_TIMING") != nullptr;
+    const bool search_debug = std::getenv("ROCCO_SEARCH_DEBUG") != nullptr;
     const double tick0 = Tick::now();
     int tick_iter = 0;
     std::vector<ChainProblem> problems(problems_in);
@@ -408,6 +412,8 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
         s.phase = (s.target == (long long)p.n) ? State::kAll : State::kLowerBracket;
         s.out.zone_iters = -1;
         s.lower_count = (long long)p.n;
+        s.nodes.reserve(160);  // (here, while the device still works on what was queued before: not between two rounds)
+        s.queue.reserve(320);
         if (opt.use_bounds && !s.use_exact && s.phase != State::kAll && bound_epsilon(p, p.score_min - 1.0, &s.eps)) {
             // penalties outside [s_min - 1, s_max + 1] are decided analytically: the search starts there
             s.searching = true;
@@ -447,7 +453,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 s.search_rounds = ps.rounds;
                 s.out.passes += ps.rounds;
                 s.open_before = (s.G_real && s.L_real) ? (s.cG - s.cL) : (long long)p.n;
-                if (std::getenv("ROCCO_SEARCH_DEBUG") != nullptr) {
+                if (search_debug) {
                     std::fprintf(stderr, "[search] problem %zu presearch (%zu counts, %d rounds%s): G %.17g (%lld) L %.17g (%lld) width %.3g eps %.3g\n",
                                  b, ps.evals.size(), ps.rounds, ps.done ? ", ended" : "", s.G, s.cG, s.L, s.cL, s.L - s.G, s.eps);
                 }
@@ -462,18 +468,40 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
     }
 
     if (timing) std::fprintf(stderr, "[search timing] setup %.1f us\n", Tick::now() - tick0);
+    // (the request lists live across the iterations: their storage is taken once, here, not between two rounds)
+    std::vector<ProbeRequest> probes;
+    std::vector<WindowRequest> windows;
+    std::vector<ExactRequest> exacts;
+    std::vector<MapRequest> maps;
+    std::vector<SpineRequest> spines;
+    std::vector<size_t> probe_owner, window_owner, exact_owner, map_owner, spine_owner, compact_owner;
+    std::vector<WindowRequest> surveys;
+    std::vector<CompactRequest> compacts;
+    std::vector<size_t> first_maps;  // positions in `maps` of maps asked for right after a threshold search
+    std::vector<size_t> final_windows;  // positions in `windows` of windows that only certify and write a decided penalty
+    probes.reserve(B);
+    windows.reserve(B);
+    maps.reserve(B);
+    probe_owner.reserve(B);
+    window_owner.reserve(B);
+    map_owner.reserve(B);
     for (;;) {
         const double tick_a = Tick::now();
-        std::vector<ProbeRequest> probes;
-        std::vector<WindowRequest> windows;
-        std::vector<ExactRequest> exacts;
-        std::vector<MapRequest> maps;
-        std::vector<SpineRequest> spines;
-        std::vector<size_t> probe_owner, window_owner, exact_owner, map_owner, spine_owner, compact_owner;
-        std::vector<WindowRequest> surveys;
-        std::vector<CompactRequest> compacts;
-        std::vector<size_t> first_maps;  // positions in `maps` of maps asked for right after a threshold search
-        std::vector<size_t> final_windows;  // positions in `windows` of windows that only certify and write a decided penalty
+        probes.clear();
+        windows.clear();
+        exacts.clear();
+        maps.clear();
+        spines.clear();
+        probe_owner.clear();
+        window_owner.clear();
+        exact_owner.clear();
+        map_owner.clear();
+        spine_owner.clear();
+        compact_owner.clear();
+        surveys.clear();
+        compacts.clear();
+        first_maps.clear();
+        final_windows.clear();
 
         // speculation depth of this iteration's probe rounds, from the loci they will cover
         double round_loci = 0.0;
@@ -519,6 +547,10 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                        ? opt.spec_depth + 3
                        : ((round_loci < opt.small_round_loci) ? opt.spec_depth + 1 : opt.spec_depth));
 
+        const double tick_w = Tick::now();
+        double tick_tree = 0.0;
+        long long tick_nodes = 0;
+        if (timing) std::fprintf(stderr, "[search timing]   depth rule %.1f us\n", tick_w - tick_a);
         for (size_t b = 0; b < B; ++b) {
             const ChainProblem &p = problems[b];
             State &s = st[b];
@@ -543,7 +575,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 }
                 if (!r.lambdas.empty()) {
                     s.pilot_round = true;
-                    probes.push_back(r);
+                    probes.push_back(std::move(r));
                     probe_owner.push_back(b);
                     continue;
                 }
@@ -613,7 +645,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 }
                 if (!r.lambdas.empty()) {
                     s.bound_round = true;
-                    probes.push_back(r);
+                    probes.push_back(std::move(r));
                     probe_owner.push_back(b);
                     continue;
                 }
@@ -788,7 +820,10 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                 } else {
                     ProbeRequest r;
                     r.problem = b;
+                    const double tick_t = Tick::now();
                     build_open_tree(p, s, s.tree_depth, s.iters_left, s.nodes, r.lambdas);
+                    tick_tree += Tick::now() - tick_t;
+                    tick_nodes += (long long)s.nodes.size();
                     if (all_compacted && s.has_map && !s.point_pending) {
                         BisectionAhead &a = r.ahead;
                         a.valid = true;
@@ -811,7 +846,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                         a.open_depth = spec_depth;
                         a.depth_floor = deep_floor;
                     }
-                    probes.push_back(r);
+                    probes.push_back(std::move(r));
                     probe_owner.push_back(b);
                 }
                 break;
@@ -888,6 +923,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
         }
         int rc;
         const double tick_b = Tick::now();
+        if (timing) std::fprintf(stderr, "[search timing]   trees %.1f us, %lld nodes\n", tick_tree, tick_nodes);
         if ((rc = ev.round_all(compacts, maps, surveys, probes, windows, spines)) != ROCCO_HIP_OK) {
             return rc;
         }
@@ -980,7 +1016,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                     s.pilot_left = 0;
                     s.pilot_hint = true;
                 }
-                if (std::getenv("ROCCO_SEARCH_DEBUG") != nullptr) {
+                if (search_debug) {
                     std::fprintf(stderr, "[pilot] problem %zu: crossing estimated in (%.17g, %.17g)\n", probe_owner[q], s.pg, s.pl);
                 }
                 continue;
@@ -1003,7 +1039,7 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
                         s.L_real = true;
                     }
                 }
-                if (std::getenv("ROCCO_SEARCH_DEBUG") != nullptr) {
+                if (search_debug) {
                     std::fprintf(stderr, "[search] problem %zu round %d: G %.17g (%lld) L %.17g (%lld) width %.3g eps %.3g\n",
                                  probe_owner[q], s.search_rounds, s.G, s.cG, s.L, s.cL, s.L - s.G, s.eps);
                 }

@@ -28,6 +28,19 @@ def delta_build_map_device(scores_t, switch_costs, lambda_ref: float, margin: fl
     return emap_t
 
 
+def delta_build_map_lean_device(scores_t, gamma: float, lambda_ref: float, margin: float):
+    """The same codes from the lean kernels (rocco_hip_delta_build_map_lean_f64): scalar switch cost, n >= 2."""
+    import torch
+
+    n = int(scores_t.shape[0])
+    emap_t = torch.empty((n + 31) // 32, dtype=torch.uint8, device=scores_t.device)
+    solver = _native.solver_for(scores_t.device.index)
+    _native.check(_native.load().rocco_hip_delta_build_map_lean_f64(
+        solver.handle, scores_t.data_ptr(), float(gamma), n, float(lambda_ref), float(margin), emap_t.data_ptr(),
+        _dp._stream_ptr(scores_t)), "rocco_hip_delta_build_map_lean_f64")
+    return emap_t
+
+
 def delta_probe_device(scores_t, switch_costs, lambdas: Sequence[float], emap_t=None) -> List[Dict[str, int]]:
     n = int(scores_t.shape[0])
     costs_t, gamma = _dp._costs_arg(switch_costs, n, scores_t.device)
