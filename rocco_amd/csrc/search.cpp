@@ -412,8 +412,8 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
         s.phase = (s.target == (long long)p.n) ? State::kAll : State::kLowerBracket;
         s.out.zone_iters = -1;
         s.lower_count = (long long)p.n;
-        s.nodes.reserve(160);  // (here, while the device still works on what was queued before: not between two rounds)
-        s.queue.reserve(320);
+        s.nodes.reserve(32);  // (here, while the device still works on what was queued before: not between two rounds)
+        s.queue.reserve(64);
         if (opt.use_bounds && !s.use_exact && s.phase != State::kAll && bound_epsilon(p, p.score_min - 1.0, &s.eps)) {
             // penalties outside [s_min - 1, s_max + 1] are decided analytically: the search starts there
             s.searching = true;
@@ -554,6 +554,16 @@ int calibrate_batch(Evaluator &ev, const std::vector<ChainProblem> &problems_in,
         for (size_t b = 0; b < B; ++b) {
             const ChainProblem &p = problems[b];
             State &s = st[b];
+            if (b + 1 < B) {
+                // (the evaluator's launch calls between two iterations leave little of this in the near caches)
+                const char *next = reinterpret_cast<const char *>(&st[b + 1]);
+                for (size_t off = 0; off < sizeof(State); off += 64) {
+                    __builtin_prefetch(next + off);
+                }
+                __builtin_prefetch(&problems[b + 1]);
+                __builtin_prefetch(st[b + 1].nodes.data());
+                __builtin_prefetch(st[b + 1].queue.data());
+            }
             if (s.phase == State::kDone) {
                 continue;
             }
