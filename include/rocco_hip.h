@@ -421,6 +421,12 @@ int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *
 int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const size_t *rows, const size_t *cols,
                                  double penalty_lambda, void *stream);
 long long rocco_hip_buffer_growths(void);
+/* Diagnostic, process-wide since load: the batched baseline sweeps cut long rows into segments whose workgroups start from
+ * a warm-up (csrc/whittaker.hip); a seam whose warm-up had not reached the row's own values is recomputed from the true
+ * state -- the results are the sequential sweep's (rocco/native/baseline_backend.c:142-172) either way.  How many seams
+ * (row, parity, sweep) were recomputed so far.  ROCCO_HIP_WHITTAKER_SEGMENT_LOCI / ROCCO_HIP_WHITTAKER_WARM_LOCI (read
+ * per call) set the segment length (0: rows are never cut) and the warm-up. */
+long long rocco_hip_whittaker_seam_repairs(void);
 /* device memory the solver's scratch buffers hold now (they are kept between calls) */
 long long rocco_hip_solver_device_bytes(const rocco_hip_solver *solver);
 /* Diagnostic, process-wide since load: how the last bisection steps of the calibrations (rocco/dp.py:141-162) were

@@ -209,6 +209,7 @@ PROTOTYPES = [
      [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.c_double,
       ctypes.c_void_p]),
     ("rocco_hip_buffer_growths", ctypes.c_longlong, []),
+    ("rocco_hip_whittaker_seam_repairs", ctypes.c_longlong, []),
     ("rocco_hip_model_chain_counters", None, [ctypes.POINTER(ctypes.c_longlong)]),
     ("rocco_hip_model_chain_written_counters", None, [ctypes.POINTER(ctypes.c_longlong)]),
     ("rocco_hip_solver_device_bytes", ctypes.c_longlong, [ctypes.c_void_p]),

@@ -28,15 +28,19 @@ int DeviceBuffer::reserve(size_t want)
         return ROCCO_HIP_OK;
     }
     g_buffer_growths.fetch_add(1, std::memory_order_relaxed);
+    // small buffers double (few growths); large ones take what is asked for + 1/16 -- a 40 GB scratch must not become 80 --
+    // and the old block goes first (nothing is carried over: a scratch buffer's contents end with the call that wrote them)
     size_t grow = bytes ? bytes * 2 : (size_t)1 << 16;
-    if (grow < want) {
-        grow = want;
+    if (grow < want || want >= ((size_t)256 << 20)) {
+        grow = want + ((want >= ((size_t)256 << 20)) ? want / 16 : 0);
+    }
+    if (ptr != nullptr) {
+        (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
     }
     void *p = nullptr;
     ROCCO_HIP_TRY(hipMalloc(&p, grow));
-    if (ptr != nullptr) {
-        (void)hipFree(ptr);
-    }
     ptr = p;
     bytes = grow;
     return ROCCO_HIP_OK;
@@ -779,30 +783,30 @@ int rocco_hip_crossfit_whittaker_baseline_batch_f64(rocco_hip_solver *solver, si
     if (solver == nullptr || (count > 0 && (matrices_dev == nullptr || rows == nullptr || cols == nullptr || baselines_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    size_t longest = 0, groups = 0;
+    size_t longest = 0;
     for (size_t i = 0; i < count; ++i) {
         if (rows[i] * cols[i] > 0 && (matrices_dev[i] == nullptr || baselines_dev[i] == nullptr)) {
             return ROCCO_HIP_EINVAL;
         }
         if (rows[i] > 0) {
             longest = std::max(longest, cols[i]);
-            groups += (rows[i] + (size_t)whittaker_group_rows() - 1) / (size_t)whittaker_group_rows();
         }
     }
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
     int rc;
     if ((rc = solver->dev_misc.reserve(whittaker_batch_scratch_bytes(rows, cols, count))) != ROCCO_HIP_OK) return rc;
-    if ((rc = solver->host_stage.reserve(2 * groups * sizeof(WhittakerRowTask) + 64)) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->host_stage.reserve(whittaker_batch_stage_bytes(rows, cols, count))) != ROCCO_HIP_OK) return rc;
     if ((rc = ensure_whittaker_factor(solver, longest, penalty_lambda, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
     const rocco::SharedFactor *factor = (longest >= 25) ? solver->factor.get() : nullptr;
     rc = launch_crossfit_whittaker_batch(matrices_dev, rows, cols, count, penalty_lambda,
                                          factor != nullptr ? (const double *)factor->buf.ptr : nullptr,
                                          factor != nullptr ? factor->cap : 0, baselines_dev, solver->dev_misc.ptr,
-                                         (WhittakerRowTask *)solver->host_stage.ptr, (hipStream_t)stream);
+                                         solver->host_stage.ptr, (hipStream_t)stream);
     if (rc != ROCCO_HIP_OK) {
         return rc;
     }
     ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the scratch buffers are the solver's
+    whittaker_collect_repairs(solver->host_stage.ptr);
     return ROCCO_HIP_OK;
 }
 
@@ -870,6 +874,8 @@ int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t c
 
 long long rocco_hip_buffer_growths(void) { return g_buffer_growths.load(std::memory_order_relaxed); }
 
+long long rocco_hip_whittaker_seam_repairs(void) { return whittaker_seam_repairs(); }
+
 void rocco_hip_model_chain_counters(long long out[4])
 {
     if (out != nullptr) {
@@ -907,7 +913,7 @@ int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const s
         return ROCCO_HIP_EINVAL;
     }
     ROCCO_HIP_TRY(hipSetDevice(solver->device));
-    size_t misc = whittaker_batch_scratch_bytes(rows, cols, count), groups = 0, total_rows = 0, most_rows = 0, longest = 0;
+    size_t misc = whittaker_batch_scratch_bytes(rows, cols, count), stage_single = 0, total_rows = 0, most_rows = 0, longest = 0;
     for (size_t i = 0; i < count; ++i) {
         if (rows[i] == 0 || cols[i] == 0) {
             continue;
@@ -916,7 +922,7 @@ int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const s
         misc = std::max(misc, wls_scratch_bytes(rows[i], cols[i], 31, false));
         misc = std::max(misc, log_scale_scratch_bytes(rows[i], cols[i]));
         misc = std::max(misc, whittaker_batch_scratch_bytes(&rows[i], &cols[i], 1));
-        groups += (rows[i] + (size_t)whittaker_group_rows() - 1) / (size_t)whittaker_group_rows();
+        stage_single = std::max(stage_single, whittaker_batch_stage_bytes(&rows[i], &cols[i], 1));
         total_rows += rows[i];
         most_rows = std::max(most_rows, rows[i]);
         longest = std::max(longest, cols[i]);
@@ -924,7 +930,7 @@ int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const s
     int rc;
     if ((rc = solver->dev_misc.reserve(misc)) != ROCCO_HIP_OK) return rc;
     if ((rc = solver->dev_tasks.reserve(total_rows * sizeof(WlsRollingTask) + 256)) != ROCCO_HIP_OK) return rc;
-    if ((rc = solver->host_stage.reserve(std::max(2 * groups * sizeof(WhittakerRowTask) + 64, total_rows * sizeof(WlsRollingTask) + 256))) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->host_stage.reserve(std::max(std::max(whittaker_batch_stage_bytes(rows, cols, count), stage_single), total_rows * sizeof(WlsRollingTask) + 256))) != ROCCO_HIP_OK) return rc;
     if ((rc = solver->host_back.reserve(256 + most_rows * sizeof(int))) != ROCCO_HIP_OK) return rc;
     if ((rc = solver->dev_results.reserve(256)) != ROCCO_HIP_OK) return rc;
     if (penalty_lambda > 0.0 && (rc = ensure_whittaker_factor(solver, longest, penalty_lambda, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;

@@ -4,6 +4,20 @@
 #include "common.h"
 
 namespace rocco {
+#if defined(__HIPCC__)
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wavefront's global loads and stores
+// (s_waitcnt vmcnt(0)): a wavefront that has just issued the loads of a tile it needs three trips later then sits out a
+// memory latency at every barrier -- measured in round 5 on the rolling-sums launch: 22 ns per locus with the chain AND the
+// variances compiled out.  The tiles these kernels hand over live in LDS; what they read from or write to global memory
+// is touched by one thread only.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#endif
+
 
 // ---- chain_exact.hip ------------------------------------------------------------------------
 struct ExactTask {
@@ -128,21 +142,45 @@ int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_de
 // with the stream drained
 int build_whittaker_factor_on_host(size_t cap, double penalty_lambda, double *factor_dev, hipStream_t stream,
                                    const double *old_factor_dev = nullptr, size_t old_cap = 0);
-// one group of up to 32 rows of one matrix: a workgroup of the row-parallel sweeps (whittaker.hip)
+// one group of rows of one matrix over one SEGMENT of its loci: a workgroup of the row-parallel sweeps (whittaker.hip).
+// Tiles are 64 loci, counted from locus 0.  The workgroup writes the tiles [tile_begin, tile_end); a segment that does not
+// start where the sweep starts first walks `warm_tiles` tiles ahead of it (below tile_begin forward, above tile_end
+// backward) from a zero state, leaves the state it reaches in `spec` and goes on from it; the state at the segment's far
+// end goes to `edge`.  spec / edge: 2 x group rows chains x (last value, the one before), see whittaker.hip.
 struct WhittakerRowTask {
     const double *src0, *src1;
     double *dst0, *dst1;
     long long n;
     int row0, rows;
     const double *tail;  // the three factor entries per parity that depend on the length
+    long long tile_begin, tile_end;
+    long long warm_tiles;
+    double *spec, *edge;
 };
-// several matrices of one penalty (the chromosomes of a genome) in ONE pair of launches; tasks_host_pinned: room for
-// 2 x (groups of 32 rows over all matrices) records, must stay untouched until the stream has passed the copy
+// one matrix of a batch for the seam check behind a sweep (whittaker.hip: whittaker_seam_kernel)
+struct WhittakerSeamMatrix {
+    const double *src0, *src1;  // as the sweep's tasks
+    double *dst0, *dst1;
+    long long n;
+    int rows;
+    int n_seg;                 // segments per row
+    int group_rows;            // rows per workgroup (the matrix's rows dealt evenly)
+    long long seg_tiles;       // tiles per segment (the last one may be shorter)
+    long long task_base;       // the matrix's first task: task = task_base + group * n_seg + segment
+    const double *tail;
+};
+// several matrices of one penalty (the chromosomes of a genome) in ONE pair of launches (+ one seam check each);
+// tasks_host_pinned: room for whittaker_batch_stage_bytes(...), must stay untouched until the stream has passed the copy
 size_t whittaker_batch_scratch_bytes(const size_t *rows, const size_t *cols, size_t count);
-int whittaker_group_rows();  // rows per workgroup of the batched sweeps (one task record per group and sweep)
+size_t whittaker_batch_stage_bytes(const size_t *rows, const size_t *cols, size_t count);
+int whittaker_group_rows();  // rows per workgroup of the batched sweeps
+// how often a segment's warm-up had NOT reached the row's own values at the seam (each such seam was recomputed from
+// the true state: results are the sequential sweep's either way); process-wide, for tests and diagnostics
+long long whittaker_seam_repairs();
+void whittaker_collect_repairs(const void *tasks_host_pinned);  // after the stream of a batch launch has been waited for
 int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const size_t *rows, const size_t *cols, size_t count,
                                     double penalty_lambda, const double *factor_dev, size_t factor_cap, double *const *baselines_dev,
-                                    void *scratch_dev, WhittakerRowTask *tasks_host_pinned, hipStream_t stream);
+                                    void *scratch_dev, void *tasks_host_pinned, hipStream_t stream);
 
 // ---- wls.hip --------------------------------------------------------------------------------
 // scratch: at least wls_scratch_bytes(K, n) bytes; synchronises the stream before returning

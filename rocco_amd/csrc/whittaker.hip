@@ -21,6 +21,10 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 namespace rocco {
 
@@ -152,6 +156,11 @@ struct Factor {
         return (i == n - 2) ? l1_n2 : ((i > n - 2) ? 0.0 : l1[i]);
     }
     __device__ __forceinline__ double ll2(long long i) const { return (i > n - 3) ? 0.0 : l2[i]; }
+    // the same from a value loaded earlier from d[i] / l1[i] / l2[i] (i < n): a select on a value just loaded waits for the
+    // load, so the staging wavefronts load the table entries untouched and apply the end cases when they store the tile
+    __device__ __forceinline__ double dd_of(double raw, long long i) const { return (i == n - 2) ? d_n2 : ((i == n - 1) ? d_n1 : raw); }
+    __device__ __forceinline__ double ll1_of(double raw, long long i) const { return (i == n - 2) ? l1_n2 : ((i > n - 2) ? 0.0 : raw); }
+    __device__ __forceinline__ double ll2_of(double raw, long long i) const { return (i > n - 3) ? 0.0 : raw; }
 };
 
 __device__ __forceinline__ Factor factor_of(const double *factor, const double *tail, long long n, long long cap,
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(2 * kLanes + kSweepHelpers) void whittaker_sweep_ke
         stage_load(0);
         stage_store(0);
     }
-    __syncthreads();
+    lds_barrier();
     double p1 = 0.0, p2 = 0.0;
     for (long long k = 0; k < n_tiles; ++k) {
         if (!helper) {
@@ -356,31 +365,45 @@ __global__ __launch_bounds__(2 * kLanes + kSweepHelpers) void whittaker_sweep_ke
             }
 #endif
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (helper) {
         write_back(n_tiles - 1);
     }
 }
 
-// ---- the same sweeps with several chains per wavefront (round 3) ----------------------------------------------------
-// A chain advances one locus per ~25 ns whatever its wavefront's other 63 lanes do (three dependent FP64 operations of
-// ~19 cycles each), so a wavefront that carries ONE chain wastes them: above, K rows keep K workgroups busy for n x 25 ns,
-// and the 2 400 rows of a genome's count matrices take sum(n) x 25 ns / (workgroups in flight).  Here lane L of the chain
-// wavefront is chain (parity L / G, row L % G) of a group of G rows: both parities of a row read the same input, and all
-// 2 G chains step through the loci in lockstep with the same instructions as one did before.  The rows of EVERY matrix of a
-// batch (the chromosomes of a genome) are groups of one launch; the launch lasts as long as its longest row.  G = 8: with
-// 32 rows (all 64 lanes busy) the four helper wavefronts, each streaming 8 far-apart rows in and out, need 39 ns per locus
-// against the chain's 28 and the launch runs at 36; with 8 rows they stay under the chain and the launch runs at 27 ns per
-// locus (a genome's 2 400 rows are 312 workgroups, all resident); 16 rows 29 ns, 4 rows 45 ns (too few lanes per LDS access).
+// ---- the same sweeps with several chains per wavefront (round 3), over SEGMENTS of the rows (round 5) -----------------------
+// A chain advances one locus per ~25 ns whatever its wavefront's other 63 lanes do (three dependent FP64 operations), so a
+// wavefront that carries ONE chain wastes them: above, K rows keep K workgroups busy for n x 25 ns, and the 2 400 rows of a
+// genome's count matrices take sum(n) x 25 ns / (workgroups in flight).  Here lane L of the chain wavefront is chain
+// (parity L / G, row L % G) of a group of G rows: both parities of a row read the same input, and all 2 G chains step through
+// the loci in lockstep with the same instructions as one did before.  The rows of EVERY matrix of a batch (the chromosomes of
+// a genome) are groups of one launch.  G = 8: with 32 rows (all 64 lanes busy) the four helper wavefronts, each streaming 8
+// far-apart rows in and out, need 39 ns per locus against the chain's 28 and the launch runs at 36; with 8 rows they stay
+// under the chain and the launch runs at 27 ns per locus; 16 rows 29 ns, 4 rows 45 ns (too few lanes per LDS access).
 //   * the helpers load a tile of 64 loci of each row (512 contiguous bytes per wavefront instruction) and store it
 //     TRANSPOSED in LDS -- element (locus t, chain L) at t * (2 G + 1) + L: the chain wavefront's lanes read consecutive
 //     doubles, a helper's 64 lanes (one row, 64 loci) write at an odd stride: no conflicts either way;
 //   * the multipliers of a locus are the same for every row: one (a, b) pair per parity and locus, read as a broadcast;
 //   * two input and two output tiles alternate (chain on k, staging of k + 1, write-back of k - 1), one barrier per tile.
+//
+// Segments (round 5).  Until round 5 a launch lasted as long as its longest row: 4.98 M loci x 27 ns per sweep for a genome,
+// with most of the device idle.  The substitution is a CONTRACTING recurrence (its homogeneous part decays by ~0.96 per
+// locus at the count path's penalty), so a chain started from a zero state some way ahead of a locus forgets its start:
+// its values approach the row's own, and -- the values being doubles -- after a while they ARE the row's own, bit for
+// bit, from some locus on and for good (two consecutive values equal => everything behind them equal: the recurrence has
+// no other memory).  Measured on six kinds of rows, both sweeps (scripts/ubench/coalesce.c): the two sequences meet after
+// 8-20 thousand loci on average, 99 % within 55 thousand, none later than 93 thousand.  So a row is cut into segments; a
+// workgroup walks `warm_tiles` tiles ahead of its segment from a zero state without writing anything, notes the state it
+// has reached at the segment's start (`spec`), goes on through its segment writing results, and notes the state at the
+// segment's end (`edge`).  whittaker_seam_kernel then compares, seam by seam, the state a segment started from with the
+// state its predecessor ended in: EQUAL BITS PROVE the segment's values are the sequential sweep's (induction from the
+// row's first segment, which starts from the reference's own start).  A seam that differs (not seen at the default
+// warm-up, forced in tests/test_gpu_baseline.py) is recomputed from the true state until the recomputed values meet the
+// stored ones.  Results are the sequential sweep's bits in every case; only the time depends on the data.
 constexpr int kRowTile = 64;    // loci per tile
 #ifndef ROCCO_GROUP_ROWS
-#define ROCCO_GROUP_ROWS 8
+#define ROCCO_GROUP_ROWS 32
 #endif
 constexpr int kGroupRows = ROCCO_GROUP_ROWS;  // rows per workgroup (x 2 parities <= 64 lanes of the chain wavefront)
 constexpr int kPitch = 2 * kGroupRows + 1;
@@ -402,10 +425,40 @@ struct RowRegs {  // what a helper lane holds of one tile between its loads and 
     double ca[2], cb[2];  // wavefront 0 of the helpers: the multipliers of the lane's locus, per parity
 };
 
+// the multipliers of locus i, end cases as zeros: forward l1[i-1], l2[i-2] (baseline_backend.c:142-151), backward l1[i],
+// l2[i] (158-172); Factor::ll1 / ll2 hold the entries that depend on the length
+template <bool BACKWARD>
+__device__ __forceinline__ void multiplier_loci(long long i, long long n, long long &i1, long long &i2)
+{
+    const long long ii = (i < n) ? i : (n - 1);
+    i1 = BACKWARD ? ii : ((ii >= 1) ? (ii - 1) : 0);
+    i2 = BACKWARD ? ii : ((ii >= 2) ? (ii - 2) : 0);
+}
+
+template <bool BACKWARD>
+__device__ __forceinline__ void multipliers_from(const Factor &f, long long i, long long n, double raw1, double raw2, double &a, double &b)
+{
+    long long i1, i2;
+    multiplier_loci<BACKWARD>(i, n, i1, i2);
+    const bool has1 = BACKWARD ? (i < n - 1) : (i >= 1 && i < n), has2 = BACKWARD ? (i < n - 2) : (i >= 2 && i < n);
+    const double a0 = f.ll1_of(raw1, i1), b0 = f.ll2_of(raw2, i2);
+    a = has1 ? a0 : 0.0;
+    b = has2 ? b0 : 0.0;
+}
+
+template <bool BACKWARD>
+__device__ __forceinline__ void multipliers_at(const Factor &f, long long i, long long n, double &a, double &b)
+{
+    long long i1, i2;
+    multiplier_loci<BACKWARD>(i, n, i1, i2);
+    multipliers_from<BACKWARD>(f, i, n, f.l1[(i1 < n - 1) ? i1 : 0], f.l2[(i2 < n - 2) ? i2 : 0], a, b);
+}
+
 // forward (BACKWARD = false): src0 = the matrix (rhs = W_p y); dst0 / dst1 = f of parity 0 / 1, the forward substitution
 // BEFORE its division by the diagonal (baseline_backend.c:142-156) -- the division rides on the backward sweep's staging,
 // where the diagonal entry arrives with the tile's other loads instead of queueing for three tiles in registers.
-// backward: src0 / src1 = f of parity 0 / 1, dst0 = the baseline 0.5 (x0 + x1) (158-172, 296-299); dst0 may be src0.
+// backward: src0 / src1 = f of parity 0 / 1, dst0 = the baseline 0.5 (x0 + x1) (158-172, 296-299); dst0 must be neither
+// src0 nor src1 once rows are cut into segments (a neighbour's warm-up reads what this segment would overwrite).
 template <bool BACKWARD>
 __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kernel(const WhittakerRowTask *__restrict__ tasks,
                                                                                   long long cap, const double *__restrict__ factor)
@@ -413,12 +466,23 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
     extern __shared__ __attribute__((aligned(16))) double smem[];
     RowTiles &T = *reinterpret_cast<RowTiles *>(smem);
     const WhittakerRowTask task = tasks[blockIdx.x];
+    // (pointers read from a record are generic to the compiler: flat loads and stores, which count on the LDS counter too
+    // and force full waits; these are global)
+    typedef const __attribute__((address_space(1))) double *gconst_t;
+    typedef __attribute__((address_space(1))) double *gmut_t;
+    const gconst_t src0 = (gconst_t)task.src0, src1 = (gconst_t)task.src1;
+    const gmut_t dst0 = (gmut_t)task.dst0, dst1 = (gmut_t)task.dst1;
     const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
     const int h = wave - 1;  // helper number
     const long long n = task.n;
     const Factor f0 = factor_of(factor, task.tail, n, cap, 0), f1 = factor_of(factor, task.tail, n, cap, 1);
-    const long long n_tiles = (n + kRowTile - 1) / kRowTile;
-    auto tile_base = [&](long long k) { return (BACKWARD ? (n_tiles - 1 - k) : k) * kRowTile; };
+    const long long all_tiles = (n + kRowTile - 1) / kRowTile;
+    // the tiles this workgroup walks, in sweep order: `warm` tiles ahead of the segment, then the segment's own
+    const long long first = BACKWARD ? (((task.tile_end + task.warm_tiles < all_tiles) ? (task.tile_end + task.warm_tiles) : all_tiles) - 1)
+                                     : ((task.tile_begin > task.warm_tiles) ? (task.tile_begin - task.warm_tiles) : 0);
+    const long long warm = BACKWARD ? (first - (task.tile_end - 1)) : (task.tile_begin - first);
+    const long long n_tiles = warm + (task.tile_end - task.tile_begin);
+    auto tile_base = [&](long long k) { return (BACKWARD ? (first - k) : (first + k)) * kRowTile; };
     constexpr int kMine = kGroupRows / kRowHelpers;  // rows a helper wavefront moves per tile
 
     // helpers: lane = locus of the tile.  A tile is loaded into registers TWO trips before it is stored to LDS (two
@@ -431,23 +495,22 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
         for (int q = 0; q < kMine; ++q) {
             const int r = h + q * kRowHelpers;
             const long long at = (long long)(task.row0 + ((r < task.rows) ? r : 0)) * n + ii;
-            R.x0[q] = task.src0[at];
-            R.x1[q] = BACKWARD ? task.src1[at] : 0.0;
+            R.x0[q] = src0[at];
+            R.x1[q] = BACKWARD ? src1[at] : 0.0;
         }
+        // (table entries as they are: the end cases are applied in stage_store, two trips later)
         if (BACKWARD) {
-            R.d0 = f0.dd(ii);
-            R.d1 = f1.dd(ii);
+            R.d0 = f0.d[ii];
+            R.d1 = f1.d[ii];
         }
         if (h == 0) {
-            // the multipliers of locus i, end cases as zeros: forward l1[i-1], l2[i-2] (baseline_backend.c:142-151),
-            // backward l1[i], l2[i] (158-172); Factor::ll1 / ll2 hold the entries that depend on the length
-            const long long i1 = BACKWARD ? ii : ((ii >= 1) ? (ii - 1) : 0), i2 = BACKWARD ? ii : ((ii >= 2) ? (ii - 2) : 0);
-            const bool has1 = BACKWARD ? (i < n - 1) : (i >= 1 && i < n), has2 = BACKWARD ? (i < n - 2) : (i >= 2 && i < n);
-            const double a0 = f0.ll1(i1), a1 = f1.ll1(i1), b0 = f0.ll2(i2), b1 = f1.ll2(i2);
-            R.ca[0] = has1 ? a0 : 0.0;
-            R.ca[1] = has1 ? a1 : 0.0;
-            R.cb[0] = has2 ? b0 : 0.0;
-            R.cb[1] = has2 ? b1 : 0.0;
+            long long i1, i2;
+            multiplier_loci<BACKWARD>(i, n, i1, i2);
+            const long long j1 = (i1 < n - 1) ? i1 : 0, j2 = (i2 < n - 2) ? i2 : 0;  // (l1 has n - 1 entries, l2 n - 2)
+            R.ca[0] = f0.l1[j1];
+            R.ca[1] = f1.l1[j1];
+            R.cb[0] = f0.l2[j2];
+            R.cb[1] = f1.l2[j2];
         }
     };
     auto stage_store = [&](long long k, const RowRegs &R) {
@@ -462,8 +525,8 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             const bool live = inside && r < task.rows;
             double v0, v1;
             if (BACKWARD) {
-                v0 = R.x0[q] / R.d0;  // z = f / d (baseline_backend.c:153-156)
-                v1 = R.x1[q] / R.d1;
+                v0 = R.x0[q] / f0.dd_of(R.d0, ii);  // z = f / d (baseline_backend.c:153-156)
+                v1 = R.x1[q] / f1.dd_of(R.d1, ii);
             } else {
                 v0 = rhs_value(R.x0[q], ii, n, 0);
                 v1 = rhs_value(R.x0[q], ii, n, 1);
@@ -472,13 +535,19 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             in[lane * kPitch + kGroupRows + r] = live ? v1 : 0.0;
         }
         if (h == 0) {
-            T.coef[buf][0][lane][0] = R.ca[0];
-            T.coef[buf][0][lane][1] = R.cb[0];
-            T.coef[buf][1][lane][0] = R.ca[1];
-            T.coef[buf][1][lane][1] = R.cb[1];
+            double a0, b0, a1, b1;
+            multipliers_from<BACKWARD>(f0, i, n, R.ca[0], R.cb[0], a0, b0);
+            multipliers_from<BACKWARD>(f1, i, n, R.ca[1], R.cb[1], a1, b1);
+            T.coef[buf][0][lane][0] = a0;
+            T.coef[buf][0][lane][1] = b0;
+            T.coef[buf][1][lane][0] = a1;
+            T.coef[buf][1][lane][1] = b1;
         }
     };
     auto write_back = [&](long long k) {
+        if (k < warm) {
+            return;  // (ahead of the segment: another workgroup's loci)
+        }
         const double *__restrict__ out = T.out[k & 1];
         const long long i = tile_base(k) + lane;
         if (i >= n) {
@@ -487,10 +556,10 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
         for (int r = h; r < task.rows; r += kRowHelpers) {
             const long long at = (long long)(task.row0 + r) * n + i;
             if (BACKWARD) {
-                task.dst0[at] = 0.5 * (out[lane * kPitch + r] + out[lane * kPitch + kGroupRows + r]);
+                dst0[at] = 0.5 * (out[lane * kPitch + r] + out[lane * kPitch + kGroupRows + r]);
             } else {
-                task.dst0[at] = out[lane * kPitch + r];
-                task.dst1[at] = out[lane * kPitch + kGroupRows + r];
+                dst0[at] = out[lane * kPitch + r];
+                dst1[at] = out[lane * kPitch + kGroupRows + r];
             }
         }
     };
@@ -548,6 +617,11 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
 #else
         if (wave == 0) {
 #endif
+            if (k == warm && warm > 0 && chain_lane) {
+                // the state the warm-up has reached where the segment starts
+                task.spec[2 * col] = p1;
+                task.spec[2 * col + 1] = p2;
+            }
             chain(k);
 #ifdef ROCCO_ROWS_NOHELP
         } else if (false) {
@@ -564,7 +638,7 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
                 write_back(k - 1);
             }
         }
-        __syncthreads();
+        lds_barrier();
     };
 
     RowRegs A, B;
@@ -580,7 +654,7 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
     } else {
         __builtin_amdgcn_s_setprio(3);  // the chain wavefront shares its SIMD with a helper: its instructions go first
     }
-    __syncthreads();
+    lds_barrier();
     for (long long k = 0; k < n_tiles; k += 2) {
         trip(k, B);  // even trips store odd tiles (set B), odd trips even tiles (set A)
         if (k + 1 < n_tiles) {
@@ -589,6 +663,150 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
     }
     if (wave > 0) {
         write_back(n_tiles - 1);
+    } else if (chain_lane && task.edge != nullptr) {
+        task.edge[2 * col] = p1;  // the state at the segment's far end: what the next segment of the sweep must start from
+        task.edge[2 * col + 1] = p2;
+    }
+}
+
+// ---- the seams between segments ---------------------------------------------------------------------------------------------
+// One wavefront per 64 rows of a matrix walks the rows' seams in sweep order, lane = row.  At each seam and for each
+// parity: the state the following segment started from (`spec`, reached by its warm-up) against the state the segment
+// before it ended in (`edge`).  Equal bits: the following segment's stored values are the sequential sweep's (see above).
+// Otherwise that segment is recomputed from the true state, side by side with the sequence the workgroup had computed
+// (restarted from `spec`), storing the true values until both sequences give the same two values in a row -- from there
+// on the stored values are right; a segment recomputed to its end hands its true end state to the next seam's comparison.
+// A recomputation is one lane's sequential work; the wavefront's other lanes fetch its operands -- 64 loci at a time,
+// through LDS -- and carry its results to memory.
+__device__ __forceinline__ bool same_bits(double x, double y) { return __double_as_longlong(x) == __double_as_longlong(y); }
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(kLanes) void whittaker_seam_kernel(const WhittakerSeamMatrix *__restrict__ matrices, double *__restrict__ states,
+                                                                long long tasks_per_sweep, long long cap, const double *__restrict__ factor,
+                                                                unsigned long long *__restrict__ repairs)
+{
+    __shared__ double s_v[2][kRowTile], s_a[2][kRowTile], s_b[2][kRowTile], s_out[2][kRowTile];
+    const WhittakerSeamMatrix m = matrices[blockIdx.y];
+    if (m.n_seg < 2) {
+        return;
+    }
+    const int lane = threadIdx.x;
+    const int row = (int)(blockIdx.x * kLanes + threadIdx.x);
+    const bool valid = row < m.rows;
+    const long long n = m.n, all_tiles = (n + kRowTile - 1) / kRowTile;
+    const Factor f[2] = {factor_of(factor, m.tail, n, cap, 0), factor_of(factor, m.tail, n, cap, 1)};
+    const int my = valid ? row : 0, group = my / m.group_rows, r = my % m.group_rows;
+    // states: [sweep][task][spec | edge][chain][2]; chain = parity * G + row of the group
+    double *const sweep_states = states + (BACKWARD ? tasks_per_sweep : 0) * (long long)(8 * kGroupRows);
+    auto spec_of = [&](int seg, int parity) { return sweep_states + ((m.task_base + (long long)group * m.n_seg + seg) * 2 + 0) * (4 * kGroupRows) + 2 * (parity * kGroupRows + r); };
+    auto edge_of = [&](int seg, int parity) { return sweep_states + ((m.task_base + (long long)group * m.n_seg + seg) * 2 + 1) * (4 * kGroupRows) + 2 * (parity * kGroupRows + r); };
+    for (int step = 1; step < m.n_seg; ++step) {
+        // forward: the seam below segment `step`; backward: the seam above segment n_seg - 1 - step
+        const int seg = BACKWARD ? (m.n_seg - 1 - step) : step, before = BACKWARD ? (seg + 1) : (seg - 1);
+        double tp1[2], tp2[2], sp1[2], sp2[2];
+        int open[2];
+        for (int p = 0; p < 2; ++p) {
+            tp1[p] = edge_of(before, p)[0];
+            tp2[p] = edge_of(before, p)[1];
+            sp1[p] = spec_of(seg, p)[0];
+            sp2[p] = spec_of(seg, p)[1];
+            open[p] = (valid && !(same_bits(tp1[p], sp1[p]) && same_bits(tp2[p], sp2[p]))) ? 1 : 0;
+        }
+        unsigned long long todo = __ballot((open[0] | open[1]) != 0);
+        if (todo == 0ULL) {
+            continue;
+        }
+        const long long t_lo = (long long)seg * m.seg_tiles, t_hi = (seg + 1 == m.n_seg) ? all_tiles : (t_lo + m.seg_tiles);
+        const long long lo = t_lo * kRowTile, hi = (t_hi * kRowTile < n) ? (t_hi * kRowTile) : n;  // the segment's loci [lo, hi)
+        while (todo != 0ULL) {
+            const int owner = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ULL;
+            const int orow = __shfl(row, owner);
+            const bool oopen[2] = {__shfl(open[0], owner) != 0, __shfl(open[1], owner) != 0};
+            // backward writes 0.5 (x0 + x1): an open parity needs the other parity's values too, so both are walked there
+            const bool walk[2] = {oopen[0] || (BACKWARD && oopen[1]), oopen[1] || (BACKWARD && oopen[0])};
+            const long long at_row = (long long)orow * n;
+            int met[2] = {oopen[0] ? 0 : 2, oopen[1] ? 0 : 2};  // consecutive loci at which the two sequences agreed (the owner's count)
+            long long walked = 0;
+            bool done = false;
+            for (long long base = 0; base < hi - lo && !done; base += kRowTile) {
+                // the tile's loci in sweep order: lane j holds the j-th
+                const long long i = BACKWARD ? (hi - 1 - base - lane) : (lo + base + lane);
+                const bool inside = BACKWARD ? (i >= lo) : (i < hi);
+                const long long ii = inside ? i : (BACKWARD ? lo : (hi - 1));
+                for (int p = 0; p < 2; ++p) {
+                    if (!walk[p]) {
+                        continue;
+                    }
+                    double a, b, v;
+                    multipliers_at<BACKWARD>(f[p], ii, n, a, b);
+                    if (BACKWARD) {
+                        v = (p == 0 ? m.src0 : m.src1)[at_row + ii] / f[p].dd(ii);
+                    } else {
+                        v = rhs_value(m.src0[at_row + ii], ii, n, p);
+                    }
+                    s_v[p][lane] = v;
+                    s_a[p][lane] = a;
+                    s_b[p][lane] = b;
+                }
+                __syncthreads();
+                const long long left = hi - lo - base;
+                const int count = (left < kRowTile) ? (int)left : kRowTile;
+                int upto = count;
+                if (lane == owner) {
+                    for (int j = 0; j < count; ++j) {
+                        for (int p = 0; p < 2; ++p) {
+                            if (!walk[p]) {
+                                continue;
+                            }
+                            const double v = s_v[p][j], a = s_a[p][j], b = s_b[p][j];
+                            const double tr = chain_step(v, a, b, tp1[p], tp2[p]);
+                            tp2[p] = tp1[p];
+                            tp1[p] = tr;
+                            s_out[p][j] = tr;
+                            if (oopen[p]) {
+                                const double sr = chain_step(v, a, b, sp1[p], sp2[p]);
+                                sp2[p] = sp1[p];
+                                sp1[p] = sr;
+                                met[p] = (met[p] >= 2) ? 2 : (same_bits(sr, tr) ? (met[p] + 1) : 0);
+                            }
+                        }
+                        if (met[0] >= 2 && met[1] >= 2) {
+                            upto = j + 1;
+                            break;
+                        }
+                    }
+                }
+                __syncthreads();
+                upto = __shfl(upto, owner);
+                done = __shfl((met[0] >= 2 && met[1] >= 2) ? 1 : 0, owner) != 0;
+                if (lane < upto) {
+                    if (BACKWARD) {
+                        m.dst0[at_row + i] = 0.5 * (s_out[0][lane] + s_out[1][lane]);
+                    } else {
+                        if (oopen[0]) {
+                            m.dst0[at_row + i] = s_out[0][lane];
+                        }
+                        if (oopen[1]) {
+                            m.dst1[at_row + i] = s_out[1][lane];
+                        }
+                    }
+                }
+                walked += upto;
+                __syncthreads();
+            }
+            if (lane == owner) {
+                atomicAdd(repairs, (unsigned long long)((oopen[0] ? 1 : 0) + (oopen[1] ? 1 : 0)));
+                atomicAdd(repairs + 1, (unsigned long long)walked);  // loci recomputed
+                for (int p = 0; p < 2; ++p) {
+                    if (oopen[p] && met[p] < 2) {
+                        // recomputed to its end without meeting: its true end state for the next seam
+                        edge_of(seg, p)[0] = tp1[p];
+                        edge_of(seg, p)[1] = tp2[p];
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -627,6 +845,10 @@ int launch_whittaker_factor(size_t cap, double penalty_lambda, double *factor_de
 
 namespace {
 
+// workgroups of the rows kernels the device holds at once (registers and LDS decide how many per CU): the segment plan
+// cuts a batch into about that many
+std::atomic<long long> g_rows_resident{0};
+
 int configure_rows_kernels()
 {
     static bool attr_set = false;
@@ -635,6 +857,14 @@ int configure_rows_kernels()
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowTiles)));
         ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_rows_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowTiles)));
+        int per_cu[2] = {1, 1}, device = 0, cus = 256;
+        ROCCO_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], reinterpret_cast<const void *>(whittaker_rows_kernel<false>),
+                                                                   kLanes * (1 + kRowHelpers), sizeof(RowTiles)));
+        ROCCO_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], reinterpret_cast<const void *>(whittaker_rows_kernel<true>),
+                                                                   kLanes * (1 + kRowHelpers), sizeof(RowTiles)));
+        ROCCO_HIP_TRY(hipGetDevice(&device));
+        ROCCO_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        g_rows_resident.store((long long)std::max(1, std::min(per_cu[0], per_cu[1])) * (long long)std::max(1, cus));
         attr_set = true;
     }
     return ROCCO_HIP_OK;
@@ -644,25 +874,201 @@ int configure_rows_kernels()
 
 int whittaker_group_rows() { return kGroupRows; }
 
+namespace {
+
+std::atomic<long long> g_seam_repairs{0};
+
+long long env_loci(const char *name, long long fallback)
+{
+    const char *v = std::getenv(name);
+    return (v != nullptr && *v != '\0') ? std::atoll(v) : fallback;
+}
+
+// How a batch's rows are cut.  A workgroup's time is (warm-up + segment) x the chain's step, so a row is cut into as many
+// segments as keep every workgroup of the batch resident at once (resident_workgroups()) -- but none shorter than the warm-up, which
+// would then be most of the work.  ROCCO_HIP_WHITTAKER_SEGMENT_LOCI: a fixed segment length (0: rows are never cut);
+// ROCCO_HIP_WHITTAKER_WARM_LOCI: the warm-up.  Measured on a genome's 66 thousand seams (K = 100, both sweeps): 2.5 % had
+// not met after 65 536 loci, 0.045 % after 131 072 (an e-fold per ~16 thousand) -- the default of 196 608 leaves about
+// one seam in a hundred thousand to be recomputed (whittaker_seam_kernel).
+constexpr long long kWarmLoci = 196608;
+
+long long resident_workgroups()
+{
+    const long long forced = env_loci("ROCCO_HIP_WHITTAKER_RESIDENT", 0);
+    const long long known = g_rows_resident.load();
+    return (forced > 0) ? forced : ((known > 0) ? known : 256);
+}
+
+struct SegmentPlan {
+    long long seg_tiles = 0;  // tiles per segment
+    int n_seg = 1;
+    long long warm_tiles = 0;
+};
+
+// rows of a matrix are dealt to ceil(rows / G) workgroups evenly (100 rows, G = 32: four groups of 25, not 32 + 32 + 32 + 4:
+// a workgroup's helpers move its rows, so even groups finish together)
+size_t groups_of(size_t rows) { return (rows + kGroupRows - 1) / kGroupRows; }
+size_t group_rows_of(size_t rows) { return (rows + groups_of(rows) - 1) / std::max<size_t>(1, groups_of(rows)); }
+
+long long batch_group_loci(const size_t *rows, const size_t *cols, size_t count)
+{
+    long long total = 0;
+    for (size_t i = 0; i < count; ++i) {
+        if (rows[i] > 0 && cols[i] >= 25) {
+            total += (long long)groups_of(rows[i]) * (long long)cols[i];
+        }
+    }
+    return total;
+}
+
+long long warm_loci() { return std::max<long long>(kRowTile, env_loci("ROCCO_HIP_WHITTAKER_WARM_LOCI", kWarmLoci)); }
+
+// a row of `cols` loci cut into `pieces` segments of whole tiles
+SegmentPlan cut(size_t cols, long long pieces)
+{
+    SegmentPlan plan;
+    const long long all_tiles = ((long long)cols + kRowTile - 1) / kRowTile;
+    plan.warm_tiles = (warm_loci() + kRowTile - 1) / kRowTile;
+    plan.seg_tiles = all_tiles;
+    if (pieces > 1) {
+        plan.seg_tiles = (all_tiles + pieces - 1) / pieces;
+        plan.n_seg = (int)((all_tiles + plan.seg_tiles - 1) / plan.seg_tiles);
+    }
+    if (plan.n_seg < 2) {
+        plan.n_seg = 1;
+        plan.seg_tiles = all_tiles;
+    }
+    return plan;
+}
+
+// The plan of a batch is ONE number, the loci a workgroup may walk (`budget`): a row no longer than that stays whole, a
+// longer one is cut into the fewest pieces whose length + warm-up fit (a piece never shorter than the warm-up).  A launch
+// lasts (workgroups / resident, rounded up) x budget chain steps: among one, two and three rounds of resident workgroups
+// the smallest such product wins.  ROCCO_HIP_WHITTAKER_SEGMENT_LOCI fixes the piece length instead (0: rows are never cut).
+long long pieces_of(size_t cols, long long budget)
+{
+    const long long fixed = env_loci("ROCCO_HIP_WHITTAKER_SEGMENT_LOCI", -1), warm = warm_loci(), n = (long long)cols;
+    if (fixed >= 0) {
+        return (fixed > 0 && n >= 2 * fixed) ? ((n + fixed / 2) / fixed) : 1;
+    }
+    if (budget <= 0 || n <= budget) {
+        return 1;
+    }
+    const long long room = std::max(warm, budget - warm);
+    return std::max<long long>(1, std::min((n + room - 1) / room, n / warm));
+}
+
+long long batch_budget_loci(const size_t *rows, const size_t *cols, size_t count)
+{
+    if (env_loci("ROCCO_HIP_WHITTAKER_SEGMENT_LOCI", -1) >= 0) {
+        return 0;
+    }
+    const long long resident = resident_workgroups(), warm = warm_loci();
+    long long longest = 0;
+    for (size_t i = 0; i < count; ++i) {
+        if (rows[i] > 0 && cols[i] >= 25) {
+            longest = std::max(longest, (long long)cols[i]);
+        }
+    }
+    auto tasks_at = [&](long long budget) {
+        long long tasks = 0;
+        for (size_t i = 0; i < count; ++i) {
+            if (rows[i] > 0 && cols[i] >= 25) {
+                tasks += (long long)groups_of(rows[i]) * pieces_of(cols[i], budget);
+            }
+        }
+        return tasks;
+    };
+    long long best_budget = longest, best_cost = ((tasks_at(longest) + resident - 1) / resident) * longest;
+    for (long long rounds = 1; rounds <= 3; ++rounds) {
+        long long lo = 2 * warm, hi = longest;  // the smallest budget whose workgroups fit `rounds` rounds
+        if (lo >= hi || tasks_at(hi) > rounds * resident) {
+            continue;
+        }
+        while (hi - lo > kRowTile) {
+            const long long mid = lo + (hi - lo) / 2;
+            if (tasks_at(mid) <= rounds * resident) {
+                hi = mid;
+            } else {
+                lo = mid;
+            }
+        }
+        const long long cost = ((tasks_at(hi) + resident - 1) / resident) * hi;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best_budget = hi;
+        }
+    }
+    return best_budget;
+}
+
+SegmentPlan plan_segments(size_t cols, long long budget) { return cut(cols, pieces_of(cols, budget)); }
+
+size_t batch_tasks(const size_t *rows, const size_t *cols, size_t count, long long budget)
+{
+    size_t n_tasks = 0;
+    for (size_t i = 0; i < count; ++i) {
+        if (rows[i] > 0 && cols[i] >= 25) {
+            n_tasks += groups_of(rows[i]) * (size_t)plan_segments(cols[i], budget).n_seg;
+        }
+    }
+    return n_tasks;
+}
+
+// an upper bound of batch_tasks() that does not depend on what else is in the batch (a solver's scratch is sized before the
+// batches are formed): no plan cuts a row into more than cols / (shortest segment) + 1 pieces
+size_t batch_tasks_bound(const size_t *rows, const size_t *cols, size_t count)
+{
+    const long long warm = warm_loci();
+    const long long fixed = env_loci("ROCCO_HIP_WHITTAKER_SEGMENT_LOCI", -1);
+    const long long shortest = (fixed < 0) ? warm : std::max<long long>(fixed / 2, 1);
+    size_t n_tasks = 0;
+    for (size_t i = 0; i < count; ++i) {
+        if (rows[i] > 0 && cols[i] >= 25) {
+            const size_t pieces = (fixed == 0) ? 1 : (size_t)((long long)cols[i] / shortest + 1);
+            n_tasks += groups_of(rows[i]) * pieces;
+        }
+    }
+    return n_tasks;
+}
+
+constexpr size_t kStateDoubles = 8 * kGroupRows;  // per task and sweep: spec | edge, 2 G chains x 2 values each
+
+size_t round256(size_t bytes) { return (bytes + 255) / 256 * 256; }
+
+}  // namespace
+
+long long whittaker_seam_repairs() { return g_seam_repairs.load(std::memory_order_relaxed); }
+
+// what launch_crossfit_whittaker_batch copies up from pinned memory: both sweeps' task records, the seam records, and
+// (coming back) the count of recomputed seams in the first 64 bytes
+size_t whittaker_batch_stage_bytes(const size_t *rows, const size_t *cols, size_t count)
+{
+    return 64 + round256(2 * batch_tasks_bound(rows, cols, count) * sizeof(WhittakerRowTask)) + round256(2 * count * sizeof(WhittakerSeamMatrix)) + 256;
+}
+
 size_t whittaker_batch_scratch_bytes(const size_t *rows, const size_t *cols, size_t count)
 {
-    // per matrix: the z of parity 1 (rows x cols doubles) and 8 doubles of end entries; per group of rows two task records
-    size_t bytes = 256;
+    // the staged records, the seam states of both sweeps, a counter; per matrix: the forward sweep's f of both parities
+    // (2 x rows x cols doubles) and 8 doubles of end entries
+    const size_t n_tasks = batch_tasks_bound(rows, cols, count);
+    size_t bytes = whittaker_batch_stage_bytes(rows, cols, count) + round256(2 * n_tasks * kStateDoubles * sizeof(double)) + 512;
     for (size_t i = 0; i < count; ++i) {
-        bytes += (rows[i] * cols[i] + 8) * sizeof(double) + 2 * ((rows[i] + kGroupRows - 1) / kGroupRows) * sizeof(WhittakerRowTask) + 256;
+        bytes += round256((2 * rows[i] * cols[i] + 8) * sizeof(double));
     }
     return bytes;
 }
 
 int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const size_t *rows, const size_t *cols, size_t count,
                                     double penalty_lambda, const double *factor_dev, size_t factor_cap, double *const *baselines_dev,
-                                    void *scratch_dev, WhittakerRowTask *tasks_host_pinned, hipStream_t stream)
+                                    void *scratch_dev, void *tasks_host_pinned, hipStream_t stream)
 {
     int rc;
-    if (count == 1 && rows[0] > 0 && cols[0] >= 25) {
-        // ONE matrix: a workgroup per row with one chain per wavefront steps ~25 ns per locus, the grouped wavefronts below
-        // ~27 ns -- both last as long as one row, so the lone matrix takes the faster step; two matrices or more take the
-        // launch that lasts as long as its longest
+    if ((rc = configure_rows_kernels()) != ROCCO_HIP_OK) return rc;
+    const long long seg_loci = batch_budget_loci(rows, cols, count);
+    if (count == 1 && rows[0] > 0 && cols[0] >= 25 && plan_segments(cols[0], seg_loci).n_seg < 2) {
+        // ONE matrix of rows too short to cut: a workgroup per row with one chain per wavefront steps ~25 ns per locus, the
+        // grouped wavefronts below ~27 ns -- both last as long as one row, so the lone matrix takes the faster step
         if (factor_dev == nullptr || factor_cap < cols[0]) {
             return ROCCO_HIP_EINVAL;
         }
@@ -688,18 +1094,22 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
         ROCCO_HIP_TRY(hipGetLastError());
         return ROCCO_HIP_OK;
     }
-    if ((rc = configure_rows_kernels()) != ROCCO_HIP_OK) return rc;
-    // scratch: [tasks forward | tasks backward] then per matrix [tail (8 doubles) | z1]
-    size_t n_tasks = 0;
-    for (size_t i = 0; i < count; ++i) {
-        if (rows[i] > 0 && cols[i] >= 25) {
-            n_tasks += (rows[i] + kGroupRows - 1) / kGroupRows;
-        }
-    }
+    const size_t n_tasks = batch_tasks(rows, cols, count, seg_loci);
+    // scratch: [counter | tasks forward | tasks backward | seam records forward | backward] [states] then per matrix
+    // [tail (8 doubles) | f of parity 0 | f of parity 1]; the pinned staging area mirrors the first part
+    const size_t stage_bytes = 64 + round256(2 * n_tasks * sizeof(WhittakerRowTask)) + round256(2 * count * sizeof(WhittakerSeamMatrix));
     char *at = (char *)scratch_dev;
-    WhittakerRowTask *tasks_dev = (WhittakerRowTask *)at;
-    at += ((2 * n_tasks * sizeof(WhittakerRowTask) + 255) / 256) * 256;
-    size_t t = 0;
+    unsigned long long *repairs_dev = (unsigned long long *)at;
+    WhittakerRowTask *tasks_dev = (WhittakerRowTask *)(at + 64);
+    WhittakerSeamMatrix *seams_dev = (WhittakerSeamMatrix *)(at + 64 + round256(2 * n_tasks * sizeof(WhittakerRowTask)));
+    at += round256(stage_bytes);
+    double *states_dev = (double *)at;
+    at += round256(2 * n_tasks * kStateDoubles * sizeof(double));
+    char *stage = (char *)tasks_host_pinned;
+    std::memset(stage, 0, 64);
+    WhittakerRowTask *tasks_host = (WhittakerRowTask *)(stage + 64);
+    WhittakerSeamMatrix *seams_host = (WhittakerSeamMatrix *)(stage + 64 + round256(2 * n_tasks * sizeof(WhittakerRowTask)));
+    size_t t = 0, n_seams = 0, most_rows = 0;
     for (size_t i = 0; i < count; ++i) {
         if (rows[i] == 0 || cols[i] == 0) {
             continue;
@@ -713,39 +1123,99 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
             return ROCCO_HIP_EINVAL;
         }
         double *tail = (double *)at;
-        double *z1 = tail + 8;
-        at += ((rows[i] * cols[i] + 8) * sizeof(double) + 255) / 256 * 256;
+        double *z0 = tail + 8;
+        double *z1 = z0 + rows[i] * cols[i];
+        at += round256((2 * rows[i] * cols[i] + 8) * sizeof(double));
         hipLaunchKernelGGL(whittaker_tail_kernel, dim3(1), dim3(64), 0, stream, (long long)cols[i], (long long)factor_cap, penalty_lambda,
                            factor_dev, tail);
-        for (size_t r0 = 0; r0 < rows[i]; r0 += kGroupRows, ++t) {
-            WhittakerRowTask &fw = tasks_host_pinned[t], &bw = tasks_host_pinned[n_tasks + t];
+        const SegmentPlan plan = plan_segments(cols[i], seg_loci);
+        const size_t group_rows = group_rows_of(rows[i]);
+        const long long all_tiles = ((long long)cols[i] + kRowTile - 1) / kRowTile;
+        if (plan.n_seg > 1) {
+            WhittakerSeamMatrix &fw = seams_host[n_seams], &bw = seams_host[count + n_seams];
             fw.src0 = matrices_dev[i];
             fw.src1 = nullptr;
-            fw.dst0 = baselines_dev[i];  // z of parity 0 lives in the output until the backward sweep replaces it
+            fw.dst0 = z0;
             fw.dst1 = z1;
             fw.n = (long long)cols[i];
-            fw.row0 = (int)r0;
-            fw.rows = (int)std::min<size_t>(kGroupRows, rows[i] - r0);
+            fw.rows = (int)rows[i];
+            fw.n_seg = plan.n_seg;
+            fw.group_rows = (int)group_rows;
+            fw.seg_tiles = plan.seg_tiles;
+            fw.task_base = (long long)t;
             fw.tail = tail;
             bw = fw;
-            bw.src0 = baselines_dev[i];
+            bw.src0 = z0;
             bw.src1 = z1;
             bw.dst0 = baselines_dev[i];
             bw.dst1 = nullptr;
+            ++n_seams;
+            most_rows = std::max(most_rows, rows[i]);
+        }
+        for (size_t r0 = 0; r0 < rows[i]; r0 += group_rows) {
+            for (int seg = 0; seg < plan.n_seg; ++seg, ++t) {
+                WhittakerRowTask &fw = tasks_host[t], &bw = tasks_host[n_tasks + t];
+                fw.src0 = matrices_dev[i];
+                fw.src1 = nullptr;
+                fw.dst0 = z0;
+                fw.dst1 = z1;
+                fw.n = (long long)cols[i];
+                fw.row0 = (int)r0;
+                fw.rows = (int)std::min<size_t>(group_rows, rows[i] - r0);
+                fw.tail = tail;
+                fw.tile_begin = (long long)seg * plan.seg_tiles;
+                fw.tile_end = (seg + 1 == plan.n_seg) ? all_tiles : (fw.tile_begin + plan.seg_tiles);
+                fw.warm_tiles = (seg > 0) ? plan.warm_tiles : 0;
+                fw.spec = states_dev + (2 * t + 0) * (kStateDoubles / 2);
+                fw.edge = states_dev + (2 * t + 1) * (kStateDoubles / 2);
+                bw = fw;
+                bw.src0 = z0;
+                bw.src1 = z1;
+                bw.dst0 = baselines_dev[i];
+                bw.dst1 = nullptr;
+                bw.warm_tiles = (seg + 1 < plan.n_seg) ? plan.warm_tiles : 0;
+                bw.spec = states_dev + (2 * (n_tasks + t) + 0) * (kStateDoubles / 2);
+                bw.edge = states_dev + (2 * (n_tasks + t) + 1) * (kStateDoubles / 2);
+            }
         }
     }
-    if (n_tasks == 0) {
+    if (n_tasks == 0 || t == 0) {
         ROCCO_HIP_TRY(hipGetLastError());
         return ROCCO_HIP_OK;
     }
-    ROCCO_HIP_TRY(hipMemcpyAsync(tasks_dev, tasks_host_pinned, 2 * n_tasks * sizeof(WhittakerRowTask), hipMemcpyHostToDevice, stream));
+    if (env_loci("ROCCO_HIP_WHITTAKER_TRACE", 0) != 0) {
+        std::fprintf(stderr, "[whittaker] %zu matrices: a workgroup walks <= %lld loci, warm-up %lld, %zu workgroups of <= %d rows (%lld resident), %zu matrices cut\n",
+                     count, seg_loci, env_loci("ROCCO_HIP_WHITTAKER_WARM_LOCI", kWarmLoci), t, kGroupRows, resident_workgroups(), n_seams);
+    }
+    ROCCO_HIP_TRY(hipMemcpyAsync(scratch_dev, stage, stage_bytes, hipMemcpyHostToDevice, stream));
     const dim3 block(kLanes * (1 + kRowHelpers));
-    hipLaunchKernelGGL(whittaker_rows_kernel<false>, dim3((unsigned)n_tasks), block, sizeof(RowTiles), stream,
+    const dim3 seam_grid((unsigned)((most_rows + kLanes - 1) / kLanes), (unsigned)n_seams);
+    hipLaunchKernelGGL(whittaker_rows_kernel<false>, dim3((unsigned)t), block, sizeof(RowTiles), stream,  // (t <= n_tasks records are filled)
                        (const WhittakerRowTask *)tasks_dev, (long long)factor_cap, factor_dev);
-    hipLaunchKernelGGL(whittaker_rows_kernel<true>, dim3((unsigned)n_tasks), block, sizeof(RowTiles), stream,
+    if (n_seams > 0) {
+        hipLaunchKernelGGL(whittaker_seam_kernel<false>, seam_grid, dim3(kLanes), 0, stream, (const WhittakerSeamMatrix *)seams_dev,
+                           states_dev, (long long)n_tasks, (long long)factor_cap, factor_dev, repairs_dev);
+    }
+    hipLaunchKernelGGL(whittaker_rows_kernel<true>, dim3((unsigned)t), block, sizeof(RowTiles), stream,
                        (const WhittakerRowTask *)(tasks_dev + n_tasks), (long long)factor_cap, factor_dev);
+    if (n_seams > 0) {
+        hipLaunchKernelGGL(whittaker_seam_kernel<true>, seam_grid, dim3(kLanes), 0, stream, (const WhittakerSeamMatrix *)(seams_dev + count),
+                           states_dev, (long long)n_tasks, (long long)factor_cap, factor_dev, repairs_dev);
+        // the count of recomputed seams comes back into the staging area's first word (read by whittaker_collect_repairs
+        // once the caller has waited for the stream)
+        ROCCO_HIP_TRY(hipMemcpyAsync(stage, repairs_dev, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    }
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
+}
+
+void whittaker_collect_repairs(const void *tasks_host_pinned)
+{
+    const unsigned long long *back = (const unsigned long long *)tasks_host_pinned;
+    g_seam_repairs.fetch_add((long long)back[0], std::memory_order_relaxed);
+    if (back[0] != 0 && env_loci("ROCCO_HIP_WHITTAKER_TRACE", 0) != 0) {
+        std::fprintf(stderr, "[whittaker] %llu seams recomputed over %llu loci\n", back[0], back[1]);
+    }
 }
 
 }  // namespace rocco

@@ -59,53 +59,74 @@ struct RollingShape {
 template <int G>
 struct RollingRows {
     double S[2][RollingShape<G>::kTile][RollingShape<G>::kPitch];  // (first: within reach of immediate offsets in every shape)
-    double P[RollingShape<G>::kRing][RollingShape<G>::kPitch];
+    // + a copy of the ring's first 8 lines behind its last one: a batch of 8 consecutive lines that starts inside the ring
+    // never needs its line indices masked one by one (round 5; until then every access of every fourth tile was masked:
+    // three integer instructions per operand on the chain wavefront)
+    double P[RollingShape<G>::kRing + 8][RollingShape<G>::kPitch];
 };
 
-// the chains of one tile: batches of 8 start positions, the operand registers ping-pong (the next batch's operands are
-// fetched while this batch's chain runs); past the row's last start the updates read staged zeros, results unused
+// the chains of one tile: batches of 8 start positions; past the row's last start the updates read staged zeros, results
+// unused.  Round 5 (scripts/ubench/chain_ladder.hip, chain_mix.hip): a lone wavefront's LDS instructions do not overlap its
+// dependent FP64 chain -- a ds_read_b64 costs the chain ~7 cycles, a ds_write_b64 ~17 when the next instruction overwrites
+// its source -- and a wait placed by the compiler between a batch's reads and its chain costs an LDS round trip per batch.
+// So: ONE explicit wait per batch, behind it the next batch's reads and the last batch's sums (from registers nothing
+// overwrites for a whole batch), then the batch's 16 additions on registers alone.
+#define ROCCO_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)  // s_waitcnt lgkmcnt(0) (gfx9 encoding; vmcnt / expcnt left open)
 template <int G, bool WRAP>
 __device__ __forceinline__ void rolling_rows_tile(RollingRows<G> &T, long long tile, int a0, int b0, int col, double &sum)
 {
-    constexpr int kTile = RollingShape<G>::kTile, kRing = RollingShape<G>::kRing, kPitch = RollingShape<G>::kPitch;
+    constexpr int kTile = RollingShape<G>::kTile, kPitch = RollingShape<G>::kPitch;
     double(*__restrict__ S)[kPitch] = T.S[tile & 1];
     const double(*__restrict__ A)[kPitch] = T.P + a0;
     auto leaving = [&](int t) -> double { return A[t][col]; };
-    auto entering = [&](int t) -> double { return WRAP ? T.P[(b0 + t) & (kRing - 1)][col] : T.P[b0 + t][col]; };
-    // four operand sets in rotation, fetched TWO batches ahead: when a batch starts, the only LDS accesses younger than its
-    // operands' are one batch's worth (the compiler can wait for exactly those; with the next batch's fetch issued right
-    // before, it waits for everything and the chain stalls for an LDS round trip per batch)
-    double a[4][8], b[4][8];
+    constexpr int kRing = RollingShape<G>::kRing;
+    double a[2][8], b[2][8], s[2][8];
     constexpr int kBatches = kTile / 8;
-    static_assert(kBatches % 4 == 0, "four batches per trip");
+    static_assert(kBatches % 2 == 0, "two batches per trip");
     auto fetch = [&](int set, int batch) {
         const int t = 8 * ((batch < kBatches) ? batch : (kBatches - 1));  // (past the tile's end: the last batch again)
+        // the batch's first entering line (inside the ring; its seven successors may run into the copy behind the ring's end)
+        const double(*__restrict__ B)[kPitch] = T.P + (WRAP ? ((b0 + t) & (kRing - 1)) : (b0 + t));
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             a[set][u] = leaving(t + u);
-            b[set][u] = entering(t + u);
+            b[set][u] = B[u][col];
         }
     };
-    auto run = [&](int set, int batch) {
+    auto flush = [&](int set, int batch) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            S[8 * batch + u][col] = sum;
+            S[8 * batch + u][col] = s[set][u];
+        }
+    };
+    auto run = [&](int set) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s[set][u] = sum;
             sum = (sum - a[set][u]) + b[set][u];  // wls_backend.c:711-722
         }
     };
     fetch(0, 0);
-    fetch(1, 1);
 #pragma unroll 1
-    for (int j = 0; j < kBatches; j += 4) {
-        fetch(2, j + 2);
-        run(0, j);
-        fetch(3, j + 3);
-        run(1, j + 1);
-        fetch(0, j + 4);
-        run(2, j + 2);
-        fetch(1, j + 5);
-        run(3, j + 3);
+    for (int j = 0; j < kBatches; j += 2) {
+        ROCCO_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(1, j + 1);
+        if (j > 0) {
+            flush(1, j - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        run(0);
+        __builtin_amdgcn_sched_barrier(0);
+        ROCCO_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0, j + 2);
+        flush(0, j);
+        __builtin_amdgcn_sched_barrier(0);
+        run(1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    flush(1, kBatches - 1);
 }
 
 template <int G>
@@ -122,21 +143,40 @@ __global__ __launch_bounds__(kLanes + kRowsHelpers) void wls_rolling_rows_kernel
     const int lane = threadIdx.x, hl = (int)threadIdx.x - kLanes;
     const bool helper = hl >= 0;
     const int ht = hl & (kTile - 1), hr = hl / kTile;  // helper: locus within the chunk, row of the group
-    double rv = 0.0, rnx = 0.0;
-    const double *__restrict__ my_row = task.row + (long long)((helper && hr < rows) ? hr : 0) * n;
+    // a chunk is loaded kAhead trips before it is stored to LDS (round 5: with one trip between load and store every tile
+    // waited for a memory latency -- the launch took 22 ns per locus with the chain AND the variances compiled out)
+    constexpr int kAhead = 4;
+    double rv[kAhead], rnx[kAhead];
+#pragma unroll
+    for (int q = 0; q < kAhead; ++q) {
+        rv[q] = 0.0;
+        rnx[q] = 0.0;
+    }
+    typedef const __attribute__((address_space(1))) double *global_row_t;  // (global_load, not flat_load: its own counter)
+    const global_row_t my_row = (global_row_t)(task.row + (long long)((helper && hr < rows) ? hr : 0) * n);
 
-    auto load_chunk = [&](long long chunk) {  // (zeros past the row's end and for rows the task does not have)
+    // (the loaded values stay untouched in their registers until store_chunk: a select on a value just loaded is a wait
+    // for the load -- a memory latency per trip, which is what the launch took until round 5)
+    auto load_chunk = [&](long long chunk, double &v_out, double &nx_out) {
         const long long i = chunk * kTile + ht;
         const long long i0 = (i < n) ? i : (n - 1), i1 = (i + 1 < n) ? (i + 1) : (n - 1);
-        const double v = my_row[i0], nx = my_row[i1];
-        rv = (hr < rows && i < n) ? v : 0.0;
-        rnx = (hr < rows && i + 1 < n) ? nx : 0.0;
+        v_out = my_row[i0];
+        nx_out = my_row[i1];
     };
-    auto store_chunk = [&](long long chunk) {
-        double *__restrict__ line = T.P[(int)((chunk * kTile + ht) & (kRing - 1))];
-        line[3 * hr] = rv;
-        line[3 * hr + 1] = rv * rv;
-        line[3 * hr + 2] = rv * rnx;
+    auto store_chunk = [&](long long chunk, double v_raw, double nx_raw) {  // (zeros past the row's end and for rows the task does not have)
+        const long long i = chunk * kTile + ht;
+        const double v = (hr < rows && i < n) ? v_raw : 0.0, nx = (hr < rows && i + 1 < n) ? nx_raw : 0.0;
+        const int at = (int)(i & (kRing - 1));
+        double *__restrict__ line = T.P[at];
+        line[3 * hr] = v;
+        line[3 * hr + 1] = v * v;
+        line[3 * hr + 2] = v * nx;
+        if (at < 8) {  // (the copy behind the ring's end)
+            double *__restrict__ copy = T.P[kRing + at];
+            copy[3 * hr] = v;
+            copy[3 * hr + 1] = v * v;
+            copy[3 * hr + 2] = v * nx;
+        }
     };
     // the variances of tile `tile` from its sums (wls_backend.c:667-709; the divisions are off the chains)
     auto variances = [&](long long tile) {
@@ -173,17 +213,21 @@ __global__ __launch_bounds__(kLanes + kRowsHelpers) void wls_rolling_rows_kernel
         if (omb < 0.0) {
             omb = 0.0;
         }
-        task.out[(long long)hr * stride_out + t] = fmax(gamma0 * omb, 0.0);
+        ((__attribute__((address_space(1))) double *)task.out)[(long long)hr * stride_out + t] = fmax(gamma0 * omb, 0.0);  // (global_store: flat_store would tie the load counter to the LDS counter)
     };
 
     if (helper) {
-        load_chunk(0);
-        store_chunk(0);
-        load_chunk(1);
-        store_chunk(1);
-        load_chunk(2);
+        double v0, nx0;
+        load_chunk(0, v0, nx0);
+        store_chunk(0, v0, nx0);
+        load_chunk(1, v0, nx0);
+        store_chunk(1, v0, nx0);
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) {
+            load_chunk(2 + q, rv[q], rnx[q]);  // (chunk c waits in set (c - 2) % kAhead)
+        }
     }
-    __syncthreads();
+    lds_barrier();
     const int chain = lane % 3;
     const int off = (chain == 2) ? (window - 1) : window;
     const bool runs = !helper && lane < 3 * G;
@@ -197,7 +241,14 @@ __global__ __launch_bounds__(kLanes + kRowsHelpers) void wls_rolling_rows_kernel
             sum += T.P[i][col];
         }
     }
-    for (long long tile = 0; tile < n_tiles; ++tile) {
+#ifdef ROCCO_ROLL_STAMPS  // (timing experiments only: where the wavefronts of workgroup 0 spend their cycles)
+    long long st_work = 0, st_wait = 0, st_a = 0, st_b = 0, st_c = 0;
+#define ROCCO_STAMP(x) const long long x = __builtin_readcyclecounter()
+#else
+#define ROCCO_STAMP(x)
+#endif
+    auto trip = [&](long long tile, double &set_v, double &set_nx) {
+        ROCCO_STAMP(t0);
 #ifdef ROCCO_ROLL_NOCHAIN  // (timing experiments only)
         if (false) {
 #else
@@ -205,6 +256,8 @@ __global__ __launch_bounds__(kLanes + kRowsHelpers) void wls_rolling_rows_kernel
 #endif
             // a tile's own lines are consecutive ring lines; the lines `off` further on are consecutive too unless the
             // ring's end falls among them (every fourth tile): only then is the line index masked per access
+            // a tile's own lines are consecutive ring lines; the lines `off` further on are consecutive too unless the
+            // ring's end falls among them (every fourth tile): only then is the line index masked, once per batch
             const int a0 = (int)((tile * kTile) & (kRing - 1)), b0 = (a0 + off) & (kRing - 1);
             if (b0 + kTile <= kRing) {
                 rolling_rows_tile<G, false>(T, tile, a0, b0, col, sum);
@@ -212,19 +265,50 @@ __global__ __launch_bounds__(kLanes + kRowsHelpers) void wls_rolling_rows_kernel
                 rolling_rows_tile<G, true>(T, tile, a0, b0, col, sum);
             }
         } else if (helper) {
-            store_chunk(tile + 2);  // (in the registers since the tile before)
-            load_chunk(tile + 3);
+            store_chunk(tile + 2, set_v, set_nx);  // (in the registers since kAhead trips)
+            ROCCO_STAMP(ta);
+            load_chunk(tile + 2 + kAhead, set_v, set_nx);
+            ROCCO_STAMP(tb);
 #ifndef ROCCO_ROLL_NOVAR
             if (tile > 0) {
                 variances(tile - 1);
             }
 #endif
+#ifdef ROCCO_ROLL_STAMPS
+            ROCCO_STAMP(tc);
+            st_a += ta - t0;
+            st_b += tb - ta;
+            st_c += tc - tb;
+#endif
         }
-        __syncthreads();
+        ROCCO_STAMP(t1);
+        lds_barrier();
+#ifdef ROCCO_ROLL_STAMPS
+        ROCCO_STAMP(t2);
+        st_work += t1 - t0;
+        st_wait += t2 - t1;
+#endif
+    };
+    for (long long tile = 0; tile < n_tiles; tile += kAhead) {
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) {
+            if (tile + q < n_tiles) {
+                trip(tile + q, rv[q], rnx[q]);
+            }
+        }
     }
     if (helper) {
         variances(n_tiles - 1);
     }
+#ifdef ROCCO_ROLL_STAMPS
+    if (blockIdx.x == 0 && (threadIdx.x % kLanes) == 0) {
+        const int w = threadIdx.x / kLanes;
+        if (w < 3) {
+            printf("[roll stamps] wave %d: tiles %lld, cycles per tile: work %lld (store %lld, load %lld, variances %lld), barrier wait %lld\n", w, n_tiles,
+                   st_work / n_tiles, st_a / n_tiles, st_b / n_tiles, st_c / n_tiles, st_wait / n_tiles);
+        }
+    }
+#endif
 }
 
 // ---- any window (above the LDS-tiled kernel's 63 loci): the same three chains straight from global memory, one

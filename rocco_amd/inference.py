@@ -155,21 +155,29 @@ def wls_spatial_window(n: int, requested: int = 31) -> int:
     return w if w >= 5 else 0
 
 
-def wls_rolling_variances_batch_device(centered_list, spatial_window: int = 31):
+def wls_rolling_variances_batch_device(centered_list, spatial_window: int = 31, arena=None):
     """Every row's rolling AR(1) innovation variances (wls_backend.c:610-742) for the rows of SEVERAL centred matrices in
     one launch (rocco_hip_wls_rolling_variances_batch_f64).  Returns one tensor [K_i, n_i - window_i + 1] per matrix
-    (None where the scoring does not use them: fewer than 5 loci)."""
+    (None where the scoring does not use them: fewer than 5 loci).  ``arena``: a flat float64 CUDA tensor of at least
+    the matrices' values, which the results are then views of (the count-path batch hands each pipeline ONE block for
+    its baselines and, after them, its variances: no allocation while the pipelines run)."""
     import ctypes
 
     import torch
 
     centered_list = list(centered_list)
     count = len(centered_list)
-    outs = []
+    outs, used = [], 0
     for c in centered_list:
         K, n = int(c.shape[0]), int(c.shape[1])
         w = wls_spatial_window(n, spatial_window)
-        outs.append(torch.empty((K, n - w + 1), dtype=torch.float64, device=c.device) if (w > 0 and n >= 4) else None)
+        if not (w > 0 and n >= 4):
+            outs.append(None)
+        elif arena is None:
+            outs.append(torch.empty((K, n - w + 1), dtype=torch.float64, device=c.device))
+        else:
+            outs.append(arena[used:used + K * (n - w + 1)].view(K, n - w + 1))
+            used += K * (n - w + 1)
     if count == 0:
         return outs
     solver = _native.solver_for(centered_list[0].device.index)
@@ -464,11 +472,11 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
             stream.wait_event(start)
             for part in chunks_of[slot]:
-                run_chunk(solver, stream, part, stamp)
+                run_chunk(solver, stream, part, stamp, slot)
             stream.synchronize()
             stamp("done")
 
-    def run_chunk(solver, stream, idx, stamp):
+    def run_chunk(solver, stream, idx, stamp, slot):
         # phase 1: log scale, pilot offset (rocco/inference.py:325, 333-334)
         centred = {i: log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite[i] else None,
                                                    apply_log2=(input_scale == "counts"))[0] for i in idx}
@@ -476,9 +484,15 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         # phase 2: local baselines (335), the group's matrices of one penalty together, and their subtraction (338)
         windows = {i: _resolve_local_baseline_window(int(centred[i].shape[1]), target_window=101) for i in idx}
         penalties = {i: (0.0 if windows[i] == 0 else _consenrich_whittaker_lambda(windows[i])) for i in idx}
+        arena = arenas[slot]
         for lam in sorted({penalties[i] for i in idx if windows[i] != 0}):
             same = [i for i in idx if windows[i] != 0 and penalties[i] == lam]
-            baselines = crossfit_whittaker_baseline_batch_device([centred[i] for i in same], lam)
+            views, used = [], 0
+            for i in same:  # (the pipeline's one block: the baselines now, the rolling variances after them)
+                k_i, n_i = int(centred[i].shape[0]), int(centred[i].shape[1])
+                views.append(arena[used:used + k_i * n_i].view(k_i, n_i))
+                used += k_i * n_i
+            baselines = crossfit_whittaker_baseline_batch_device([centred[i] for i in same], lam, outs=views)
             for i, b in zip(same, baselines):
                 c = centred[i]
                 rc = _native.load().rocco_hip_subtract_finite_f64(solver.handle, c.data_ptr(), b.data_ptr(), c.data_ptr(),
@@ -490,7 +504,7 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         stamp("rolling variances start")
         # phase 3: the centred WLS (342-348): the rolling variances of every row of the group in one launch (one
         # workgroup per row), then rank finding, trend fits and accumulation matrix by matrix
-        variances = dict(zip(idx, wls_rolling_variances_batch_device([centred[i] for i in idx], spatial_window=31)))
+        variances = dict(zip(idx, wls_rolling_variances_batch_device([centred[i] for i in idx], spatial_window=31, arena=arena)))
         stamp("trend fits and accumulation start")
         for i in idx:
             c = centred[i]
@@ -522,25 +536,34 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         # Every pipeline's solver is sized HERE, on the calling thread, for the matrices it is about to see (scratch of the
         # baseline sweeps, the rolling task table, the trend fit's scratch, the Whittaker factor of its longest row): no
         # worker thread allocates or frees device memory -- both synchronise the whole device -- while the others are in flight.
-        # chunks: what a pipeline holds beside the inputs is ~4x the chunk it works on (+ a copy of every matrix that
-        # may not be centred in place, which stays as the result's centred matrix)
+        # chunks: beside the inputs a pipeline holds, for the chunk of C bytes it works on, C of tensors (the baselines, then
+        # the rolling variances in their place) and 2 C of solver scratch (the forward sweep's two parities: the backward
+        # sweep's segments read beyond their own ends, so it does not run in place); the solver keeps its scratch
+        # between calls, so only what it has to GROW counts against what is free
         torch.cuda.synchronize(device)
+        if memory_budget_bytes is None and sum(8 * v for v in sizes) > (8 << 30):
+            torch.cuda.empty_cache()  # (blocks cached in other sizes are of no use to this call: hand them back first)
         free_now, _total = torch.cuda.mem_get_info(device)
-        # what the call may take: free memory, what PyTorch's allocator caches without using, and what the pipelines'
-        # solvers already hold from earlier calls (their scratch is reused, not allocated again)
         cached = max(0, int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device)))
-        held = sum(int(_native.load().rocco_hip_solver_device_bytes(_batch_worker(device.index, slot)[0].handle))
-                   for slot in range(len(groups)))
-        budget = int(0.92 * (free_now + cached + held)) if memory_budget_bytes is None else int(memory_budget_bytes)
+        holds = [int(_native.load().rocco_hip_solver_device_bytes(_batch_worker(device.index, slot)[0].handle))
+                 for slot in range(len(groups))]
+        budget = int(0.88 * (free_now + cached)) if memory_budget_bytes is None else int(memory_budget_bytes)
         copies = sum(8 * sizes[i] for i in range(len(counts_list)) if not overwrite[i])
+        # (what the call returns stays allocated: eight tracks of n doubles per matrix -- 20 GB for 309 M loci -- + slack)
+        results = sum(10 * 8 * int(c.shape[1]) for c in counts_list) + (2 << 30)
         everything = max(1, sum(8 * sizes[i] for idx in groups for i in idx))
         chunks_of = []
-        for idx in groups:
+        for slot, idx in enumerate(groups):
             # (a pipeline's share of the budget is its share of the values)
-            per_group = max(0, budget - copies) * sum(8 * sizes[i] for i in idx) // everything
+            per_group = max(0, budget - copies - (results if memory_budget_bytes is None else 0)) * sum(8 * sizes[i] for i in idx) // everything
+
+            def need(chunk_bytes, slot=slot):
+                grow = int(2.2 * chunk_bytes) + (64 << 20) - (holds[slot] if memory_budget_bytes is None else 0)  # (2 C + 1/16 + records)
+                return chunk_bytes + max(0, grow)
+
             parts, part, held = [], [], 0
             for i in idx:  # (longest first: a chunk's first matrix holds its longest rows)
-                if part and 4 * (held + 8 * sizes[i]) > per_group:
+                if part and need(held + 8 * sizes[i]) > per_group:
                     parts.append(part)
                     part, held = [], 0
                 part.append(i)
@@ -549,6 +572,9 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
             chunks_of.append(parts)
         if trace:
             print(f"[batch] {len(groups)} pipelines, chunks per pipeline {[len(p) for p in chunks_of]}, budget {budget / 1e9:.1f} GB", flush=True)
+        # each pipeline's block for its baselines and (after them) its rolling variances: its largest chunk, allocated here
+        arenas = [torch.empty(max(sum(sizes[i] for i in part) for part in parts), dtype=torch.float64, device=device)
+                  for parts in chunks_of]
         for slot, parts in enumerate(chunks_of):
             solver, _stream = _batch_worker(device.index, slot)
             for idx in parts:

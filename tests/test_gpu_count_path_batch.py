@@ -55,6 +55,64 @@ def test_whittaker_batch_row_groups_and_lengths(gpu, oracle):
         inference.crossfit_whittaker_baseline_batch_device([m], lam, outs=[m])
 
 
+def _seam_repairs():
+    from rocco_amd import _native
+
+    return int(_native.load().rocco_hip_whittaker_seam_repairs())
+
+
+def test_rows_cut_into_segments_are_the_sequential_sweeps_bits(gpu, oracle, monkeypatch):
+    """Round 5: long rows are cut into segments whose workgroups start from a warm-up (csrc/whittaker.hip).  Default
+    settings on rows long enough to be cut (2 and 3 segments, lengths around the 64-locus tiles, a lone matrix and a
+    batch): every baseline the oracle's bit for bit, and no seam had to be recomputed."""
+    import torch
+    from rocco_amd import inference
+
+    rng = np.random.default_rng(51)
+    lam = inference._consenrich_whittaker_lambda(101)
+    before = _seam_repairs()
+    shapes = [(3, 262144), (9, 300001), (2, 393279), (17, 262207)]
+    hosts = [rng.normal(0.0, 1.3, size=s) for s in shapes]
+    hosts[1][:, 1000:90000] = 0.0  # a long run of exact zeros
+    hosts[2][:] = np.round(hosts[2] * 4.0) / 4.0  # a coarse grid: many ties
+    outs = inference.crossfit_whittaker_baseline_batch_device([torch.from_numpy(h).to(gpu) for h in hosts], lam)
+    for h, o in zip(hosts, outs):
+        assert o.cpu().numpy().tobytes() == oracle.crossfit_whittaker_baseline(h, lam).tobytes(), h.shape
+    one = inference.crossfit_whittaker_baseline_batch_device([torch.from_numpy(hosts[1]).to(gpu)], lam)[0]
+    assert one.cpu().numpy().tobytes() == oracle.crossfit_whittaker_baseline(hosts[1], lam).tobytes()
+    assert _seam_repairs() == before, "a warm-up of 131 072 loci did not reach the row's own values"
+
+
+@pytest.mark.parametrize("segment,warm", [(4096, 64), (1024, 128), (8192, 2048), (20000, 20000)])
+def test_seams_that_have_not_met_are_recomputed(gpu, oracle, monkeypatch, segment, warm):
+    """The same with segments and warm-ups far too short (ROCCO_HIP_WHITTAKER_SEGMENT_LOCI / _WARM_LOCI): nearly every
+    seam differs from its predecessor's end state and is recomputed from it -- some to the segment's end, which moves
+    the next seam's truth.  Results are the oracle's bits all the same; the counter says the seams were recomputed."""
+    import torch
+    from rocco_amd import inference
+
+    monkeypatch.setenv("ROCCO_HIP_WHITTAKER_SEGMENT_LOCI", str(segment))
+    monkeypatch.setenv("ROCCO_HIP_WHITTAKER_WARM_LOCI", str(warm))
+    rng = np.random.default_rng(segment + warm)
+    shapes = [(3, 50000), (10, 33333), (1, 70001), (8, 2 * segment), (5, 2 * segment - 1), (4, 3 * segment + 65)]
+    for lam in (inference._consenrich_whittaker_lambda(101), inference._consenrich_whittaker_lambda(9)):
+        before = _seam_repairs()
+        hosts = [rng.normal(0.0, 2.0, size=s) for s in shapes]
+        hosts[0][:, ::7] = 0.0
+        outs = inference.crossfit_whittaker_baseline_batch_device([torch.from_numpy(h).to(gpu) for h in hosts], lam)
+        for h, o in zip(hosts, outs):
+            assert o.cpu().numpy().tobytes() == oracle.crossfit_whittaker_baseline(h, lam).tobytes(), (h.shape, lam)
+        if warm < 1000 and lam > 1000.0:
+            assert _seam_repairs() > before
+    monkeypatch.setenv("ROCCO_HIP_WHITTAKER_SEGMENT_LOCI", "0")  # rows are never cut: the round-3 launch
+    h = rng.normal(size=(9, 40000))
+    lam = inference._consenrich_whittaker_lambda(101)
+    before = _seam_repairs()
+    o = inference.crossfit_whittaker_baseline_batch_device([torch.from_numpy(h).to(gpu), torch.from_numpy(h[:2]).to(gpu)], lam)[0]
+    assert o.cpu().numpy().tobytes() == oracle.crossfit_whittaker_baseline(h, lam).tobytes()
+    assert _seam_repairs() == before
+
+
 def test_batch_errors(gpu):
     import torch
     from rocco_amd import inference
