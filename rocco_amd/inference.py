@@ -541,8 +541,6 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         # sweep's segments read beyond their own ends, so it does not run in place); the solver keeps its scratch
         # between calls, so only what it has to GROW counts against what is free
         torch.cuda.synchronize(device)
-        if memory_budget_bytes is None and sum(8 * v for v in sizes) > (8 << 30):
-            torch.cuda.empty_cache()  # (blocks cached in other sizes are of no use to this call: hand them back first)
         free_now, _total = torch.cuda.mem_get_info(device)
         cached = max(0, int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device)))
         holds = [int(_native.load().rocco_hip_solver_device_bytes(_batch_worker(device.index, slot)[0].handle))
@@ -573,8 +571,16 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         if trace:
             print(f"[batch] {len(groups)} pipelines, chunks per pipeline {[len(p) for p in chunks_of]}, budget {budget / 1e9:.1f} GB", flush=True)
         # each pipeline's block for its baselines and (after them) its rolling variances: its largest chunk, allocated here
-        arenas = [torch.empty(max(sum(sizes[i] for i in part) for part in parts), dtype=torch.float64, device=device)
-                  for parts in chunks_of]
+        def make_arenas():
+            return [torch.empty(max(sum(sizes[i] for i in part) for part in parts), dtype=torch.float64, device=device)
+                    for parts in chunks_of]
+
+        try:
+            arenas = make_arenas()
+        except torch.OutOfMemoryError:
+            # (the budget counted what the allocator caches as usable: cached blocks of other sizes are not -- hand them back)
+            torch.cuda.empty_cache()
+            arenas = make_arenas()
         for slot, parts in enumerate(chunks_of):
             solver, _stream = _batch_worker(device.index, slot)
             for idx in parts:
