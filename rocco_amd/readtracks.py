@@ -9,12 +9,21 @@ There is no CPU fallback: without the library or a GPU these raise.
 from __future__ import annotations
 
 import ctypes
+import logging
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from . import _native
 from . import dp as _dp
+
+try:  # (optional, as in the reference: rocco/readtracks.py:17-20)
+    import pyBigWig
+except ImportError:  # pragma: no cover - depends on an optional package
+    pyBigWig = None
+
+logger = logging.getLogger(__name__)
 
 
 def assemble_chrom_matrix_device(interval_matrix: Sequence, vals_matrix: Sequence, track_type: str = "bam",
@@ -130,3 +139,118 @@ def bigwig_dense_fill(starts, ends, vals, const_scale: float = 1.0, round_digits
     first, step, full_t = bigwig_dense_fill_device(starts, ends, vals, const_scale, round_digits, bigwig_file, chromosome)
     full_intervals = np.arange(first, first + step * int(full_t.shape[0]), step, dtype=np.int64)
     return full_intervals.astype(int), full_t.cpu().numpy()
+
+
+# --------------------------------------------------------------------------------------------
+# the reference's two entry points around the kernels above (same names, arguments, return values and errors)
+# --------------------------------------------------------------------------------------------
+
+def _require_pybigwig():
+    """rocco/readtracks.py:75-80."""
+    if pyBigWig is None:
+        raise ImportError("bigWig input requires the optional `pyBigWig` dependency...try `python -m pip install pybigwig`")
+    return pyBigWig
+
+
+def _get_track_type(track_file: str) -> str:
+    """rocco/readtracks.py:83-91."""
+    ext = os.path.splitext(track_file)[1].lower().lstrip(".")
+    if ext == "bam":
+        return "bam"
+    if ext in {"bw", "bigwig"}:
+        return "bigwig"
+    raise ValueError(f"Unsupported input file type for `{track_file}`. Expected BAM or bigWig.")
+
+
+def get_chroms_and_sizes(chrom_sizes_file) -> dict:
+    """rocco/readtracks.py:362-386: ``{chromosome: size}`` from a two-column tab-separated file."""
+    if chrom_sizes_file is None or not os.path.exists(chrom_sizes_file):
+        raise FileNotFoundError(f"Sizes file, {chrom_sizes_file}, not found or is `None`")
+    sizes = {}
+    with open(chrom_sizes_file, "r", encoding="utf-8") as handle:
+        for line in handle:
+            if not line.strip():
+                continue
+            fields = line.rstrip("\n").split("\t")
+            sizes[fields[0]] = int(fields[1])
+    return sizes
+
+
+def get_bam_chrom_reads(bam_file, *_args, **_kwargs):
+    """The reference counts reads here through htslib (rocco/readtracks.py:389-518 over rocco/_hts_counts.c): BAM decoding
+    is out of this package's scope.  ``generate_chrom_matrix`` looks this name up in the
+    module when it is called, so an integrator puts the reference's reader (or any ``(starts, values)`` source) here."""
+    raise RuntimeError("rocco_amd does not decode BAM files: replace rocco_amd.readtracks.get_bam_chrom_reads with the "
+                       f"reference's reader (asked for {bam_file})")
+
+
+def get_bigwig_chrom_scores(bigwig_file: str, chromosome: str, chrom_sizes_file: str, const_scale: float = 1.0,
+                            round_digits: int = 5):
+    """rocco/readtracks.py:94-186 with the same arguments, return value and errors: pyBigWig (when installed) hands back the
+    chromosome's intervals; validation, dense fill of the fixed-step grid, scaling and rounding run on the device
+    (`bigwig_dense_fill`).  Pinned by tests/golden/assemble_vectors.npz, which the reference's own function wrote over a
+    stand-in pyBigWig object."""
+    if not os.path.exists(bigwig_file):
+        raise FileNotFoundError(f"bigWig file not found: {bigwig_file}")
+    if not os.path.exists(chrom_sizes_file):
+        raise FileNotFoundError(f"Chromosome sizes file not found: {chrom_sizes_file}")
+    if chromosome not in get_chroms_and_sizes(chrom_sizes_file):
+        raise ValueError(f"Chromosome {chromosome} not found in chromosome sizes file: {chrom_sizes_file}")
+    bw = _require_pybigwig().open(bigwig_file)
+    if bw is None:
+        raise RuntimeError(f"Could not open bigWig file: {bigwig_file}...try installing `pyBigWig`: `python -m pip install pybigwig`")
+    try:
+        if chromosome not in bw.chroms():
+            logger.warning("Chromosome %s not found in bigWig file: %s. Returning (None,None).", chromosome, bigwig_file)
+            return None, None
+        intervals_raw = bw.intervals(chromosome)
+    finally:
+        bw.close()
+    if intervals_raw is None or len(intervals_raw) == 0:
+        logger.warning("No intervals found in bigWig file: %s for chromosome: %s. Returning (None,None).", bigwig_file, chromosome)
+        return None, None
+    starts = np.asarray([int(entry[0]) for entry in intervals_raw], dtype=np.int64)
+    ends = np.asarray([int(entry[1]) for entry in intervals_raw], dtype=np.int64)
+    vals = np.asarray([float(entry[2]) for entry in intervals_raw], dtype=np.float64)
+    if const_scale == 0:
+        logger.warning("You are scaling the values by 0.")
+    return bigwig_dense_fill(starts, ends, vals, const_scale=const_scale, round_digits=round_digits, bigwig_file=bigwig_file,
+                             chromosome=chromosome)
+
+
+def generate_chrom_matrix(chromosome: str, input_files: list, chrom_sizes_file: str, step: int, const_scale: float = 1.0,
+                          round_digits: int = 5, scale_by_step: bool = False, effective_genome_size: float = -1,
+                          norm_method: str = "RPGC", min_mapping_score: int = 10, flag_include=None, flag_exclude: int = 3844,
+                          extend_reads: int = -1, center_reads: bool = False, ignore_for_norm=None, scale_factor: float = 1.0,
+                          num_processors: int = -1, low_memory: bool = False):
+    """rocco/readtracks.py:521-633 with the same signature: one ``(starts, values)`` list per input file from the per-file
+    reader of its type (`get_bam_chrom_reads` / `get_bigwig_chrom_scores`, looked up in this module when called, with the
+    reference's positional arguments), files without data excluded, ``(None, None)`` when none has any; then the union
+    of starts, the bigWig fixed-step check and the dense K x m matrix on the device (`assemble_chrom_matrix`).  The
+    readers run one after the other in this process (one process per GPU: no fork pool behind an initialised device).
+    Pinned by tests/golden/assemble_vectors.npz, written by the reference's own function with its readers replaced."""
+    track_types = {_get_track_type(input_file) for input_file in input_files}
+    if len(track_types) != 1:
+        raise ValueError("All input files must share the same type.")
+    track_type = next(iter(track_types))
+    threads = max((os.cpu_count() or 2) - 1, 1) if (num_processors is None or int(num_processors) < 1) else int(num_processors)
+    reads = globals()
+    if track_type == "bam":
+        count_results = [reads["get_bam_chrom_reads"](input_file, chromosome, chrom_sizes_file, step, effective_genome_size, norm_method,
+                                                      min_mapping_score, flag_include, flag_exclude, extend_reads, center_reads,
+                                                      ignore_for_norm, scale_factor, threads, const_scale, round_digits, scale_by_step)
+                         for input_file in input_files]
+    else:
+        count_results = [reads["get_bigwig_chrom_scores"](input_file, chromosome, chrom_sizes_file, const_scale, round_digits)
+                         for input_file in input_files]
+    interval_matrix, vals_matrix = [], []
+    for input_file, (intervals_, vals_) in zip(input_files, count_results):
+        if intervals_ is None or vals_ is None:
+            logger.warning(f"No data found for {input_file} in chromosome {chromosome}. Excluding this track for {chromosome}.")
+            continue
+        interval_matrix.append(intervals_)
+        vals_matrix.append(vals_)
+    if len(interval_matrix) == 0:
+        logger.warning(f"No data found in the files {str(input_files)} for chromosome {chromosome}. Returning (None,None).")
+        return None, None
+    return assemble_chrom_matrix(interval_matrix, vals_matrix, track_type=track_type, low_memory=low_memory, chromosome=chromosome)

@@ -1,10 +1,95 @@
-"""GPU: signal-matrix assembly (the tail of generate_chrom_matrix, rocco/readtracks.py:614-633; SURVEY.md section 8
-(f), item 2) through the C ABI against the same NumPy statements: exact.  (The reference's tests reach this code
-only through file readers that are not installed here, so there is no reference fixture for it.)"""
+"""GPU: signal-matrix assembly (generate_chrom_matrix, rocco/readtracks.py:521-633, and get_bigwig_chrom_scores, 94-186;
+SURVEY.md section 8 (f), item 2) through the C ABI: against fixtures the REFERENCE's own two functions wrote
+(tests/golden/make_golden_assemble.py: its per-file readers replaced in the module, a stand-in pyBigWig) and against the
+oracle's NumPy statements on larger random tracks -- arrays bit for bit, errors word for word."""
+import os
+import types
+
 import numpy as np
 import pytest
 
+import assemble_golden as ag
+
 pytestmark = pytest.mark.gpu
+
+
+def test_generate_chrom_matrix_as_the_reference_ran_it(gpu, monkeypatch):
+    """Every scenario of tests/golden/assemble_vectors.json through rocco_amd.readtracks.generate_chrom_matrix, called as the
+    reference's function is called and with the per-file readers replaced in the module as the fixture script replaced the
+    reference's: ragged, repeated and unsorted starts, a file without data (excluded), none with data ((None, None)),
+    bigWig tracks of two phases, a broken step (the reference's ValueError text), --low_memory float32, one track."""
+    from rocco_amd import readtracks
+
+    arrays, meta = ag.load()
+    for record in meta["matrix"]:
+        name = record["name"]
+        table = dict(zip(record["files"], ag.matrix_tracks(arrays, record)))
+        calls = []
+
+        def reader(track_file, *args, _table=table, _calls=calls):
+            _calls.append((track_file, len(args)))
+            entry = _table[track_file]
+            return (None, None) if entry is None else (entry[0], entry[1])
+
+        monkeypatch.setattr(readtracks, "get_bam_chrom_reads", reader)
+        monkeypatch.setattr(readtracks, "get_bigwig_chrom_scores", reader)
+        call = lambda: readtracks.generate_chrom_matrix("chrT", list(record["files"]), "unused.sizes", 50, num_processors=1, **record["kwargs"])
+        if "error" in record:
+            with pytest.raises(ValueError) as info:
+                call()
+            assert str(info.value) == record["error"], name
+            continue
+        intervals, matrix = call()
+        # (one call per file, in order, with the reference's positional arguments: 16 after the file for BAM, 4 for bigWig)
+        assert [c[0] for c in calls] == record["files"] and {c[1] for c in calls} <= {16, 4}, name
+        if record.get("none"):
+            assert intervals is None and matrix is None, name
+            continue
+        want_i, want_m = arrays[f"m_{name}_intervals"], arrays[f"m_{name}_matrix"]
+        assert intervals.dtype == want_i.dtype and np.array_equal(intervals, want_i), name
+        assert matrix.dtype == want_m.dtype and matrix.shape == want_m.shape and matrix.tobytes() == want_m.tobytes(), name
+
+
+def test_get_bigwig_chrom_scores_as_the_reference_ran_it(gpu, monkeypatch, tmp_path):
+    """Every get_bigwig_chrom_scores scenario of the fixture through rocco_amd.readtracks.get_bigwig_chrom_scores over the
+    same stand-in pyBigWig object: gaps zero-filled, np.round at 0 / 2 / 5 / 6 digits incl. half-way values, the constant
+    scale (1/2, 1/3, 0, negative = none), the five validations and the three early returns, the handle closed every time."""
+    from rocco_amd import readtracks
+
+    arrays, meta = ag.load()
+    sizes = tmp_path / "t.sizes"
+    sizes.write_text("chrT\t1000000\nchrU\t5000\n")
+    bw = tmp_path / "t.bw"
+    bw.write_bytes(b"")
+    for record in meta["bigwig"]:
+        name = record["name"]
+        intervals = ag.bigwig_intervals(arrays, record)
+        chroms = {c: 1 for c in record["chroms"]}
+        handle = ag.FakeBigWig(chroms, {record["chromosome"]: intervals} if intervals is not None else {})
+        fake = types.ModuleType("pyBigWig")
+        fake.open = lambda _path, _handle=handle: _handle
+        monkeypatch.setattr(readtracks, "pyBigWig", fake)
+        call = lambda: readtracks.get_bigwig_chrom_scores(str(bw), record["chromosome"], str(sizes), **record["kwargs"])
+        if "error" in record:
+            with pytest.raises(ValueError) as info:
+                call()
+            assert str(info.value) == record["error"].replace("{file}", str(bw)).replace("{sizes}", str(sizes)), name
+            continue
+        out_i, out_v = call()
+        assert handle.closed, name
+        if record.get("none"):
+            assert out_i is None and out_v is None, name
+            continue
+        want_i, want_v = arrays[f"b_{name}_intervals"], arrays[f"b_{name}_out"]
+        assert out_i.dtype == want_i.dtype and np.array_equal(out_i, want_i), name
+        assert out_v.dtype == want_v.dtype and out_v.tobytes() == want_v.tobytes(), name
+    monkeypatch.setattr(readtracks, "pyBigWig", None)
+    with pytest.raises(ImportError, match="pyBigWig"):
+        readtracks.get_bigwig_chrom_scores(str(bw), "chrT", str(sizes))
+    with pytest.raises(FileNotFoundError):
+        readtracks.get_bigwig_chrom_scores(str(tmp_path / "missing.bw"), "chrT", str(sizes))
+    with pytest.raises(RuntimeError, match="does not decode BAM"):
+        readtracks.generate_chrom_matrix("chrT", ["a.bam"], str(sizes), 50)
 
 
 def make_tracks(rng, K, n, step, ragged, duplicates):
