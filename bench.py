@@ -199,11 +199,11 @@ def _composed_driver_leg(args, genome, device, works, mine, po):
     names = [n for n, _ in genome]
     total = sum(n for _, n in genome)
 
-    def run(inputs, chroms, track_type, multipliers, tmp):
+    def run(inputs, chroms, track_type, multipliers, tmp, **more):
         phases, mult = {}, {}
         budget.collect_timings(mult)
         run_args = dict(base, input_track_type=track_type, budget_null_multipliers=multipliers, _phase_seconds=phases,
-                        output=os.path.join(tmp, f"{track_type}_{multipliers}.bed"))
+                        output=os.path.join(tmp, f"{track_type}_{multipliers}{'_consumed' if more else ''}.bed"), **more)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = rr.run_chromosomes(chroms, inputs, run_args, run_id="b")
@@ -265,8 +265,13 @@ def _composed_driver_leg(args, genome, device, works, mine, po):
             one_dev, bed_dev = run({small: counts[small]}, [small], "bam", "device", tmp)
             one_host, bed_host = run({small: counts[small]}, [small], "bam", "host", tmp)
             one_dev["bed_equal_to_host_multipliers_run"] = open(bed_dev).read() == open(bed_host).read()
+            # the same with the matrices handed over (`consume_inputs`: centred in place, no copies; they are the caller's no more)
+            torch.cuda.reset_peak_memory_stats()
+            consumed, bed_consumed = run(counts, order, "bam", "device", tmp, consume_inputs=True)
+            consumed["peak_torch_memory_GB"] = round(torch.cuda.max_memory_allocated() / 1e9, 1)
+            consumed["bed_equal_to_the_run_that_kept_its_inputs"] = open(bed_consumed).read() == open(_bed).read()
             leg[f"counts_K{args.samples}_whole_genome"] = {
-                "device_multipliers": genome_counts,
+                "device_multipliers": genome_counts, "device_multipliers_inputs_consumed": consumed,
                 "one_chromosome": {"chromosome": small, "device_multipliers": one_dev, "host_multipliers": one_host,
                                    "note": "host multipliers (NumPy normals + SciPy FFT for K rows per draw) on the whole genome take "
                                            "hours; their cost is shown on the shortest chromosome"}}

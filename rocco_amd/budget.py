@@ -439,6 +439,10 @@ def estimate_budget_nonnull_fraction_from_score_track(score_track, dependence_la
                                    ahead=1 if on_device else int(max(1, num_processes)))
     elif source.n != n or source.max_draws != max_draws or not np.array_equal(source.taps, taps):
         raise ValueError("`weights_source` was made for another track")
+    elif on_device and (source.pool is not None or source.issued > 0):
+        # (a source that makes draws ahead has already taken normals from the generator the device would continue: every
+        # draw would come from another place of the stream than the reference's, silently)
+        raise ValueError("`weights_source` has drawn ahead on the host: device multipliers need one made with ahead=1 and unused")
     rng = source.rng
     next_weights = source.next
     import time as _time

@@ -791,9 +791,21 @@ public:
         if ((rc = solver_->host_objective.reserve(b_scatter + b_tasks + b_out)) != ROCCO_HIP_OK) return rc;
         char *dv = (char *)solver_->dev_objective.ptr;
         char *ho = (char *)solver_->host_objective.ptr;
+        // The descriptors of an earlier prefetch may still be waiting in the stream for their copy to the device (behind a
+        // chain the host runs ahead of the stream: it resumes when the last director publishes `finished`, before that
+        // prefetch's copy has run): the pinned block is written again only once that copy has been done.
+        if (objective_staged_pending_) {
+            objective_staged_pending_ = false;
+            ROCCO_HIP_TRY(hipEventSynchronize(objective_staged_event_));
+        }
         if (!scatters.empty()) std::memcpy(ho, scatters.data(), scatters.size() * sizeof(LeanScatterTask));
         std::memcpy(ho + b_scatter, tasks.data(), W * sizeof(ObjectiveTask));
         ROCCO_HIP_TRY(hipMemcpyAsync(dv, ho, b_scatter + b_tasks, hipMemcpyHostToDevice, stream_));
+        if (objective_staged_event_ == nullptr) {
+            ROCCO_HIP_TRY(hipEventCreateWithFlags(&objective_staged_event_, hipEventDisableTiming));
+        }
+        ROCCO_HIP_TRY(hipEventRecord(objective_staged_event_, stream_));
+        objective_staged_pending_ = true;
         if (!scatters.empty()) {
             if ((rc = launch_lean_scatter_batch((const LeanScatterTask *)dv, (int)scatters.size(), zero_blocks, scatter_blocks, stream_)) != ROCCO_HIP_OK) return rc;
         }
@@ -809,6 +821,8 @@ public:
     }
     const double *objective_back_ = nullptr;
     bool objective_behind_chain_ = false;  // the pending sums were queued behind a chain: valid for the problems it wrote
+    hipEvent_t objective_staged_event_ = nullptr;  // behind the last prefetch's copy of its descriptors to the device
+    bool objective_staged_pending_ = false;
 
     // after the wait: keep the sums of the problems whose window certified its solution; the others are scattered again later
     void objective_collect(const std::vector<char> &certified)
@@ -1084,8 +1098,17 @@ public:
     bool staged_pending_ = false;
     ~HipEvaluator() override
     {
+        // An evaluator that goes away with work still queued (a call that ends on an error with a chain running, or with
+        // sums on their way): the queued kernels write into the caller's buffers and into the solver's pinned memory, which
+        // the next call clears -- so the stream is drained first.
+        if (model_chain_running_ || !objective_pending_.empty() || objective_staged_pending_ || staged_pending_) {
+            (void)hipStreamSynchronize(stream_);
+        }
         if (staged_event_ != nullptr) {
             (void)hipEventDestroy(staged_event_);
+        }
+        if (objective_staged_event_ != nullptr) {
+            (void)hipEventDestroy(objective_staged_event_);
         }
     }
     int stage_wait()

@@ -564,6 +564,10 @@ class _CachePlan:
     def __init__(self, args: dict):
         self.bigwig = args["input_track_type"] == "bigwig"
         self.low_memory = bool(args.get("low_memory", False))
+        # (not in the reference: a caller that hands over CUDA count matrices it no longer needs lets the scoring centre them
+        # in place instead of in copies -- `args["consume_inputs"] = True`; default off: a caller's tensor is never written to)
+        self.consume_inputs = bool(args.get("consume_inputs", False))
+        self.warned_many_tracks = False
         self.draws = args["budget_null_draws"]
         workers = 1 if self.low_memory else _resolve_parallel_process_count(int(self.draws), int(args["threads"]))
         self.null_processes = min(int(self.draws), int(workers))
@@ -593,8 +597,9 @@ def _gather_chromosomes(chroms_to_process: list, signal_inputs, args: dict, plan
         logger.info("Chromosome %s matrix: %s", name, tuple(matrix.shape))
         if not _all_finite(matrix):
             raise ValueError(f"{name} matrix contains non-finite values")
-        if plan.bigwig and matrix.shape[0] > 1:
-            logger.warning("Multiple bigwig tracks detected for %s: aggregated by the column-wise median, not WLS.", name)
+        if plan.bigwig and matrix.shape[0] > 1 and not plan.warned_many_tracks:
+            plan.warned_many_tracks = True  # (the reference logs this per chromosome, rocco/rocco.py:977-981: once per run is enough)
+            logger.warning("Multiple bigwig tracks detected (first: %s): aggregated by the column-wise median, not WLS.", name)
         matrix_t = _matrix_to_device(matrix)
         yield name, starts, matrix_t, matrix_t is not matrix  # (a matrix that came in as a CUDA tensor is the caller's: never written to)
 
@@ -628,7 +633,7 @@ def _score_gathered(batch: list, plan: _CachePlan, own_wls: bool, wls):
                 raise ValueError("`chrom_matrix` must be two-dimensional")
             m64 = m.to(torch.float64).contiguous()
             mats.append(m64)
-            ours.append(owned or m64 is not m)  # centred in place where the matrix is a copy this call made
+            ours.append(plan.consume_inputs or owned or m64 is not m)  # centred in place where the matrix is a copy this call made (or handed over)
         return _inf.score_loci_wls_batch_device(mats, overwrite_input=ours, **plan.wls)
     return [wls(m, low_memory=plan.low_memory, return_details=True, resident=True, **plan.wls) if own_wls else
             wls(m, low_memory=plan.low_memory, return_details=True, **plan.wls) for _n, _s, m, _o in batch]
@@ -765,6 +770,15 @@ def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> di
             centred = None
             if not plan.bigwig:
                 centred = details.pop("centered_matrix")
+                # the reference casts what the scorer returned (rocco/rocco.py:1020-1023): float32 under --low_memory, float64
+                # otherwise -- a replaced scorer may hand back either
+                if _dp._is_tensor(centred):
+                    import torch as _torch
+
+                    want = _torch.float32 if plan.low_memory else _torch.float64
+                    centred = centred if centred.dtype == want else centred.to(want)
+                else:
+                    centred = np.asarray(centred, dtype=np.float32 if plan.low_memory else np.float64)
                 if not _all_finite(centred):
                     raise ValueError(f"{name} centered matrix contains non-finite values")
             ready.append((name, starts, _host_scores(scores), details, centred))

@@ -119,6 +119,56 @@ def test_count_branch_budget_estimates_side_by_side_give_the_same_bed(gpu, tmp_p
         assert caches["1"][c]["budget_rate_meta"] == caches["3"][c]["budget_rate_meta"], c
 
 
+def test_inputs_handed_over_give_the_same_bed_and_are_centred_in_place(gpu, tmp_path, monkeypatch):
+    """`args["consume_inputs"] = True` (round 5; not in the reference): CUDA count matrices the caller no longer needs are
+    centred in place instead of in copies.  Default: the caller's tensors are never written to.  Same combined BED."""
+    import torch
+
+    from rocco_amd import rocco as impl
+
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(99)
+    hosts = {}
+    for chrom, n in (("chr3", 21011), ("chr8", 9300), ("chr14", 15000)):
+        m = rng.poisson(2.0, size=(5, n)).astype(np.float64)
+        for p in range(300, n - 100, 1100):
+            m[:, p:p + int(rng.integers(5, 40))] += rng.poisson(20.0, size=(5, 1))
+        hosts[chrom] = m
+    args = {"input_track_type": "bam", "budget_null_draws": 8, "threads": -1, "gamma": None, "budget": None,
+            "scale_chrom_budgets": 1.0, "budget_posterior_quantile": 0.01, "selection_penalty": None, "min_length_bp": None,
+            "score_lower_bound_z": 1.0, "score_prior_df": 5.0, "score_min_effect": None, "score_precision_floor_ratio": 0.01,
+            "low_memory": False, "narrowPeak": False, "budget_null_multipliers": "device"}
+    beds = {}
+    for consume in (False, True):
+        inputs = {c: (np.arange(m.shape[1], dtype=np.int64) * 50, torch.from_numpy(m).cuda()) for c, m in hosts.items()}
+        a = dict(args, consume_inputs=consume, output=str(tmp_path / f"out{int(consume)}.bed"))
+        beds[consume] = open(impl.run_chromosomes(list(inputs), inputs, a, run_id=str(int(consume))), "rb").read()
+        untouched = all(bool(torch.equal(inputs[c][1].cpu(), torch.from_numpy(hosts[c]))) for c in hosts)
+        assert untouched == (not consume)
+    assert beds[False] == beds[True] and len(beds[True]) > 0
+
+
+def test_device_multipliers_refuse_a_source_that_has_drawn_ahead(gpu):
+    """A `TrackWeightsAhead` made with ahead > 1 has already taken normals from its generator: continuing that generator on
+    the device would put every draw somewhere else in the stream than the reference's -- refused, not done silently."""
+    import torch
+
+    from rocco_amd import budget
+
+    rng = np.random.default_rng(5)
+    track = torch.from_numpy(rng.normal(0.2, 1.0, size=6000)).cuda()
+    ahead = budget.TrackWeightsAhead(6000, None, 6, random_seed=0, ahead=3)
+    try:
+        with pytest.raises(ValueError, match="drawn ahead"):
+            budget.estimate_budget_nonnull_fraction_from_score_track(track, num_null_draws=6, multipliers="device", weights_source=ahead)
+    finally:
+        ahead.close()
+    fresh = budget.TrackWeightsAhead(6000, None, 6, random_seed=0, ahead=1)
+    got = budget.estimate_budget_nonnull_fraction_from_score_track(track, num_null_draws=6, multipliers="device", weights_source=fresh)
+    want = budget.estimate_budget_nonnull_fraction_from_score_track(track, num_null_draws=6, multipliers="device")
+    assert got == want
+
+
 def test_track_branch_budget_estimates_side_by_side_give_the_same_bed(gpu, tmp_path, monkeypatch):
     """The same for score tracks (rocco/rocco.py:994-1008)."""
     from rocco_amd import rocco as impl

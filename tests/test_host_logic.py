@@ -199,3 +199,21 @@ def test_delta_definition_self_consistency(oracle):
         else:
             assert abs(st["count"] - o_cnt) <= st["effect"]
     assert agree >= 20
+
+
+def test_host_logic_under_address_and_undefined_behaviour_sanitizers():
+    """The product's search.cpp (1 400 lines of index-heavy host logic with prefetches ahead of the problem being planned) in
+    ONE executable with the harness, the oracle's C sources and a driver, all compiled with -fsanitize=address,undefined
+    (tests/host_logic/san_driver.cpp): 160 random calibrations + 320 fixed-penalty solves over six kinds of score arrays
+    and eight imitated device-side behaviours, each compared with the oracle's sequential calibration.  Exit code 0 and an
+    empty sanitizer log (CPU only: the pool has no GPU sanitizers)."""
+    import os
+    import subprocess
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_logic")
+    subprocess.run(["make", "-C", here, "hostlogic_san"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    run = subprocess.run([os.path.join(here, "hostlogic_san"), "160"], capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "160 cases, 0 mismatches" in run.stdout
+    assert "Sanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr
