@@ -177,6 +177,93 @@ def rehearse(args, rank, world):
         dist.destroy_process_group()
 
 
+def _solve_by_track_kind_leg(args, genome, device, po):
+    """What the budgeted solve (rocco/dp.py:89-164 through rocco_hip_solve_budget_batch_f64) costs OFF the benchmark's one
+    input distribution: chr1 alone and the whole genome in one batch, for (i) score tracks made by SURVEY.md section 8(d)'s
+    recipe (K = 10: gamma background rounded to 5 decimals, a peak every 1500 +- 300 loci of width 4..40 and amplitude
+    gamma(6, 1) in 80 % of the samples; column medians), (ii) zero-inflated tracks (63 % exact zeros, the same peaks on top),
+    (iii) integer-valued tracks, (iv) the benchmark's hash tracks at the corners of the driver's ranges, gamma in {0.5, 10} x
+    budget in {0.005, 0.1}.  Per case: milliseconds (median of three calls), the search's passes, which path every chromosome
+    took, binade maps and zone iterations; the shortest chromosome's penalty / count / solution against the oracle."""
+    import torch
+
+    from rocco_amd import dp as _dp
+    from rocco_amd import rocco as rr
+    from rocco_amd import synth
+
+    def peaks_on(base, gen, integer=False):
+        """base [K, n]: + a peak every 1500 +- 300 loci, width 4 .. 40, amplitude gamma(6, 1) in 80 % of the rows."""
+        K, n = base.shape
+        count = max(1, n // 1500)
+        starts = (torch.arange(count, device=device) * 1500 + torch.randint(0, 601, (count,), device=device, generator=gen)).clamp_(max=n - 1)
+        widths = torch.randint(4, 41, (count,), device=device, generator=gen)
+        amp = torch._standard_gamma(torch.full((K, count), 6.0, device=device, dtype=torch.float64), generator=gen)
+        amp = amp * (torch.rand((K, count), device=device, generator=gen) < 0.8)
+        if integer:
+            amp = torch.floor(amp)
+        locus = torch.arange(n, device=device)
+        which = (torch.searchsorted(starts, locus, right=True) - 1).clamp_(min=0)
+        inside = (locus >= starts[which]) & (locus < starts[which] + widths[which])
+        return base + amp[:, which] * inside
+
+    def track(kind, n, seed):
+        gen = torch.Generator(device=device)
+        gen.manual_seed(int(seed))
+        if kind == "hash":
+            return rr.score_central_tendency_chrom_device(synth.hash_matrix_device(10, n, seed, device=device))
+        K = 10
+        gamma1 = torch._standard_gamma(torch.ones((K, n), device=device, dtype=torch.float64), generator=gen)
+        if kind == "survey":
+            m = peaks_on(torch.round(gamma1 * 0.3 * 1e5) / 1e5, gen)
+        elif kind == "zero_inflated":
+            zero = torch.rand((K, n), device=device, generator=gen) < 0.6  # (the column median of ten is then zero at ~63 % of the loci)
+            m = peaks_on(torch.where(zero, torch.zeros_like(gamma1), torch.round(gamma1 * 0.3 * 1e5) / 1e5), gen)
+        else:  # integers
+            m = peaks_on(torch.floor(gamma1 * 1.5), gen, integer=True)
+        return rr.score_central_tendency_chrom_device(m.contiguous())
+
+    def solve(scores, gamma, budget):
+        targets = [int(np.floor(int(s.shape[0]) * budget)) for s in scores]
+        times, out = [], None
+        for _rep in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = _dp.calibrate_batch_device(scores, [gamma] * len(scores), targets)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        ms = 1e3 * float(np.median(times[1:]))
+        paths = {}
+        for r in out:
+            paths[str(r[4]["path"])] = paths.get(str(r[4]["path"]), 0) + 1
+        loci = sum(int(s.shape[0]) for s in scores)
+        return {"ms": round(ms, 3), "ns_per_locus": round(1e6 * ms / loci, 4), "passes_max": max(r[4]["passes"] for r in out),
+                "paths": paths, "maps": sum(r[4]["maps"] for r in out), "zone_iters": sum(max(0, r[4]["zone_iters"]) for r in out)}, out
+
+    small = int(np.argmin([n for _, n in genome]))
+    leg, cases = {}, [("hash", 1.0, 0.02), ("survey", 1.0, 0.02), ("zero_inflated", 1.0, 0.02), ("integers", 1.0, 0.02),
+                      ("hash", 0.5, 0.005), ("hash", 0.5, 0.1), ("hash", 10.0, 0.005), ("hash", 10.0, 0.1)]
+    made = {}
+    for kind, gamma, budget in cases:
+        if kind not in made:
+            made[kind] = [track(kind, n, synth.chrom_seed(args.seed + 77, idx)) for idx, (_name, n) in enumerate(genome)]
+        scores = made[kind]
+        entry = {"gamma": gamma, "budget": budget, "exact_zero_fraction": round(float((scores[0] == 0).double().mean()), 3)}
+        entry["chr1"], _ = solve(scores[:1], gamma, budget)
+        entry["genome"], out = solve(scores, gamma, budget)
+        # the shortest chromosome against the oracle's sequential calibration
+        s_h = scores[small].cpu().numpy()
+        o_sol, _o_obj, o_det = po.solve_chrom_exact(s_h, budget=budget, gamma=gamma, return_details=True)
+        pen, sol_t, _val, cnt, _info = out[small]
+        entry["oracle_check"] = {"chromosome": genome[small][0], "penalty_equal": pen == float(o_det["selection_penalty"]),
+                                 "count_equal": cnt == int(o_det["selected_count"]),
+                                 "solution_equal": bool(np.array_equal(sol_t.cpu().numpy(), o_sol))}
+        leg[f"{kind}, gamma {gamma:g}, budget {budget:g}"] = entry
+    ref = leg["hash, gamma 1, budget 0.02"]["genome"]["ns_per_locus"]
+    for entry in leg.values():
+        entry["genome"]["vs_hash_tracks"] = round(entry["genome"]["ns_per_locus"] / ref, 2)
+    return leg
+
+
 def _composed_driver_leg(args, genome, device, works, mine, po):
     """`rocco_amd.rocco.run_chromosomes` -- cache (scores, budget estimates, switch costs), pooled budgets, solve, BED text --
     on the whole genome: K = 10 bigWig-style tracks with the bootstrap multipliers made on the host (the reference's own
@@ -622,6 +709,7 @@ def main():
     # ---- the composed driver (rocco/rocco.py:933-1196, 1269-1300: matrices -> scores -> data-driven budgets and switch costs ->
     # solve -> combined BED) on the BASELINE configurations, reported beside the headline, not part of it ----
     if next_rows is not None and names is None and not args.no_composed:
+        next_rows["solve_by_track_kind"] = _solve_by_track_kind_leg(args, genome, device, po)
         next_rows["composed_driver"] = _composed_driver_leg(args, genome, device, works, mine, po)
 
     if rank == 0:

@@ -733,7 +733,8 @@ namespace {
 // starts a new one.
 std::mutex g_factor_mutex;
 // per device; on the heap and never destroyed: at process exit the HIP runtime may be gone before static destructors run
-std::map<int, std::shared_ptr<rocco::SharedFactor>> &g_factors = *new std::map<int, std::shared_ptr<rocco::SharedFactor>>();
+// per (device, penalty): a batch that mixes short contigs (a window below 101 loci: another penalty) with chromosomes keeps both
+std::map<std::pair<int, double>, std::shared_ptr<rocco::SharedFactor>> &g_factors = *new std::map<std::pair<int, double>, std::shared_ptr<rocco::SharedFactor>>();
 
 // the device's factor covers `cols` loci at this penalty when this returns; solver->factor holds it for the call
 int ensure_whittaker_factor(rocco_hip_solver *solver, size_t cols, double penalty_lambda, hipStream_t stream)
@@ -742,7 +743,7 @@ int ensure_whittaker_factor(rocco_hip_solver *solver, size_t cols, double penalt
         return ROCCO_HIP_OK;
     }
     std::lock_guard<std::mutex> lock(g_factor_mutex);  // (a second thread waits for the first one's factor rather than building its own)
-    std::shared_ptr<rocco::SharedFactor> &current = g_factors[solver->device];
+    std::shared_ptr<rocco::SharedFactor> &current = g_factors[std::make_pair(solver->device, penalty_lambda)];
     if (current && current->cap >= cols && current->lambda == penalty_lambda) {
         solver->factor = current;
         return ROCCO_HIP_OK;

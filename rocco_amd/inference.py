@@ -586,11 +586,20 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
             for idx in parts:
                 rows_a = (ctypes.c_size_t * len(idx))(*[int(counts_list[i].shape[0]) for i in idx])
                 cols_a = (ctypes.c_size_t * len(idx))(*[int(counts_list[i].shape[1]) for i in idx])
-                lams = {_consenrich_whittaker_lambda(w) for w in (_resolve_local_baseline_window(int(counts_list[i].shape[1]), target_window=101)
-                                                                    for i in idx) if w != 0}
-                _native.check(_native.load().rocco_hip_count_path_reserve(solver.handle, len(idx), rows_a, cols_a,
-                                                                          max(lams) if len(lams) == 1 else 0.0,
+                _native.check(_native.load().rocco_hip_count_path_reserve(solver.handle, len(idx), rows_a, cols_a, 0.0,
                                                                           caller_stream.cuda_stream), "rocco_hip_count_path_reserve")
+                # ... and the Whittaker factor of every penalty the chunk holds (contigs of 25 .. 100 loci have windows -- and
+                # penalties -- of their own): the device keeps one factor per penalty, all of them built here
+                by_lam = {}
+                for i in idx:
+                    w = _resolve_local_baseline_window(int(counts_list[i].shape[1]), target_window=101)
+                    if w != 0:
+                        by_lam.setdefault(_consenrich_whittaker_lambda(w), []).append(i)
+                for lam, same in by_lam.items():
+                    r_s = (ctypes.c_size_t * len(same))(*[int(counts_list[i].shape[0]) for i in same])
+                    c_s = (ctypes.c_size_t * len(same))(*[int(counts_list[i].shape[1]) for i in same])
+                    _native.check(_native.load().rocco_hip_count_path_reserve(solver.handle, len(same), r_s, c_s, float(lam),
+                                                                              caller_stream.cuda_stream), "rocco_hip_count_path_reserve")
         start = torch.cuda.Event()
         start.record(caller_stream)
         t_start = _time.perf_counter()

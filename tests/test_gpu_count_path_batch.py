@@ -164,6 +164,24 @@ def test_no_solver_buffer_grows_while_the_pipelines_run(gpu):
         assert torch.equal(a, b) and torch.equal(a, single)
 
 
+def test_a_tiny_contig_among_chromosomes_grows_nothing_in_flight(gpu):
+    """A batch that mixes a contig of 25 .. 100 loci (its baseline window, and so its Whittaker penalty, is its own) with
+    longer matrices: the device keeps one factor per penalty and every one of them is built before the pipelines start --
+    no solver buffer grows, and no factor is rebuilt, while they run."""
+    import torch
+    from rocco_amd import inference
+
+    rng = np.random.default_rng(77)
+    shapes = [(6, 30000), (6, 60), (6, 21000), (6, 99), (6, 45), (6, 12000)]
+    mats = [torch.from_numpy(rng.poisson(3.0, size=s).astype(np.float64)).to(gpu) for s in shapes]
+    inference.score_loci_wls_batch_device([m.clone() for m in mats])
+    out = inference.score_loci_wls_batch_device([m.clone() for m in mats])
+    assert inference.last_batch_growths_in_flight == 0
+    for m, (scores, _details) in zip(mats, out):
+        one, _d = inference.score_loci_wls_device(m.clone())
+        assert torch.equal(scores, one)
+
+
 def test_chunks_within_a_memory_budget_give_the_same_tracks(gpu):
     """A budget that forces every pipeline to walk its matrices in several chunks (each paying its baseline and rolling
     launches again): bit for bit the results of the call that holds everything at once."""
