@@ -31,6 +31,10 @@
 //    scaling of every row by its mean and standard deviation (fixed-order trees).
 #include "common.h"
 #include "kernels.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include "ziggurat_tables.h"
 
 #include <hipcub/hipcub.hpp>
@@ -121,9 +125,17 @@ __device__ __forceinline__ void load_tables(ZigTables &t, const unsigned long lo
 // value's attempt ends on, until the chunk's end.  EMIT: the values go to out[0 ...], at most `limit` of them; the raw
 // draws used up to and including the limit-th value are reported.  Returns the number of values; `spill` = draws taken
 // beyond the chunk's end.
+// where the tail values of a fill went, for the host to compute them again with ITS log1p (see rocco_hip_pcg64_standard_normal_f64)
+struct TailList {
+    unsigned long long *count;  // values listed (may exceed capacity: then the list is incomplete)
+    long long *index;           // position in the output | sign in bit 62
+    double *u;                  // the uniform of the accepted turn's first draw
+    long long capacity;
+};
+
 template <bool EMIT>
 __device__ __forceinline__ int walk_chunk(Pcg g, int entry, const ZigTables &t, double *out, long long limit, int *spill,
-                                          int *used_at_limit)
+                                          int *used_at_limit, const TailList *tails = nullptr, long long first_index = 0)
 {
     int pos = entry, n_out = 0;
     while (pos < kZigChunk) {
@@ -140,11 +152,20 @@ __device__ __forceinline__ int walk_chunk(Pcg g, int entry, const ZigTables &t, 
             if (idx == 0) {
                 // tail: NumPy's loop, two draws per turn
                 for (;;) {
-                    const double xx = -kZigInvR * log1p(-g.next_double());
+                    const double u1 = g.next_double();
+                    const double xx = -kZigInvR * log1p(-u1);
                     const double yy = -log1p(-g.next_double());
                     pos += 2;
                     if (yy + yy > xx * xx) {
-                        x = ((rabs >> 8) & 1ull) ? -(kZigR + xx) : kZigR + xx;
+                        const bool minus = ((rabs >> 8) & 1ull) != 0ull;
+                        x = minus ? -(kZigR + xx) : kZigR + xx;
+                        if (EMIT && tails != nullptr && (long long)n_out < limit) {
+                            const unsigned long long slot = atomicAdd(tails->count, 1ull);
+                            if ((long long)slot < tails->capacity) {
+                                tails->index[slot] = (first_index + n_out) | (minus ? (1LL << 62) : 0LL);
+                                tails->u[slot] = u1;
+                            }
+                        }
                         break;
                     }
                 }
@@ -233,7 +254,7 @@ __global__ __launch_bounds__(kZigThreads) void zig_fix_kernel(ZigArgs a, const i
 }
 
 __global__ __launch_bounds__(kZigThreads) void zig_fill_kernel(ZigArgs a, const long long *__restrict__ offsets, long long count,
-                                                               double *__restrict__ values, unsigned long long *consumed)
+                                                               double *__restrict__ values, unsigned long long *consumed, TailList tails)
 {
     __shared__ ZigTables t;
     load_tables(t, a.ki, a.wi, a.fi);
@@ -248,10 +269,18 @@ __global__ __launch_bounds__(kZigThreads) void zig_fill_kernel(ZigArgs a, const 
     }
     Pcg g{pcg_advance(a.state, a.inc, (unsigned long long)c * kZigChunk + (unsigned long long)entry), a.inc};
     int spill = 0, used = -1;
-    walk_chunk<true>(g, entry, t, values + first, count - first, &spill, &used);
+    walk_chunk<true>(g, entry, t, values + first, count - first, &spill, &used, (tails.capacity > 0) ? &tails : nullptr, first);
     if (used >= 0) {
         // this chunk holds the last value asked for: the raw draws up to the end of its attempt
         *consumed = (unsigned long long)c * kZigChunk + (unsigned long long)used;
+    }
+}
+
+__global__ void scatter_tail_kernel(const long long *__restrict__ index, const double *__restrict__ value, long long n, double *__restrict__ values)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        values[index[i] & ~(1LL << 62)] = value[i];
     }
 }
 
@@ -264,47 +293,99 @@ __global__ void widen_counts_kernel(const int *__restrict__ n_out, long long *__
 }
 
 // ---- Bartlett smoothing + standardisation -------------------------------------------------------------------
+// Round 5: every thread owns EIGHT CONSECUTIVE outputs and walks the taps eight at a time with its inputs in a sliding
+// window of sixteen registers: per eight taps and eight outputs one wavefront issues 4 ds_read_b128 and 64 v_fma_f64 with
+// the taps as scalar operands (round 4's kernel: five ds_read_b64 and eight VALU instructions per tap for four outputs --
+// LDS-issue-bound at a tenth of the FP64 rate).  The inputs of a tile sit in LDS in chunks of 8 doubles at a pitch of 10:
+// thread t reads chunk t + block, 80 bytes from its neighbour's -- conflict-free b128 reads.  Each output is the same sum
+// in the same order as before (taps ascending), now with one rounding per term (v_fma_f64) instead of two; the multipliers
+// were never the reference's bits (it convolves by FFT: rocco/inference.py:561), the tests hold them to 1e-12 of it.
 constexpr int kConvThreads = 256;
-constexpr int kConvPerThread = 4;
+constexpr int kConvPerThread = 8;
 constexpr int kConvTile = kConvThreads * kConvPerThread;  // outputs per workgroup
 constexpr int kConvMaxTapsLds = 2048;
+constexpr int kConvPitch = 10;  // doubles per chunk of 8 in LDS
+
+typedef double conv2_t __attribute__((ext_vector_type(2)));
 
 // weights[row][j] = sum_{t = 0}^{n_taps - 1} innovations[row][j + t] * taps[n_taps - 1 - t]   (np.convolve "valid")
+// rev: the taps reversed, padded with zeros to `padded` (a multiple of 8) entries
 __global__ __launch_bounds__(kConvThreads) void bartlett_conv_kernel(const double *__restrict__ innovations, long long row_stride,
-                                                                    long long n, const double *__restrict__ taps, int n_taps,
+                                                                    long long n, const double *__restrict__ rev, int n_taps, int padded,
                                                                     double *__restrict__ weights)
 {
-    extern __shared__ double lds[];  // [kConvTile + n_taps - 1] inputs, then [n_taps] reversed taps
-    double *in = lds;
-    double *rev = lds + kConvTile + n_taps - 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // (kConvThreads + padded / 8) chunks of kConvPitch doubles
     const long long row = blockIdx.y;
     const long long j0 = (long long)blockIdx.x * kConvTile;
     const double *src = innovations + row * row_stride;
-    const long long have = min((long long)(kConvTile + n_taps - 1), n + n_taps - 1 - j0);
-    for (long long i = threadIdx.x; i < have; i += kConvThreads) {
-        in[i] = src[j0 + i];
-    }
-    for (int i = threadIdx.x; i < n_taps; i += kConvThreads) {
-        rev[i] = taps[n_taps - 1 - i];
+    const long long have = (n + n_taps - 1) - j0;  // inputs of this row from j0 on
+    const int n_in = kConvTile + padded;
+    for (int i = threadIdx.x; i < n_in; i += kConvThreads) {
+        lds[(i >> 3) * kConvPitch + (i & 7)] = (i < have) ? src[j0 + i] : 0.0;
     }
     __syncthreads();
-    double acc[kConvPerThread];
+    // Three chunks of inputs (this block's two + the one the next block adds) and two blocks of taps (uniform: scalar
+    // registers) are in registers at any time, in three sets that take turns: what a block needs was fetched while the block
+    // before it ran its 64 FMAs, so no block starts by waiting for LDS or for the scalar cache.
+    double acc[kConvPerThread], c0[8], c1[8], c2[8], t0[8], t1[8], t2[8];
+    const int blocks = padded / 8;
+    auto fetch = [&](int chunk, double(&into)[8]) {
+        const conv2_t *at = reinterpret_cast<const conv2_t *>(lds + chunk * kConvPitch);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const conv2_t v = at[q];
+            into[2 * q] = v.x;
+            into[2 * q + 1] = v.y;
+        }
+    };
+    auto taps_of = [&](int tb, double(&into)[8]) {
+        const double *__restrict__ at = rev + 8 * ((tb < blocks) ? tb : (blocks - 1));
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            into[tt] = at[tt];
+        }
+    };
 #pragma unroll
     for (int k = 0; k < kConvPerThread; ++k) {
         acc[k] = 0.0;
     }
-    for (int t = 0; t < n_taps; ++t) {
-        const double w = rev[t];
+    // block tb: inputs lo = chunk (thread + tb), hi = chunk (thread + tb + 1), taps w; fetches chunk (thread + tb + 2) and
+    // the taps of block tb + 1 for its successor (the chunk index stays inside the staged tile: see n_in)
+    auto block = [&](int tb, const double(&lo)[8], const double(&hi)[8], double(&ahead)[8], const double(&w)[8], double(&w_ahead)[8]) {
+        // (an explicit wait for what the block before fetched, BEFORE this block's fetches go out: scalar loads return out
+        // of order, so a wait the compiler places behind them is a wait for them too)
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // s_waitcnt lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        fetch((int)threadIdx.x + ((tb + 2 <= blocks) ? (tb + 2) : blocks), ahead);
+        taps_of(tb + 1, w_ahead);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < kConvPerThread; ++k) {
-            acc[k] += in[threadIdx.x + k * kConvThreads + t] * w;
+        for (int tt = 0; tt < 8; ++tt) {
+#pragma unroll
+            for (int k = 0; k < kConvPerThread; ++k) {
+                const double x = (tt + k < 8) ? lo[tt + k] : hi[tt + k - 8];
+                acc[k] = __builtin_fma(x, w[tt], acc[k]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    fetch((int)threadIdx.x, c0);
+    fetch((int)threadIdx.x + 1, c1);
+    taps_of(0, t0);
+    for (int tb = 0; tb < blocks; tb += 3) {
+        block(tb, c0, c1, c2, t0, t1);
+        if (tb + 1 < blocks) {
+            block(tb + 1, c1, c2, c0, t1, t2);
+        }
+        if (tb + 2 < blocks) {
+            block(tb + 2, c2, c0, c1, t2, t0);
         }
     }
+    const long long j = j0 + (long long)threadIdx.x * kConvPerThread;
 #pragma unroll
     for (int k = 0; k < kConvPerThread; ++k) {
-        const long long j = j0 + threadIdx.x + k * kConvThreads;
-        if (j < n) {
-            weights[row * n + j] = acc[k];
+        if (j + k < n) {
+            weights[row * n + j + k] = acc[k];
         }
     }
 }
@@ -322,7 +403,7 @@ __global__ __launch_bounds__(kConvThreads) void bartlett_conv_slow_kernel(const 
     const double *src = innovations + row * row_stride + j;
     double acc = 0.0;
     for (int t = 0; t < n_taps; ++t) {
-        acc += src[t] * taps[n_taps - 1 - t];
+        acc = __builtin_fma(src[t], taps[n_taps - 1 - t], acc);  // (as the tiled kernel: one rounding per term)
     }
     weights[row * n + j] = acc;
 }
@@ -433,6 +514,18 @@ int rocco_hip_pcg64_standard_normal_f64(rocco_hip_solver *solver, unsigned long 
     const size_t o_offsets = carve((size_t)n_chunks * sizeof(long long));
     const size_t o_flag = carve(4 * sizeof(unsigned));
     const size_t o_consumed = carve(sizeof(unsigned long long));
+    // The tail of the ziggurat (|x| > 3.654: one value in 3 800) is -log1p(-u) / r + r, and NumPy takes log1p from the host's
+    // libm -- not correctly rounded, and not the same function on every host (glibc picks an FMA build where the CPU has
+    // one) -- so no device log1p gives NumPy's bits everywhere.  The fill lists where its tail values went and the uniform
+    // each came from; the host computes them again with ITS log1p -- the function the NumPy of this host calls -- and a
+    // small kernel puts them in place: the device's normals are then this host's NumPy's, bit for bit (round 4: 130 of
+    // 10^8 values one ulp off).  ROCCO_HIP_NORMAL_TAIL=device keeps the device's log1p (one synchronisation less).
+    const char *tail_mode = std::getenv("ROCCO_HIP_NORMAL_TAIL");
+    const bool host_tails = !(tail_mode != nullptr && std::strcmp(tail_mode, "device") == 0);
+    const long long tail_capacity = host_tails ? ((long long)(count / 500) + 65536) : 0;
+    const size_t o_tail_count = carve(sizeof(unsigned long long));
+    const size_t o_tail_index = carve((size_t)tail_capacity * sizeof(long long));
+    const size_t o_tail_u = carve((size_t)tail_capacity * sizeof(double));
     size_t scan_bytes = 0;
     ROCCO_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const long long *)nullptr, (long long *)nullptr, (int)n_chunks, stream));
     const size_t o_scan = carve(scan_bytes + 256);
@@ -445,6 +538,12 @@ int rocco_hip_pcg64_standard_normal_f64(rocco_hip_solver *solver, unsigned long 
     std::memcpy((char *)solver->host_stage.ptr + 4096, kZigguratFiBits, 256 * sizeof(unsigned long long));
     ROCCO_HIP_TRY(hipMemcpyAsync(dv + o_tables, solver->host_stage.ptr, 3 * 2048, hipMemcpyHostToDevice, stream));
     ROCCO_HIP_TRY(hipMemsetAsync(dv + o_flag, 0, 4 * sizeof(unsigned) + 256 + sizeof(unsigned long long), stream));
+    ROCCO_HIP_TRY(hipMemsetAsync(dv + o_tail_count, 0, sizeof(unsigned long long), stream));
+    TailList tails;
+    tails.count = (unsigned long long *)(dv + o_tail_count);
+    tails.index = (long long *)(dv + o_tail_index);
+    tails.u = (double *)(dv + o_tail_u);
+    tails.capacity = tail_capacity;
     ZigArgs a;
     a.state = U128{state_hi, state_lo};
     a.inc = U128{inc_hi, inc_lo};
@@ -472,14 +571,37 @@ int rocco_hip_pcg64_standard_normal_f64(rocco_hip_solver *solver, unsigned long 
     ROCCO_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(dv + o_scan, scan_bytes, (const long long *)(dv + o_wide), (long long *)(dv + o_offsets),
                                                    (int)n_chunks, stream));
     hipLaunchKernelGGL(zig_fill_kernel, dim3(blocks), dim3(kZigThreads), 0, stream, a, (const long long *)(dv + o_offsets), (long long)count,
-                       values_dev, (unsigned long long *)(dv + o_consumed));
+                       values_dev, (unsigned long long *)(dv + o_consumed), tails);
     ROCCO_HIP_TRY(hipGetLastError());
-    if ((rc = solver->host_back.reserve(64)) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->host_back.reserve(64 + (size_t)tail_capacity * 16)) != ROCCO_HIP_OK) return rc;
     ROCCO_HIP_TRY(hipMemcpyAsync(solver->host_back.ptr, dv + o_flag, 16, hipMemcpyDeviceToHost, stream));
     ROCCO_HIP_TRY(hipMemcpyAsync((char *)solver->host_back.ptr + 16, dv + o_consumed, 8, hipMemcpyDeviceToHost, stream));
+    ROCCO_HIP_TRY(hipMemcpyAsync((char *)solver->host_back.ptr + 24, dv + o_tail_count, 8, hipMemcpyDeviceToHost, stream));
     ROCCO_HIP_TRY(hipStreamSynchronize(stream));
     const unsigned *flag = (const unsigned *)solver->host_back.ptr;
     const unsigned long long consumed = *(const unsigned long long *)((const char *)solver->host_back.ptr + 16);
+    const unsigned long long n_tail = *(const unsigned long long *)((const char *)solver->host_back.ptr + 24);
+    if (host_tails && n_tail > 0ull) {
+        if ((long long)n_tail > tail_capacity) {
+            set_last_error("rocco_hip_pcg64_standard_normal_f64: more tail values than one in 500 (not a ziggurat stream?)");
+            return ROCCO_HIP_EHIP;
+        }
+        long long *idx_host = (long long *)((char *)solver->host_back.ptr + 64);
+        double *val_host = (double *)((char *)solver->host_back.ptr + 64 + (size_t)tail_capacity * 8);
+        ROCCO_HIP_TRY(hipMemcpyAsync(idx_host, dv + o_tail_index, (size_t)n_tail * 8, hipMemcpyDeviceToHost, stream));
+        ROCCO_HIP_TRY(hipMemcpyAsync(val_host, dv + o_tail_u, (size_t)n_tail * 8, hipMemcpyDeviceToHost, stream));
+        ROCCO_HIP_TRY(hipStreamSynchronize(stream));
+        for (unsigned long long i = 0; i < n_tail; ++i) {
+            // numpy/random/src/distributions/distributions.c, random_standard_normal: the accepted turn's value
+            const double xx = -kZigInvR * std::log1p(-val_host[i]);
+            val_host[i] = (idx_host[i] & (1LL << 62)) ? -(kZigR + xx) : (kZigR + xx);
+        }
+        ROCCO_HIP_TRY(hipMemcpyAsync(dv + o_tail_u, val_host, (size_t)n_tail * 8, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(scatter_tail_kernel, dim3((unsigned)((n_tail + 255) / 256)), dim3(256), 0, stream, (const long long *)(dv + o_tail_index),
+                           (const double *)(dv + o_tail_u), (long long)n_tail, values_dev);
+        ROCCO_HIP_TRY(hipGetLastError());
+        ROCCO_HIP_TRY(hipStreamSynchronize(stream));  // (the staging area is the solver's)
+    }
     if (flag[1] != 0u) {
         set_last_error("rocco_hip_pcg64_standard_normal_f64: the chunk walks did not settle (a tail loop ran across chunks)");
         return ROCCO_HIP_EHIP;
@@ -509,24 +631,31 @@ int rocco_hip_bartlett_multipliers_f64(rocco_hip_solver *solver, const double *i
         off += (bytes + 255) / 256 * 256;
         return at;
     };
+    const size_t padded = (n_taps + 7) / 8 * 8;
     const size_t o_taps = carve(n_taps * sizeof(double));
+    const size_t o_rev = carve(padded * sizeof(double));
     const size_t o_part = carve(rows * (size_t)segments * sizeof(double));
     const size_t o_mean = carve(rows * sizeof(double));
     const size_t o_sd = carve(rows * sizeof(double));
     const size_t o_flag = carve(sizeof(int));
     int rc;
     if ((rc = solver->dev_misc.reserve(off)) != ROCCO_HIP_OK) return rc;
-    if ((rc = solver->host_stage.reserve(n_taps * sizeof(double))) != ROCCO_HIP_OK) return rc;
+    if ((rc = solver->host_stage.reserve((n_taps + padded) * sizeof(double))) != ROCCO_HIP_OK) return rc;
     if ((rc = solver->host_back.reserve(64)) != ROCCO_HIP_OK) return rc;
     char *dv = (char *)solver->dev_misc.ptr;
     std::memcpy(solver->host_stage.ptr, taps_host, n_taps * sizeof(double));
+    double *rev_host = (double *)solver->host_stage.ptr + n_taps;  // reversed, zeros behind the last one
+    for (size_t t = 0; t < padded; ++t) {
+        rev_host[t] = (t < n_taps) ? taps_host[n_taps - 1 - t] : 0.0;
+    }
     ROCCO_HIP_TRY(hipMemcpyAsync(dv + o_taps, solver->host_stage.ptr, n_taps * sizeof(double), hipMemcpyHostToDevice, stream));
+    ROCCO_HIP_TRY(hipMemcpyAsync(dv + o_rev, rev_host, padded * sizeof(double), hipMemcpyHostToDevice, stream));
     ROCCO_HIP_TRY(hipMemsetAsync(dv + o_flag, 0, sizeof(int), stream));
     const long long row_stride = (long long)(n + n_taps - 1);
     if (n_taps <= (size_t)kConvMaxTapsLds) {
-        const size_t lds = ((size_t)kConvTile + 2 * n_taps) * sizeof(double);
+        const size_t lds = ((size_t)kConvThreads + padded / 8 + 1) * kConvPitch * sizeof(double);
         hipLaunchKernelGGL(bartlett_conv_kernel, dim3((unsigned)((n + kConvTile - 1) / kConvTile), (unsigned)rows), dim3(kConvThreads), lds,
-                           stream, innovations_dev, row_stride, (long long)n, (const double *)(dv + o_taps), (int)n_taps, weights_dev);
+                           stream, innovations_dev, row_stride, (long long)n, (const double *)(dv + o_rev), (int)n_taps, (int)padded, weights_dev);
     } else {
         hipLaunchKernelGGL(bartlett_conv_slow_kernel, dim3((unsigned)((n + kConvThreads - 1) / kConvThreads), (unsigned)rows),
                            dim3(kConvThreads), 0, stream, innovations_dev, row_stride, (long long)n, (const double *)(dv + o_taps),
