@@ -139,6 +139,7 @@ void rocco_hip_solver_destroy(rocco_hip_solver *solver)
     solver->dev_lean_pool.release();
     solver->dev_lean_round.release();
     solver->dev_lean_look.release();
+    solver->dev_lean_progress.release();
     solver->dev_lean_desc.release();
     solver->dev_lean_wcap.release();
     solver->dev_chain.release();
@@ -898,7 +899,7 @@ long long rocco_hip_solver_device_bytes(const rocco_hip_solver *solver)
     }
     const rocco::DeviceBuffer *all[] = {&solver->dev_tasks, &solver->dev_params, &solver->dev_results, &solver->dev_bits, &solver->dev_misc,
                                         &solver->dev_median_partials, &solver->dev_solution, &solver->dev_maps, &solver->dev_frozen,
-                                        &solver->dev_lean_pool, &solver->dev_lean_round, &solver->dev_lean_look, &solver->dev_lean_desc,
+                                        &solver->dev_lean_pool, &solver->dev_lean_round, &solver->dev_lean_look, &solver->dev_lean_progress, &solver->dev_lean_desc,
                                         &solver->dev_lean_wcap, &solver->dev_chain};
     long long total = 0;
     for (const rocco::DeviceBuffer *b : all) {

@@ -1483,8 +1483,21 @@ public:
         const int grid_eval = (int)std::max(1LL, std::min(512LL, tiles * 16));
         const int grid_finish = (int)std::max(1LL, std::min(1536LL, (long long)B * (kLeanMaxPoints - 1)));
         solver_->lean_look_dirty = 1;
+        // (round 5: evaluation and finish of a round as one launch, as the threshold search's rounds)
+        const int fused_mode = env("ROCCO_HIP_CHAIN_FUSED") == nullptr ? 0 : std::atoi(env("ROCCO_HIP_CHAIN_FUSED"));
+        const bool fused = fused_mode == 1 || fused_mode == 3;
+        A.reset = LeanRoundReset{nullptr, 0, nullptr, nullptr};
+        if (fused) {
+            const size_t words = (size_t)kLeanProgressPairs + (size_t)B * (size_t)kLeanMaxPoints;
+            if ((rc = solver_->dev_lean_progress.reserve(words * sizeof(unsigned))) != ROCCO_HIP_OK) return rc;
+            A.reset = LeanRoundReset{(unsigned *)solver_->dev_lean_progress.ptr, (int)words, L.ticket, L.error};
+        }
         for (int r = 0; r < rounds; ++r) {
             if ((rc = launch_model_chain_director(A, r, 0, stream_)) != ROCCO_HIP_OK) return rc;
+            if (fused) {
+                if ((rc = launch_lean_round_chain(M, nullptr, A.reset.progress, grid_eval, 1, stream_)) != ROCCO_HIP_OK) return rc;
+                continue;
+            }
             if ((rc = launch_lean_model_chain(M, grid_eval, stream_)) != ROCCO_HIP_OK) return rc;
             if ((rc = launch_lean_finish_chain(L, grid_finish, stream_)) != ROCCO_HIP_OK) return rc;
         }
@@ -2550,8 +2563,33 @@ public:
         const int compact_grid = (int)std::min<long long>(1024, std::max<long long>(1, tiles0));
         const int finish_grid = (int)std::min<size_t>(2048, B * (size_t)kLeanMaxPoints);
         solver_->lean_look_dirty = 1;  // until every finish launch that restores the scratch is in the stream
+        // Round 5, measured and NOT adopted: a round's compaction, evaluation and finish as ONE launch
+        // (lean.h: LeanRoundReset; the director in front of the next round restores what the finish launch restored).  Whole
+        // genome, same box, interleaved: three launches 2.71-2.87 ms, one launch 3.29-3.45 (the pairs of a round are finished
+        // by the few workgroups that held the last tiles instead of 1 536 at once, and the compactions run two to a CU behind
+        // fences), compactions + evaluation as one and the finish apart 3.11-3.18; the rounding-model rounds as one launch
+        // 2.71-2.90 against 2.71-2.87.  ROCCO_HIP_CHAIN_FUSED: 0 (default) neither chain, 1 both, 2 the threshold search only,
+        // 3 the rounding-model rounds only, 4 the threshold search's compactions + evaluation.
+        const int fused_mode = env("ROCCO_HIP_CHAIN_FUSED") == nullptr ? 0 : std::atoi(env("ROCCO_HIP_CHAIN_FUSED"));
+        const bool fused = fused_mode == 1 || fused_mode == 2, half_fused = fused_mode == 4;  // (4: compactions + evaluation, finish apart)
+        A.reset = LeanRoundReset{nullptr, 0, nullptr, nullptr};
+        if (fused || half_fused) {
+            const size_t words = (size_t)kLeanProgressPairs + B * (size_t)kLeanMaxPoints;
+            if ((rc = solver_->dev_lean_progress.reserve(words * sizeof(unsigned))) != ROCCO_HIP_OK) return rc;
+            A.reset = LeanRoundReset{(unsigned *)solver_->dev_lean_progress.ptr, half_fused ? kLeanProgressPairs : (int)words,
+                                     half_fused ? nullptr : L.ticket, L.error};
+        }
         for (int r = 0; r < R; ++r) {
             if ((rc = launch_chain_director(A, r, 0, stream_)) != ROCCO_HIP_OK) return rc;
+            if (fused) {
+                if ((rc = launch_lean_round_chain(L, A.pre, A.reset.progress, eval_grid, 0, stream_)) != ROCCO_HIP_OK) return rc;
+                continue;
+            }
+            if (half_fused) {
+                if ((rc = launch_lean_round_chain(L, A.pre, A.reset.progress, eval_grid, 0, stream_, 0)) != ROCCO_HIP_OK) return rc;
+                if ((rc = launch_lean_finish_chain(L, finish_grid, stream_)) != ROCCO_HIP_OK) return rc;
+                continue;
+            }
             if ((rc = launch_lean_compact_chain(A.pre, A.ctl, compact_grid, stream_)) != ROCCO_HIP_OK) return rc;
             if ((rc = launch_lean_eval_chain(L, eval_grid, stream_)) != ROCCO_HIP_OK) return rc;
             if ((rc = launch_lean_finish_chain(L, finish_grid, stream_)) != ROCCO_HIP_OK) return rc;

@@ -164,6 +164,7 @@ struct ChainArgs {
     int follow_words;
     int follow_ctl_word;
     ChainTuning tune;
+    LeanRoundReset reset;   // rounds as one launch each: what their finish launch used to restore (lean.h)
 };
 
 // plan round `round` (consuming the results of round - 1); `last`: consume only

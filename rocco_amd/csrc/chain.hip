@@ -521,6 +521,7 @@ __global__ __launch_bounds__(kDirectorThreads) void chain_director_kernel(ChainA
     __shared__ int s_task[kChainMaxProblems], s_unit[kChainMaxProblems], s_rec[kChainMaxProblems], s_stride[kChainMaxProblems];
     __shared__ int s_pre_idx[kChainMaxProblems], s_pre_block[kChainMaxProblems];
     __shared__ int s_want, s_pilot_want, s_batch;
+    lean_round_reset(A.reset, A.ctl);  // (what the round before left: tickets, error word, progress counters)
     if (round > 0 && A.ctl->all_done != 0) {
         return;  // every search has ended: the remaining launches of the chain find all sizes zero
     }

@@ -76,6 +76,7 @@ struct rocco_hip_solver {
     rocco::DeviceBuffer dev_lean_pool;   // compacted levels of the problems being solved (lean.hip)
     rocco::DeviceBuffer dev_lean_round;  // per-round scratch of the lean evaluation (tile records)
     rocco::DeviceBuffer dev_lean_look;   // its tickets, error word and hand-off granules (restored by every round)
+    rocco::DeviceBuffer dev_lean_progress;  // progress counters of chained rounds that are one launch each (lean.h: LeanRoundReset)
     int lean_look_dirty = 1;             // ... unless a round failed: then the next one initialises it again
     rocco::DeviceBuffer dev_lean_desc;   // its descriptors
     rocco::DeviceBuffer dev_lean_wcap;   // per problem: tolerance cap of the rounding-model evaluation

@@ -105,6 +105,42 @@ struct LeanLaunch {
     LeanRoundCtl *ctl;          // nullptr: n_tasks / n_units above hold; else the sizes are read from the device (chain.hip)
 };
 
+// A chained round as ONE launch (round 5: lean_round_chain_kernel): compaction, evaluation and finish used to be three
+// launches behind the director's; now the workgroups of one launch take the compactions' blocks as tickets, then (once every
+// block has been written -- each is held by a RUNNING workgroup, so the wait ends) the evaluation's tickets, and the
+// workgroup that completes the last tile of a (task, penalty) pair finishes that pair.  `progress`: words that are zero
+// before the launch -- [0] compaction tickets taken, [1] compaction blocks done, [kLeanProgressPairs + result index] tiles of
+// a pair done.  What the finish launch did once per round (tickets back to all-ones, the error word to the round sizes)
+// cannot be done while workgroups still take tickets: the NEXT director kernel does it (lean_round_reset).
+constexpr int kLeanProgressPairs = 8;
+struct LeanRoundReset {
+    unsigned *progress;   // nullptr: the rounds are three launches each (the finish kernel resets)
+    int progress_words;
+    unsigned *tickets;    // LeanLaunch::ticket of the rounds (words 0 and 2 are ticket counters)
+    unsigned *error;      // LeanLaunch::error
+};
+#if defined(__HIPCC__)
+// by every thread of a director kernel, first thing (before a barrier of its own)
+__device__ __forceinline__ void lean_round_reset(const LeanRoundReset &R, LeanRoundCtl *ctl)
+{
+    if (R.progress == nullptr) {
+        return;
+    }
+    for (int i = threadIdx.x; i < R.progress_words; i += blockDim.x) {
+        R.progress[i] = 0u;
+    }
+    if (threadIdx.x == 0 && R.tickets != nullptr) {
+        const unsigned e = *R.error;
+        if (e != 0u) {
+            atomicOr(&ctl->error, e);
+            *R.error = 0u;
+        }
+        R.tickets[0] = 0xFFFFFFFFu;
+        R.tickets[2] = 0xFFFFFFFFu;
+    }
+}
+#endif
+
 // compaction of one task at one of its evaluated penalties
 struct LeanCompactTask {
     const double *s;          // parent level
@@ -161,6 +197,11 @@ int launch_lean_eval(const LeanLaunch &L, hipStream_t stream);
 int launch_lean_eval_chain(const LeanLaunch &L, int grid, hipStream_t stream);
 int launch_lean_finish_chain(const LeanLaunch &L, int grid, hipStream_t stream);
 int launch_lean_compact_chain(const LeanCompactTask *tasks_dev, LeanRoundCtl *ctl, int grid, hipStream_t stream);
+// the three of them as one launch (`pre` may be nullptr: a round without compactions; `model`: rounding-model tasks)
+// `finish` = 0: compactions and evaluation only, the pairs finished by launch_lean_finish_chain behind it (which then also
+// restores the tickets: LeanRoundReset::tickets stays nullptr)
+int launch_lean_round_chain(const LeanLaunch &L, const LeanCompactTask *pre, unsigned *progress, int grid, int model, hipStream_t stream,
+                            int finish = 1);
 // the same for rounding-model tasks (kLeanModelBatch penalties per workgroup)
 constexpr int kLeanModelBatch = 4;
 int launch_lean_model(const LeanLaunch &L, hipStream_t stream);

@@ -833,6 +833,8 @@ __device__ __forceinline__ void eval_body(const LeanLaunch &L, const LeanTask &t
     }
 }
 
+__device__ __forceinline__ void finish_task_pair(const LeanLaunch &L, const LeanTask &task, int p, int lane, bool round_too);
+
 // One wavefront per (task, penalty): close the fill across tiles, lay out the compaction.
 __device__ __forceinline__ void finish_pair(const LeanLaunch &L, int n_tasks, int pair)
 {
@@ -859,7 +861,12 @@ __device__ __forceinline__ void finish_pair(const LeanLaunch &L, int n_tasks, in
         ti = min(n_tasks - 1, base + 63);
     }
     const LeanTask task = L.tasks[ti];
-    const int p = pair - acc;
+    finish_task_pair(L, task, pair - acc, lane, pair == 0);
+}
+
+// penalty `p` of `task`, by one wavefront (`lane` = its lane); `round_too`: also what is restored once per round
+__device__ __forceinline__ void finish_task_pair(const LeanLaunch &L, const LeanTask &task, int p, int lane, bool round_too)
+{
     const LeanTileRec *recs = L.recs + (long long)task.rec_begin + (long long)p * task.n_tiles;
     const int nt = task.n_tiles;
 
@@ -941,7 +948,7 @@ __device__ __forceinline__ void finish_pair(const LeanLaunch &L, int n_tasks, in
         for (int k = lane; k < 4 * nt; k += 64) {
             mine[k] = kSentinel;
         }
-        if (pair == 0 && lane == 0) {
+        if (round_too && lane == 0) {
             const unsigned e = __hip_atomic_load(L.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (L.error_out != nullptr) {
                 *L.error_out = e;
@@ -1528,6 +1535,137 @@ __global__ __launch_bounds__(kLeanThreads, 2) void lean_model_chain_kernel(LeanL
     }
 }
 
+// A chained round as ONE launch (lean.h: LeanRoundReset): the compactions' blocks by tickets, then -- once every block is
+// written -- the evaluation's tickets; the workgroup that completes the last tile of a (task, penalty) pair finishes the
+// pair with one of its wavefronts.  Every wait is for work a RUNNING workgroup holds (a block or a tile is taken only by a
+// workgroup that is running), so the launch cannot wait for a workgroup that has not started.
+template <bool MODEL, bool FINISH>
+__global__ __launch_bounds__(kLeanThreads, 2) void lean_round_chain_kernel(LeanLaunch L, const LeanCompactTask *pre, unsigned *progress)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *lds = smem;
+    Scratch *sc = reinterpret_cast<Scratch *>(smem + kTileLds);
+    __shared__ int s_block, s_nfin, s_fin[kLeanBatch];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n_units = L.ctl->n_units, n_tasks = L.ctl->n_tasks;
+    const int n_pre_blocks = (MODEL || pre == nullptr) ? 0 : L.ctl->n_pre_blocks, n_pre_tasks = L.ctl->n_pre_tasks;
+    if (n_units <= 0 && n_pre_blocks <= 0) {
+        return;  // (before a ticket is touched)
+    }
+    if (n_pre_blocks > 0) {
+        static_assert(sizeof(CompactShared) <= (size_t)kTileLds * sizeof(double), "the compaction's lists fit the tile");
+        CompactShared &sh = *reinterpret_cast<CompactShared *>(smem);
+        // (the loop's condition is a scalar and thread 0's extra work sits INSIDE the body: with the ticket taken at the top of
+        // a for (;;) that is left by `break`, the compiler split the loop by lane -- thread 0 never took a second ticket and
+        // the other lanes ran the same block for ever)
+        if (t == 0) {
+            s_block = (int)atomicAdd(&progress[0], 1u);
+        }
+        __syncthreads();
+        int block = __builtin_amdgcn_readfirstlane(s_block);
+        while (block < n_pre_blocks) {
+            compact_block(pre, n_pre_tasks, &L.ctl->error, block, sh);
+            __syncthreads();  // (every thread's stores are issued; the lists are free again)
+            if (t == 0) {
+                __threadfence();
+                atomicAdd(&progress[1], 1u);
+                s_block = (int)atomicAdd(&progress[0], 1u);
+            }
+            __syncthreads();
+            block = __builtin_amdgcn_readfirstlane(s_block);
+        }
+        // the levels the evaluation reads are complete when every block is: all of them are held by running workgroups
+        if (t == 0) {
+            unsigned spins = 0;  // (bounded, as every wait of these kernels: gives up and reports rather than hang the device)
+            while (__hip_atomic_load(&progress[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_pre_blocks) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > kSpinLimit) {
+                    atomicOr(L.error, 1u);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (n_units <= 0) {
+        return;
+    }
+    unsigned *ticket_word = L.ticket;
+    for (;;) {
+        if (t == 0) {
+            sc->ticket = (int)(atomicAdd(ticket_word, 1u) + 1u);
+        }
+        if (t < kLeanBatch * 4) {
+            (&sc->red[0][0])[t] = 0u;
+        }
+        if (MODEL && t < kLeanBatch) {
+            sc->uncertain[t] = 0u;
+        }
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(sc->ticket);
+        if (ticket >= n_units) {
+            return;
+        }
+        const int ti = find_task(n_tasks, ticket, [&](int i) { return L.tasks[i].unit_begin; });
+        const LeanTask task = L.tasks[ti];
+        const int unit = ticket - task.unit_begin;
+        const int tile = unit / task.n_groups, group = unit % task.n_groups;
+        const int p0 = group * task.batch;
+        const int np = min(task.batch, task.n_points - p0);
+        if (MODEL) {
+            stage_tile<true>(task.s, task.m, (long long)tile * kLeanTile, task.magic, lds);
+            if (np > 2) {
+                eval_body<4, true>(L, task, tile, p0, np, lds, sc);
+            } else if (np > 1) {
+                eval_body<2, true>(L, task, tile, p0, np, lds, sc);
+            } else {
+                eval_body<1, true>(L, task, tile, p0, np, lds, sc);
+            }
+        } else {
+            stage_tile<false>(task.s, task.m, (long long)tile * task.tile_stride * kLeanTile, task.magic, lds);
+            if (np > 4) {
+                eval_body<8, false>(L, task, tile, p0, np, lds, sc);
+            } else if (np > 2) {
+                eval_body<4, false>(L, task, tile, p0, np, lds, sc);
+            } else if (np > 1) {
+                eval_body<2, false>(L, task, tile, p0, np, lds, sc);
+            } else {
+                eval_body<1, false>(L, task, tile, p0, np, lds, sc);
+            }
+        }
+        __syncthreads();  // the tile's records (and words) are written
+        if (!FINISH) {
+            continue;  // (the pairs are finished by a launch of their own behind this one)
+        }
+        // which of this unit's pairs are complete with it
+        if (t < 64) {
+            // (lane p counts for penalty p: the counters' round trips side by side, not one after the other)
+            __threadfence();
+            bool last = false;
+            if (t < np) {
+                last = atomicAdd(&progress[kLeanProgressPairs + task.result_begin + p0 + t], 1u) + 1u == (unsigned)task.n_tiles;
+            }
+            const unsigned long long lasts = __ballot(last);
+            if (last) {
+                s_fin[__builtin_popcountll(lasts & ((1ull << t) - 1ull))] = p0 + t;
+            }
+            if (t == 0) {
+                s_nfin = __builtin_popcountll(lasts);
+            }
+        }
+        __syncthreads();
+        const int nf = __builtin_amdgcn_readfirstlane(s_nfin);
+        if (nf > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other tiles' records, written by other workgroups
+            for (int k = wave; k < nf; k += kLeanThreads / 64) {
+                finish_task_pair(L, task, s_fin[k], lane, false);
+            }
+        }
+        __syncthreads();  // the tile and the scratch are reused
+    }
+}
+
 // What a locus can inherit at most (see lean_model_kernel): the weights of every hazard chunk's steps and of every
 // exact half-way tie rn_u(s) in a clean chunk, plus the largest hazard base.  Counted per exponent (integers: no
 // order dependence) by one workgroup per tile, summed by one thread per task, which also clears the counters.
@@ -1684,6 +1822,29 @@ int launch_lean_finish_chain(const LeanLaunch &L, int grid, hipStream_t stream)
 int launch_lean_compact_chain(const LeanCompactTask *tasks_dev, LeanRoundCtl *ctl, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL(lean_compact_chain_kernel, dim3((unsigned)grid), dim3(kLeanThreads), 0, stream, tasks_dev, ctl);
+    return ROCCO_HIP_OK;
+}
+
+int launch_lean_round_chain(const LeanLaunch &L, const LeanCompactTask *pre, unsigned *progress, int grid, int model, hipStream_t stream, int finish)
+{
+    static bool configured = false;
+    const size_t lds = (size_t)kTileLds * sizeof(double) + sizeof(Scratch);
+    if (!configured) {
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lean_round_chain_kernel<false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lean_round_chain_kernel<false, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lean_round_chain_kernel<true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    if (model) {
+        hipLaunchKernelGGL((lean_round_chain_kernel<true, true>), dim3((unsigned)grid), dim3(kLeanThreads), lds, stream, L, pre, progress);
+    } else if (finish) {
+        hipLaunchKernelGGL((lean_round_chain_kernel<false, true>), dim3((unsigned)grid), dim3(kLeanThreads), lds, stream, L, pre, progress);
+    } else {
+        hipLaunchKernelGGL((lean_round_chain_kernel<false, false>), dim3((unsigned)grid), dim3(kLeanThreads), lds, stream, L, pre, progress);
+    }
     return ROCCO_HIP_OK;
 }
 

@@ -108,6 +108,7 @@ struct ModelChainArgs {
     unsigned *entering;
     LeanWriteTask *writes;
     int *n_writes;
+    LeanRoundReset reset;  // rounds as one launch each: what their finish launch used to restore (lean.h)
 };
 
 // round: 0 .. n_rounds; the call with last = 1 only reads the last round's results

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(kDirectorThreads) void model_chain_director_kernel(
     __shared__ DirectorShared sh;
     const int B = A.n_problems;
     const int t = threadIdx.x;
+    lean_round_reset(A.reset, A.ctl);  // (what the round before left: tickets, error word, progress counters)
     if (t == 0) {
         sh.tiles_before = 0ull;
         sh.asked = 0;

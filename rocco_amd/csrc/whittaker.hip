@@ -719,7 +719,7 @@ __global__ __launch_bounds__(kLanes) void whittaker_seam_kernel(const WhittakerS
         const long long t_lo = (long long)seg * m.seg_tiles, t_hi = (seg + 1 == m.n_seg) ? all_tiles : (t_lo + m.seg_tiles);
         const long long lo = t_lo * kRowTile, hi = (t_hi * kRowTile < n) ? (t_hi * kRowTile) : n;  // the segment's loci [lo, hi)
         while (todo != 0ULL) {
-            const int owner = __ffsll((long long)todo) - 1;
+            const int owner = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
             todo &= todo - 1ULL;
             const int orow = __shfl(row, owner);
             const bool oopen[2] = {__shfl(open[0], owner) != 0, __shfl(open[1], owner) != 0};
@@ -778,8 +778,9 @@ __global__ __launch_bounds__(kLanes) void whittaker_seam_kernel(const WhittakerS
                     }
                 }
                 __syncthreads();
-                upto = __shfl(upto, owner);
-                done = __shfl((met[0] >= 2 && met[1] >= 2) ? 1 : 0, owner) != 0;
+                // (the same in every lane, and said so: a loop exit the compiler takes for divergent must not hold barriers)
+                upto = __builtin_amdgcn_readfirstlane(__shfl(upto, owner));
+                done = __builtin_amdgcn_readfirstlane(__shfl((met[0] >= 2 && met[1] >= 2) ? 1 : 0, owner)) != 0;
                 if (lane < upto) {
                     if (BACKWARD) {
                         m.dst0[at_row + i] = 0.5 * (s_out[0][lane] + s_out[1][lane]);

@@ -187,3 +187,30 @@ def test_model_chain_depth_override_and_single_problem(gpu, oracle, monkeypatch)
             a = _solve([s], [1.0], [6000], chain, monkeypatch)[0]
             assert a[0] == ref[0] and a[3] == ref[3], (depth, chain)
             assert np.array_equal(a[1].cpu().numpy(), ref[1])
+
+
+@pytest.mark.parametrize("mode", ["1", "2", "3", "4"])
+def test_rounds_as_one_launch_give_the_same_calibration(gpu, oracle, monkeypatch, mode):
+    """Round 5's experiment, kept as an option (ROCCO_HIP_CHAIN_FUSED, default 0; csrc/lean.hip: lean_round_chain_kernel): a
+    chained round's compactions, evaluation and finish as ONE launch -- blocks and tiles by tickets, the workgroup that
+    completes a (chromosome, penalty) pair's last tile finishes the pair, the next director restores tickets and counters.
+    Measured slower than three launches, but it must give the same penalties, counts and
+    solutions: a batch large enough for both chains, against the three-launch form and (one chromosome) the oracle."""
+    import torch
+
+    from rocco_amd import dp, synth
+    from rocco_amd import rocco as rr
+
+    monkeypatch.setenv("ROCCO_HIP_CHAIN_MIN_TILES", "1")
+    sizes = [1_200_001, 700_000, 2_100_000, 65_000, 900_123, 1_500_000]
+    scores = [rr.score_central_tendency_chrom_device(synth.hash_matrix_device(6, n, 900 + i)) for i, n in enumerate(sizes)]
+    targets = [int(np.floor(n * 0.02)) for n in sizes]
+    monkeypatch.setenv("ROCCO_HIP_CHAIN_FUSED", "0")
+    want = dp.calibrate_batch_device(scores, [1.0] * len(scores), targets)
+    monkeypatch.setenv("ROCCO_HIP_CHAIN_FUSED", mode)
+    for _rep in range(2):  # (the second call starts from the scratch the first one left)
+        got = dp.calibrate_batch_device(scores, [1.0] * len(scores), targets)
+        for g, w in zip(got, want):
+            assert g[0] == w[0] and g[3] == w[3] and g[4]["path"] == w[4]["path"] and torch.equal(g[1], w[1])
+    o_sol, _obj, o_det = oracle.solve_chrom_exact(scores[3].cpu().numpy(), budget=0.02, gamma=1.0, return_details=True)
+    assert got[3][0] == o_det["selection_penalty"] and np.array_equal(got[3][1].cpu().numpy(), o_sol)
