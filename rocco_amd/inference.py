@@ -395,7 +395,7 @@ def release_batch_workers() -> None:
 
 def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
                                 precision_floor_ratio: float = 0.01, overwrite_input: bool = False,
-                                input_scale: str = "counts", workers: int = 3, memory_budget_bytes: Optional[int] = None):
+                                input_scale: str = "counts", workers: int = 2, memory_budget_bytes: Optional[int] = None):
     """`score_loci_wls_device` for several [K_i, n_i] float64 CUDA count matrices -- the chromosomes a rank owns
     (the loop of rocco/rocco.py:948-1018 around rocco/inference.py:302-379).  Returns one (scores, details) pair per
     matrix, bit for bit what the single-matrix call returns.  What is shared: the matrices are dealt to `workers`
@@ -405,16 +405,18 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
     the pair lasts as long as the longest row, not as long as all rows one after the other) and the rolling variances
     of every row come from ONE launch (`wls_rolling_variances_batch_device`); the per-matrix steps (log scale + row
     medians; rank finding, dealing, selects and accumulation of the trend fit) are launches over whole matrices.
-    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values): 0.70 s with one pipeline, 0.60 s with two, 0.58 s with three
-    (the default; the baselines of the longest rows -- 5 M loci x 27 ns x 2 sweeps -- are 0.27-0.30 s of it whatever
-    runs beside them).
+    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values), round 5: 0.52-0.55 s with one pipeline (log scale
+    and row medians 0.12, baselines 0.12 -- their rows are cut into segments since, whittaker.hip --, rolling sums 0.11,
+    trend fits 0.17), 0.47-0.48 s with two of equal parts, the second starting when the first has its baselines behind it
+    (the default: its bandwidth-bound phases then run under the first one's rolling launch, the one phase left that lasts
+    as long as its longest row), 0.50-0.52 with three (round 4: 0.59, of which the baselines' longest rows were 0.29).
 
-    Memory: beside its matrices a pipeline holds, while it works on a set of them of S bytes, their baselines (S), the
-    sweeps' scratch (2 S) and then their rolling variances (S) -- four times the set.  A pipeline therefore walks its
-    matrices in CHUNKS whose size the device's free memory allows (`memory_budget_bytes`: what the whole call may hold
-    beside the inputs; default 92 % of what is free or reusable when it starts): everything at once when that fits (the K = 100
-    genome: 49 GB of matrices, ~200 GB in all), several chunks one after the other when it does not (K = 50 at 10 bp,
-    123 GB of matrices, centred in place: chunks of ~40 GB, each paying its longest row's chains again)."""
+    Memory: beside its matrices a pipeline holds, for the chunk of C bytes it works on, ONE block of C bytes (its baselines,
+    then in their place its rolling variances) and 2 C of solver scratch (the forward sweep's two parities; kept between
+    calls).  A pipeline therefore walks its matrices in CHUNKS whose size the device's free memory allows
+    (`memory_budget_bytes`: what the whole call may hold beside the inputs and the tracks it returns; default 88 % of what is
+    free or cached when it starts): everything at once when that fits (the K = 100 genome: 49 GB of matrices, ~200 GB in
+    all), several chunks one after the other when it does not (K = 50 at 10 bp, 123 GB of matrices, centred in place)."""
     import concurrent.futures
 
     import torch
@@ -444,7 +446,9 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
     # group's longest row set how long its baseline and rolling launches last while using a fraction of the device, and
     # the bandwidth-bound phases of the other groups (log scale and row medians before, rank finding, dealing, selects
     # and accumulation after) run under them.  The group with the longest rows therefore holds the fewest values.
-    shares = [g + 1 for g in range(workers)]
+    # (round 5: equal parts -- the pipelines are staggered on their baselines, see run_group_body; until the baselines were cut
+    # into segments the parts were 1 : 2 : 3 with the longest rows in the smallest)
+    shares = [1 for _g in range(workers)]
     if os.environ.get("ROCCO_BATCH_SHARES"):  # (experiments: other splits, e.g. "2,3,4")
         given = [float(x) for x in os.environ["ROCCO_BATCH_SHARES"].split(",")]
         if len(given) == workers and all(x > 0 for x in given):
@@ -469,14 +473,29 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
                 stream.synchronize()
                 print(f"[batch] group {slot} ({len(idx)} matrices): {what} at {1e3 * (_time.perf_counter() - t_start):.1f} ms", flush=True)
 
+        try:
+            run_group_body(slot, idx, start, solver, stream, stamp)
+        finally:
+            baselines_done[slot].set()  # (whatever happened: the next pipeline must not wait for ever)
+
+    def run_group_body(slot, idx, start, solver, stream, stamp):
         with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
             stream.wait_event(start)
-            for part in chunks_of[slot]:
-                run_chunk(solver, stream, part, stamp, slot)
+            if stagger and slot > 0:
+                # Round 5: since the baselines are cut into segments their launches fill the device, and the one phase that
+                # does not is the rolling sums (the latency of the longest row): a pipeline starts when the one before it
+                # has its baselines behind it, so that ITS bandwidth-bound phases run under the other's rolling launch
+                baselines_done[slot - 1].wait()
+                stream.wait_event(baselines_event[slot - 1])
+            for k, part in enumerate(chunks_of[slot]):
+                run_chunk(solver, stream, part, stamp, slot, first=(k == 0))
+            if not baselines_done[slot].is_set():  # (a pipeline without a baseline phase still lets the next one go)
+                baselines_event[slot].record(stream)
+                baselines_done[slot].set()
             stream.synchronize()
             stamp("done")
 
-    def run_chunk(solver, stream, idx, stamp, slot):
+    def run_chunk(solver, stream, idx, stamp, slot, first=True):
         # phase 1: log scale, pilot offset (rocco/inference.py:325, 333-334)
         centred = {i: log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite[i] else None,
                                                    apply_log2=(input_scale == "counts"))[0] for i in idx}
@@ -501,6 +520,9 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
                     raise ValueError("Local baseline fit produced non-finite values")
                 _native.check(rc, "rocco_hip_subtract_finite_f64")
             del baselines
+        if first and not baselines_done[slot].is_set():
+            baselines_event[slot].record(stream)
+            baselines_done[slot].set()
         stamp("rolling variances start")
         # phase 3: the centred WLS (342-348): the rolling variances of every row of the group in one launch (one
         # workgroup per row), then rank finding, trend fits and accumulation matrix by matrix
@@ -600,6 +622,11 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
                     c_s = (ctypes.c_size_t * len(same))(*[int(counts_list[i].shape[1]) for i in same])
                     _native.check(_native.load().rocco_hip_count_path_reserve(solver.handle, len(same), r_s, c_s, float(lam),
                                                                               caller_stream.cuda_stream), "rocco_hip_count_path_reserve")
+        import threading
+
+        stagger = os.environ.get("ROCCO_BATCH_STAGGER", "1") != "0" and len(groups) > 1
+        baselines_event = [torch.cuda.Event() for _ in groups]
+        baselines_done = [threading.Event() for _ in groups]
         start = torch.cuda.Event()
         start.record(caller_stream)
         t_start = _time.perf_counter()
