@@ -349,6 +349,7 @@ def _composed_driver_leg(args, genome, device, works, mine, po):
             torch.cuda.reset_peak_memory_stats()
             genome_counts, _bed = run(counts, order, "bam", "device", tmp)
             genome_counts["peak_torch_memory_GB"] = round(torch.cuda.max_memory_allocated() / 1e9, 1)
+            bed_kept_inputs = open(_bed).read()  # (the one-chromosome runs below write to the same name)
             one_dev, bed_dev = run({small: counts[small]}, [small], "bam", "device", tmp)
             one_host, bed_host = run({small: counts[small]}, [small], "bam", "host", tmp)
             one_dev["bed_equal_to_host_multipliers_run"] = open(bed_dev).read() == open(bed_host).read()
@@ -356,7 +357,7 @@ def _composed_driver_leg(args, genome, device, works, mine, po):
             torch.cuda.reset_peak_memory_stats()
             consumed, bed_consumed = run(counts, order, "bam", "device", tmp, consume_inputs=True)
             consumed["peak_torch_memory_GB"] = round(torch.cuda.max_memory_allocated() / 1e9, 1)
-            consumed["bed_equal_to_the_run_that_kept_its_inputs"] = open(bed_consumed).read() == open(_bed).read()
+            consumed["bed_equal_to_the_run_that_kept_its_inputs"] = open(bed_consumed).read() == bed_kept_inputs
             leg[f"counts_K{args.samples}_whole_genome"] = {
                 "device_multipliers": genome_counts, "device_multipliers_inputs_consumed": consumed,
                 "one_chromosome": {"chromosome": small, "device_multipliers": one_dev, "host_multipliers": one_host,

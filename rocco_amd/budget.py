@@ -657,9 +657,41 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
             inflight = int(max(1, min(look_every, (psutil.virtual_memory().available // 2) // max(1, K * n * 8))))
         except Exception:  # noqa: BLE001 (no psutil: the pool's size is the bound)
             pass
+    # device multipliers: the draws between two looks at the stopping rule are computed together, as many at a time as the
+    # free memory holds (each keeps its K x n product and its rolling variances): their rolling launch is ONE
+    at_once = 1
+    if on_device and look_every > 1 and os.environ.get("ROCCO_BUDGET_NULL_DRAWS_AT_ONCE", "") != "1":
+        free_now, _total = torch.cuda.mem_get_info(template_t.device)
+        cached = max(0, int(torch.cuda.memory_reserved(template_t.device)) - int(torch.cuda.memory_allocated(template_t.device)))
+        share = max(1, int(os.environ.get("ROCCO_BUDGET_NULL_STREAMS", "3")))  # (estimates may run side by side on that many streams)
+        at_once = int(max(1, min(look_every, (6 * (free_now + cached) // (10 * share)) // max(1, 3 * K * n * 8))))
     for first in range(0, max_draws, look_every):
         batch = list(range(first, min(max_draws, first + look_every)))
         pending, to_submit = {}, list(batch)
+        if at_once > 1:
+            at = 0
+            while at < len(batch):
+                group, weights = batch[at:at + at_once], []
+                t_mult = _time.perf_counter()
+                for draw in group:
+                    made = device_multipliers(np.random.default_rng(int(random_seed) + (104729 * (draw + 1))), K, n, taps)
+                    weights.append(made if made is not None else torch.from_numpy(host_weights(draw)).to(template_t.device))
+                _note("multipliers_device_s", _time.perf_counter() - t_mult)
+                for d_mass, d_units, d_fraction, d_tail in _inf.compute_budget_null_draws_device(
+                        template_t, weights, lower_bound_z, prior_df, draw_min_effect, floor_ratio, null_center, soft_scale, null_threshold):
+                    mass.add(d_mass)
+                    units.add(d_units)
+                    fraction.add(d_fraction)
+                    tail.add(d_tail)
+                del weights
+                torch.cuda.current_stream().synchronize()
+                if progress_label:
+                    sys.stderr.write(f"\r{progress_label}: {units.count}/{max_draws}")
+                    sys.stderr.flush()
+                at += at_once
+            if _stable_enough(units, min_draws, stability_abs_tol, stability_rel_tol):
+                break
+            continue
         for draw in batch:
             made = None
             t_mult = _time.perf_counter()

@@ -734,6 +734,41 @@ def fit_budget_null_residual_template_device(centered_t, lower_bound_z: float = 
     return residual, scores, torch.clamp_min(mean, 0.0)
 
 
+def compute_budget_null_draws_device(residual_template_t, weights_list, lower_bound_z: float, prior_df: float, min_effect,
+                                     precision_floor_ratio: float, null_center: float, null_soft_scale: float,
+                                     null_threshold: float):
+    """Several draws of the budget null at once (round 5): what `compute_budget_null_draw_device` computes for each of
+    `weights_list` (one [K, n] float64 CUDA tensor of multipliers per draw; they are OVERWRITTEN by the draws' products),
+    with the rolling variances of every draw's K rows in ONE launch -- that launch lasts as long as one row whatever the
+    number of rows (csrc/wls.hip), and it is most of a draw: four draws of a chromosome cost little more than one.  The
+    reference's worker pool computes `num_processes` draws side by side before it looks at its stopping rule
+    (rocco/inference.py:871-937), so batching that many changes nothing it decides.  Returns one 4-tuple per draw."""
+    import ctypes
+
+    import torch
+
+    K, n = int(residual_template_t.shape[0]), int(residual_template_t.shape[1])
+    lib, solver, stream = _native.load(), _native.solver_for(residual_template_t.device.index), _dp._stream_ptr(residual_template_t)
+    for w in weights_list:
+        if w.shape != residual_template_t.shape or w.dtype != torch.float64 or not w.is_cuda or not w.is_contiguous():
+            raise ValueError("every draw's multipliers must be a contiguous float64 CUDA tensor shaped as the residual template")
+        _native.check(lib.rocco_hip_multiply_f64(solver.handle, residual_template_t.data_ptr(), w.data_ptr(), w.data_ptr(), K * n, stream),
+                      "rocco_hip_multiply_f64")
+    variances = wls_rolling_variances_batch_device(weights_list, spatial_window=31)
+    out = []
+    for boot, var in zip(weights_list, variances):
+        scores = score_centered_wls_device(boot, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df),
+                                           min_effect=(None if min_effect is None else float(max(min_effect, 0.0))), spatial_window=31,
+                                           precision_floor_ratio=float(max(precision_floor_ratio, 0.0)), variances_t=var)[0]
+        if not bool(torch.isfinite(scores).all()):
+            raise ValueError("EB scoring produced non-finite values")
+        stats = (ctypes.c_double * 4)()
+        _native.check(lib.rocco_hip_budget_null_draw_stats_f64(solver.handle, scores.data_ptr(), n, float(null_center), float(null_soft_scale),
+                                                               float(null_threshold), stats, stream), "rocco_hip_budget_null_draw_stats_f64")
+        out.append((float(stats[0]), float(stats[1]), float(stats[2]), float(stats[3])))
+    return out
+
+
 def compute_budget_null_draw_device(residual_template_t, wild_weights_t, lower_bound_z: float, prior_df: float,
                                     min_effect, precision_floor_ratio: float, null_center: float,
                                     null_soft_scale: float, null_threshold: float, work_t=None):
