@@ -594,15 +594,23 @@ __device__ __forceinline__ unsigned long long order_key(double v)
     return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
 }
 
-// pass `p` looks at the `width` bits above bit `low`; hist[row][digit] += keys of the row matching its prefix
+// pass `p` looks at the `width` bits above bit `low`; hist[row][digit] += keys of the row matching its prefix.
+// SPAN (round 5, the passes behind the gathered-cell shortcut): also the smallest and the largest key that matches the
+// prefix -- a row of counts has its median inside a RUN of equal values, which no cell of kCellMax values holds; when the
+// two agree every key of the cell is the wanted one and the row is complete without the passes that remain
+// (row_select_span_kernel): three passes instead of six over such rows.
+template <bool SPAN>
 __global__ __launch_bounds__(256) void row_select_count_kernel(const double *__restrict__ matrix, long long n, int low, int width,
-                                                              const RowSelect *__restrict__ state, unsigned *__restrict__ hist)
+                                                              const RowSelect *__restrict__ state, unsigned *__restrict__ hist,
+                                                              unsigned long long *__restrict__ span, const unsigned *__restrict__ complete)
 {
     __shared__ unsigned local[kSelectBuckets];
+    __shared__ unsigned long long wave_lo[4], wave_hi[4];
     const long long row = blockIdx.y;
-    if (state[row].rank < 0) {  // settled from its gathered cell (row_gather_kernel)
+    if (state[row].rank < 0 || (complete != nullptr && complete[row] != 0u)) {  // settled from its gathered cell (row_gather_kernel), or complete
         return;
     }
+    unsigned long long lo_key = ~0ULL, hi_key = 0ULL;
     for (int b = threadIdx.x; b < kSelectBuckets; b += 256) {
         local[b] = 0u;
     }
@@ -619,7 +627,23 @@ __global__ __launch_bounds__(256) void row_select_count_kernel(const double *__r
             const unsigned long long k = order_key(x[i]);
             if (above_bits >= 64 || (k >> above_bits) == prefix) {
                 atomicAdd(&local[(unsigned)((k >> low) & mask)], 1u);
+                if (SPAN) {
+                    lo_key = (k < lo_key) ? k : lo_key;
+                    hi_key = (k > hi_key) ? k : hi_key;
+                }
             }
+        }
+    }
+    if (SPAN) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long l2 = __shfl_xor(lo_key, off), h2 = __shfl_xor(hi_key, off);
+            lo_key = (l2 < lo_key) ? l2 : lo_key;
+            hi_key = (h2 > hi_key) ? h2 : hi_key;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            wave_lo[threadIdx.x >> 6] = lo_key;
+            wave_hi[threadIdx.x >> 6] = hi_key;
         }
     }
     __syncthreads();
@@ -629,17 +653,46 @@ __global__ __launch_bounds__(256) void row_select_count_kernel(const double *__r
             atomicAdd(&mine[b], local[b]);
         }
     }
+    if (SPAN && threadIdx.x == 0) {
+        unsigned long long l = wave_lo[0], h = wave_hi[0];
+        for (int w = 1; w < 4; ++w) {
+            l = (wave_lo[w] < l) ? wave_lo[w] : l;
+            h = (wave_hi[w] > h) ? wave_hi[w] : h;
+        }
+        if (l <= h) {
+            atomicMin(&span[2 * row], l);
+            atomicMax(&span[2 * row + 1], h);
+        }
+    }
+}
+
+// behind a SPAN pass and its pick: a row whose matching keys were all ONE key has that key for its median's lower middle
+// element -- its prefix is complete, the counting passes that remain skip it (the pass for the upper middle element does not)
+__global__ __launch_bounds__(256) void row_select_span_kernel(RowSelect *__restrict__ state, unsigned long long *__restrict__ span,
+                                                             unsigned *__restrict__ complete, long long rows, int init)
+{
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) {
+        return;
+    }
+    const unsigned long long l = span[2 * row], h = span[2 * row + 1];
+    span[2 * row] = ~0ULL;  // (empty again for the next pass)
+    span[2 * row + 1] = 0ULL;
+    if (init == 0 && state[row].rank >= 0 && complete[row] == 0u && l == h) {
+        state[row].prefix = l;
+        complete[row] = 1u;
+    }
 }
 
 // one workgroup per row: the digit whose bucket holds the wanted rank joins the prefix; the histogram is cleared for the next pass
 // (`bucket`, may be null: how many keys the chosen digit's bucket holds; rows whose rank is negative are settled already)
 __global__ __launch_bounds__(256) void row_select_pick_kernel(RowSelect *__restrict__ state, unsigned *__restrict__ hist, int width,
-                                                             unsigned *__restrict__ bucket)
+                                                             unsigned *__restrict__ bucket, const unsigned *__restrict__ complete = nullptr)
 {
     __shared__ unsigned part[256];
     __shared__ unsigned long long chosen[2];
     const long long row = blockIdx.x;
-    if (state[row].rank < 0) {
+    if (state[row].rank < 0 || (complete != nullptr && complete[row] != 0u)) {
         return;
     }
     unsigned *__restrict__ mine = hist + row * kSelectBuckets;
@@ -2236,7 +2289,8 @@ size_t log_scale_scratch_bytes(size_t K, size_t n)
 {
     (void)n;
     return align_up(K * 8, 256) + align_up(K * sizeof(RowSelect), 256) + align_up(K * kSelectBuckets * sizeof(unsigned), 256) + 512 +
-           2 * align_up(K * sizeof(unsigned), 256) + align_up(K * (size_t)kCellMax * 8, 256);  // gathered cells of the medians
+           2 * align_up(K * sizeof(unsigned), 256) + align_up(K * (size_t)kCellMax * 8, 256) +  // gathered cells of the medians
+           align_up(K * 16, 256) + align_up(K * sizeof(unsigned), 256);                        // the cells' spans, the complete rows
 }
 
 int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount, int apply_log,
@@ -2252,7 +2306,10 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
     unsigned *bucket = (unsigned *)((char *)bad + 512);
     unsigned *filled = (unsigned *)((char *)bucket + align_up(K * sizeof(unsigned), 256));
     unsigned long long *cand = (unsigned long long *)((char *)filled + align_up(K * sizeof(unsigned), 256));
+    unsigned long long *span = (unsigned long long *)((char *)cand + align_up(K * (size_t)kCellMax * 8, 256));
+    unsigned *complete = (unsigned *)((char *)span + align_up(K * 16, 256));
     ROCCO_HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), stream));
+    ROCCO_HIP_TRY(hipMemsetAsync(complete, 0, K * sizeof(unsigned), stream));
     const unsigned blocks_all = (unsigned)((count + 255) / 256);
     hipLaunchKernelGGL(log_scale_kernel, dim3(blocks_all), dim3(256), 0, stream, counts_dev, centered_out_dev, count,
                        pseudocount, apply_log, bad);
@@ -2261,11 +2318,20 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
                        rows, nn, filled);
     const dim3 grid((unsigned)((nn + kSelectChunk - 1) / kSelectChunk), (unsigned)K);
     const int lows[6] = {53, 42, 31, 20, 9, 0}, widths[6] = {11, 11, 11, 11, 11, 9};
+    hipLaunchKernelGGL(row_select_span_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, state, span, complete, rows, 1);  // (span := empty)
     for (int p = 0; p < 6; ++p) {
-        hipLaunchKernelGGL(row_select_count_kernel, grid, dim3(256), 0, stream, (const double *)centered_out_dev, nn, lows[p], widths[p],
-                           (const RowSelect *)state, hist);
+        if (p >= 2) {
+            hipLaunchKernelGGL(row_select_count_kernel<true>, grid, dim3(256), 0, stream, (const double *)centered_out_dev, nn, lows[p], widths[p],
+                               (const RowSelect *)state, hist, span, (const unsigned *)complete);
+        } else {
+            hipLaunchKernelGGL(row_select_count_kernel<false>, grid, dim3(256), 0, stream, (const double *)centered_out_dev, nn, lows[p], widths[p],
+                               (const RowSelect *)state, hist, (unsigned long long *)nullptr, (const unsigned *)nullptr);
+        }
         hipLaunchKernelGGL(row_select_pick_kernel, dim3((unsigned)K), dim3(256), 0, stream, state, hist, (p == 0) ? 64 : widths[p],
-                           (p == 1) ? bucket : (unsigned *)nullptr);
+                           (p == 1) ? bucket : (unsigned *)nullptr, (const unsigned *)complete);
+        if (p >= 2 && p < 5) {
+            hipLaunchKernelGGL(row_select_span_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, state, span, complete, rows, 0);
+        }
         if (p == 1) {
             // 22 key bits known: a row whose median's cell holds at most kCellMax values (continuous signal; not a row of small
             // integer counts, whose median is a run of equal values) is settled from the gathered cell and skips the rest
