@@ -15,6 +15,13 @@ while time.time() < t_end:
     n = int(rng.choice([5, 24, 25, 26, 31, 32, 63, 64, 500, 511, 512, 513, 1025, 4000, 8191, 8192, 8193, 30000, 100000]))
     which = rng.choice(["baseline", "wls", "loci_pow2", "batch", "batch"])
     os.environ["ROCCO_HIP_ROLLING_GROUP"] = str(rng.choice([0, 1, 2, 4, 8]))  # (0: the library's own choice)
+    # round 5: rows of the batched baselines cut into segments that start from a warm-up and are verified at their seams --
+    # forced short here (the library cuts only rows far longer than these), warm-ups short enough that seams get repaired
+    for name, choices in (("ROCCO_HIP_WHITTAKER_SEGMENT_LOCI", [None, 0, 1024, 4096]), ("ROCCO_HIP_WHITTAKER_WARM_LOCI", [None, 64, 512, 4096])):
+        pick = choices[int(rng.integers(0, len(choices)))]
+        os.environ.pop(name, None)
+        if pick is not None:
+            os.environ[name] = str(pick)
     try:
         if which == "batch":
             # several matrices through the batched launches (grouped baselines, grouped rolling sums, pipelines) against the
@@ -63,4 +70,5 @@ while time.time() < t_end:
     if not ok:
         bad += 1; print(f"MISMATCH it={it} K={K} n={n} {which}", flush=True)
     it += 1
-print(f"{it} cases, {bad} mismatches; {sorted(counts.items())}")
+from rocco_amd import _native
+print(f"{it} cases, {bad} mismatches; {sorted(counts.items())}; seams repaired along the way: {int(_native.load().rocco_hip_whittaker_seam_repairs())}")
