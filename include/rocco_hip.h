@@ -287,6 +287,15 @@ int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, c
 int rocco_hip_crossfit_whittaker_baseline_batch_f64(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev,
                                                     const size_t *rows, const size_t *cols, double penalty_lambda,
                                                     double *const *baselines_dev, void *stream);
+/* The batch form with the two elementwise statements around the fit folded into its sweeps (rocco/inference.py:330-338:
+ * `global_centered = log_matrix - offsets; local = baseline(global_centered); centered = global_centered - local`):
+ * centered_out_dev[i] = (matrices_dev[i] - row_offsets_dev[i][row]) - baseline of (matrices_dev[i] - row_offsets_dev[i][row]),
+ * every operation rounded as the separate statements round it.  row_offsets_dev (may be NULL, entries may be NULL): K_i doubles per
+ * matrix.  centered_out_dev[i] must not be matrices_dev[i].  ROCCO_HIP_EINVAL ("Local baseline fit produced non-finite values",
+ * inference.py:207-208) when a baseline is not finite. */
+int rocco_hip_crossfit_whittaker_residual_batch_f64(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev,
+                                                    const double *const *row_offsets_dev, const size_t *rows, const size_t *cols,
+                                                    double penalty_lambda, double *const *centered_out_dev, void *stream);
 
 /* ---- centred-WLS locus scores ------------------------------------
  * Replaces rocco_score_centered_wls_f64 (rocco/native/wls_backend.h:11-28, wls_backend.c:744-947) as
@@ -350,6 +359,13 @@ int rocco_hip_log_scale_f64(rocco_hip_solver *solver, const double *values_dev, 
 int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *counts_dev, size_t K, size_t n,
                                         double pseudocount, int apply_log2, double *centered_out_dev,
                                         double *row_offsets_out_dev, void *stream);
+
+/* The same log scale and the same row medians WITHOUT subtracting them: log_out_dev = log2(max(counts, 0) + pseudocount)
+ * (may alias counts_dev), row_offsets_out_dev (K doubles, required) = the medians (rocco/inference.py:330).  For callers whose next
+ * pass subtracts the offsets on its way (rocco_hip_crossfit_whittaker_residual_batch_f64): one pass over the matrix less. */
+int rocco_hip_log_scale_row_offsets_f64(rocco_hip_solver *solver, const double *counts_dev, size_t K, size_t n,
+                                        double pseudocount, int apply_log2, double *log_out_dev, double *row_offsets_out_dev,
+                                        void *stream);
 
 /* out = a - b, element by element (rocco/inference.py:335 `centered = global_centered - local_baselines`);
  * out_dev may alias a_dev or b_dev. */

@@ -168,6 +168,9 @@ PROTOTYPES = [
     ("rocco_hip_crossfit_whittaker_baseline_batch_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), c_size_p, c_size_p, ctypes.c_double,
       ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    ("rocco_hip_crossfit_whittaker_residual_batch_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_size_p, c_size_p,
+      ctypes.c_double, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     ("rocco_hip_crossfit_whittaker_baseline_matrix_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_void_p,
       ctypes.c_void_p]),
@@ -183,6 +186,9 @@ PROTOTYPES = [
       ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_int_p, ctypes.c_void_p]),
     ("rocco_hip_log_scale_center_rows_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
+      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("rocco_hip_log_scale_row_offsets_f64", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_double, ctypes.c_int,
       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ("rocco_hip_wls_sorted_rows", ctypes.c_int, [ctypes.c_void_p]),

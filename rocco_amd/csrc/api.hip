@@ -778,16 +778,18 @@ int ensure_whittaker_factor(rocco_hip_solver *solver, size_t cols, double penalt
 
 }  // namespace
 
-int rocco_hip_crossfit_whittaker_baseline_batch_f64(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev,
-                                                    const size_t *rows, const size_t *cols, double penalty_lambda,
-                                                    double *const *baselines_dev, void *stream)
+namespace {
+
+int whittaker_batch(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev, const double *const *offsets_dev,
+                    const size_t *rows, const size_t *cols, double penalty_lambda, double *const *baselines_dev, int residual,
+                    void *stream)
 {
     if (solver == nullptr || (count > 0 && (matrices_dev == nullptr || rows == nullptr || cols == nullptr || baselines_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
     size_t longest = 0;
     for (size_t i = 0; i < count; ++i) {
-        if (rows[i] * cols[i] > 0 && (matrices_dev[i] == nullptr || baselines_dev[i] == nullptr)) {
+        if (rows[i] * cols[i] > 0 && (matrices_dev[i] == nullptr || baselines_dev[i] == nullptr || (residual != 0 && baselines_dev[i] == matrices_dev[i]))) {
             return ROCCO_HIP_EINVAL;
         }
         if (rows[i] > 0) {
@@ -803,13 +805,32 @@ int rocco_hip_crossfit_whittaker_baseline_batch_f64(rocco_hip_solver *solver, si
     rc = launch_crossfit_whittaker_batch(matrices_dev, rows, cols, count, penalty_lambda,
                                          factor != nullptr ? (const double *)factor->buf.ptr : nullptr,
                                          factor != nullptr ? factor->cap : 0, baselines_dev, solver->dev_misc.ptr,
-                                         solver->host_stage.ptr, (hipStream_t)stream);
+                                         solver->host_stage.ptr, (hipStream_t)stream, offsets_dev, residual);
     if (rc != ROCCO_HIP_OK) {
         return rc;
     }
     ROCCO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // the scratch buffers are the solver's
-    whittaker_collect_repairs(solver->host_stage.ptr);
+    if (whittaker_collect_repairs(solver->host_stage.ptr) != 0 && residual != 0) {
+        set_last_error("Local baseline fit produced non-finite values");
+        return ROCCO_HIP_EINVAL;
+    }
     return ROCCO_HIP_OK;
+}
+
+}  // namespace
+
+int rocco_hip_crossfit_whittaker_baseline_batch_f64(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev,
+                                                    const size_t *rows, const size_t *cols, double penalty_lambda,
+                                                    double *const *baselines_dev, void *stream)
+{
+    return whittaker_batch(solver, count, matrices_dev, nullptr, rows, cols, penalty_lambda, baselines_dev, 0, stream);
+}
+
+int rocco_hip_crossfit_whittaker_residual_batch_f64(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev,
+                                                    const double *const *row_offsets_dev, const size_t *rows, const size_t *cols,
+                                                    double penalty_lambda, double *const *centered_out_dev, void *stream)
+{
+    return whittaker_batch(solver, count, matrices_dev, row_offsets_dev, rows, cols, penalty_lambda, centered_out_dev, 1, stream);
 }
 
 int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, const double *matrix_dev,
@@ -1046,6 +1067,27 @@ int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *
     }
     return launch_log_scale_center_rows(counts_dev, K, n, pseudocount, apply_log2, centered_out_dev, row_offsets_out_dev,
                                         solver->dev_misc.ptr, (hipStream_t)stream, (int *)solver->host_back.ptr);
+}
+
+int rocco_hip_log_scale_row_offsets_f64(rocco_hip_solver *solver, const double *counts_dev, size_t K, size_t n,
+                                        double pseudocount, int apply_log2, double *log_out_dev, double *row_offsets_out_dev,
+                                        void *stream)
+{
+    if (solver == nullptr || counts_dev == nullptr || log_out_dev == nullptr || row_offsets_out_dev == nullptr || K == 0 || n == 0 ||
+        n > (size_t)0x7fffffff) {
+        set_last_error("rocco_hip_log_scale_row_offsets_f64: null buffer, empty matrix or more than 2^31-1 loci");
+        return ROCCO_HIP_EINVAL;
+    }
+    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    int rc;
+    if ((rc = solver->dev_misc.reserve(log_scale_scratch_bytes(K, n))) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    if ((rc = solver->host_back.reserve(256)) != ROCCO_HIP_OK) {
+        return rc;
+    }
+    return launch_log_scale_center_rows(counts_dev, K, n, pseudocount, apply_log2, log_out_dev, row_offsets_out_dev,
+                                        solver->dev_misc.ptr, (hipStream_t)stream, (int *)solver->host_back.ptr, 0);
 }
 
 int rocco_hip_subtract_finite_f64(rocco_hip_solver *solver, const double *a_dev, const double *b_dev, double *out_dev,

@@ -156,6 +156,12 @@ struct WhittakerRowTask {
     long long tile_begin, tile_end;
     long long warm_tiles;
     double *spec, *edge;
+    // round 5: the two elementwise passes around the sweeps ride on them.  offsets (may be null): one value per row of the
+    // matrix, the sweeps' input is  src - offsets[row]  (the pilot offset of rocco/inference.py:330-331); minus (backward
+    // only, may be null): the forward sweep's input matrix -- dst0 receives  (minus - offsets[row]) - baseline  instead of
+    // the baseline (inference.py:335), and *bad is raised when a baseline is not finite (inference.py:207-208)
+    const double *offsets, *minus;
+    int *bad;
 };
 // one matrix of a batch for the seam check behind a sweep (whittaker.hip: whittaker_seam_kernel)
 struct WhittakerSeamMatrix {
@@ -168,6 +174,8 @@ struct WhittakerSeamMatrix {
     long long seg_tiles;       // tiles per segment (the last one may be shorter)
     long long task_base;       // the matrix's first task: task = task_base + group * n_seg + segment
     const double *tail;
+    const double *offsets, *minus;  // as the sweep's tasks
+    int *bad;
 };
 // several matrices of one penalty (the chromosomes of a genome) in ONE pair of launches (+ one seam check each);
 // tasks_host_pinned: room for whittaker_batch_stage_bytes(...), must stay untouched until the stream has passed the copy
@@ -177,10 +185,14 @@ int whittaker_group_rows();  // rows per workgroup of the batched sweeps
 // how often a segment's warm-up had NOT reached the row's own values at the seam (each such seam was recomputed from
 // the true state: results are the sequential sweep's either way); process-wide, for tests and diagnostics
 long long whittaker_seam_repairs();
-void whittaker_collect_repairs(const void *tasks_host_pinned);  // after the stream of a batch launch has been waited for
+// after the stream of a batch launch has been waited for; returns non-zero when a residual launch met a non-finite baseline
+int whittaker_collect_repairs(const void *tasks_host_pinned);
+// offsets_dev (may be null, entries may be null): per matrix, one value per row that the sweeps subtract from their input;
+// residual != 0: baselines_dev[i] receives (matrix - offsets) - baseline instead of the baseline (must not be the matrix)
 int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const size_t *rows, const size_t *cols, size_t count,
                                     double penalty_lambda, const double *factor_dev, size_t factor_cap, double *const *baselines_dev,
-                                    void *scratch_dev, void *tasks_host_pinned, hipStream_t stream);
+                                    void *scratch_dev, void *tasks_host_pinned, hipStream_t stream,
+                                    const double *const *offsets_dev = nullptr, int residual = 0);
 
 // ---- wls.hip --------------------------------------------------------------------------------
 // scratch: at least wls_scratch_bytes(K, n) bytes; synchronises the stream before returning
@@ -213,7 +225,7 @@ int launch_log2_selfcheck(int family, unsigned long long seed, unsigned long lon
 size_t log_scale_scratch_bytes(size_t K, size_t n);
 int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount, int apply_log,
                                  double *centered_out_dev, double *row_offsets_out_dev, void *scratch_dev,
-                                 hipStream_t stream, int *flag_host_pinned);
+                                 hipStream_t stream, int *flag_host_pinned, int center = 1);
 // out = log2(max(in, 0) + pseudocount), correctly rounded; *bad_dev |= 1 if a value is not finite
 int launch_log_scale(const double *in_dev, double *out_dev, size_t count, double pseudocount, int *bad_dev, hipStream_t stream);
 int launch_subtract(const double *a_dev, const double *b_dev, double *out_dev, size_t count, hipStream_t stream, int *bad_dev = nullptr);

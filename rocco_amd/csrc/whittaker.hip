@@ -417,6 +417,7 @@ struct RowTiles {
     double in[2][kRowTile * kPitch];
     double out[2][kRowTile * kPitch];
     double coef[2][2][kRowTile][2];  // [buffer][parity][locus] = multipliers of the previous / one-before-previous value
+    double off[kGroupRows];          // the offsets of the group's rows (0.0 where the task has none; registers are short here)
 };
 
 struct RowRegs {  // what a helper lane holds of one tile between its loads and its LDS stores
@@ -459,10 +460,15 @@ __device__ __forceinline__ void multipliers_at(const Factor &f, long long i, lon
 // where the diagonal entry arrives with the tile's other loads instead of queueing for three tiles in registers.
 // backward: src0 / src1 = f of parity 0 / 1, dst0 = the baseline 0.5 (x0 + x1) (158-172, 296-299); dst0 must be neither
 // src0 nor src1 once rows are cut into segments (a neighbour's warm-up reads what this segment would overwrite).
-template <bool BACKWARD>
+// RESIDUAL (backward only, round 5): dst0 receives (minus - offset of the row) - baseline, the centred matrix of
+// rocco/inference.py:335, instead of the baseline; a non-finite baseline raises task.bad (inference.py:207-208).  The
+// forward sweep subtracts the row's offset (the pilot offset of inference.py:330-331; 0.0 when the task has none: x - 0.0 is x)
+// on its way into LDS.  Both used to be passes of their own over the matrix (24 + 16 bytes per value).
+template <bool BACKWARD, bool RESIDUAL = false>
 __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kernel(const WhittakerRowTask *__restrict__ tasks,
                                                                                   long long cap, const double *__restrict__ factor)
 {
+    static_assert(BACKWARD || !RESIDUAL, "the residual is formed where the baseline is");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     RowTiles &T = *reinterpret_cast<RowTiles *>(smem);
     const WhittakerRowTask task = tasks[blockIdx.x];
@@ -484,6 +490,12 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
     const long long n_tiles = warm + (task.tile_end - task.tile_begin);
     auto tile_base = [&](long long k) { return (BACKWARD ? (first - k) : (first + k)) * kRowTile; };
     constexpr int kMine = kGroupRows / kRowHelpers;  // rows a helper wavefront moves per tile
+    const gconst_t minus = (gconst_t)task.minus;
+    if (threadIdx.x < kGroupRows) {
+        const int r = (int)threadIdx.x;
+        T.off[r] = (task.offsets != nullptr && r < task.rows) ? task.offsets[task.row0 + r] : 0.0;
+    }
+    lds_barrier();
 
     // helpers: lane = locus of the tile.  A tile is loaded into registers TWO trips before it is stored to LDS (two
     // register sets take turns), every load of a trip issued before anything waits for one: a load has two chains of a
@@ -528,8 +540,9 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
                 v0 = R.x0[q] / f0.dd_of(R.d0, ii);  // z = f / d (baseline_backend.c:153-156)
                 v1 = R.x1[q] / f1.dd_of(R.d1, ii);
             } else {
-                v0 = rhs_value(R.x0[q], ii, n, 0);
-                v1 = rhs_value(R.x0[q], ii, n, 1);
+                const double y = R.x0[q] - T.off[r];
+                v0 = rhs_value(y, ii, n, 0);
+                v1 = rhs_value(y, ii, n, 1);
             }
             in[lane * kPitch + r] = live ? v0 : 0.0;
             in[lane * kPitch + kGroupRows + r] = live ? v1 : 0.0;
@@ -544,13 +557,41 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             T.coef[buf][1][lane][1] = b1;
         }
     };
-    auto write_back = [&](long long k) {
+    // RESIDUAL: the values the baselines of tile k are subtracted from -- loaded at the start of the trip that writes the tile
+    // back, used at its end (a load used at once would cost the helper a memory latency per tile)
+    auto load_minus = [&](long long k, double(&m)[kMine]) {
+        if (!RESIDUAL || k < warm) {
+            return;
+        }
+        const long long i = tile_base(k) + lane;
+        const long long ii = (i < n) ? i : (n - 1);
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) {
+            const int r = h + q * kRowHelpers;
+            m[q] = minus[(long long)(task.row0 + ((r < task.rows) ? r : 0)) * n + ii];
+        }
+    };
+    auto write_back = [&](long long k, const double(&m)[kMine]) {
         if (k < warm) {
             return;  // (ahead of the segment: another workgroup's loci)
         }
         const double *__restrict__ out = T.out[k & 1];
         const long long i = tile_base(k) + lane;
         if (i >= n) {
+            return;
+        }
+        if (RESIDUAL) {
+#pragma unroll
+            for (int q = 0; q < kMine; ++q) {
+                const int r = h + q * kRowHelpers;
+                if (r < task.rows) {
+                    const double base = 0.5 * (out[lane * kPitch + r] + out[lane * kPitch + kGroupRows + r]);
+                    if (!isfinite(base)) {
+                        atomicOr(task.bad, 1);
+                    }
+                    dst0[(long long)(task.row0 + r) * n + i] = (m[q] - T.off[r]) - base;
+                }
+            }
             return;
         }
         for (int r = h; r < task.rows; r += kRowHelpers) {
@@ -609,40 +650,60 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             run(v2, a2, b2, j + 1);
         }
     };
-    // one trip: the chain wavefront runs tile k; the helpers store tile k + 1 (in `set` since two trips), refill `set`
-    // with tile k + 3 and carry tile k - 1 to memory
-    auto trip = [&](long long k, RowRegs &set) {
+    // The chain wavefront and the helpers walk the tiles in loops of their own (round 5: one loop with a branch per trip kept
+    // the helpers' two register sets alive across the chain's code -- 254 registers, none left for the residual form); they
+    // meet at one barrier per tile.  The branch is on a scalar (readfirstlane): every wavefront runs one of the loops only,
+    // and both pass 1 + n_tiles barriers.
+    // One trip: the chain wavefront runs tile k; the helpers carry tile k - 1 to memory, store tile k + 1 (in `set` since two
+    // trips) and refill `set` with tile k + 3
 #ifdef ROCCO_ROWS_NOCHAIN  // (timing experiments only)
-        if (false) {
+    constexpr bool kRunChain = false;
 #else
-        if (wave == 0) {
+    constexpr bool kRunChain = true;
 #endif
-            if (k == warm && warm > 0 && chain_lane) {
-                // the state the warm-up has reached where the segment starts
-                task.spec[2 * col] = p1;
-                task.spec[2 * col + 1] = p2;
-            }
-            chain(k);
 #ifdef ROCCO_ROWS_NOHELP
-        } else if (false) {
+    constexpr bool kRunHelpers = false;
 #else
-        } else if (wave > 0) {
+    constexpr bool kRunHelpers = true;
 #endif
-            if (k + 1 < n_tiles) {
-                stage_store(k + 1, set);
-            }
-            if (k + 3 < n_tiles) {
-                stage_load(k + 3, set);
-            }
-            if (k > 0) {
-                write_back(k - 1);
-            }
-        }
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+        __builtin_amdgcn_s_setprio(3);  // the chain wavefront shares its SIMD with a helper: its instructions go first
         lds_barrier();
-    };
-
-    RowRegs A, B;
-    if (wave > 0) {
+        for (long long k = 0; k < n_tiles; ++k) {
+            if (kRunChain) {
+                if (k == warm && warm > 0 && chain_lane) {
+                    // the state the warm-up has reached where the segment starts
+                    task.spec[2 * col] = p1;
+                    task.spec[2 * col + 1] = p2;
+                }
+                chain(k);
+            }
+            lds_barrier();
+        }
+        if (chain_lane && task.edge != nullptr) {
+            task.edge[2 * col] = p1;  // the state at the segment's far end: what the next segment of the sweep must start from
+            task.edge[2 * col + 1] = p2;
+        }
+    } else {
+        RowRegs A, B;
+        double minus_set[kMine] = {};
+        // (RESIDUAL: the values tile k - 1's baselines are subtracted from are loaded at the end of the trip before -- live
+        // across the barrier, where the helpers wait for the chain anyway, and not across the staging)
+        auto trip = [&](long long k, RowRegs &set) {
+            if (kRunHelpers) {
+                if (k > 0) {
+                    write_back(k - 1, minus_set);
+                }
+                if (k + 1 < n_tiles) {
+                    stage_store(k + 1, set);
+                }
+                if (k + 3 < n_tiles) {
+                    stage_load(k + 3, set);
+                }
+                load_minus(k, minus_set);
+            }
+            lds_barrier();
+        };
         stage_load(0, A);
         stage_store(0, A);
         if (n_tiles > 1) {
@@ -651,21 +712,14 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
         if (n_tiles > 2) {
             stage_load(2, A);
         }
-    } else {
-        __builtin_amdgcn_s_setprio(3);  // the chain wavefront shares its SIMD with a helper: its instructions go first
-    }
-    lds_barrier();
-    for (long long k = 0; k < n_tiles; k += 2) {
-        trip(k, B);  // even trips store odd tiles (set B), odd trips even tiles (set A)
-        if (k + 1 < n_tiles) {
-            trip(k + 1, A);
+        lds_barrier();
+        for (long long k = 0; k < n_tiles; k += 2) {
+            trip(k, B);  // even trips store odd tiles (set B), odd trips even tiles (set A)
+            if (k + 1 < n_tiles) {
+                trip(k + 1, A);
+            }
         }
-    }
-    if (wave > 0) {
-        write_back(n_tiles - 1);
-    } else if (chain_lane && task.edge != nullptr) {
-        task.edge[2 * col] = p1;  // the state at the segment's far end: what the next segment of the sweep must start from
-        task.edge[2 * col + 1] = p2;
+        write_back(n_tiles - 1, minus_set);  // (loaded at the end of the last trip)
     }
 }
 
@@ -726,6 +780,7 @@ __global__ __launch_bounds__(kLanes) void whittaker_seam_kernel(const WhittakerS
             // backward writes 0.5 (x0 + x1): an open parity needs the other parity's values too, so both are walked there
             const bool walk[2] = {oopen[0] || (BACKWARD && oopen[1]), oopen[1] || (BACKWARD && oopen[0])};
             const long long at_row = (long long)orow * n;
+            const double off_o = (m.offsets != nullptr) ? m.offsets[orow] : 0.0;  // (the sweeps' input is src - offset of the row)
             int met[2] = {oopen[0] ? 0 : 2, oopen[1] ? 0 : 2};  // consecutive loci at which the two sequences agreed (the owner's count)
             long long walked = 0;
             bool done = false;
@@ -743,7 +798,7 @@ __global__ __launch_bounds__(kLanes) void whittaker_seam_kernel(const WhittakerS
                     if (BACKWARD) {
                         v = (p == 0 ? m.src0 : m.src1)[at_row + ii] / f[p].dd(ii);
                     } else {
-                        v = rhs_value(m.src0[at_row + ii], ii, n, p);
+                        v = rhs_value(m.src0[at_row + ii] - off_o, ii, n, p);
                     }
                     s_v[p][lane] = v;
                     s_a[p][lane] = a;
@@ -783,7 +838,15 @@ __global__ __launch_bounds__(kLanes) void whittaker_seam_kernel(const WhittakerS
                 done = __builtin_amdgcn_readfirstlane(__shfl((met[0] >= 2 && met[1] >= 2) ? 1 : 0, owner)) != 0;
                 if (lane < upto) {
                     if (BACKWARD) {
-                        m.dst0[at_row + i] = 0.5 * (s_out[0][lane] + s_out[1][lane]);
+                        const double base = 0.5 * (s_out[0][lane] + s_out[1][lane]);
+                        if (m.minus != nullptr) {  // (the residual form: what whittaker_rows_kernel<true, true> writes)
+                            if (!isfinite(base)) {
+                                atomicOr(m.bad, 1);
+                            }
+                            m.dst0[at_row + i] = (m.minus[at_row + i] - off_o) - base;
+                        } else {
+                            m.dst0[at_row + i] = base;
+                        }
                     } else {
                         if (oopen[0]) {
                             m.dst0[at_row + i] = s_out[0][lane];
@@ -808,6 +871,15 @@ __global__ __launch_bounds__(kLanes) void whittaker_seam_kernel(const WhittakerS
                 }
             }
         }
+    }
+}
+
+// out = matrix - offset of the row (rows too short for a baseline: the baseline is zero, baseline_backend.c:265-272)
+__global__ void offset_rows_kernel(const double *matrix, const double *offsets, long long n, long long count, double *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        out[i] = (matrix[i] - ((offsets != nullptr) ? offsets[i / n] : 0.0)) - 0.0;
     }
 }
 
@@ -857,6 +929,8 @@ int configure_rows_kernels()
         ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_rows_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowTiles)));
         ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_rows_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowTiles)));
+        ROCCO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(whittaker_rows_kernel<true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowTiles)));
         int per_cu[2] = {1, 1}, device = 0, cus = 256;
         ROCCO_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], reinterpret_cast<const void *>(whittaker_rows_kernel<false>),
@@ -1062,12 +1136,15 @@ size_t whittaker_batch_scratch_bytes(const size_t *rows, const size_t *cols, siz
 
 int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const size_t *rows, const size_t *cols, size_t count,
                                     double penalty_lambda, const double *factor_dev, size_t factor_cap, double *const *baselines_dev,
-                                    void *scratch_dev, void *tasks_host_pinned, hipStream_t stream)
+                                    void *scratch_dev, void *tasks_host_pinned, hipStream_t stream,
+                                    const double *const *offsets_dev, int residual)
 {
     int rc;
     if ((rc = configure_rows_kernels()) != ROCCO_HIP_OK) return rc;
+    std::memset(tasks_host_pinned, 0, 64);  // (the counters whittaker_collect_repairs reads, whichever way this call goes)
     const long long seg_loci = batch_budget_loci(rows, cols, count);
-    if (count == 1 && rows[0] > 0 && cols[0] >= 25 && plan_segments(cols[0], seg_loci).n_seg < 2) {
+    auto offsets_of = [&](size_t i) { return (offsets_dev != nullptr) ? offsets_dev[i] : (const double *)nullptr; };
+    if (residual == 0 && offsets_dev == nullptr && count == 1 && rows[0] > 0 && cols[0] >= 25 && plan_segments(cols[0], seg_loci).n_seg < 2) {
         // ONE matrix of rows too short to cut: a workgroup per row with one chain per wavefront steps ~25 ns per locus, the
         // grouped wavefronts below ~27 ns -- both last as long as one row, so the lone matrix takes the faster step
         if (factor_dev == nullptr || factor_cap < cols[0]) {
@@ -1101,6 +1178,7 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
     const size_t stage_bytes = 64 + round256(2 * n_tasks * sizeof(WhittakerRowTask)) + round256(2 * count * sizeof(WhittakerSeamMatrix));
     char *at = (char *)scratch_dev;
     unsigned long long *repairs_dev = (unsigned long long *)at;
+    int *bad_dev = (int *)(repairs_dev + 2);  // (the counter block's third word)
     WhittakerRowTask *tasks_dev = (WhittakerRowTask *)(at + 64);
     WhittakerSeamMatrix *seams_dev = (WhittakerSeamMatrix *)(at + 64 + round256(2 * n_tasks * sizeof(WhittakerRowTask)));
     at += round256(stage_bytes);
@@ -1117,7 +1195,12 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
         }
         if (cols[i] < 25) {  // baseline_backend.c:265-272
             const long long total = (long long)(rows[i] * cols[i]);
-            hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, baselines_dev[i], total);
+            if (residual != 0) {
+                hipLaunchKernelGGL(offset_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, matrices_dev[i], offsets_of(i),
+                                   (long long)cols[i], total, baselines_dev[i]);
+            } else {
+                hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, baselines_dev[i], total);
+            }
             continue;
         }
         if (factor_dev == nullptr || factor_cap < cols[i]) {
@@ -1145,7 +1228,11 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
             fw.seg_tiles = plan.seg_tiles;
             fw.task_base = (long long)t;
             fw.tail = tail;
+            fw.offsets = offsets_of(i);
+            fw.minus = nullptr;
+            fw.bad = bad_dev;
             bw = fw;
+            bw.minus = (residual != 0) ? matrices_dev[i] : nullptr;
             bw.src0 = z0;
             bw.src1 = z1;
             bw.dst0 = baselines_dev[i];
@@ -1169,7 +1256,11 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
                 fw.warm_tiles = (seg > 0) ? plan.warm_tiles : 0;
                 fw.spec = states_dev + (2 * t + 0) * (kStateDoubles / 2);
                 fw.edge = states_dev + (2 * t + 1) * (kStateDoubles / 2);
+                fw.offsets = offsets_of(i);
+                fw.minus = nullptr;
+                fw.bad = bad_dev;
                 bw = fw;
+                bw.minus = (residual != 0) ? matrices_dev[i] : nullptr;
                 bw.src0 = z0;
                 bw.src1 = z1;
                 bw.dst0 = baselines_dev[i];
@@ -1197,26 +1288,34 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
         hipLaunchKernelGGL(whittaker_seam_kernel<false>, seam_grid, dim3(kLanes), 0, stream, (const WhittakerSeamMatrix *)seams_dev,
                            states_dev, (long long)n_tasks, (long long)factor_cap, factor_dev, repairs_dev);
     }
-    hipLaunchKernelGGL(whittaker_rows_kernel<true>, dim3((unsigned)t), block, sizeof(RowTiles), stream,
-                       (const WhittakerRowTask *)(tasks_dev + n_tasks), (long long)factor_cap, factor_dev);
+    if (residual != 0) {
+        hipLaunchKernelGGL((whittaker_rows_kernel<true, true>), dim3((unsigned)t), block, sizeof(RowTiles), stream,
+                           (const WhittakerRowTask *)(tasks_dev + n_tasks), (long long)factor_cap, factor_dev);
+    } else {
+        hipLaunchKernelGGL((whittaker_rows_kernel<true, false>), dim3((unsigned)t), block, sizeof(RowTiles), stream,
+                           (const WhittakerRowTask *)(tasks_dev + n_tasks), (long long)factor_cap, factor_dev);
+    }
     if (n_seams > 0) {
         hipLaunchKernelGGL(whittaker_seam_kernel<true>, seam_grid, dim3(kLanes), 0, stream, (const WhittakerSeamMatrix *)(seams_dev + count),
                            states_dev, (long long)n_tasks, (long long)factor_cap, factor_dev, repairs_dev);
-        // the count of recomputed seams comes back into the staging area's first word (read by whittaker_collect_repairs
-        // once the caller has waited for the stream)
-        ROCCO_HIP_TRY(hipMemcpyAsync(stage, repairs_dev, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    }
+    if (n_seams > 0 || residual != 0) {
+        // the count of recomputed seams (and the residual form's flag) come back into the staging area's first words (read
+        // by whittaker_collect_repairs once the caller has waited for the stream)
+        ROCCO_HIP_TRY(hipMemcpyAsync(stage, repairs_dev, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     }
     ROCCO_HIP_TRY(hipGetLastError());
     return ROCCO_HIP_OK;
 }
 
-void whittaker_collect_repairs(const void *tasks_host_pinned)
+int whittaker_collect_repairs(const void *tasks_host_pinned)
 {
     const unsigned long long *back = (const unsigned long long *)tasks_host_pinned;
     g_seam_repairs.fetch_add((long long)back[0], std::memory_order_relaxed);
     if (back[0] != 0 && env_loci("ROCCO_HIP_WHITTAKER_TRACE", 0) != 0) {
         std::fprintf(stderr, "[whittaker] %llu seams recomputed over %llu loci\n", back[0], back[1]);
     }
+    return (back[2] != 0ULL) ? 1 : 0;
 }
 
 }  // namespace rocco

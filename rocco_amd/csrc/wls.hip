@@ -2295,7 +2295,7 @@ size_t log_scale_scratch_bytes(size_t K, size_t n)
 
 int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, double pseudocount, int apply_log,
                                  double *centered_out_dev, double *row_offsets_out_dev, void *scratch_dev,
-                                 hipStream_t stream, int *flag_host_pinned)
+                                 hipStream_t stream, int *flag_host_pinned, int center)
 {
     const long long count = (long long)(K * n), nn = (long long)n, rows = (long long)K;
     char *sc = (char *)scratch_dev;
@@ -2346,8 +2346,10 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
     }
     hipLaunchKernelGGL(row_select_median_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, (const RowSelect *)state, rows,
                        nn, med);
-    hipLaunchKernelGGL(subtract_row_offset_kernel, dim3((unsigned)((nn + 1023) / 1024), (unsigned)K), dim3(256), 0, stream, centered_out_dev, med,
-                       nn);
+    if (center != 0) {  // (0: the caller's next pass subtracts the offsets on its way -- the batched baseline sweeps do)
+        hipLaunchKernelGGL(subtract_row_offset_kernel, dim3((unsigned)((nn + 1023) / 1024), (unsigned)K), dim3(256), 0, stream, centered_out_dev, med,
+                           nn);
+    }
     if (row_offsets_out_dev != nullptr) {
         ROCCO_HIP_TRY(hipMemcpyAsync(row_offsets_out_dev, med, K * 8, hipMemcpyDeviceToDevice, stream));
     }

@@ -309,6 +309,66 @@ def log_scale_center_rows_device(counts_t, pseudocount: float = 1.0, out_t=None,
     return out_t, offsets
 
 
+def log_scale_row_offsets_device(counts_t, pseudocount: float = 1.0, out_t=None, apply_log2: bool = True):
+    """`log_scale_center_rows_device` WITHOUT the subtraction: (log matrix [K, n], row medians [K]) -- for the batched baseline
+    sweeps that subtract the medians on their way (`crossfit_whittaker_residual_batch_device`): one pass over the matrix less
+    (rocco_hip_log_scale_row_offsets_f64)."""
+    import torch
+
+    if counts_t.dim() != 2:
+        raise ValueError("`chrom_matrix` must be two-dimensional")
+    if counts_t.dtype != torch.float64 or not counts_t.is_cuda or not counts_t.is_contiguous():
+        raise ValueError("counts_t must be a contiguous float64 CUDA tensor")
+    K, n = int(counts_t.shape[0]), int(counts_t.shape[1])
+    if K == 0 or n == 0:
+        raise ValueError("`chrom_matrix` must be non-empty")
+    if out_t is None:
+        out_t = torch.empty_like(counts_t)
+    offsets = torch.empty(K, dtype=torch.float64, device=counts_t.device)
+    solver = _native.solver_for(counts_t.device.index)
+    _native.check(_native.load().rocco_hip_log_scale_row_offsets_f64(
+        solver.handle, counts_t.data_ptr(), K, n, float(pseudocount), 1 if apply_log2 else 0, out_t.data_ptr(),
+        offsets.data_ptr(), _dp._stream_ptr(counts_t)), "rocco_hip_log_scale_row_offsets_f64")
+    return out_t, offsets
+
+
+def crossfit_whittaker_residual_batch_device(values_list, offsets_list, penalty_lambda: float, outs=None):
+    """rocco/inference.py:330-338 for several matrices of ONE penalty in the baseline sweeps' own launches
+    (rocco_hip_crossfit_whittaker_residual_batch_f64): out_i = (values_i - offsets_i[row]) - baseline(values_i - offsets_i[row]),
+    rounded as the reference's separate statements round.  `offsets_list`: one [K_i] tensor or None per matrix (or None for
+    all).  Raises ValueError("Local baseline fit produced non-finite values") as the reference does (207-208)."""
+    import ctypes
+
+    import torch
+
+    values_list = list(values_list)
+    if not values_list:
+        return []
+    offsets_list = [None] * len(values_list) if offsets_list is None else list(offsets_list)
+    for v, o in zip(values_list, offsets_list):
+        if v.dim() != 2 or v.dtype != torch.float64 or not v.is_cuda or not v.is_contiguous():
+            raise ValueError("every matrix must be a contiguous two-dimensional float64 CUDA tensor")
+        if o is not None and (o.dtype != torch.float64 or not o.is_cuda or not o.is_contiguous() or int(o.numel()) != int(v.shape[0])):
+            raise ValueError("offsets must be one contiguous float64 CUDA value per row")
+    if outs is None:
+        outs = [torch.empty_like(v) for v in values_list]
+    for v, o in zip(values_list, outs):
+        if o.shape != v.shape or o.dtype != torch.float64 or not o.is_contiguous() or o.data_ptr() == v.data_ptr():
+            raise ValueError("every output must be a distinct contiguous float64 tensor of its matrix's shape")
+    count = len(values_list)
+    solver = _native.solver_for(values_list[0].device.index)
+    rc = _native.load().rocco_hip_crossfit_whittaker_residual_batch_f64(
+        solver.handle, count, (ctypes.c_void_p * count)(*[v.data_ptr() for v in values_list]),
+        (ctypes.c_void_p * count)(*[(None if o is None else o.data_ptr()) for o in offsets_list]),
+        (ctypes.c_size_t * count)(*[int(v.shape[0]) for v in values_list]),
+        (ctypes.c_size_t * count)(*[int(v.shape[1]) for v in values_list]), float(penalty_lambda),
+        (ctypes.c_void_p * count)(*[o.data_ptr() for o in outs]), _dp._stream_ptr(values_list[0]))
+    if rc == _native.EINVAL and "non-finite" in _native.last_error():
+        raise ValueError("Local baseline fit produced non-finite values")
+    _native.check(rc, "rocco_hip_crossfit_whittaker_residual_batch_f64")
+    return outs
+
+
 def score_loci_wls_device(counts_t, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
                           precision_floor_ratio: float = 0.01, overwrite_input: bool = False,
                           input_scale: str = "counts"):
@@ -496,30 +556,53 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
             stamp("done")
 
     def run_chunk(solver, stream, idx, stamp, slot, first=True):
-        # phase 1: log scale, pilot offset (rocco/inference.py:325, 333-334)
-        centred = {i: log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite[i] else None,
-                                                   apply_log2=(input_scale == "counts"))[0] for i in idx}
-        stamp("baselines start")
-        # phase 2: local baselines (335), the group's matrices of one penalty together, and their subtraction (338)
-        windows = {i: _resolve_local_baseline_window(int(centred[i].shape[1]), target_window=101) for i in idx}
+        windows = {i: _resolve_local_baseline_window(int(counts_list[i].shape[1]), target_window=101) for i in idx}
         penalties = {i: (0.0 if windows[i] == 0 else _consenrich_whittaker_lambda(windows[i])) for i in idx}
         arena = arenas[slot]
-        for lam in sorted({penalties[i] for i in idx if windows[i] != 0}):
-            same = [i for i in idx if windows[i] != 0 and penalties[i] == lam]
-            views, used = [], 0
-            for i in same:  # (the pipeline's one block: the baselines now, the rolling variances after them)
-                k_i, n_i = int(centred[i].shape[0]), int(centred[i].shape[1])
-                views.append(arena[used:used + k_i * n_i].view(k_i, n_i))
+        if fused:
+            # Round 5: the two elementwise statements around the baseline fit (330-331: minus the row medians; 338: minus the
+            # baselines) ride on the sweeps.  phase 1: log scale and row medians (325, 330), the LOG matrix into the pipeline's
+            # block; phase 2: the sweeps read it minus the medians and write the centred matrix -- into the caller's tensor when it
+            # may be overwritten, a fresh one otherwise -- 40 bytes per value and 24 waits for the stream less per genome
+            logs, offsets, centred, used = {}, {}, {}, 0
+            for i in idx:
+                k_i, n_i = int(counts_list[i].shape[0]), int(counts_list[i].shape[1])
+                if windows[i] == 0:  # (too short for a baseline, 198-199: the centred matrix is the log matrix minus its medians)
+                    centred[i] = log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite[i] else None,
+                                                              apply_log2=(input_scale == "counts"))[0]
+                    continue
+                view = arena[used:used + k_i * n_i].view(k_i, n_i)
                 used += k_i * n_i
-            baselines = crossfit_whittaker_baseline_batch_device([centred[i] for i in same], lam, outs=views)
-            for i, b in zip(same, baselines):
-                c = centred[i]
-                rc = _native.load().rocco_hip_subtract_finite_f64(solver.handle, c.data_ptr(), b.data_ptr(), c.data_ptr(),
-                                                                  int(c.shape[0]) * int(c.shape[1]), stream.cuda_stream)
-                if rc == _native.EINVAL:
-                    raise ValueError("Local baseline fit produced non-finite values")
-                _native.check(rc, "rocco_hip_subtract_finite_f64")
-            del baselines
+                logs[i], offsets[i] = log_scale_row_offsets_device(counts_list[i], 1.0, view, apply_log2=(input_scale == "counts"))
+            stamp("baselines start")
+            for lam in sorted({penalties[i] for i in idx if windows[i] != 0}):
+                same = [i for i in idx if windows[i] != 0 and penalties[i] == lam]
+                outs = [counts_list[i] if overwrite[i] else torch.empty_like(counts_list[i]) for i in same]
+                crossfit_whittaker_residual_batch_device([logs[i] for i in same], [offsets[i] for i in same], lam, outs=outs)
+                centred.update(zip(same, outs))
+            del logs, offsets
+        else:
+            # phase 1: log scale, pilot offset (rocco/inference.py:325, 333-334)
+            centred = {i: log_scale_center_rows_device(counts_list[i], 1.0, counts_list[i] if overwrite[i] else None,
+                                                       apply_log2=(input_scale == "counts"))[0] for i in idx}
+            stamp("baselines start")
+            # phase 2: local baselines (335), the group's matrices of one penalty together, and their subtraction (338)
+            for lam in sorted({penalties[i] for i in idx if windows[i] != 0}):
+                same = [i for i in idx if windows[i] != 0 and penalties[i] == lam]
+                views, used = [], 0
+                for i in same:  # (the pipeline's one block: the baselines now, the rolling variances after them)
+                    k_i, n_i = int(centred[i].shape[0]), int(centred[i].shape[1])
+                    views.append(arena[used:used + k_i * n_i].view(k_i, n_i))
+                    used += k_i * n_i
+                baselines = crossfit_whittaker_baseline_batch_device([centred[i] for i in same], lam, outs=views)
+                for i, b in zip(same, baselines):
+                    c = centred[i]
+                    rc = _native.load().rocco_hip_subtract_finite_f64(solver.handle, c.data_ptr(), b.data_ptr(), c.data_ptr(),
+                                                                      int(c.shape[0]) * int(c.shape[1]), stream.cuda_stream)
+                    if rc == _native.EINVAL:
+                        raise ValueError("Local baseline fit produced non-finite values")
+                    _native.check(rc, "rocco_hip_subtract_finite_f64")
+                del baselines
         if first and not baselines_done[slot].is_set():
             baselines_event[slot].record(stream)
             baselines_done[slot].set()
@@ -625,6 +708,7 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         import threading
 
         stagger = os.environ.get("ROCCO_BATCH_STAGGER", "1") != "0" and len(groups) > 1
+        fused = os.environ.get("ROCCO_BATCH_FUSED_RESIDUAL", "1") != "0"  # (0: medians and baselines subtracted by passes of their own)
         baselines_event = [torch.cuda.Event() for _ in groups]
         baselines_done = [threading.Event() for _ in groups]
         start = torch.cuda.Event()

@@ -113,6 +113,67 @@ def test_seams_that_have_not_met_are_recomputed(gpu, oracle, monkeypatch, segmen
     assert _seam_repairs() == before
 
 
+@pytest.mark.parametrize("segment,warm", [(None, None), (2048, 64), (4096, 4096)])
+def test_residual_form_is_the_three_statements(gpu, oracle, monkeypatch, segment, warm):
+    """Round 5: `crossfit_whittaker_residual_batch_device` folds rocco/inference.py:330-331 (minus the row medians) and 338
+    (minus the baselines) into the sweeps.  Against the statements done one by one in NumPy around the oracle's baselines, bit for
+    bit -- whole rows, rows cut into segments, segments whose seams are recomputed (the repair writes the residual too), with and
+    without offsets, rows too short for a baseline; the fused and the unfused scoring of a batch agree on every track."""
+    import torch
+    from rocco_amd import inference
+
+    if segment is not None:
+        monkeypatch.setenv("ROCCO_HIP_WHITTAKER_SEGMENT_LOCI", str(segment))
+        monkeypatch.setenv("ROCCO_HIP_WHITTAKER_WARM_LOCI", str(warm))
+    rng = np.random.default_rng(77 + (segment or 0))
+    lam = inference._consenrich_whittaker_lambda(101)
+    shapes = [(3, 30000), (33, 9001), (1, 24), (2, 25), (40, 129), (8, 20000)]
+    hosts = [rng.normal(3.0, 2.0, size=s) for s in shapes]
+    offs = [np.median(h, axis=1) for h in hosts]
+    offs[3] = None
+    mats = [torch.from_numpy(h).to(gpu) for h in hosts]
+    outs = inference.crossfit_whittaker_residual_batch_device(mats, [None if o is None else torch.from_numpy(o).to(gpu) for o in offs], lam)
+    for h, f, o in zip(hosts, offs, outs):
+        g = h if f is None else (h - f[:, None])
+        want = g - oracle.crossfit_whittaker_baseline(g, lam)
+        assert o.cpu().numpy().tobytes() == want.tobytes(), h.shape
+    for m, h in zip(mats, hosts):
+        assert m.cpu().numpy().tobytes() == h.tobytes()  # the inputs are untouched
+    # one matrix alone, no offsets at all
+    one = inference.crossfit_whittaker_residual_batch_device([mats[0]], None, lam)[0]
+    assert one.cpu().numpy().tobytes() == (hosts[0] - oracle.crossfit_whittaker_baseline(hosts[0], lam)).tobytes()
+    with pytest.raises(ValueError):
+        inference.crossfit_whittaker_residual_batch_device([mats[0]], None, lam, outs=[mats[0]])
+    # the whole scoring with and without the folded statements
+    counts = [torch.from_numpy(_counts(rng, K, n)).to(gpu) for K, n in [(9, 30000), (33, 5000), (2, 24), (5, 64)]]
+    fused = inference.score_loci_wls_batch_device(counts, workers=2)
+    monkeypatch.setenv("ROCCO_BATCH_FUSED_RESIDUAL", "0")
+    plain = inference.score_loci_wls_batch_device(counts, workers=2)
+    for (fs, fd), (ps, pd) in zip(fused, plain):
+        assert torch.equal(fs, ps)
+        for key in TRACKS:
+            assert torch.equal(fd[key], pd[key]), key
+    monkeypatch.delenv("ROCCO_BATCH_FUSED_RESIDUAL")
+    kept = [c.clone() for c in counts]
+    over = inference.score_loci_wls_batch_device(counts, workers=2, overwrite_input=True)
+    for c, k, (s_o, d_o), (fs, fd) in zip(counts, kept, over, fused):
+        assert torch.equal(s_o, fs) and torch.equal(d_o["centered_matrix"], fd["centered_matrix"])
+        assert d_o["centered_matrix"].data_ptr() == c.data_ptr()  # the caller's tensor holds the centred values
+
+
+def test_residual_form_reports_a_baseline_that_is_not_finite(gpu):
+    import torch
+    from rocco_amd import inference
+
+    lam = inference._consenrich_whittaker_lambda(101)
+    m = torch.zeros((3, 5000), dtype=torch.float64, device=gpu)
+    m[1, 2500] = float("inf")
+    with pytest.raises(ValueError, match="non-finite"):
+        inference.crossfit_whittaker_residual_batch_device([m], None, lam)
+    m[1, 2500] = 1.0
+    inference.crossfit_whittaker_residual_batch_device([m], None, lam)
+
+
 def test_batch_errors(gpu):
     import torch
     from rocco_amd import inference
