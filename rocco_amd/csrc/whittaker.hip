@@ -386,6 +386,12 @@ __global__ __launch_bounds__(2 * kLanes + kSweepHelpers) void whittaker_sweep_ke
 //     doubles, a helper's 64 lanes (one row, 64 loci) write at an odd stride: no conflicts either way;
 //   * the multipliers of a locus are the same for every row: one (a, b) pair per parity and locus, read as a broadcast;
 //   * two input and two output tiles alternate (chain on k, staging of k + 1, write-back of k - 1), one barrier per tile.
+// Round 5, once rows are cut into segments the launch fills the device and lasts what its slowest ROLE takes per tile, and
+// that was the helpers (89 ms per K = 100 genome with the chain compiled out, 93 with it): the wavefronts have loops of their own
+// by role -- chain | loaders of the odd tiles | loaders of the even tiles | storers (see kRowHelpers) -- and G = 16 with two
+// loaders per group and two storers (7 wavefronts, 71 KB of LDS: two workgroups per CU) runs both sweeps in 80 ms, 88 with
+// the residual folded in (G = 32 with 4 + 4 + 4: 89 / 97).  Still the helpers' pace: 3.4-3.7 TB/s over ~25 thousand
+// row streams advancing 512 bytes per tile.
 //
 // Segments (round 5).  Until round 5 a launch lasted as long as its longest row: 4.98 M loci x 27 ns per sweep for a genome,
 // with most of the device idle.  The substitution is a CONTRACTING recurrence (its homogeneous part decays by ~0.96 per
@@ -403,15 +409,27 @@ __global__ __launch_bounds__(2 * kLanes + kSweepHelpers) void whittaker_sweep_ke
 // stored ones.  Results are the sequential sweep's bits in every case; only the time depends on the data.
 constexpr int kRowTile = 64;    // loci per tile
 #ifndef ROCCO_GROUP_ROWS
-#define ROCCO_GROUP_ROWS 32
+#define ROCCO_GROUP_ROWS 16
 #endif
 constexpr int kGroupRows = ROCCO_GROUP_ROWS;  // rows per workgroup (x 2 parities <= 64 lanes of the chain wavefront)
 constexpr int kPitch = 2 * kGroupRows + 1;
 static_assert(2 * kGroupRows <= kLanes, "one lane per chain");
+// Helper wavefronts come in two kinds since round 5: LOADERS (memory -> registers -> LDS) and STORERS (LDS -> memory).  A
+// wavefront that has loads AND stores in flight cannot wait for "the loads of two trips ago": on this target both count on
+// vmcnt and may complete out of order with respect to each other, so the compiler's wait for a loaded register is
+// vmcnt(0) -- every trip then waited for the stores it had just issued, the kernels ran at the helpers' pace (2.1 us per
+// tile against the chain's 1.5) and at 3.3 TB/s.  A loader has only loads in flight (precise in-order counts: the loads
+// of two trips ago, the newer ones still flying), a storer only stores (it never waits for them).
 #ifndef ROCCO_ROW_HELPERS
-#define ROCCO_ROW_HELPERS 4
+#define ROCCO_ROW_HELPERS 2
 #endif
-constexpr int kRowHelpers = ROCCO_ROW_HELPERS;  // helper wavefronts
+#ifndef ROCCO_ROW_STORERS
+#define ROCCO_ROW_STORERS 2
+#endif
+constexpr int kRowHelpers = ROCCO_ROW_HELPERS;  // loader wavefronts per tile parity (two groups: odd tiles, even tiles)
+constexpr int kRowStorers = ROCCO_ROW_STORERS;  // storer wavefronts
+constexpr int kRowThreads = kLanes * (1 + 2 * kRowHelpers + kRowStorers);
+static_assert(kGroupRows % kRowHelpers == 0 && kGroupRows % kRowStorers == 0, "rows dealt evenly to the helper wavefronts");
 
 struct RowTiles {
     double in[2][kRowTile * kPitch];
@@ -465,7 +483,7 @@ __device__ __forceinline__ void multipliers_at(const Factor &f, long long i, lon
 // forward sweep subtracts the row's offset (the pilot offset of inference.py:330-331; 0.0 when the task has none: x - 0.0 is x)
 // on its way into LDS.  Both used to be passes of their own over the matrix (24 + 16 bytes per value).
 template <bool BACKWARD, bool RESIDUAL = false>
-__global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kernel(const WhittakerRowTask *__restrict__ tasks,
+__global__ __launch_bounds__(kRowThreads) void whittaker_rows_kernel(const WhittakerRowTask *__restrict__ tasks,
                                                                                   long long cap, const double *__restrict__ factor)
 {
     static_assert(BACKWARD || !RESIDUAL, "the residual is formed where the baseline is");
@@ -479,7 +497,7 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
     const gconst_t src0 = (gconst_t)task.src0, src1 = (gconst_t)task.src1;
     const gmut_t dst0 = (gmut_t)task.dst0, dst1 = (gmut_t)task.dst1;
     const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
-    const int h = wave - 1;  // helper number
+    const int h = (wave - 1) % kRowHelpers;  // loader number within its group
     const long long n = task.n;
     const Factor f0 = factor_of(factor, task.tail, n, cap, 0), f1 = factor_of(factor, task.tail, n, cap, 1);
     const long long all_tiles = (n + kRowTile - 1) / kRowTile;
@@ -489,7 +507,9 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
     const long long warm = BACKWARD ? (first - (task.tile_end - 1)) : (task.tile_begin - first);
     const long long n_tiles = warm + (task.tile_end - task.tile_begin);
     auto tile_base = [&](long long k) { return (BACKWARD ? (first - k) : (first + k)) * kRowTile; };
-    constexpr int kMine = kGroupRows / kRowHelpers;  // rows a helper wavefront moves per tile
+    constexpr int kMine = kGroupRows / kRowHelpers;   // rows a loader moves per tile
+    constexpr int kStore = kGroupRows / kRowStorers;  // rows a storer moves per tile
+    const int hs = wave - 1 - 2 * kRowHelpers;        // storer number
     const gconst_t minus = (gconst_t)task.minus;
     if (threadIdx.x < kGroupRows) {
         const int r = (int)threadIdx.x;
@@ -515,7 +535,7 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             R.d0 = f0.d[ii];
             R.d1 = f1.d[ii];
         }
-        if (h == 0) {
+        if (__builtin_amdgcn_readfirstlane(h) == 0) {
             long long i1, i2;
             multiplier_loci<BACKWARD>(i, n, i1, i2);
             const long long j1 = (i1 < n - 1) ? i1 : 0, j2 = (i2 < n - 2) ? i2 : 0;  // (l1 has n - 1 entries, l2 n - 2)
@@ -525,8 +545,7 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             R.cb[1] = f1.l2[j2];
         }
     };
-    auto stage_store = [&](long long k, const RowRegs &R) {
-        const int buf = (int)(k & 1);
+    auto stage_store = [&](long long k, const RowRegs &R, int buf) {  // (buf: k & 1 -- but for a tile staged a second time past the end)
         const long long i = tile_base(k) + lane;
         const bool inside = i < n;
         const long long ii = inside ? i : (n - 1);
@@ -547,7 +566,7 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             in[lane * kPitch + r] = live ? v0 : 0.0;
             in[lane * kPitch + kGroupRows + r] = live ? v1 : 0.0;
         }
-        if (h == 0) {
+        if (__builtin_amdgcn_readfirstlane(h) == 0) {
             double a0, b0, a1, b1;
             multipliers_from<BACKWARD>(f0, i, n, R.ca[0], R.cb[0], a0, b0);
             multipliers_from<BACKWARD>(f1, i, n, R.ca[1], R.cb[1], a1, b1);
@@ -559,19 +578,19 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
     };
     // RESIDUAL: the values the baselines of tile k are subtracted from -- loaded at the start of the trip that writes the tile
     // back, used at its end (a load used at once would cost the helper a memory latency per tile)
-    auto load_minus = [&](long long k, double(&m)[kMine]) {
+    auto load_minus = [&](long long k, double(&m)[kStore]) {
         if (!RESIDUAL || k < warm) {
             return;
         }
         const long long i = tile_base(k) + lane;
         const long long ii = (i < n) ? i : (n - 1);
 #pragma unroll
-        for (int q = 0; q < kMine; ++q) {
-            const int r = h + q * kRowHelpers;
+        for (int q = 0; q < kStore; ++q) {
+            const int r = hs + q * kRowStorers;
             m[q] = minus[(long long)(task.row0 + ((r < task.rows) ? r : 0)) * n + ii];
         }
     };
-    auto write_back = [&](long long k, const double(&m)[kMine]) {
+    auto write_back = [&](long long k, const double(&m)[kStore]) {
         if (k < warm) {
             return;  // (ahead of the segment: another workgroup's loci)
         }
@@ -581,20 +600,35 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             return;
         }
         if (RESIDUAL) {
+            // every result first, then every store: with stores and the loads of `m` in flight together a wait for a loaded
+            // value is a wait for everything (they complete out of order with respect to each other) -- one such wait per
+            // tile, for operations a whole tile old, instead of one in front of every store
+            double res[kStore];
+            bool bad = false;
 #pragma unroll
-            for (int q = 0; q < kMine; ++q) {
-                const int r = h + q * kRowHelpers;
+            for (int q = 0; q < kStore; ++q) {
+                const int r = hs + q * kRowStorers, rr = (r < task.rows) ? r : 0;
+                const double base = 0.5 * (out[lane * kPitch + rr] + out[lane * kPitch + kGroupRows + rr]);
+                bad = bad || (r < task.rows && !isfinite(base));
+                res[q] = (m[q] - T.off[rr]) - base;
+            }
+#pragma unroll
+            for (int q = 0; q < kStore; ++q) {
+                asm volatile("" : "+v"(res[q]));  // (computed HERE: the compiler otherwise sinks each result into its store's branch, wait and all)
+            }
+#pragma unroll
+            for (int q = 0; q < kStore; ++q) {
+                const int r = hs + q * kRowStorers;
                 if (r < task.rows) {
-                    const double base = 0.5 * (out[lane * kPitch + r] + out[lane * kPitch + kGroupRows + r]);
-                    if (!isfinite(base)) {
-                        atomicOr(task.bad, 1);
-                    }
-                    dst0[(long long)(task.row0 + r) * n + i] = (m[q] - T.off[r]) - base;
+                    dst0[(long long)(task.row0 + r) * n + i] = res[q];
                 }
+            }
+            if (bad) {
+                atomicOr(task.bad, 1);
             }
             return;
         }
-        for (int r = h; r < task.rows; r += kRowHelpers) {
+        for (int r = hs; r < task.rows; r += kRowStorers) {
             const long long at = (long long)(task.row0 + r) * n + i;
             if (BACKWARD) {
                 dst0[at] = 0.5 * (out[lane * kPitch + r] + out[lane * kPitch + kGroupRows + r]);
@@ -661,11 +695,7 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
 #else
     constexpr bool kRunChain = true;
 #endif
-#ifdef ROCCO_ROWS_NOHELP
-    constexpr bool kRunHelpers = false;
-#else
-    constexpr bool kRunHelpers = true;
-#endif
+    constexpr bool kRunHelpers = true;  // (never compiled out: without their values every seam differs and is recomputed in full -- minutes)
     if (__builtin_amdgcn_readfirstlane(wave) == 0) {
         __builtin_amdgcn_s_setprio(3);  // the chain wavefront shares its SIMD with a helper: its instructions go first
         lds_barrier();
@@ -684,42 +714,59 @@ __global__ __launch_bounds__(kLanes *(1 + kRowHelpers)) void whittaker_rows_kern
             task.edge[2 * col] = p1;  // the state at the segment's far end: what the next segment of the sweep must start from
             task.edge[2 * col + 1] = p2;
         }
-    } else {
-        RowRegs A, B;
-        double minus_set[kMine] = {};
-        // (RESIDUAL: the values tile k - 1's baselines are subtracted from are loaded at the end of the trip before -- live
-        // across the barrier, where the helpers wait for the chain anyway, and not across the staging)
-        auto trip = [&](long long k, RowRegs &set) {
-            if (kRunHelpers) {
-                if (k > 0) {
-                    write_back(k - 1, minus_set);
-                }
+    } else if (__builtin_amdgcn_readfirstlane(wave) <= 2 * kRowHelpers) {
+        // Loaders, two groups: one serves the odd tiles, one the even ones.  A loader works every other trip -- tile k + 1 (in
+        // its registers since two trips) into LDS, the registers refilled with tile k + 3 -- and has ONE set of loads in
+        // flight, two trips to land.  (One wavefront alternating two sets had the compiler drain every load in flight once
+        // per trip: where paths join it counts the loads in flight conservatively, and it reuses a set's dead registers --
+        // a write-after-write wait on everything newer.  Here a full drain is exact: nothing newer is in flight.)
+        // Past the end the last tile is staged again, into the buffer nobody reads.
+        RowRegs R;
+        const long long last = n_tiles - 1;
+        const bool even_tiles = __builtin_amdgcn_readfirstlane(wave) > kRowHelpers;
+        auto work = [&](long long k) {
+            stage_store((k + 1 < last) ? (k + 1) : last, R, (int)((k + 1) & 1));
+            stage_load((k + 3 < last) ? (k + 3) : last, R);
+        };
+        if (even_tiles) {
+            stage_load(0, R);
+            stage_store(0, R, 0);
+            stage_load((2 < last) ? 2 : last, R);
+            lds_barrier();
+            for (long long k = 0; k < n_tiles; k += 2) {
+                lds_barrier();  // (trip k: the other group's)
                 if (k + 1 < n_tiles) {
-                    stage_store(k + 1, set);
+                    work(k + 1);
+                    lds_barrier();
                 }
-                if (k + 3 < n_tiles) {
-                    stage_load(k + 3, set);
+            }
+        } else {
+            stage_load((1 < last) ? 1 : last, R);
+            lds_barrier();
+            for (long long k = 0; k < n_tiles; k += 2) {
+                work(k);
+                lds_barrier();
+                if (k + 1 < n_tiles) {
+                    lds_barrier();  // (trip k + 1: the other group's)
                 }
+            }
+        }
+    } else {
+        // storers: tile k - 1 to memory.  RESIDUAL: the values its baselines are subtracted from were loaded a trip earlier
+        // (the one kind of load a storer has; its wait for them is a wait for the stores of the trip before too -- both a
+        // whole tile old by then)
+        double minus_set[kStore] = {};
+        lds_barrier();
+        load_minus(0, minus_set);
+        lds_barrier();
+        for (long long k = 1; k < n_tiles; ++k) {
+            if (kRunHelpers) {
+                write_back(k - 1, minus_set);
                 load_minus(k, minus_set);
             }
             lds_barrier();
-        };
-        stage_load(0, A);
-        stage_store(0, A);
-        if (n_tiles > 1) {
-            stage_load(1, B);
         }
-        if (n_tiles > 2) {
-            stage_load(2, A);
-        }
-        lds_barrier();
-        for (long long k = 0; k < n_tiles; k += 2) {
-            trip(k, B);  // even trips store odd tiles (set B), odd trips even tiles (set A)
-            if (k + 1 < n_tiles) {
-                trip(k + 1, A);
-            }
-        }
-        write_back(n_tiles - 1, minus_set);  // (loaded at the end of the last trip)
+        write_back(n_tiles - 1, minus_set);
     }
 }
 
@@ -934,9 +981,9 @@ int configure_rows_kernels()
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowTiles)));
         int per_cu[2] = {1, 1}, device = 0, cus = 256;
         ROCCO_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], reinterpret_cast<const void *>(whittaker_rows_kernel<false>),
-                                                                   kLanes * (1 + kRowHelpers), sizeof(RowTiles)));
+                                                                   kRowThreads, sizeof(RowTiles)));
         ROCCO_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], reinterpret_cast<const void *>(whittaker_rows_kernel<true>),
-                                                                   kLanes * (1 + kRowHelpers), sizeof(RowTiles)));
+                                                                   kRowThreads, sizeof(RowTiles)));
         ROCCO_HIP_TRY(hipGetDevice(&device));
         ROCCO_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         g_rows_resident.store((long long)std::max(1, std::min(per_cu[0], per_cu[1])) * (long long)std::max(1, cus));
@@ -1280,7 +1327,7 @@ int launch_crossfit_whittaker_batch(const double *const *matrices_dev, const siz
                      count, seg_loci, env_loci("ROCCO_HIP_WHITTAKER_WARM_LOCI", kWarmLoci), t, kGroupRows, resident_workgroups(), n_seams);
     }
     ROCCO_HIP_TRY(hipMemcpyAsync(scratch_dev, stage, stage_bytes, hipMemcpyHostToDevice, stream));
-    const dim3 block(kLanes * (1 + kRowHelpers));
+    const dim3 block(kRowThreads);
     const dim3 seam_grid((unsigned)((most_rows + kLanes - 1) / kLanes), (unsigned)n_seams);
     hipLaunchKernelGGL(whittaker_rows_kernel<false>, dim3((unsigned)t), block, sizeof(RowTiles), stream,  // (t <= n_tasks records are filled)
                        (const WhittakerRowTask *)tasks_dev, (long long)factor_cap, factor_dev);

@@ -6,11 +6,11 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-un
 VARIANTS=${VARIANTS:-8:4 16:4 32:4 32:8}
 ENVS=${ENVS:-X=0}
 for v in $VARIANTS; do
-  g=${v%%:*}; h=${v##*:}
+  g=$(echo "$v" | cut -d: -f1); h=$(echo "$v" | cut -d: -f2); d=$(echo "$v" | cut -d: -f3 | tr '+' ' ')  # (third field: -D flags, '+' between them)
   touch rocco_amd/csrc/whittaker.hip
-  make -C rocco_amd/csrc CXXFLAGS="$BASE -DROCCO_GROUP_ROWS=$g -DROCCO_ROW_HELPERS=$h" > /dev/null 2>&1
+  make -C rocco_amd/csrc CXXFLAGS="$BASE -DROCCO_GROUP_ROWS=$g -DROCCO_ROW_HELPERS=$h $d" > /dev/null 2>&1
   for e in $ENVS; do
-    echo "== rows per workgroup $g, helpers $h, $e"
+    echo "== rows per workgroup $g, helpers $h, $d $e"
     env $(echo "$e" | tr ',' ' ') timeout -k 10 200 python scripts/whittaker_batch_probe.py ${PROBE_ARGS:-100 all} 2>&1 | grep -v amdgpu.ids | tail -n 3
   done
 done
