@@ -93,11 +93,18 @@ __device__ __forceinline__ void rolling_rows_tile(RollingRows<G> &T, long long t
             b[set][u] = B[u][col];
         }
     };
+    // (Round 5, measured and dropped: the chain wavefront storing only every eighth sum -- ROCCO_ROLL_FLUSH=8, 48.8 -> 33 cycles per
+    // position -- with the helper wavefronts re-running the batches from those checkpoints: the re-runs' LDS traffic, 24 of 64
+    // lanes per instruction, cost the helpers 1000 cycles per tile and the chain its gain: 113 -> 133 ms.  DESIGN.md 13.3)
     auto flush = [&](int set, int batch) {
+#if defined(ROCCO_ROLL_FLUSH) && ROCCO_ROLL_FLUSH == 8  // (timing experiments only: what the chain wavefront's LDS writes cost)
+        S[8 * batch][col] = s[set][0];
+#else
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             S[8 * batch + u][col] = s[set][u];
         }
+#endif
     };
     auto run = [&](int set) {
 #pragma unroll
