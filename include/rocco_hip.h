@@ -297,6 +297,16 @@ int rocco_hip_crossfit_whittaker_residual_batch_f64(rocco_hip_solver *solver, si
                                                     const double *const *row_offsets_dev, const size_t *rows, const size_t *cols,
                                                     double penalty_lambda, double *const *centered_out_dev, void *stream);
 
+/* The same with the sweeps' scratch (the forward sweep's two parities: twice the matrices' bytes, + records) in a block of
+ * the caller's -- a framework that pools device memory keeps one pool that way instead of two that cannot see each other's reserves
+ * (round 5: the composed driver's budget null wanted the ~100 GB a K = 100 genome's sweeps had left idle in the solver).
+ * scratch_dev: at least rocco_hip_whittaker_batch_scratch_bytes(count, rows, cols) bytes, aligned to 256. */
+size_t rocco_hip_whittaker_batch_scratch_bytes(size_t count, const size_t *rows, const size_t *cols);
+int rocco_hip_crossfit_whittaker_residual_batch_scratch_f64(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev,
+                                                            const double *const *row_offsets_dev, const size_t *rows,
+                                                            const size_t *cols, double penalty_lambda, double *const *centered_out_dev,
+                                                            void *scratch_dev, size_t scratch_bytes, void *stream);
+
 /* ---- centred-WLS locus scores ------------------------------------
  * Replaces rocco_score_centered_wls_f64 (rocco/native/wls_backend.h:11-28, wls_backend.c:744-947) as
  * called through rocco/_wls.c from rocco/inference.py:231-299 (`_score_centered_wls_matrix`), on device
@@ -436,6 +446,10 @@ int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *
  * any solver buffer of the process has grown so far (diagnostic). */
 int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const size_t *rows, const size_t *cols,
                                  double penalty_lambda, void *stream);
+/* sweeps_scratch_is_the_callers != 0: the baseline sweeps will get their scratch from the caller
+ * (rocco_hip_crossfit_whittaker_residual_batch_scratch_f64), nothing is reserved for them */
+int rocco_hip_count_path_reserve_ex(rocco_hip_solver *solver, size_t count, const size_t *rows, const size_t *cols,
+                                    double penalty_lambda, int sweeps_scratch_is_the_callers, void *stream);
 long long rocco_hip_buffer_growths(void);
 /* Diagnostic, process-wide since load: the batched baseline sweeps cut long rows into segments whose workgroups start from
  * a warm-up (csrc/whittaker.hip); a seam whose warm-up had not reached the row's own values is recomputed from the true

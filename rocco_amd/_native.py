@@ -214,6 +214,13 @@ PROTOTYPES = [
     ("rocco_hip_count_path_reserve", ctypes.c_int,
      [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.c_double,
       ctypes.c_void_p]),
+    ("rocco_hip_count_path_reserve_ex", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.c_double,
+      ctypes.c_int, ctypes.c_void_p]),
+    ("rocco_hip_whittaker_batch_scratch_bytes", ctypes.c_size_t, [ctypes.c_size_t, c_size_p, c_size_p]),
+    ("rocco_hip_crossfit_whittaker_residual_batch_scratch_f64", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_size_p, c_size_p,
+      ctypes.c_double, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("rocco_hip_buffer_growths", ctypes.c_longlong, []),
     ("rocco_hip_whittaker_seam_repairs", ctypes.c_longlong, []),
     ("rocco_hip_model_chain_counters", None, [ctypes.POINTER(ctypes.c_longlong)]),
@@ -238,10 +245,47 @@ PROTOTYPES = [
       ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]),
 ]
 
-_lib: Optional[ctypes.CDLL] = None
+class _Library:
+    """The loaded library with one policy in front of every status-returning entry point: a device allocation of the
+    library's own (hipMalloc for a solver's scratch) can fail while PyTorch's caching allocator sits on blocks it does not
+    use -- the two do not see each other's reserves.  On ROCCO_HIP_ENOMEM the cached blocks are handed back to the runtime
+    and the call is made once more (every entry point is a function of its arguments: a failed reserve has launched
+    nothing).  Round 5: the composed driver at K = 100 on the whole genome ran out of memory in its second run of a
+    process this way."""
+
+    def __init__(self, cdll: ctypes.CDLL):
+        object.__setattr__(self, "_cdll", cdll)
+        object.__setattr__(self, "_wrapped", {})
+
+    def __getattr__(self, name):
+        wrapped = self._wrapped.get(name)
+        if wrapped is not None:
+            return wrapped
+        fn = getattr(self._cdll, name)
+        if getattr(fn, "restype", None) is not ctypes.c_int:
+            self._wrapped[name] = fn
+            return fn
+
+        def call(*args, _fn=fn):
+            rc = _fn(*args)
+            if rc == ENOMEM:
+                import torch
+
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                    rc = _fn(*args)
+            return rc
+
+        call.__name__ = name
+        self._wrapped[name] = call
+        return call
 
 
-def load() -> ctypes.CDLL:
+_lib: Optional[_Library] = None
+
+
+def load() -> _Library:
     """Load librocco_hip.so and bind every prototype.  Raises RuntimeError if it is not built."""
     global _lib
     if _lib is not None:
@@ -262,8 +306,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
-    _lib = lib
-    return lib
+    _lib = _Library(lib)
+    return _lib
 
 
 def last_error() -> str:

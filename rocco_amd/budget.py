@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes
 import logging
+import threading
 from typing import Any, Dict, Optional, Tuple
 
 import numpy as np
@@ -213,7 +214,27 @@ def device_standard_normal(rng: np.random.Generator, count: int, out_t=None, dev
     return out_t.reshape(-1)[:count]
 
 
-def device_multipliers(rng: np.random.Generator, rows: int, n_loci: int, kernel: np.ndarray):
+# bytes one estimate of the count branch may hold for its draws (set by the composed driver around its estimates; None: every
+# estimate asks the device what is free when it starts)
+_null_memory_hint = None
+
+
+def set_null_memory_hint(bytes_per_estimate) -> None:
+    global _null_memory_hint
+    _null_memory_hint = None if bytes_per_estimate is None else int(bytes_per_estimate)
+
+
+# A thread's workspace for the count branch's draws: an `inference.BlockCarver` over blocks borrowed from the batch scoring
+# (set by the composed driver for each of its estimate threads).  With one, the draws' three big tensors -- innovations,
+# multipliers / products, rolling variances -- are carved from it: no allocation, and as many draws at once as it holds.
+_null_workspace = threading.local()
+
+
+def set_null_workspace(carver) -> None:
+    _null_workspace.carver = carver
+
+
+def device_multipliers(rng: np.random.Generator, rows: int, n_loci: int, kernel: np.ndarray, out=None, innovations_out=None):
     """What `rows` successive calls of ``_generate_dependent_wild_weights(n_loci, kernel, rng)`` return, as a [rows,
     n_loci] float64 CUDA tensor made on the device: the innovations are NumPy's own stream (`device_standard_normal`),
     the smoothing is a direct sum instead of SciPy's FFT (same values to ~1e-15 of their scale, not bit for bit), centring
@@ -229,8 +250,11 @@ def device_multipliers(rng: np.random.Generator, rows: int, n_loci: int, kernel:
         return torch.ones((rows, 1), dtype=torch.float64, device=f"cuda:{_dp._device_index()}")
     before = rng.bit_generator.state
     width = n + taps.size - 1
-    innovations = device_standard_normal(rng, rows * width)
-    weights = torch.empty((rows, n), dtype=torch.float64, device=innovations.device)
+    # (`out` [rows, n] / `innovations_out` (rows x (n + taps - 1) elements): the caller's blocks instead of fresh tensors)
+    innovations = device_standard_normal(rng, rows * width, out_t=innovations_out)
+    weights = out if out is not None else torch.empty((rows, n), dtype=torch.float64, device=innovations.device)
+    if tuple(weights.shape) != (rows, n) or weights.dtype != torch.float64 or not weights.is_contiguous():
+        raise ValueError("`out` must be a contiguous float64 [rows, n_loci] CUDA tensor")
     solver = _native.solver_for(weights.device.index)
     degenerate = ctypes.c_int(0)
     _native.check(_native.load().rocco_hip_bartlett_multipliers_f64(
@@ -660,30 +684,75 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
     # device multipliers: the draws between two looks at the stopping rule are computed together, as many at a time as the
     # free memory holds (each keeps its K x n product and its rolling variances): their rolling launch is ONE
     at_once = 1
+    workspace = None
     if on_device and look_every > 1 and os.environ.get("ROCCO_BUDGET_NULL_DRAWS_AT_ONCE", "") != "1":
-        free_now, _total = torch.cuda.mem_get_info(template_t.device)
-        cached = max(0, int(torch.cuda.memory_reserved(template_t.device)) - int(torch.cuda.memory_allocated(template_t.device)))
-        share = max(1, int(os.environ.get("ROCCO_BUDGET_NULL_STREAMS", "3")))  # (estimates may run side by side on that many streams)
-        at_once = int(max(1, min(look_every, (6 * (free_now + cached) // (10 * share)) // max(1, 3 * K * n * 8))))
+        per_draw = max(1, 3 * K * n * 8)  # (innovations while the multipliers are made, then product and rolling variances)
+        carver = getattr(_null_workspace, "carver", None)
+        if carver is not None:
+            # (blocks borrowed from the batch scoring: as many draws at once as they hold -- innovations, then one block of
+            # multipliers per draw, then the variances of all of them)
+            for a in range(int(look_every), 0, -1):
+                carver.reset()
+                if carver.fits([K * (n + len(taps) - 1)] + [K * n] * a + [a * K * n]):
+                    workspace, at_once = carver, a
+                    break
+        if workspace is not None:
+            pass
+        elif _null_memory_hint is not None:
+            # (the composed driver looked at the device once, before its estimates started side by side: estimates that each
+            # ask what is free NOW, while the others allocate, see numbers that mean little)
+            at_once = int(max(1, min(look_every, int(_null_memory_hint) // per_draw)))
+        else:
+            free_now, _total = torch.cuda.mem_get_info(template_t.device)
+            cached = max(0, int(torch.cuda.memory_reserved(template_t.device)) - int(torch.cuda.memory_allocated(template_t.device)))
+            share = max(1, int(os.environ.get("ROCCO_BUDGET_NULL_STREAMS", "3")))  # (estimates may run side by side on that many streams)
+            at_once = int(max(1, min(look_every, (6 * (free_now + cached) // (10 * share)) // per_draw)))
     for first in range(0, max_draws, look_every):
         batch = list(range(first, min(max_draws, first + look_every)))
         pending, to_submit = {}, list(batch)
-        if at_once > 1:
+        if at_once > 1 or workspace is not None:
             at = 0
             while at < len(batch):
                 group, weights = batch[at:at + at_once], []
                 t_mult = _time.perf_counter()
-                for draw in group:
-                    made = device_multipliers(np.random.default_rng(int(random_seed) + (104729 * (draw + 1))), K, n, taps)
-                    weights.append(made if made is not None else torch.from_numpy(host_weights(draw)).to(template_t.device))
-                _note("multipliers_device_s", _time.perf_counter() - t_mult)
-                for d_mass, d_units, d_fraction, d_tail in _inf.compute_budget_null_draws_device(
-                        template_t, weights, lower_bound_z, prior_df, draw_min_effect, floor_ratio, null_center, soft_scale, null_threshold):
+                try:
+                    variances_block = None
+                    if workspace is not None:
+                        workspace.reset()
+                        innovations_block = workspace.take(K * (n + len(taps) - 1))
+                        blocks = [workspace.take(K * n).view(K, n) for _draw in group]
+                        variances_block = workspace.take(len(group) * K * n)
+                    for j, draw in enumerate(group):
+                        rng_draw = np.random.default_rng(int(random_seed) + (104729 * (draw + 1)))
+                        if workspace is not None:
+                            made = device_multipliers(rng_draw, K, n, taps, out=blocks[j], innovations_out=innovations_block)
+                        else:
+                            made = device_multipliers(rng_draw, K, n, taps)
+                        if made is None:  # (a degenerate row: the reference's own calls)
+                            made = torch.from_numpy(host_weights(draw)).to(template_t.device)
+                            if workspace is not None:
+                                blocks[j].copy_(made)
+                                made = blocks[j]
+                        weights.append(made)
+                    _note("multipliers_device_s", _time.perf_counter() - t_mult)
+                    results = _inf.compute_budget_null_draws_device(
+                        template_t, weights, lower_bound_z, prior_df, draw_min_effect, floor_ratio, null_center, soft_scale, null_threshold,
+                        variances_arena=variances_block)
+                except (torch.OutOfMemoryError, MemoryError):
+                    # (the draws are seeded one by one: the same group again, fewer at a time, gives the same numbers)
+                    if at_once == 1:
+                        raise
+                    del weights
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                    at_once = max(1, at_once // 2)
+                    continue
+                for d_mass, d_units, d_fraction, d_tail in results:
                     mass.add(d_mass)
                     units.add(d_units)
                     fraction.add(d_fraction)
                     tail.add(d_tail)
-                del weights
+                del weights, results
                 torch.cuda.current_stream().synchronize()
                 if progress_label:
                     sys.stderr.write(f"\r{progress_label}: {units.count}/{max_draws}")

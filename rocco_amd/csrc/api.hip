@@ -195,7 +195,7 @@ int rocco_hip_score_median_batch(rocco_hip_solver *solver, const void *const *ma
             return ROCCO_HIP_EINVAL;
         }
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_median_batch(matrices_dev, dtype, K, n, row_strides, scores_dev, count, (hipStream_t)stream);
 }
 
@@ -215,7 +215,7 @@ int rocco_hip_score_median_batch_stats(rocco_hip_solver *solver, const void *con
             return ROCCO_HIP_EINVAL;  // (statistics of an empty score array do not exist)
         }
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     const size_t blocks = median_partials_count(n, count);
     int rc;
     if ((rc = solver->dev_median_partials.reserve(3 * blocks * sizeof(double) + 256)) != ROCCO_HIP_OK) return rc;
@@ -230,7 +230,7 @@ int rocco_hip_score_median(rocco_hip_solver *solver, const void *matrix_dev, int
         row_stride < n || (dtype != 0 && dtype != 1)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_median(matrix_dev, dtype, K, n, row_stride, scores_dev, (hipStream_t)stream);
 }
 
@@ -241,7 +241,7 @@ int rocco_hip_score_order_statistic(rocco_hip_solver *solver, const void *matrix
         (dtype != 0 && dtype != 1) || rank < 0 || (size_t)rank >= K) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_order_statistic(matrix_dev, dtype, K, n, row_stride, rank, scores_dev, (hipStream_t)stream);
 }
 
@@ -252,7 +252,7 @@ int rocco_hip_score_trimmed_mean(rocco_hip_solver *solver, const void *matrix_de
         (dtype != 0 && dtype != 1) || rank_lo < 0 || rank_hi < rank_lo || rank_hi >= (int)K) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_trimmed_mean(matrix_dev, dtype, K, n, row_stride, rank_lo, rank_hi, scores_dev, (hipStream_t)stream);
 }
 
@@ -261,7 +261,7 @@ int rocco_hip_power_f64(rocco_hip_solver *solver, const double *x_dev, double po
     if (solver == nullptr || (n > 0 && (x_dev == nullptr || out_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_power(x_dev, power, out_dev, n, (hipStream_t)stream);
 }
 
@@ -272,7 +272,7 @@ int rocco_hip_score_mean(rocco_hip_solver *solver, const void *matrix_dev, int d
         (dtype != 0 && dtype != 1)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_column_mean(matrix_dev, dtype, K, n, row_stride, scores_dev, (hipStream_t)stream);
 }
 
@@ -285,7 +285,7 @@ int rocco_hip_solve_penalized_chain_f64(rocco_hip_solver *solver, const double *
     if (solver == nullptr || scores_dev == nullptr || n == 0 || n >= ((size_t)1 << 31)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return solve_fixed_penalty(solver, scores_dev, switch_costs_dev, gamma, n, selection_penalty,
                                solution_dev, value_out, count_out, path_out, (hipStream_t)stream);
 }
@@ -303,7 +303,7 @@ int rocco_hip_solve_budget_batch_f64(rocco_hip_solver *solver, size_t n_tasks,
             return ROCCO_HIP_EINVAL;
         }
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return solve_budget_batch(solver, n_tasks, tasks, results, (hipStream_t)stream);
 }
 
@@ -322,7 +322,7 @@ int rocco_hip_solve_budget_batch_stats_f64(rocco_hip_solver *solver, size_t n_ta
             return ROCCO_HIP_EINVAL;  // min <= max (also refuses NaN)
         }
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return solve_budget_batch(solver, n_tasks, tasks, results, (hipStream_t)stream, score_stats_host);
 }
 
@@ -334,7 +334,7 @@ int rocco_hip_delta_model_lean_f64(rocco_hip_solver *solver, const double *score
         (n_lambdas > 0 && (lambdas == nullptr || counts_out == nullptr || open_out == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return delta_model_lean(solver, scores_dev, gamma, n, emap_dev, lambdas, n_lambdas, counts_out, open_out, (hipStream_t)stream);
 }
 
@@ -347,7 +347,7 @@ int rocco_hip_delta_probe_f64(rocco_hip_solver *solver, const double *scores_dev
         (n_lambdas > 0 && (lambdas == nullptr || stats_out == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return delta_probe(solver, scores_dev, switch_costs_dev, gamma, n, emap_dev, lambdas, n_lambdas,
                        stats_out, (hipStream_t)stream);
 }
@@ -362,7 +362,7 @@ int rocco_hip_delta_bound_rounds_f64(rocco_hip_solver *solver, const double *sco
                           counts_out == nullptr || level_len_out == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return delta_bound_rounds(solver, scores_dev, gamma, n, lambdas, round_sizes, n_rounds, lambdas_used_out, counts_out,
                               level_len_out, (hipStream_t)stream);
 }
@@ -378,7 +378,7 @@ int rocco_hip_delta_spine_f64(rocco_hip_solver *solver, const double *scores_dev
         solution_index >= (int)n_lambdas || (solution_index >= 0 && solution_dev == nullptr)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return delta_spine(solver, scores_dev, switch_costs_dev, gamma, n, emap_dev, lambdas, n_lambdas,
                        solution_index, solution_dev, counts_out, (hipStream_t)stream);
 }
@@ -391,7 +391,7 @@ int rocco_hip_delta_build_map_f64(rocco_hip_solver *solver, const double *scores
         !(margin >= 0.0)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return delta_build_map(solver, scores_dev, switch_costs_dev, gamma, n, lambda_ref, margin, emap_dev,
                            (hipStream_t)stream);
 }
@@ -402,7 +402,7 @@ int rocco_hip_delta_build_map_lean_f64(rocco_hip_solver *solver, const double *s
     if (solver == nullptr || scores_dev == nullptr || n < 2 || n >= ((size_t)1 << 31) || emap_dev == nullptr || !(margin >= 0.0)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return delta_build_map_lean(solver, scores_dev, gamma, n, lambda_ref, margin, emap_dev, (hipStream_t)stream);
 }
 
@@ -415,7 +415,7 @@ int rocco_hip_delta_window_f64(rocco_hip_solver *solver, const double *scores_de
         solution_dev == nullptr || stats_out == nullptr || !(lambda_lo <= lambda_hi)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return delta_window(solver, scores_dev, switch_costs_dev, gamma, n, emap_dev, lambda_lo, lambda_hi,
                         solution_dev, stats_out, (hipStream_t)stream);
 }
@@ -427,7 +427,7 @@ int rocco_hip_objective_value_f64(rocco_hip_solver *solver, const uint8_t *solut
     if (solver == nullptr || objective_out == nullptr || (n > 0 && (solution_dev == nullptr || scores_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc = solver->dev_misc.reserve(objective_scratch_bytes(n));
     if (rc != ROCCO_HIP_OK) {
         return rc;
@@ -452,7 +452,7 @@ int rocco_hip_peak_signal_stat_f64(rocco_hip_solver *solver, const double *count
         (n_peaks > 0 && (counts_dev == nullptr || lengths_dev == nullptr || stat_out_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     const int rc = solver->dev_misc.reserve(n_peaks * n_samples * sizeof(double) + 256);
     if (rc != ROCCO_HIP_OK) return rc;
     return launch_peak_signal(counts_dev, lengths_dev, n_peaks, n_samples, row_scale, pc, percentile, stat_out_dev, solver->dev_misc.ptr,
@@ -466,7 +466,7 @@ int rocco_hip_ecdf_survival_f64(rocco_hip_solver *solver, const double *stat_dev
                                               null_offsets_dev == nullptr || pvals_out_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_ecdf_survival(stat_dev, bin_dev, null_values_dev, null_offsets_dev, n_peaks, pvals_out_dev, (hipStream_t)stream);
 }
 
@@ -475,7 +475,7 @@ int rocco_hip_bh_adjust_f64(rocco_hip_solver *solver, const double *pvals_dev, s
     if (solver == nullptr || m >= ((size_t)1 << 31) || (m > 0 && (pvals_dev == nullptr || qvals_out_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     const int rc = solver->dev_misc.reserve(bh_scratch_bytes(m));
     if (rc != ROCCO_HIP_OK) return rc;
     return launch_bh_adjust(pvals_dev, m, qvals_out_dev, solver->dev_misc.ptr, (hipStream_t)stream);
@@ -486,7 +486,7 @@ int rocco_hip_sort_f64(rocco_hip_solver *solver, const double *x_dev, size_t n, 
     if (solver == nullptr || (n > 0 && (x_dev == nullptr || sorted_out_dev == nullptr)) || n >= ((size_t)1 << 31)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     const int rc = solver->dev_misc.reserve(sort_f64_scratch_bytes(n));
     if (rc != ROCCO_HIP_OK) return rc;
     return launch_sort_f64(x_dev, n, sorted_out_dev, solver->dev_misc.ptr, (hipStream_t)stream);
@@ -501,7 +501,7 @@ int rocco_hip_sorted_probe_f64(rocco_hip_solver *solver, const double *sorted_de
         (n_thresholds > 0 && (thresholds == nullptr || counts_le_out == nullptr || counts_lt_out == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     SortedProbe p;
     p.n_ranks = (int)n_ranks;
     p.n_thresholds = (int)n_thresholds;
@@ -537,7 +537,7 @@ int rocco_hip_autocovariance_sums_f64(rocco_hip_solver *solver, const double *x_
     if (solver == nullptr || x_dev == nullptr || n == 0 || sums_out == nullptr || max_lag < 0 || (size_t)max_lag >= n) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc = solver->dev_misc.reserve(autocov_scratch_bytes(n, max_lag));
     if (rc != ROCCO_HIP_OK) return rc;
     rc = solver->dev_results.reserve(((size_t)max_lag + 1024) * sizeof(double));
@@ -558,7 +558,7 @@ int rocco_hip_negative_part_f64(rocco_hip_solver *solver, const double *scores_d
     if (solver == nullptr || (n > 0 && (scores_dev == nullptr || out_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_negative_part(scores_dev, out_dev, n, (hipStream_t)stream);
 }
 
@@ -568,7 +568,7 @@ int rocco_hip_soft_counts_f64(rocco_hip_solver *solver, const double *scores_dev
     if (solver == nullptr || (n > 0 && (scores_dev == nullptr || out_dev == nullptr)) || !(scale > 0.0)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_soft_counts(scores_dev, center, scale, out_dev, n, (hipStream_t)stream);
 }
 
@@ -580,7 +580,7 @@ int rocco_hip_decode_runs_batch(rocco_hip_solver *solver, size_t count, const ui
                                             run_end_dev == nullptr || capacities == nullptr || n_runs_out == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     size_t at = 0;
     while (at < count) {
         DecodeBatch batch;
@@ -631,7 +631,7 @@ int rocco_hip_decode_runs_table(rocco_hip_solver *solver, size_t count, const ui
         (count > 0 && (solutions_dev == nullptr || n == nullptr || units == nullptr)) || (capacity_rows > 0 && table_dev == nullptr)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     if (table_host_out != nullptr) {
         *table_host_out = nullptr;
     }
@@ -707,7 +707,7 @@ int rocco_hip_decode_runs(rocco_hip_solver *solver, const uint8_t *solution_dev,
         (capacity > 0 && (run_begin_dev == nullptr || run_end_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc = solver->dev_misc.reserve(decode_scratch_bytes(n));
     if (rc != ROCCO_HIP_OK) {
         return rc;
@@ -782,7 +782,7 @@ namespace {
 
 int whittaker_batch(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev, const double *const *offsets_dev,
                     const size_t *rows, const size_t *cols, double penalty_lambda, double *const *baselines_dev, int residual,
-                    void *stream)
+                    void *stream, void *scratch_dev = nullptr, size_t scratch_bytes = 0)
 {
     if (solver == nullptr || (count > 0 && (matrices_dev == nullptr || rows == nullptr || cols == nullptr || baselines_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
@@ -796,15 +796,23 @@ int whittaker_batch(rocco_hip_solver *solver, size_t count, const double *const 
             longest = std::max(longest, cols[i]);
         }
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc;
-    if ((rc = solver->dev_misc.reserve(whittaker_batch_scratch_bytes(rows, cols, count))) != ROCCO_HIP_OK) return rc;
+    if (scratch_dev != nullptr) {  // (the caller's block: what the sweeps need between them, see rocco_hip_whittaker_batch_scratch_bytes)
+        if (scratch_bytes < whittaker_batch_scratch_bytes(rows, cols, count) || ((uintptr_t)scratch_dev & 255u) != 0) {
+            set_last_error("the sweeps' scratch block is too small or not aligned to 256 bytes");
+            return ROCCO_HIP_EINVAL;
+        }
+    } else if ((rc = solver->dev_misc.reserve(whittaker_batch_scratch_bytes(rows, cols, count))) != ROCCO_HIP_OK) {
+        return rc;
+    }
     if ((rc = solver->host_stage.reserve(whittaker_batch_stage_bytes(rows, cols, count))) != ROCCO_HIP_OK) return rc;
     if ((rc = ensure_whittaker_factor(solver, longest, penalty_lambda, (hipStream_t)stream)) != ROCCO_HIP_OK) return rc;
     const rocco::SharedFactor *factor = (longest >= 25) ? solver->factor.get() : nullptr;
     rc = launch_crossfit_whittaker_batch(matrices_dev, rows, cols, count, penalty_lambda,
                                          factor != nullptr ? (const double *)factor->buf.ptr : nullptr,
-                                         factor != nullptr ? factor->cap : 0, baselines_dev, solver->dev_misc.ptr,
+                                         factor != nullptr ? factor->cap : 0, baselines_dev,
+                                         scratch_dev != nullptr ? scratch_dev : solver->dev_misc.ptr,
                                          solver->host_stage.ptr, (hipStream_t)stream, offsets_dev, residual);
     if (rc != ROCCO_HIP_OK) {
         return rc;
@@ -833,6 +841,23 @@ int rocco_hip_crossfit_whittaker_residual_batch_f64(rocco_hip_solver *solver, si
     return whittaker_batch(solver, count, matrices_dev, row_offsets_dev, rows, cols, penalty_lambda, centered_out_dev, 1, stream);
 }
 
+size_t rocco_hip_whittaker_batch_scratch_bytes(size_t count, const size_t *rows, const size_t *cols)
+{
+    return (rows == nullptr || cols == nullptr) ? 0 : whittaker_batch_scratch_bytes(rows, cols, count);
+}
+
+int rocco_hip_crossfit_whittaker_residual_batch_scratch_f64(rocco_hip_solver *solver, size_t count, const double *const *matrices_dev,
+                                                            const double *const *row_offsets_dev, const size_t *rows,
+                                                            const size_t *cols, double penalty_lambda, double *const *centered_out_dev,
+                                                            void *scratch_dev, size_t scratch_bytes, void *stream)
+{
+    if (scratch_dev == nullptr) {
+        return ROCCO_HIP_EINVAL;
+    }
+    return whittaker_batch(solver, count, matrices_dev, row_offsets_dev, rows, cols, penalty_lambda, centered_out_dev, 1, stream,
+                           scratch_dev, scratch_bytes);
+}
+
 int rocco_hip_crossfit_whittaker_baseline_matrix_f64(rocco_hip_solver *solver, const double *matrix_dev,
                                                      size_t rows, size_t cols, double penalty_lambda,
                                                      double *baseline_out_dev, void *stream)
@@ -851,7 +876,7 @@ int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t c
     if (solver == nullptr || (count > 0 && (centered_dev == nullptr || K == nullptr || n == nullptr || variances_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     size_t rows = 0;
     for (size_t i = 0; i < count; ++i) {
         const int window = wls_spatial_window(n[i], spatial_window);
@@ -932,11 +957,18 @@ long long rocco_hip_solver_device_bytes(const rocco_hip_solver *solver)
 int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const size_t *rows, const size_t *cols, double penalty_lambda,
                                  void *stream)
 {
+    return rocco_hip_count_path_reserve_ex(solver, count, rows, cols, penalty_lambda, 0, stream);
+}
+
+int rocco_hip_count_path_reserve_ex(rocco_hip_solver *solver, size_t count, const size_t *rows, const size_t *cols, double penalty_lambda,
+                                    int sweeps_scratch_is_the_callers, void *stream)
+{
     if (solver == nullptr || (count > 0 && (rows == nullptr || cols == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
-    size_t misc = whittaker_batch_scratch_bytes(rows, cols, count), stage_single = 0, total_rows = 0, most_rows = 0, longest = 0;
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
+    size_t misc = (sweeps_scratch_is_the_callers != 0) ? 0 : whittaker_batch_scratch_bytes(rows, cols, count);
+    size_t stage_single = 0, total_rows = 0, most_rows = 0, longest = 0;
     for (size_t i = 0; i < count; ++i) {
         if (rows[i] == 0 || cols[i] == 0) {
             continue;
@@ -944,7 +976,9 @@ int rocco_hip_count_path_reserve(rocco_hip_solver *solver, size_t count, const s
         misc = std::max(misc, wls_scratch_bytes(rows[i], cols[i], 31, true));
         misc = std::max(misc, wls_scratch_bytes(rows[i], cols[i], 31, false));
         misc = std::max(misc, log_scale_scratch_bytes(rows[i], cols[i]));
-        misc = std::max(misc, whittaker_batch_scratch_bytes(&rows[i], &cols[i], 1));
+        if (sweeps_scratch_is_the_callers == 0) {
+            misc = std::max(misc, whittaker_batch_scratch_bytes(&rows[i], &cols[i], 1));
+        }
         stage_single = std::max(stage_single, whittaker_batch_stage_bytes(&rows[i], &cols[i], 1));
         total_rows += rows[i];
         most_rows = std::max(most_rows, rows[i]);
@@ -985,7 +1019,7 @@ int rocco_hip_score_centered_wls_given_variances_f64(rocco_hip_solver *solver, c
         set_last_error("rocco_hip_score_centered_wls_f64: null buffer, empty matrix or more than 2^31-1 loci");
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc;
     if ((rc = solver->dev_misc.reserve(wls_scratch_bytes(K, n, spatial_window, variances_dev == nullptr))) != ROCCO_HIP_OK) {
         return rc;
@@ -1011,7 +1045,7 @@ int rocco_hip_log2_selfcheck(rocco_hip_solver *solver, int family, unsigned long
     if (solver == nullptr || mismatches_out == nullptr || family < 0 || family > 4 || count > ((size_t)1 << 39)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc;
     if ((rc = solver->dev_results.reserve(256)) != ROCCO_HIP_OK) return rc;
     if ((rc = solver->host_back.reserve(256)) != ROCCO_HIP_OK) return rc;
@@ -1030,7 +1064,7 @@ int rocco_hip_log_scale_f64(rocco_hip_solver *solver, const double *values_dev, 
     if (solver == nullptr || (count > 0 && (values_dev == nullptr || out_dev == nullptr))) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc = solver->dev_results.reserve(256);
     if (rc != ROCCO_HIP_OK) return rc;
     int *bad = (int *)solver->dev_results.ptr;
@@ -1057,7 +1091,7 @@ int rocco_hip_log_scale_center_rows_f64(rocco_hip_solver *solver, const double *
         set_last_error("rocco_hip_log_scale_center_rows_f64: null buffer, empty matrix or more than 2^31-1 loci");
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc;
     if ((rc = solver->dev_misc.reserve(log_scale_scratch_bytes(K, n))) != ROCCO_HIP_OK) {
         return rc;
@@ -1078,7 +1112,7 @@ int rocco_hip_log_scale_row_offsets_f64(rocco_hip_solver *solver, const double *
         set_last_error("rocco_hip_log_scale_row_offsets_f64: null buffer, empty matrix or more than 2^31-1 loci");
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc;
     if ((rc = solver->dev_misc.reserve(log_scale_scratch_bytes(K, n))) != ROCCO_HIP_OK) {
         return rc;
@@ -1096,7 +1130,7 @@ int rocco_hip_subtract_finite_f64(rocco_hip_solver *solver, const double *a_dev,
     if (solver == nullptr || ((a_dev == nullptr || b_dev == nullptr || out_dev == nullptr) && count > 0)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc = solver->dev_results.reserve(256);
     if (rc != ROCCO_HIP_OK) return rc;
     if ((rc = solver->host_back.reserve(256)) != ROCCO_HIP_OK) return rc;
@@ -1120,7 +1154,7 @@ int rocco_hip_subtract_f64(rocco_hip_solver *solver, const double *a_dev, const 
     if (solver == nullptr || ((a_dev == nullptr || b_dev == nullptr || out_dev == nullptr) && count > 0)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_subtract(a_dev, b_dev, out_dev, count, (hipStream_t)stream);
 }
 
@@ -1134,7 +1168,7 @@ int rocco_hip_narrowpeak_summit_offsets(rocco_hip_solver *solver, const int64_t 
         (n_intervals > 0 && intervals_dev == nullptr) || (n_mean > 0 && effect_mean_dev == nullptr)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_summit_offsets(intervals_dev, n_intervals, centers_dev, effect_mean_dev, n_mean, peak_start_dev, peak_end_dev,
                                  n_peaks, offsets_out_dev, (hipStream_t)stream);
 }
@@ -1153,7 +1187,7 @@ int rocco_hip_union_intervals(rocco_hip_solver *solver, const int64_t *values_de
     if (count == 0) {
         return ROCCO_HIP_OK;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc;
     if ((rc = solver->dev_misc.reserve(union_scratch_bytes(count))) != ROCCO_HIP_OK) {
         return rc;
@@ -1181,7 +1215,7 @@ int rocco_hip_scatter_tracks(rocco_hip_solver *solver, const int64_t *common_dev
     if (K * m == 0) {
         return ROCCO_HIP_OK;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc;
     if ((rc = solver->dev_misc.reserve(scatter_scratch_bytes(K, m))) != ROCCO_HIP_OK) {
         return rc;
@@ -1199,7 +1233,7 @@ int rocco_hip_numpy_sum_f64(rocco_hip_solver *solver, const double *x_dev, size_
     if (n == 0) {
         return ROCCO_HIP_OK;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc;
     if ((rc = solver->dev_misc.reserve(npsum_scratch_bytes(n))) != ROCCO_HIP_OK) {
         return rc;
@@ -1215,7 +1249,7 @@ int rocco_hip_budget_null_draw_stats_f64(rocco_hip_solver *solver, const double 
     if (solver == nullptr || stats_out == nullptr || scores_dev == nullptr || n == 0) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc;
     if ((rc = solver->dev_misc.reserve(npsum_scratch_bytes(n))) != ROCCO_HIP_OK) {
         return rc;
@@ -1238,7 +1272,7 @@ int rocco_hip_multiply_f64(rocco_hip_solver *solver, const double *a_dev, const 
     if (solver == nullptr || ((a_dev == nullptr || b_dev == nullptr || out_dev == nullptr) && count > 0)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_multiply(a_dev, b_dev, out_dev, count, (hipStream_t)stream);
 }
 
@@ -1248,7 +1282,7 @@ int rocco_hip_subtract_positive_row_f64(rocco_hip_solver *solver, const double *
     if (solver == nullptr || ((matrix_dev == nullptr || row_dev == nullptr || out_dev == nullptr) && K * n > 0)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_subtract_positive_row(matrix_dev, row_dev, K, n, out_dev, (hipStream_t)stream);
 }
 
@@ -1262,7 +1296,7 @@ int rocco_hip_bigwig_dense_fill_f64(rocco_hip_solver *solver, const int64_t *sta
         round_digits > 22 || round_digits < -22) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     int rc;
     if ((rc = solver->dev_misc.reserve(256)) != ROCCO_HIP_OK) {
         return rc;
@@ -1278,7 +1312,7 @@ int rocco_hip_synth_matrix(rocco_hip_solver *solver, void *matrix_dev, int dtype
     if (solver == nullptr || matrix_dev == nullptr || row_stride < n || (dtype != 0 && dtype != 1)) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     return launch_synth(matrix_dev, dtype, K, n, row_stride, seed, (hipStream_t)stream);
 }
 

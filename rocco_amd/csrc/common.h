@@ -21,6 +21,8 @@ void set_last_error(const std::string &msg);
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \
         if (_e != hipSuccess) {                                                              \
+            (void)hipGetLastError(); /* (the runtime keeps the error for the thread's next hipGetLastError(): a later */ \
+                                     /* call's launch check must not find this one -- round 5, a retried allocation) */ \
             ::rocco::set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));      \
             return (_e == hipErrorOutOfMemory) ? ROCCO_HIP_ENOMEM : ROCCO_HIP_EHIP;          \
         }                                                                                    \

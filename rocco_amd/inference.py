@@ -332,7 +332,17 @@ def log_scale_row_offsets_device(counts_t, pseudocount: float = 1.0, out_t=None,
     return out_t, offsets
 
 
-def crossfit_whittaker_residual_batch_device(values_list, offsets_list, penalty_lambda: float, outs=None):
+def whittaker_batch_scratch_bytes(shapes) -> int:
+    """Bytes of scratch the batched sweeps need for matrices of these (rows, cols) shapes (twice the matrices + records)."""
+    import ctypes
+
+    shapes = list(shapes)
+    count = len(shapes)
+    return int(_native.load().rocco_hip_whittaker_batch_scratch_bytes(
+        count, (ctypes.c_size_t * count)(*[int(r) for r, _c in shapes]), (ctypes.c_size_t * count)(*[int(c) for _r, c in shapes])))
+
+
+def crossfit_whittaker_residual_batch_device(values_list, offsets_list, penalty_lambda: float, outs=None, scratch=None):
     """rocco/inference.py:330-338 for several matrices of ONE penalty in the baseline sweeps' own launches
     (rocco_hip_crossfit_whittaker_residual_batch_f64): out_i = (values_i - offsets_i[row]) - baseline(values_i - offsets_i[row]),
     rounded as the reference's separate statements round.  `offsets_list`: one [K_i] tensor or None per matrix (or None for
@@ -357,12 +367,17 @@ def crossfit_whittaker_residual_batch_device(values_list, offsets_list, penalty_
             raise ValueError("every output must be a distinct contiguous float64 tensor of its matrix's shape")
     count = len(values_list)
     solver = _native.solver_for(values_list[0].device.index)
-    rc = _native.load().rocco_hip_crossfit_whittaker_residual_batch_f64(
-        solver.handle, count, (ctypes.c_void_p * count)(*[v.data_ptr() for v in values_list]),
-        (ctypes.c_void_p * count)(*[(None if o is None else o.data_ptr()) for o in offsets_list]),
-        (ctypes.c_size_t * count)(*[int(v.shape[0]) for v in values_list]),
-        (ctypes.c_size_t * count)(*[int(v.shape[1]) for v in values_list]), float(penalty_lambda),
-        (ctypes.c_void_p * count)(*[o.data_ptr() for o in outs]), _dp._stream_ptr(values_list[0]))
+    common = (solver.handle, count, (ctypes.c_void_p * count)(*[v.data_ptr() for v in values_list]),
+              (ctypes.c_void_p * count)(*[(None if o is None else o.data_ptr()) for o in offsets_list]),
+              (ctypes.c_size_t * count)(*[int(v.shape[0]) for v in values_list]),
+              (ctypes.c_size_t * count)(*[int(v.shape[1]) for v in values_list]), float(penalty_lambda),
+              (ctypes.c_void_p * count)(*[o.data_ptr() for o in outs]))
+    if scratch is not None:
+        # (`scratch`: a CUDA tensor of at least whittaker_batch_scratch_bytes(...) bytes -- the sweeps' scratch in the caller's pool)
+        rc = _native.load().rocco_hip_crossfit_whittaker_residual_batch_scratch_f64(
+            *common, scratch.data_ptr(), int(scratch.numel()) * int(scratch.element_size()), _dp._stream_ptr(values_list[0]))
+    else:
+        rc = _native.load().rocco_hip_crossfit_whittaker_residual_batch_f64(*common, _dp._stream_ptr(values_list[0]))
     if rc == _native.EINVAL and "non-finite" in _native.last_error():
         raise ValueError("Local baseline fit produced non-finite values")
     _native.check(rc, "rocco_hip_crossfit_whittaker_residual_batch_f64")
@@ -430,6 +445,12 @@ def score_loci_wls_device(counts_t, lower_bound_z: float = 1.0, prior_df: float 
 _batch_lock = threading.Lock()  # one batch at a time per process: the pipelines and their scratch are shared
 _batch_pool = None
 _batch_workers = {}
+# The pipelines' big blocks -- per pipeline one for baselines / variances, one for the sweeps' scratch -- are KEPT between
+# calls (round 5): allocating a K = 100 genome's 150 GB takes the runtime 4-6 s, ten times what the scoring takes, and a
+# caching allocator that has meanwhile cut them up for other tensors allocates them afresh.  Between scoring calls a caller
+# may borrow them (`borrow_batch_blocks`: the composed driver's budget null computes its draws in them).
+_batch_blocks = {}        # device index -> [tensor, ...] (arenas first, then the sweeps' scratch blocks)
+_batch_blocks_lent = set()
 last_batch_growths_in_flight = 0  # solver buffers that grew while the last batch's pipelines were running (must be 0)
 
 
@@ -451,11 +472,81 @@ def release_batch_workers() -> None:
     for solver, stream in workers.values():
         stream.synchronize()
         solver.close()
+    with _batch_lock:
+        _batch_blocks.clear()
+
+
+def batch_scratch_bytes() -> int:
+    """Device memory the pipelines' solvers hold between calls (`release_batch_workers` hands it back)."""
+    with _batch_lock:
+        return sum(int(_native.load().rocco_hip_solver_device_bytes(solver.handle)) for solver, _stream in _batch_workers.values())
+
+
+class BlockCarver:
+    """First-fit carving of flat float64 tensors out of a few big ones (no allocation, no freeing: `reset` starts over)."""
+
+    def __init__(self, pieces):
+        self.pieces = [p.reshape(-1) for p in pieces]
+        self.used = [0] * len(self.pieces)
+
+    def reset(self):
+        self.used = [0] * len(self.pieces)
+
+    def capacity(self) -> int:
+        return sum(int(p.numel()) for p in self.pieces)
+
+    def fits(self, requests) -> bool:
+        """Whether these element counts, taken in this order, would all be served."""
+        used = list(self.used)
+        for want in requests:
+            for j, p in enumerate(self.pieces):
+                if int(p.numel()) - used[j] >= int(want):
+                    used[j] += (int(want) + 63) // 64 * 64  # (as `take` steps)
+                    break
+            else:
+                return False
+        return True
+
+    def take(self, numel: int):
+        numel = int(numel)
+        for j, p in enumerate(self.pieces):
+            if int(p.numel()) - self.used[j] >= numel:
+                out = p[self.used[j]:self.used[j] + numel]
+                self.used[j] += (numel + 63) // 64 * 64  # (512-byte steps)
+                return out
+        raise MemoryError("the borrowed blocks do not hold this request")
+
+
+def borrow_batch_blocks(device_index: int):
+    """The blocks the last batch scoring on this device kept (flat float64 CUDA tensors; [] when there are none or they are
+    lent already).  Until `return_batch_blocks` a scoring call allocates blocks of its own."""
+    with _batch_lock:
+        if int(device_index) in _batch_blocks_lent:
+            return []
+        blocks = list(_batch_blocks.get(int(device_index), []))
+        if blocks:
+            _batch_blocks_lent.add(int(device_index))
+        return blocks
+
+
+def return_batch_blocks(device_index: int) -> None:
+    with _batch_lock:
+        _batch_blocks_lent.discard(int(device_index))
+
+
+def drop_batch_blocks(device_index: Optional[int] = None) -> None:
+    """The blocks a `keep_blocks=True` scoring call kept go back to the allocator (its cache: a next call of the same
+    shapes gets them again without asking the runtime)."""
+    with _batch_lock:
+        for index in ([int(device_index)] if device_index is not None else list(_batch_blocks)):
+            if index not in _batch_blocks_lent:
+                _batch_blocks.pop(index, None)
 
 
 def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_df: float = 5.0, min_effect=None,
                                 precision_floor_ratio: float = 0.01, overwrite_input: bool = False,
-                                input_scale: str = "counts", workers: int = 2, memory_budget_bytes: Optional[int] = None):
+                                input_scale: str = "counts", workers: int = 2, memory_budget_bytes: Optional[int] = None,
+                                keep_blocks: bool = False, reserve_bytes: int = 0):
     """`score_loci_wls_device` for several [K_i, n_i] float64 CUDA count matrices -- the chromosomes a rank owns
     (the loop of rocco/rocco.py:948-1018 around rocco/inference.py:302-379).  Returns one (scores, details) pair per
     matrix, bit for bit what the single-matrix call returns.  What is shared: the matrices are dealt to `workers`
@@ -578,7 +669,8 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
             for lam in sorted({penalties[i] for i in idx if windows[i] != 0}):
                 same = [i for i in idx if windows[i] != 0 and penalties[i] == lam]
                 outs = [counts_list[i] if overwrite[i] else torch.empty_like(counts_list[i]) for i in same]
-                crossfit_whittaker_residual_batch_device([logs[i] for i in same], [offsets[i] for i in same], lam, outs=outs)
+                crossfit_whittaker_residual_batch_device([logs[i] for i in same], [offsets[i] for i in same], lam, outs=outs,
+                                                         scratch=scratches[slot])
                 centred.update(zip(same, outs))
             del logs, offsets
         else:
@@ -645,12 +737,17 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         # the rolling variances in their place) and 2 C of solver scratch (the forward sweep's two parities: the backward
         # sweep's segments read beyond their own ends, so it does not run in place); the solver keeps its scratch
         # between calls, so only what it has to GROW counts against what is free
+        fused = os.environ.get("ROCCO_BATCH_FUSED_RESIDUAL", "1") != "0"  # (0: medians and baselines subtracted by passes of their own)
         torch.cuda.synchronize(device)
         free_now, _total = torch.cuda.mem_get_info(device)
         cached = max(0, int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device)))
         holds = [int(_native.load().rocco_hip_solver_device_bytes(_batch_worker(device.index, slot)[0].handle))
                  for slot in range(len(groups))]
-        budget = int(0.88 * (free_now + cached)) if memory_budget_bytes is None else int(memory_budget_bytes)
+        lent = device.index in _batch_blocks_lent
+        kept = [] if lent else _batch_blocks.get(device.index, [])
+        kept_bytes = sum(8 * int(t.numel()) for t in kept)  # (ours to use again)
+        # (`reserve_bytes`: device memory the caller needs for what it does next with the results -- left out of this call's plan)
+        budget = (int(0.88 * (free_now + cached + kept_bytes)) - int(max(0, reserve_bytes))) if memory_budget_bytes is None else int(memory_budget_bytes)
         copies = sum(8 * sizes[i] for i in range(len(counts_list)) if not overwrite[i])
         # (what the call returns stays allocated: eight tracks of n doubles per matrix -- 20 GB for 309 M loci -- + slack)
         results = sum(10 * 8 * int(c.shape[1]) for c in counts_list) + (2 << 30)
@@ -660,13 +757,18 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
             # (a pipeline's share of the budget is its share of the values)
             per_group = max(0, budget - copies - (results if memory_budget_bytes is None else 0)) * sum(8 * sizes[i] for i in idx) // everything
 
-            def need(chunk_bytes, slot=slot):
+            def need(chunk_bytes, largest_bytes, slot=slot):
+                if fused:
+                    # the chunk's block + the sweeps' scratch (2 C + records), both the allocator's; the solver's own scratch is
+                    # what ONE matrix's trend fit takes (its dealt values, tables: ~1.3 x the chunk's largest matrix)
+                    grow = int(1.3 * largest_bytes) + (64 << 20) - (holds[slot] if memory_budget_bytes is None else 0)
+                    return chunk_bytes + int(2.1 * chunk_bytes) + max(0, grow)
                 grow = int(2.2 * chunk_bytes) + (64 << 20) - (holds[slot] if memory_budget_bytes is None else 0)  # (2 C + 1/16 + records)
                 return chunk_bytes + max(0, grow)
 
             parts, part, held = [], [], 0
             for i in idx:  # (longest first: a chunk's first matrix holds its longest rows)
-                if part and need(held + 8 * sizes[i]) > per_group:
+                if part and need(held + 8 * sizes[i], 8 * sizes[part[0]]) > per_group:
                     parts.append(part)
                     part, held = [], 0
                 part.append(i)
@@ -676,23 +778,49 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
         if trace:
             print(f"[batch] {len(groups)} pipelines, chunks per pipeline {[len(p) for p in chunks_of]}, budget {budget / 1e9:.1f} GB", flush=True)
         # each pipeline's block for its baselines and (after them) its rolling variances: its largest chunk, allocated here
+        # ... and, round 5, the baseline sweeps' scratch (the forward sweep's two parities: twice the chunk) as a block of the
+        # framework's allocator too, not of the solver's: what this call leaves idle when it returns is then there for the
+        # caller's next step (the composed driver's budget null computes several draws at once in it) instead of sitting in
+        # a pool the allocator cannot see
+        wanted = [max(sum(sizes[i] for i in part) for part in parts) for parts in chunks_of]
+        if fused:
+            wanted += [(max(whittaker_batch_scratch_bytes([tuple(counts_list[i].shape) for i in part]) for part in parts) + 7) // 8
+                       for parts in chunks_of]
+
         def make_arenas():
-            return [torch.empty(max(sum(sizes[i] for i in part) for part in parts), dtype=torch.float64, device=device)
-                    for parts in chunks_of]
+            # (the blocks kept from the last call serve again where they are large enough -- largest wish, largest block)
+            pool = sorted(kept, key=lambda t: -int(t.numel()))
+            made = [None] * len(wanted)
+            for j in sorted(range(len(wanted)), key=lambda j: -wanted[j]):
+                if pool and int(pool[0].numel()) >= wanted[j]:
+                    made[j] = pool.pop(0)
+            del pool
+            for j in range(len(wanted)):
+                if made[j] is None:
+                    made[j] = torch.empty(wanted[j], dtype=torch.float64, device=device)
+            return made
 
         try:
-            arenas = make_arenas()
+            blocks = make_arenas()
         except torch.OutOfMemoryError:
-            # (the budget counted what the allocator caches as usable: cached blocks of other sizes are not -- hand them back)
+            # (the budget counted what the allocator caches as usable: cached blocks of other sizes are not -- hand them back,
+            # the kept blocks that did not serve included)
+            kept = []
+            if not lent:
+                _batch_blocks.pop(device.index, None)
             torch.cuda.empty_cache()
-            arenas = make_arenas()
+            blocks = make_arenas()
+        if not lent:
+            _batch_blocks[device.index] = list(blocks)
+        arenas, scratches = blocks[:len(chunks_of)], (blocks[len(chunks_of):] if fused else [None] * len(chunks_of))
+        del blocks, kept
         for slot, parts in enumerate(chunks_of):
             solver, _stream = _batch_worker(device.index, slot)
             for idx in parts:
                 rows_a = (ctypes.c_size_t * len(idx))(*[int(counts_list[i].shape[0]) for i in idx])
                 cols_a = (ctypes.c_size_t * len(idx))(*[int(counts_list[i].shape[1]) for i in idx])
-                _native.check(_native.load().rocco_hip_count_path_reserve(solver.handle, len(idx), rows_a, cols_a, 0.0,
-                                                                          caller_stream.cuda_stream), "rocco_hip_count_path_reserve")
+                _native.check(_native.load().rocco_hip_count_path_reserve_ex(solver.handle, len(idx), rows_a, cols_a, 0.0, 1 if fused else 0,
+                                                                             caller_stream.cuda_stream), "rocco_hip_count_path_reserve")
                 # ... and the Whittaker factor of every penalty the chunk holds (contigs of 25 .. 100 loci have windows -- and
                 # penalties -- of their own): the device keeps one factor per penalty, all of them built here
                 by_lam = {}
@@ -703,12 +831,12 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
                 for lam, same in by_lam.items():
                     r_s = (ctypes.c_size_t * len(same))(*[int(counts_list[i].shape[0]) for i in same])
                     c_s = (ctypes.c_size_t * len(same))(*[int(counts_list[i].shape[1]) for i in same])
-                    _native.check(_native.load().rocco_hip_count_path_reserve(solver.handle, len(same), r_s, c_s, float(lam),
-                                                                              caller_stream.cuda_stream), "rocco_hip_count_path_reserve")
+                    _native.check(_native.load().rocco_hip_count_path_reserve_ex(solver.handle, len(same), r_s, c_s, float(lam), 1 if fused else 0,
+                                                                                 caller_stream.cuda_stream), "rocco_hip_count_path_reserve")
         import threading
 
         stagger = os.environ.get("ROCCO_BATCH_STAGGER", "1") != "0" and len(groups) > 1
-        fused = os.environ.get("ROCCO_BATCH_FUSED_RESIDUAL", "1") != "0"  # (0: medians and baselines subtracted by passes of their own)
+
         baselines_event = [torch.cuda.Event() for _ in groups]
         baselines_done = [threading.Event() for _ in groups]
         start = torch.cuda.Event()
@@ -724,6 +852,11 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
             except BaseException as exc:  # noqa: BLE001
                 first_error = first_error or exc
         last_batch_growths_in_flight = int(_native.load().rocco_hip_buffer_growths()) - grown_before
+        del arenas, scratches
+        if not keep_blocks and not lent:
+            # (`keep_blocks`: the pipelines' big blocks stay for `borrow_batch_blocks` and the next call; otherwise they go
+            # back to the allocator's cache here, whole, where the next call finds them again)
+            _batch_blocks.pop(device.index, None)
         if first_error is not None:
             raise first_error
         return result
@@ -820,7 +953,7 @@ def fit_budget_null_residual_template_device(centered_t, lower_bound_z: float = 
 
 def compute_budget_null_draws_device(residual_template_t, weights_list, lower_bound_z: float, prior_df: float, min_effect,
                                      precision_floor_ratio: float, null_center: float, null_soft_scale: float,
-                                     null_threshold: float):
+                                     null_threshold: float, variances_arena=None):
     """Several draws of the budget null at once (round 5): what `compute_budget_null_draw_device` computes for each of
     `weights_list` (one [K, n] float64 CUDA tensor of multipliers per draw; they are OVERWRITTEN by the draws' products),
     with the rolling variances of every draw's K rows in ONE launch -- that launch lasts as long as one row whatever the
@@ -838,7 +971,7 @@ def compute_budget_null_draws_device(residual_template_t, weights_list, lower_bo
             raise ValueError("every draw's multipliers must be a contiguous float64 CUDA tensor shaped as the residual template")
         _native.check(lib.rocco_hip_multiply_f64(solver.handle, residual_template_t.data_ptr(), w.data_ptr(), w.data_ptr(), K * n, stream),
                       "rocco_hip_multiply_f64")
-    variances = wls_rolling_variances_batch_device(weights_list, spatial_window=31)
+    variances = wls_rolling_variances_batch_device(weights_list, spatial_window=31, arena=variances_arena)  # (`variances_arena`: the caller's block)
     out = []
     for boot, var in zip(weights_list, variances):
         scores = score_centered_wls_device(boot, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df),

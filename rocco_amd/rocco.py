@@ -634,7 +634,13 @@ def _score_gathered(batch: list, plan: _CachePlan, own_wls: bool, wls):
             m64 = m.to(torch.float64).contiguous()
             mats.append(m64)
             ours.append(plan.consume_inputs or owned or m64 is not m)  # centred in place where the matrix is a copy this call made (or handed over)
-        return _inf.score_loci_wls_batch_device(mats, overwrite_input=ours, **plan.wls)
+        # (keep_blocks: the pipelines' blocks stay allocated for the budget estimates that follow, which compute their draws in
+        # them; reserve_bytes: what those estimates hold beside the blocks -- per stream a residual template and the scoring's
+        # own scratch, about four times their chromosome's matrix.  Without it a K = 100 genome whose inputs are kept filled the
+        # device to the last GB, and a kernel whose private segment the runtime could not place aborted the process)
+        largest = max(8 * int(m.numel()) for m in mats)
+        streams = min(len(mats), _native_side_streams(), int(os.environ.get("ROCCO_BUDGET_NULL_STREAMS", "3")))
+        return _inf.score_loci_wls_batch_device(mats, overwrite_input=ours, keep_blocks=True, reserve_bytes=4 * streams * largest, **plan.wls)
     return [wls(m, low_memory=plan.low_memory, return_details=True, resident=True, **plan.wls) if own_wls else
             wls(m, low_memory=plan.low_memory, return_details=True, **plan.wls) for _n, _s, m, _o in batch]
 
@@ -649,8 +655,15 @@ def _batches_within_memory(items, plan: _CachePlan):
     for item in items:
         size = int(item[2].numel()) * 8
         if batch:
+            from . import inference as _inf
+
             free, _total = torch.cuda.mem_get_info(item[2].device)
-            room = free + held  # (what the batch holds so far is counted as held, the rest must fit beside it)
+            device = item[2].device
+            # what the batch holds so far is counted as held, the rest must fit beside it; blocks PyTorch has cached and the
+            # scratch the scoring pipelines kept from an earlier call are there to be used again (a second run of a process
+            # saw neither as room and scored one chromosome at a time)
+            cached = max(0, int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device)))
+            room = free + cached + _inf.batch_scratch_bytes() + held
             if plan.low_memory or (not plan.bigwig and 5 * (held + size) > room) or (plan.bigwig and held + size > room):
                 yield batch
                 batch, held = [], 0
@@ -699,6 +712,7 @@ def _estimates_side_by_side(ready: list, plan, estimate, streams: int) -> list:
         solver, stream = _inf._batch_worker(device.index, slot)
         with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
             stream.wait_event(start)
+            _budget.set_null_workspace(carvers[slot])
             while True:
                 with lock:
                     i = next(order, None)
@@ -713,10 +727,53 @@ def _estimates_side_by_side(ready: list, plan, estimate, streams: int) -> list:
                 ready[i] = (name, starts, scores, details, None)
                 logger.info("Budget null %s: %s draws", name, out[i][1].get("num_null_draws"))
             stream.synchronize()
+            _budget.set_null_workspace(None)
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=streams, thread_name_prefix="rocco-budget") as pool:
-        for future in [pool.submit(work, slot) for slot in range(streams)]:
-            future.result()
+    # Count matrices: how many draws an estimate computes together is a question of memory (a draw holds three K x n
+    # blocks), asked ONCE here for all the estimates that are about to run side by side: estimates that each ask what is
+    # free when they start, while the others allocate, see numbers that mean little.  (Handing the batch scoring's scratch
+    # back first -- twice the matrices' bytes, idle during the estimates -- was measured: the next scoring call then spends
+    # 1.7-6 s allocating it again, more than the larger groups of draws gain.)
+    from . import budget as _budget
+
+    hinted = False
+    carvers = [None] * streams
+    blocks = [int(e[4].shape[0]) * int(e[4].shape[1]) * 8 for e in ready if e[4] is not None and _dp._is_tensor(e[4]) and e[4].is_cuda]
+    if blocks and _budget._resolve_multipliers(plan.multipliers) == "device":
+        torch.cuda.synchronize(device)
+        want = 4 * 3 * sum(sorted(blocks, reverse=True)[:streams])
+
+        def usable():
+            free_now, _total = torch.cuda.mem_get_info(device)
+            return int(free_now) + max(0, int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device)))
+
+        _budget.set_null_memory_hint((7 * usable()) // (10 * max(1, streams)))
+        hinted = True
+        # the blocks the batch scoring keeps for its next call (its pipelines' arenas and sweep scratch: three times the
+        # matrices' bytes, idle now) are lent to the estimates, dealt largest first to the thread that holds least
+        lent = _inf.borrow_batch_blocks(device.index)
+        if lent:
+            shares, totals = [[] for _ in range(streams)], [0] * streams
+            for block in sorted(lent, key=lambda t: -int(t.numel())):
+                j = totals.index(min(totals))
+                shares[j].append(block)
+                totals[j] += int(block.numel())
+            carvers = [(_inf.BlockCarver(share) if share else None) for share in shares]
+        del lent
+        if os.environ.get("ROCCO_BATCH_TRACE"):
+            free_now, total_now = torch.cuda.mem_get_info(device)
+            print(f"[budget null] {len(blocks)} count matrices, four draws of the {streams} largest want {want / 1e9:.1f} GB; free {free_now / 1e9:.1f} of "
+                  f"{total_now / 1e9:.1f} GB, torch holds {torch.cuda.memory_allocated(device) / 1e9:.1f} GB in tensors and {torch.cuda.memory_reserved(device) / 1e9:.1f} GB "
+                  f"in all, the pipelines' solvers {_inf.batch_scratch_bytes() / 1e9:.1f} GB; per estimate {_budget._null_memory_hint / 1e9:.1f} GB", flush=True)
+    try:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=streams, thread_name_prefix="rocco-budget") as pool:
+            for future in [pool.submit(work, slot) for slot in range(streams)]:
+                future.result()
+    finally:
+        if hinted:
+            _budget.set_null_memory_hint(None)
+            _inf.return_batch_blocks(device.index)
+        carvers = None
     return out
 
 
@@ -849,6 +906,7 @@ def _build_chrom_cache(chroms_to_process: list, signal_inputs, args: dict) -> di
         finally:
             for source in ahead.values():
                 source.close()
+            _inf.drop_batch_blocks()  # (what the batch scoring kept for these estimates goes back to the allocator)
         clock = lap("budget_estimates_s", clock)
     for name, entry in cache.items():
         effect = entry.pop("effect_mean", None)

@@ -13,21 +13,35 @@ device = torch.device("cuda:0")
 genome = synth.chrom_loci(50, None)
 names = [n for n, _ in genome] if which == "all" else which.split(",")
 index = {name: i for i, (name, _n) in enumerate(genome)}
-inputs = {}
-for name in names:
-    n = genome[index[name]][1]
-    m = synth.hash_matrix_device(K, n, synth.chrom_seed(20240, index[name]), device=device)
-    if branch == "counts":
-        m.mul_(20.0).round_()
-    inputs[name] = (np.arange(n, dtype=np.int64) * 50, m)
-torch.cuda.synchronize()
+consume = bool(os.environ.get("PROBE_CONSUME"))  # (args["consume_inputs"]: the matrices are made afresh for every repetition)
+
+
+def make_inputs():
+    made = {}
+    for name in names:
+        n = genome[index[name]][1]
+        m = synth.hash_matrix_device(K, n, synth.chrom_seed(20240, index[name]), device=device)
+        if branch == "counts":
+            m.mul_(20.0).round_()
+        made[name] = (np.arange(n, dtype=np.int64) * 50, m)
+    torch.cuda.synchronize()
+    return made
+
+
+inputs = make_inputs()
 args = {"input_track_type": "bigwig" if branch == "bigwig" else "bam", "budget_null_draws": draws, "threads": -1, "gamma": None,
         "budget": None, "scale_chrom_budgets": 1.0, "budget_posterior_quantile": 0.01, "selection_penalty": None,
         "min_length_bp": None, "score_lower_bound_z": 1.0, "score_prior_df": 5.0, "score_min_effect": None,
         "score_precision_floor_ratio": 0.01, "low_memory": False, "narrowPeak": False, "budget_null_multipliers": mult}
+home = os.getcwd()
 with tempfile.TemporaryDirectory() as tmp:
     os.chdir(tmp)
-    for rep in range(2):
+    for rep in range(int(os.environ.get("PROBE_REPS", "2"))):
+        if consume:
+            args["consume_inputs"] = True
+            if rep > 0:
+                inputs = None
+                inputs = make_inputs()
         phases, mults = {}, {}
         budget.collect_timings(mults)
         args["_phase_seconds"] = phases
@@ -41,4 +55,5 @@ with tempfile.TemporaryDirectory() as tmp:
                           "multipliers": mult, "draws_max": draws, "seconds": round(total, 3), "intervals": lines,
                           "phases": {k: round(v, 3) for k, v in phases.items()},
                           "multipliers_seconds": {k: round(v, 3) for k, v in mults.items()},
-                          "max_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}), flush=True)
+                          "consume_inputs": consume, "max_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}), flush=True)
+    os.chdir(home)  # (a profiler that finalises in a deleted directory aborts)
