@@ -556,15 +556,16 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
     the pair lasts as long as the longest row, not as long as all rows one after the other) and the rolling variances
     of every row come from ONE launch (`wls_rolling_variances_batch_device`); the per-matrix steps (log scale + row
     medians; rank finding, dealing, selects and accumulation of the trend fit) are launches over whole matrices.
-    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values), round 5: 0.52-0.55 s with one pipeline (log scale
-    and row medians 0.12, baselines 0.12 -- their rows are cut into segments since, whittaker.hip --, rolling sums 0.11,
-    trend fits 0.17), 0.47-0.48 s with two of equal parts, the second starting when the first has its baselines behind it
-    (the default: its bandwidth-bound phases then run under the first one's rolling launch, the one phase left that lasts
-    as long as its longest row), 0.50-0.52 with three (round 4: 0.59, of which the baselines' longest rows were 0.29).
+    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values), round 5: 0.47-0.49 s with one pipeline (log scale
+    and row medians 0.08, baselines with both subtractions folded into their sweeps 0.09 -- rows cut into verified segments,
+    whittaker.hip --, rolling sums 0.11, trend fits 0.19), 0.42-0.44 s with two of equal parts, the second starting when the
+    first has its baselines behind it (the default: its bandwidth-bound phases then run under the first one's rolling launch,
+    the one phase left that lasts as long as its longest row) (round 4: 0.59, of which the baselines' longest rows were 0.29).
 
-    Memory: beside its matrices a pipeline holds, for the chunk of C bytes it works on, ONE block of C bytes (its baselines,
-    then in their place its rolling variances) and 2 C of solver scratch (the forward sweep's two parities; kept between
-    calls).  A pipeline therefore walks its matrices in CHUNKS whose size the device's free memory allows
+    Memory: beside its matrices a pipeline holds, for the chunk of C bytes it works on, ONE block of C bytes (the log matrix,
+    then in its place the rolling variances) and 2 C for the forward sweep's two parities -- both blocks of PyTorch's allocator
+    since round 5 (`keep_blocks=True` keeps them for `borrow_batch_blocks` and the next call; `reserve_bytes`: memory the caller
+    needs afterwards, left out of the plan) -- and the solver's own scratch for one matrix's trend fit.  A pipeline therefore walks its matrices in CHUNKS whose size the device's free memory allows
     (`memory_budget_bytes`: what the whole call may hold beside the inputs and the tracks it returns; default 88 % of what is
     free or cached when it starts): everything at once when that fits (the K = 100 genome: 49 GB of matrices, ~200 GB in
     all), several chunks one after the other when it does not (K = 50 at 10 bp, 123 GB of matrices, centred in place)."""
