@@ -618,9 +618,17 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
     if K == 0 or n == 0:
         raise ValueError("`centered_matrix` must be non-empty")
     floor_ratio = float(max(precision_floor_ratio, 0.0))
+    # (a workspace of borrowed blocks: the residual template is its first tenant and stays for the whole estimate, when it
+    # and at least one draw's three blocks fit)
+    carver, template_out = getattr(_null_workspace, "carver", None), None
+    if carver is not None:
+        carver.clear()
+        if centered_t.dtype == torch.float64 and carver.fits([K * n, K * (n + 1024), K * n, K * n]):
+            template_out = carver.take(K * n).view(K, n)
+            carver.mark()
     template_t, fitted_scores_t, positive_t = _inf.fit_budget_null_residual_template_device(
         centered_t, lower_bound_z=lower_bound_z, prior_df=prior_df, min_effect=min_effect,
-        precision_floor_ratio=floor_ratio)
+        precision_floor_ratio=floor_ratio, residual_out=template_out)
     fit_tracks = torch.stack([fitted_scores_t, positive_t])
     if not bool(torch.isfinite(fit_tracks).all()):
         raise ValueError("EB scoring produced non-finite values")
@@ -651,7 +659,7 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
     mass, units, fraction, tail = _Running(), _Running(), _Running(), _Running()
     on_device = _resolve_multipliers(multipliers) == "device" and n > 1
     weights_t = None if on_device else torch.empty_like(template_t)  # (device multipliers arrive in their own tensor)
-    product_t = torch.empty_like(template_t)
+    product_t = None  # (made when the first draw computed by itself needs it: draws computed together overwrite their multipliers)
     staging = torch.empty((2, n), dtype=torch.float64).pin_memory()
     copies = [torch.cuda.Event(), torch.cuda.Event()]
     # The multipliers of a draw are host work (NumPy's generator and SciPy's FFT convolution) and cost
@@ -788,6 +796,8 @@ def _estimate_wild_bootstrap_score_null(centered_matrix, lower_bound_z: float = 
                     weights_t[row].copy_(staging[slot], non_blocking=True)
                     copies[slot].record()
             _note("multipliers_device_s" if made is not None else "multipliers_host_s", _time.perf_counter() - t_mult)
+            if product_t is None:
+                product_t = torch.empty_like(template_t)
             d_mass, d_units, d_fraction, d_tail = _inf.compute_budget_null_draw_device(
                 template_t, draw_weights, lower_bound_z, prior_df, draw_min_effect, floor_ratio, null_center, soft_scale,
                 null_threshold, work_t=product_t)

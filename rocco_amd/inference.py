@@ -488,8 +488,18 @@ class BlockCarver:
     def __init__(self, pieces):
         self.pieces = [p.reshape(-1) for p in pieces]
         self.used = [0] * len(self.pieces)
+        self.base = [0] * len(self.pieces)
 
     def reset(self):
+        """Everything taken since the last `mark` (or `clear`) is given up."""
+        self.used = list(self.base)
+
+    def mark(self):
+        """What has been taken so far stays taken across `reset`."""
+        self.base = list(self.used)
+
+    def clear(self):
+        self.base = [0] * len(self.pieces)
         self.used = [0] * len(self.pieces)
 
     def capacity(self) -> int:
@@ -935,7 +945,7 @@ def numpy_sum_device(x_t) -> float:
 
 
 def fit_budget_null_residual_template_device(centered_t, lower_bound_z: float = 1.0, prior_df: float = 5.0,
-                                             min_effect=None, precision_floor_ratio: float = 0.01):
+                                             min_effect=None, precision_floor_ratio: float = 0.01, residual_out=None):
     """rocco/inference.py:688-722 on the device: (residual_template [K, n], observed_scores [n],
     positive_consensus [n]) with residual = centered - max(mu_hat, 0)."""
     import torch
@@ -944,7 +954,9 @@ def fit_budget_null_residual_template_device(centered_t, lower_bound_z: float = 
         centered_t, lower_bound_z=float(lower_bound_z), prior_df=float(prior_df), min_effect=min_effect,
         spatial_window=31, precision_floor_ratio=float(max(precision_floor_ratio, 0.0)))
     K, n = int(centered_t.shape[0]), int(centered_t.shape[1])
-    residual = torch.empty_like(centered_t)
+    residual = residual_out if residual_out is not None else torch.empty_like(centered_t)  # (`residual_out`: the caller's [K, n] block)
+    if residual.shape != centered_t.shape or residual.dtype != torch.float64 or not residual.is_contiguous():
+        raise ValueError("`residual_out` must be a contiguous float64 tensor shaped as the centred matrix")
     solver = _native.solver_for(centered_t.device.index)
     _native.check(_native.load().rocco_hip_subtract_positive_row_f64(
         solver.handle, centered_t.data_ptr(), mean.data_ptr(), K, n, residual.data_ptr(),

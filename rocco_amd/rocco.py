@@ -640,7 +640,7 @@ def _score_gathered(batch: list, plan: _CachePlan, own_wls: bool, wls):
         # device to the last GB, and a kernel whose private segment the runtime could not place aborted the process)
         largest = max(8 * int(m.numel()) for m in mats)
         streams = min(len(mats), _native_side_streams(), int(os.environ.get("ROCCO_BUDGET_NULL_STREAMS", "3")))
-        return _inf.score_loci_wls_batch_device(mats, overwrite_input=ours, keep_blocks=True, reserve_bytes=4 * streams * largest, **plan.wls)
+        return _inf.score_loci_wls_batch_device(mats, overwrite_input=ours, keep_blocks=True, reserve_bytes=4 * streams * largest, **plan.wls)  # noqa: E501
     return [wls(m, low_memory=plan.low_memory, return_details=True, resident=True, **plan.wls) if own_wls else
             wls(m, low_memory=plan.low_memory, return_details=True, **plan.wls) for _n, _s, m, _o in batch]
 
@@ -722,7 +722,14 @@ def _estimates_side_by_side(ready: list, plan, estimate, streams: int) -> list:
                 for t in (centred, _dp._resident_tensor(scores)):
                     if t is not None:
                         t.record_stream(stream)
-                out[i] = estimate(scores, details, centred)
+                try:
+                    out[i] = estimate(scores, details, centred)
+                except (torch.OutOfMemoryError, MemoryError):
+                    # (a fragmented cache: whole free segments go back to the runtime, the estimate -- a function of its
+                    # arguments, its generators seeded per draw -- runs once more)
+                    stream.synchronize()
+                    torch.cuda.empty_cache()
+                    out[i] = estimate(scores, details, centred)
                 del centred
                 ready[i] = (name, starts, scores, details, None)
                 logger.info("Budget null %s: %s draws", name, out[i][1].get("num_null_draws"))
