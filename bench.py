@@ -691,13 +691,14 @@ def main():
                 finite = bool(all(bool(torch.isfinite(sc).all()) for sc, _d in batch))
                 del batch, mats
             t_batch = t_calls[-1]
-            # bytes a value moves over the passes the path makes (round 5): log scale 16, row medians (3 passes) 24, forward
+            # bytes a value moves over the passes the path makes (round 5): log scale 16 (it counts the row medians' first pass on
+            # its way), row medians (2 more passes) 16, forward
             # sweep 24 (reads the log matrix minus the row medians, writes both parities), backward sweep 32 (reads both
             # parities and the log matrix, writes the centred matrix: both subtractions ride on the sweeps), rolling
             # variances 16, the x ranks 24, dealing 24, segment medians (2 counting passes + the gathered cells) 24,
-            # accumulation 16 = 200 B per value (round 4: 248 -- the offsets' and the baselines' subtractions were passes of
-            # their own, the segment medians seven passes)
-            passes_bytes = 200 * K * total_loci
+            # accumulation 16 = 192 B per value (round 4: 248 -- the offsets' and the baselines' subtractions were passes of
+            # their own, the segment medians seven passes, the log scale was read back for the first count)
+            passes_bytes = 192 * K * total_loci
             next_rows["score_loci_wls_whole_workload"] = {
                 "value": round(total_loci / t_batch, 1), "unit": "loci/s", "seconds": round(t_batch, 3),
                 "first_call_seconds": round(t_calls[0], 3), "seconds_by_call": [round(t, 3) for t in t_calls],
@@ -705,7 +706,7 @@ def main():
                 "gpu_values_per_s": round(K * total_loci / t_batch, 1),
                 "hbm_floor": {"bytes": int(passes_bytes), "achieved_GBps": round(passes_bytes / t_batch / 1e9, 1),
                               "frac_of_peak": round(passes_bytes / t_batch / 1e9 / HBM_PEAK_GBS, 4),
-                              "note": "200 B per value over the passes the path makes today (round 4: 248); ~16 B per value is "
+                              "note": "192 B per value over the passes the path makes today (round 4: 248); ~16 B per value is "
                                       "compulsory (matrix in, centred matrix out). The baseline sweeps run in verified segments "
                                       "since round 5 and are bandwidth-bound; the rolling sums remain one sequential chain per row "
                                       "(bit-exactness pins their order) and take the latency of the longest row, ~25 % of the call"},

@@ -1932,6 +1932,48 @@ __global__ __launch_bounds__(256) void log_scale_kernel(const double *__restrict
     }
 }
 
+// The log scale and the row medians' first counting pass in one (round 5): what log_scale_kernel computes and stores is
+// counted on the way -- top 11 bits of its order key, row_select_count_kernel's pass 0 -- instead of being read back for
+// it: one pass over the matrix less.  grid: (chunks of kSelectChunk loci, rows), as the counting passes'.
+__global__ __launch_bounds__(256) void log_scale_count_kernel(const double *__restrict__ in, double *__restrict__ out, long long n,
+                                                             double pseudocount, int apply_log, int *__restrict__ bad,
+                                                             unsigned *__restrict__ hist)
+{
+    __shared__ unsigned local[kSelectBuckets];
+    for (int b = threadIdx.x; b < kSelectBuckets; b += 256) {
+        local[b] = 0u;
+    }
+    __syncthreads();
+    const long long row = blockIdx.y, base = (long long)blockIdx.x * kSelectChunk;
+    const double *__restrict__ x = in + row * n;
+    double *__restrict__ y = out + row * n;
+    constexpr int kLow = 53;  // (the first pass: bits 53 .. 63 of the key)
+#pragma unroll 4
+    for (int j = 0; j < kSelectChunk / 256; ++j) {
+        const long long i = base + threadIdx.x + 256LL * j;
+        if (i < n) {
+            const double v = x[i];
+            if (!isfinite(v)) {
+                atomicOr(bad, 1);
+            }
+            double r = v;
+            if (apply_log) {
+                const double t = fmax(v, 0.0) + pseudocount;
+                r = (t > 0.0 && t < INFINITY) ? log2_correctly_rounded(t) : log2(t);
+            }
+            y[i] = r;
+            atomicAdd(&local[(unsigned)(order_key(r) >> kLow)], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned *__restrict__ mine = hist + row * kSelectBuckets;
+    for (int b = threadIdx.x; b < kSelectBuckets; b += 256) {
+        if (local[b] != 0u) {
+            atomicAdd(&mine[b], local[b]);
+        }
+    }
+}
+
 // grid: (chunks of 1024 loci, rows); four loci per thread (no division to find the row)
 __global__ __launch_bounds__(256) void subtract_row_offset_kernel(double *__restrict__ matrix, const double *__restrict__ med,
                                                                  long long n)
@@ -2317,17 +2359,20 @@ int launch_log_scale_center_rows(const double *counts_dev, size_t K, size_t n, d
     unsigned *complete = (unsigned *)((char *)span + align_up(K * 16, 256));
     ROCCO_HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), stream));
     ROCCO_HIP_TRY(hipMemsetAsync(complete, 0, K * sizeof(unsigned), stream));
-    const unsigned blocks_all = (unsigned)((count + 255) / 256);
-    hipLaunchKernelGGL(log_scale_kernel, dim3(blocks_all), dim3(256), 0, stream, counts_dev, centered_out_dev, count,
-                       pseudocount, apply_log, bad);
-    // the median of every row: radix select over the whole matrix, six passes + one (see row_select_count_kernel)
+    // the median of every row: radix select over the whole matrix, six passes + one (see row_select_count_kernel) -- the
+    // first of them rides on the log scale (log_scale_count_kernel)
     hipLaunchKernelGGL(row_select_init_kernel, dim3((unsigned)((rows * kSelectBuckets + 255) / 256)), dim3(256), 0, stream, state, hist,
                        rows, nn, filled);
     const dim3 grid((unsigned)((nn + kSelectChunk - 1) / kSelectChunk), (unsigned)K);
     const int lows[6] = {53, 42, 31, 20, 9, 0}, widths[6] = {11, 11, 11, 11, 11, 9};
+    static_assert(kSelectBuckets >= (1 << 11), "the first pass counts 11 bits");
+    hipLaunchKernelGGL(log_scale_count_kernel, grid, dim3(256), 0, stream, counts_dev, centered_out_dev, nn, pseudocount, apply_log, bad, hist);
+    (void)count;
     hipLaunchKernelGGL(row_select_span_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, state, span, complete, rows, 1);  // (span := empty)
     for (int p = 0; p < 6; ++p) {
-        if (p >= 2) {
+        if (p == 0) {
+            // (counted by log_scale_count_kernel)
+        } else if (p >= 2) {
             hipLaunchKernelGGL(row_select_count_kernel<true>, grid, dim3(256), 0, stream, (const double *)centered_out_dev, nn, lows[p], widths[p],
                                (const RowSelect *)state, hist, span, (const unsigned *)complete);
         } else {
