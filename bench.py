@@ -674,10 +674,11 @@ def main():
         # per pipeline the baselines of its chromosomes in one pair of launches, their rolling variances in one launch, the
         # rest in launches over whole matrices): the benchmark's matrices are turned into counts in place, so this leg comes
         # last; the first call also allocates its scratch (tens of GB) and the second still warms the allocator's pools: the
-        # third is the one reported, all three are listed
+        # last of five is the one reported, all are listed (round 5: with the blocks of the pipelines in PyTorch's pool the
+        # allocator takes a call or two more to settle)
         if len(works) > 1:
             t_calls = []
-            for _call in range(3):
+            for _call in range(5):
                 mats = []
                 for idx, w in enumerate(works):
                     synth.hash_matrix_device(K, w.n, synth.chrom_seed(args.seed, mine[idx]), out=w.matrix_t)

@@ -601,6 +601,31 @@ __device__ __forceinline__ unsigned long long order_key(double v)
     return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
 }
 
+// One count per active lane into an LDS histogram.  The keys of a row of counts, or the variances of one bin, crowd into a few
+// buckets: 64 lanes adding to ONE counter are serialised lane by lane.  So the two most common buckets of the wavefront are
+// counted by one lane each (a ballot of the lanes that share the leader's bucket), whoever is left adds for itself.
+__device__ __forceinline__ void lds_count(unsigned *__restrict__ local, unsigned bucket, bool active)
+{
+    unsigned long long todo = __ballot(active);
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (todo == 0ULL) {
+            break;
+        }
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned b0 = (unsigned)__shfl((int)bucket, leader);
+        const unsigned long long same = __ballot(active && bucket == b0) & todo;
+        if (lane == leader) {
+            atomicAdd(&local[b0], (unsigned)__popcll(same));
+        }
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ULL) {
+        atomicAdd(&local[bucket], 1u);
+    }
+}
+
 // pass `p` looks at the `width` bits above bit `low`; hist[row][digit] += keys of the row matching its prefix.
 // SPAN (round 5, the passes behind the gathered-cell shortcut): also the smallest and the largest key that matches the
 // prefix -- a row of counts has its median inside a RUN of equal values, which no cell of kCellMax values holds; when the
@@ -627,17 +652,23 @@ __global__ __launch_bounds__(256) void row_select_count_kernel(const double *__r
     const unsigned long long mask = (1ULL << width) - 1ULL;
     const double *__restrict__ x = matrix + row * n;
     const long long base = (long long)blockIdx.x * kSelectChunk;
-#pragma unroll 4
-    for (int j = 0; j < kSelectChunk / 256; ++j) {
-        const long long i = base + threadIdx.x + 256LL * j;
-        if (i < n) {
-            const unsigned long long k = order_key(x[i]);
-            if (above_bits >= 64 || (k >> above_bits) == prefix) {
-                atomicAdd(&local[(unsigned)((k >> low) & mask)], 1u);
-                if (SPAN) {
-                    lo_key = (k < lo_key) ? k : lo_key;
-                    hi_key = (k > hi_key) ? k : hi_key;
-                }
+    // (eight loads in flight per thread, at clamped positions: a load under `if (i < n)` is waited for before the next is issued)
+    for (int j0 = 0; j0 < kSelectChunk / 256; j0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long i = base + threadIdx.x + 256LL * (j0 + u);
+            v[u] = x[(i < n) ? i : (n - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long i = base + threadIdx.x + 256LL * (j0 + u);
+            const unsigned long long k = order_key(v[u]);
+            const bool counts = i < n && (above_bits >= 64 || (k >> above_bits) == prefix);
+            lds_count(local, (unsigned)((k >> low) & mask), counts);
+            if (SPAN && counts) {
+                lo_key = (k < lo_key) ? k : lo_key;
+                hi_key = (k > hi_key) ? k : hi_key;
             }
         }
     }
@@ -1408,14 +1439,19 @@ __global__ __launch_bounds__(256) void seg_select_count_kernel(const double *__r
     const int above_bits = low + width;
     const unsigned long long mask = (1ULL << width) - 1ULL;
     const double *__restrict__ y = ypart + off;
-#pragma unroll 4
-    for (int j = 0; j < kSelectChunk / 256; ++j) {
-        const long long i = base + threadIdx.x + 256LL * j;
-        if (i < w) {
-            const unsigned long long k = (unsigned long long)__double_as_longlong(y[i]);  // y > 0: bit order = numeric order
-            if (above_bits >= 64 || (k >> above_bits) == prefix) {
-                atomicAdd(&local[(unsigned)((k >> low) & mask)], 1u);
-            }
+    // (eight loads in flight per thread, at clamped positions: a load under `if (i < w)` is waited for before the next is issued)
+    for (int j0 = 0; j0 < kSelectChunk / 256; j0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long i = base + threadIdx.x + 256LL * (j0 + u);
+            v[u] = y[(i < w) ? i : (w - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long i = base + threadIdx.x + 256LL * (j0 + u);
+            const unsigned long long k = (unsigned long long)__double_as_longlong(v[u]);  // y > 0: bit order = numeric order
+            lds_count(local, (unsigned)((k >> low) & mask), i < w && (above_bits >= 64 || (k >> above_bits) == prefix));
         }
     }
     __syncthreads();
@@ -1951,17 +1987,20 @@ __global__ __launch_bounds__(256) void log_scale_count_kernel(const double *__re
 #pragma unroll 4
     for (int j = 0; j < kSelectChunk / 256; ++j) {
         const long long i = base + threadIdx.x + 256LL * j;
+        double r = 0.0;
         if (i < n) {
             const double v = x[i];
             if (!isfinite(v)) {
                 atomicOr(bad, 1);
             }
-            double r = v;
+            r = v;
             if (apply_log) {
                 const double t = fmax(v, 0.0) + pseudocount;
                 r = (t > 0.0 && t < INFINITY) ? log2_correctly_rounded(t) : log2(t);
             }
             y[i] = r;
+        }
+        if (i < n) {  // (a plain add: this kernel is bound by its logarithm, and lds_count's ballots cost it 6 ms per genome)
             atomicAdd(&local[(unsigned)(order_key(r) >> kLow)], 1u);
         }
     }
