@@ -566,9 +566,9 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
     the pair lasts as long as the longest row, not as long as all rows one after the other) and the rolling variances
     of every row come from ONE launch (`wls_rolling_variances_batch_device`); the per-matrix steps (log scale + row
     medians; rank finding, dealing, selects and accumulation of the trend fit) are launches over whole matrices.
-    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values), round 5: 0.47-0.49 s with one pipeline (log scale
-    and row medians 0.08, baselines with both subtractions folded into their sweeps 0.09 -- rows cut into verified segments,
-    whittaker.hip --, rolling sums 0.11, trend fits 0.19), 0.42-0.44 s with two of equal parts, the second starting when the
+    Measured (MI355X, 24 chromosomes of 50 bp loci, K = 100, 6.2e9 values), round 5: 0.42-0.43 s with one pipeline (log scale
+    and row medians 0.06, baselines with both subtractions folded into their sweeps 0.09 -- rows cut into verified segments,
+    whittaker.hip --, rolling sums 0.11, trend fits 0.16), 0.40-0.42 s with two of equal parts, the second starting when the
     first has its baselines behind it (the default: its bandwidth-bound phases then run under the first one's rolling launch,
     the one phase left that lasts as long as its longest row) (round 4: 0.59, of which the baselines' longest rows were 0.29).
 
