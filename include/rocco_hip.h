@@ -49,7 +49,9 @@ int rocco_hip_solver_create(rocco_hip_solver **solver_out, int device);
 void rocco_hip_solver_destroy(rocco_hip_solver *solver);
 
 /* Tunables (speculation depth of the lambda search, force the exact kernel, ...).  Unknown keys
- * return ROCCO_HIP_EINVAL.  Keys: "force_exact" (0/1), "spec_depth" (1..6). */
+ * return ROCCO_HIP_EINVAL.  Keys: "force_exact" (0/1), "spec_depth" (1..6), "active_set" (0/1), "lean" (0/1),
+ * "rolling_group_min" (1, 2, 4, 8: least rows per workgroup of the batched rolling launch -- fewer, fuller workgroups for a
+ * caller that runs other work beside it; none changes a result). */
 int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long value);
 
 /* ---- scoring -------------------------------------------------------------------------------

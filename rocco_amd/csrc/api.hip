@@ -175,6 +175,11 @@ int rocco_hip_solver_set(rocco_hip_solver *solver, const char *key, long long va
         solver->active_set = value ? 1 : 0;
     } else if (k == "lean") {
         solver->lean = value ? 1 : 0;
+    } else if (k == "rolling_group_min") {
+        if (value != 1 && value != 2 && value != 4 && value != 8) {
+            return ROCCO_HIP_EINVAL;
+        }
+        solver->rolling_group_min = (int)value;
     } else {
         set_last_error("rocco_hip_solver_set: unknown key " + k);
         return ROCCO_HIP_EINVAL;
@@ -894,7 +899,9 @@ int rocco_hip_wls_rolling_variances_batch_f64(rocco_hip_solver *solver, size_t c
     if (rows == 0) {
         return ROCCO_HIP_OK;
     }
-    const size_t group = (size_t)wls_rolling_group_rows(rows);  // rows per workgroup (one task record each)
+    // rows per workgroup (one task record each); a solver may ask for at least so many (rocco_hip_solver_set "rolling_group_min")
+    wls_set_rolling_group_min(solver->rolling_group_min);
+    const size_t group = (size_t)wls_rolling_group_rows(rows);
     int rc;
     if ((rc = solver->dev_tasks.reserve(rows * sizeof(WlsRollingTask))) != ROCCO_HIP_OK) return rc;
     if ((rc = solver->host_stage.reserve(rows * sizeof(WlsRollingTask))) != ROCCO_HIP_OK) return rc;
@@ -1031,6 +1038,7 @@ int rocco_hip_score_centered_wls_given_variances_f64(rocco_hip_solver *solver, c
         set_last_error("rocco_hip_score_centered_wls_given_variances_f64: windows above 63 loci compute their own variances");
         return ROCCO_HIP_EINVAL;
     }
+    wls_set_rolling_group_min(solver->rolling_group_min);
     return launch_score_centered_wls(centered_dev, K, n, lower_bound_z, prior_df, min_effect, use_min_effect,
                                      spatial_window, precision_floor_ratio, mean_dev, raw_var_dev, prior_var_dev,
                                      mod_var_dev, se_dev, scores_dev, solver->dev_misc.ptr, df_out, window_out,

@@ -64,6 +64,8 @@ struct rocco_hip_solver {
     int spec_depth = 2;
     int active_set = 1;  // skip blocks that a survey proved settled for the whole bracket
     int lean = 1;        // threshold search on compacted levels + layer-3 rounds on the compacted problem (lean.hip)
+    int rolling_group_min = 1;  // least rows per workgroup of the batched rolling launch (1, 2, 4, 8): a caller that runs other
+                                // work beside the launch wants fewer, fuller workgroups (a workgroup holds a CU's registers)
     // scratch
     rocco::DeviceBuffer dev_tasks;    // kernel task descriptors
     rocco::DeviceBuffer dev_params;   // per-launch lambda lists etc.

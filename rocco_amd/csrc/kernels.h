@@ -209,6 +209,7 @@ struct WlsRollingTask {
 };
 constexpr int kWlsRollingGroup = 8;
 int wls_rolling_group_rows(size_t total_rows);
+void wls_set_rolling_group_min(int rows_per_workgroup);  // (calling thread: at least so many rows per workgroup from now on; 1, 2, 4, 8)
 int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, int group_rows, hipStream_t stream);
 int wls_max_window();
 size_t wls_scratch_bytes(size_t K, size_t n, int spatial_window = 0, bool own_variances = true);

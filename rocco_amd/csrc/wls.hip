@@ -2344,6 +2344,12 @@ int launch_rolling_rows(const WlsRollingTask *tasks_dev, size_t n_tasks, hipStre
 
 // rows per workgroup for a launch over `total_rows` rows: the smallest group whose workgroups are all resident at once
 // (one workgroup per CU for groups of 1 or 2 rows, two for 4 or 8)
+namespace {
+thread_local int tl_rolling_group_min = 1;  // (the calling solver's "rolling_group_min", set for the duration of its entry points)
+}
+
+void wls_set_rolling_group_min(int rows_per_workgroup) { tl_rolling_group_min = rows_per_workgroup; }
+
 int wls_rolling_group_rows(size_t total_rows)
 {
     if (const char *e = std::getenv("ROCCO_HIP_ROLLING_GROUP")) {  // (tests: every shape of the kernel on small inputs)
@@ -2353,10 +2359,8 @@ int wls_rolling_group_rows(size_t total_rows)
         }
     }
     // (half the device: a second pipeline of the count-path batch may be running its rolling launch at the same time)
-    if (total_rows <= 128) return 1;
-    if (total_rows <= 256) return 2;
-    if (total_rows <= 1024) return 4;
-    return kWlsRollingGroup;
+    const int by_rows = (total_rows <= 128) ? 1 : (total_rows <= 256) ? 2 : (total_rows <= 1024) ? 4 : kWlsRollingGroup;
+    return (by_rows > tl_rolling_group_min) ? by_rows : tl_rolling_group_min;
 }
 
 int launch_wls_rolling_batch(const WlsRollingTask *tasks_dev, size_t n_tasks, int group_rows, hipStream_t stream)

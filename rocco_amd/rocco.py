@@ -713,6 +713,10 @@ def _estimates_side_by_side(ready: list, plan, estimate, streams: int) -> list:
         with torch.cuda.device(device), torch.cuda.stream(stream), _native.use_solver(solver):
             stream.wait_event(start)
             _budget.set_null_workspace(carvers[slot])
+            # (the draws' rolling launches run beside the other streams' bandwidth-bound kernels: four rows per workgroup at
+            # least -- a quarter of the workgroups, each of which holds a CU's registers while its rows' chains run: estimates
+            # of a K = 100 genome 5.0 -> 4.5 s)
+            solver.set("rolling_group_min", 4)
             while True:
                 with lock:
                     i = next(order, None)
@@ -735,6 +739,7 @@ def _estimates_side_by_side(ready: list, plan, estimate, streams: int) -> list:
                 logger.info("Budget null %s: %s draws", name, out[i][1].get("num_null_draws"))
             stream.synchronize()
             _budget.set_null_workspace(None)
+            solver.set("rolling_group_min", 1)
 
     # Count matrices: how many draws an estimate computes together is a question of memory (a draw holds three K x n
     # blocks), asked ONCE here for all the estimates that are about to run side by side: estimates that each ask what is
