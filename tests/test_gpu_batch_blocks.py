@@ -111,3 +111,37 @@ def test_out_of_memory_from_the_library_is_retried_once_after_the_cache_is_hande
     lib = _native._Library(fake)
     assert lib.status() == _native.OK and len(fake.answers) == 2  # failed, cache handed back, called again
     assert lib.status() == _native.ENOMEM and fake.answers == []  # once more only
+
+
+def test_log_scaled_input_through_the_folded_sweeps_and_rows_per_workgroup_of_the_rolling_launch(gpu, oracle):
+    """`input_scale="log2p1"` (the matrix is log-scaled already: only the medians and the baselines are subtracted) through the
+    batch, against the single-matrix call and the oracle; and a solver that asks for at least 4 / 8 rows per workgroup of its rolling
+    launches (`rolling_group_min`) gets the same variances and the same scores as one that does not."""
+    import torch
+    from rocco_amd import _native, inference
+
+    rng = np.random.default_rng(11)
+    counts = [_counts(rng, K, n) for K, n in [(7, 20000), (20, 4097), (3, 64)]]  # 2^k - 1: their log2(count + 1) is exact
+    hosts = [np.log2(c + 1.0) for c in counts]
+    mats = [torch.from_numpy(h).to(gpu) for h in hosts]
+    batch = inference.score_loci_wls_batch_device(mats, input_scale="log2p1", workers=2)
+    for c, m, (scores, details) in zip(counts, mats, batch):
+        one_scores, one_details = inference.score_loci_wls_device(m, input_scale="log2p1")
+        assert torch.equal(scores, one_scores) and torch.equal(details["centered_matrix"], one_details["centered_matrix"])
+        o_scores, o_details = oracle.score_loci_wls(c)  # (from the counts: the same numbers once their logarithms are exact)
+        assert scores.cpu().numpy().tobytes() == o_scores.tobytes()
+        assert details["centered_matrix"].cpu().numpy().tobytes() == np.asarray(o_details["centered_matrix"]).tobytes()
+    centred = batch[0][1]["centered_matrix"]
+    solver = _native.solver_for(gpu.index)
+    plain = inference.wls_rolling_variances_batch_device([centred, batch[1][1]["centered_matrix"]], spatial_window=31)
+    plain_scores = inference.score_centered_wls_device(centred)[0]
+    try:
+        for least in (4, 8):
+            solver.set("rolling_group_min", least)
+            grouped = inference.wls_rolling_variances_batch_device([centred, batch[1][1]["centered_matrix"]], spatial_window=31)
+            assert all(torch.equal(a, b) for a, b in zip(plain, grouped))
+            assert torch.equal(inference.score_centered_wls_device(centred)[0], plain_scores)
+        with pytest.raises(ValueError):
+            solver.set("rolling_group_min", 3)
+    finally:
+        solver.set("rolling_group_min", 1)
