@@ -1210,12 +1210,21 @@ __global__ __launch_bounds__(256) void rank_gather_kernel(const double *__restri
     const int low = kRankShift0 - width;
     const unsigned mask = (1u << width) - 1u;
     unsigned char mine[kGatherChunk / 256];
+    // (eight loads in flight per thread, at clamped positions: a load under `if (i < n)` is waited for by itself)
+    double held[8];
 #pragma unroll
     for (int j = 0; j < kGatherChunk / 256; ++j) {
+        if ((j & 7) == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long iu = first + t + 256LL * (j + u);
+                held[u] = x[(iu < n) ? iu : (n - 1)];
+            }
+        }
         const long long i = first + t + 256LL * j;
         unsigned c = 255u;
         if (i < n) {
-            const unsigned long long k = (unsigned long long)__double_as_longlong(fabs(x[i]));
+            const unsigned long long k = (unsigned long long)__double_as_longlong(fabs(held[j & 7]));
             const unsigned s = map0[(unsigned)(k >> kRankShift0) & (kRankBuckets0 - 1)];
             if (s != 255u) {
                 c = map1[(s << width) | ((unsigned)(k >> low) & mask)];
@@ -1238,10 +1247,9 @@ __global__ __launch_bounds__(256) void rank_gather_kernel(const double *__restri
     for (int j = 0; j < kGatherChunk / 256; ++j) {
         const unsigned c = mine[j];
         if (c != 255u) {
-            const long long i = first + t + 256LL * j;
             const unsigned at = base_of[c] + atomicAdd(&cnt[c], 1u);
             if (at < r.count1[c]) {  // (never false: the count is the histogram's)
-                out[(long long)r.offset1[c] + at] = (unsigned long long)__double_as_longlong(fabs(x[i]));
+                out[(long long)r.offset1[c] + at] = (unsigned long long)__double_as_longlong(fabs(x[first + t + 256LL * j]));
             }
         }
     }
@@ -1342,12 +1350,20 @@ __global__ __launch_bounds__(256) void wls_deal_kernel(const double *__restrict_
     const double *__restrict__ vas_row = vas + r * (max_start + 1);
     const long long first = (long long)blockIdx.x * kDealChunk;
     unsigned char mine[kDealChunk / 256];
+    double held[8];  // (eight loads in flight per thread, at clamped positions: a load under `if (i < n)` is waited for by itself)
 #pragma unroll
     for (int j = 0; j < kDealChunk / 256; ++j) {
+        if ((j & 7) == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long iu = first + t + 256LL * (j + u);
+                held[u] = row[(iu < n) ? iu : (n - 1)];
+            }
+        }
         const long long i = first + t + 256LL * j;
         int b = 0;
         if (i < n) {
-            const double x = fabs(row[i]);
+            const double x = fabs(held[j & 7]);
             // the bin: how many boundaries lie at or below x (sb ascending, +inf beyond the last bin)
 #pragma unroll
             for (int step = 32; step >= 1; step >>= 1) {
@@ -1367,10 +1383,17 @@ __global__ __launch_bounds__(256) void wls_deal_kernel(const double *__restrict_
     double *__restrict__ out = ypart + r * n;
 #pragma unroll
     for (int j = 0; j < kDealChunk / 256; ++j) {
+        if ((j & 7) == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long iu = first + t + 256LL * (j + u);
+                held[u] = obs_variance_at(vas_row, (iu < n) ? iu : (n - 1), half, max_start);
+            }
+        }
         const long long i = first + t + 256LL * j;
         if (i < n) {
             const int b = mine[j];
-            const double y = fmax(obs_variance_at(vas_row, i, half, max_start), 1.0e-8);  // wls_backend.c:429-430
+            const double y = fmax(held[j & 7], 1.0e-8);  // wls_backend.c:429-430
             if (!isfinite(y)) {
                 atomicOr(bad, 1);
             }
@@ -1530,11 +1553,18 @@ __global__ __launch_bounds__(256) void seg_gather_kernel(const double *__restric
     const unsigned long long prefix = state[seg].prefix;
     const double *__restrict__ y = ypart + off;
     unsigned long long above = ~0ULL;
-#pragma unroll 4
-    for (int j = 0; j < kSelectChunk / 256; ++j) {
-        const long long i = base + threadIdx.x + 256LL * j;
+    for (int j0 = 0; j0 < kSelectChunk / 256; j0 += 8) {
+      double v[8];  // (eight loads in flight per thread, at clamped positions)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long iu = base + threadIdx.x + 256LL * (j0 + u);
+        v[u] = y[(iu < w) ? iu : (w - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long i = base + threadIdx.x + 256LL * (j0 + u);
         if (i < w) {
-            const unsigned long long k = (unsigned long long)__double_as_longlong(y[i]);
+            const unsigned long long k = (unsigned long long)__double_as_longlong(v[u]);
             const unsigned long long cell = k >> (64 - kCellBits);
             if (cell == prefix) {
                 const unsigned at = atomicAdd(&filled[seg], 1u);
@@ -1545,6 +1575,7 @@ __global__ __launch_bounds__(256) void seg_gather_kernel(const double *__restric
                 above = k;
             }
         }
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
