@@ -347,9 +347,16 @@ def _composed_driver_leg(args, genome, device, works, mine, po):
             order = [w.name for w in works]
             small = min(works, key=lambda w: w.n).name
             torch.cuda.reset_peak_memory_stats()
+            first_run, _bed = run(counts, order, "bam", "device", tmp)
+            bed_first = open(_bed).read()
+            # (the first run of a process allocates the scoring's blocks -- ~200 GB, seconds of the runtime's time, box to box;
+            # as in the count-path leg the run after it is the one reported, both are listed)
             genome_counts, _bed = run(counts, order, "bam", "device", tmp)
+            genome_counts["first_run_seconds"] = first_run["seconds"]
+            genome_counts["first_run_split_s"] = first_run["split_s"]
             genome_counts["peak_torch_memory_GB"] = round(torch.cuda.max_memory_allocated() / 1e9, 1)
             bed_kept_inputs = open(_bed).read()  # (the one-chromosome runs below write to the same name)
+            genome_counts["bed_equal_to_the_first_run"] = bed_kept_inputs == bed_first
             one_dev, bed_dev = run({small: counts[small]}, [small], "bam", "device", tmp)
             one_host, bed_host = run({small: counts[small]}, [small], "bam", "host", tmp)
             one_dev["bed_equal_to_host_multipliers_run"] = open(bed_dev).read() == open(bed_host).read()
