@@ -1334,7 +1334,10 @@ __global__ __launch_bounds__(256) void wls_deal_kernel(const double *__restrict_
                                                       unsigned *__restrict__ cursor, double *__restrict__ ypart, int *__restrict__ bad)
 {
     __shared__ double sb[kMaxBins];
-    __shared__ unsigned cnt[kMaxBins], base[kMaxBins];
+    __shared__ unsigned cnt[kMaxBins], base[kMaxBins], before[kMaxBins], total;
+    __shared__ long long left_of[kMaxBins], right_of[kMaxBins];
+    __shared__ double stage[kDealChunk];
+    __shared__ unsigned char stage_bin[kDealChunk];
     const long long r = blockIdx.y;
     const TrendRow &tr = rows[r];
     if (tr.tie != 0) {
@@ -1374,13 +1377,26 @@ __global__ __launch_bounds__(256) void wls_deal_kernel(const double *__restrict_
         mine[j] = (unsigned char)b;
     }
     __syncthreads();
-    if (t < bins) {
-        const unsigned c = cnt[t];
+    // Round 5: the block's values go to memory SORTED BY BIN (through LDS), a bin's values side by side -- a wavefront's store is then a
+    // few runs of consecutive addresses instead of 64 lone 8-byte writes (each lane's value used to go wherever its bin's cursor stood)
+    if (t < kMaxBins) {  // (one wavefront: the bins' counts -> their places in the block's sorted order, and in the row's segments)
+        const unsigned c = (t < bins) ? cnt[t] : 0u;
         base[t] = (c != 0u) ? atomicAdd(&cursor[r * kMaxBins + t], c) : 0u;
+        unsigned run = c;
+#pragma unroll
+        for (int off = 1; off < kMaxBins; off <<= 1) {
+            const unsigned up = __shfl_up(run, off);
+            run += (t >= off) ? up : 0u;
+        }
+        before[t] = run - c;
+        left_of[t] = ((long long)t * n) / bins;
+        right_of[t] = ((long long)(t + 1) * n) / bins;
         cnt[t] = 0u;
+        if (t == kMaxBins - 1) {
+            total = run;
+        }
     }
     __syncthreads();
-    double *__restrict__ out = ypart + r * n;
 #pragma unroll
     for (int j = 0; j < kDealChunk / 256; ++j) {
         if ((j & 7) == 0) {
@@ -1397,11 +1413,18 @@ __global__ __launch_bounds__(256) void wls_deal_kernel(const double *__restrict_
             if (!isfinite(y)) {
                 atomicOr(bad, 1);
             }
-            const long long left = ((long long)b * n) / bins, right = ((long long)(b + 1) * n) / bins;
-            const long long pos = left + (long long)base[b] + (long long)atomicAdd(&cnt[b], 1u);
-            if (pos < right) {  // (never false when the boundaries are what they should be: checked by the cursor afterwards)
-                out[pos] = y;
-            }
+            const unsigned slot = before[b] + atomicAdd(&cnt[b], 1u);
+            stage[slot] = y;
+            stage_bin[slot] = (unsigned char)b;
+        }
+    }
+    __syncthreads();
+    double *__restrict__ out = ypart + r * n;
+    for (unsigned e = (unsigned)t; e < total; e += 256u) {
+        const int b = stage_bin[e];
+        const long long pos = left_of[b] + (long long)base[b] + (long long)(e - before[b]);
+        if (pos < right_of[b]) {  // (never false when the boundaries are what they should be: checked by the cursor afterwards)
+            out[pos] = stage[e];
         }
     }
 }
