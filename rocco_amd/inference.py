@@ -822,7 +822,7 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
             torch.cuda.empty_cache()
             blocks = make_arenas()
         if not lent:
-            _batch_blocks[device.index] = list(blocks)
+            _batch_blocks.pop(device.index, None)  # (this call owns them now; they are registered again when it has come through)
         arenas, scratches = blocks[:len(chunks_of)], (blocks[len(chunks_of):] if fused else [None] * len(chunks_of))
         del blocks, kept
         for slot, parts in enumerate(chunks_of):
@@ -863,11 +863,11 @@ def score_loci_wls_batch_device(counts_list, lower_bound_z: float = 1.0, prior_d
             except BaseException as exc:  # noqa: BLE001
                 first_error = first_error or exc
         last_batch_growths_in_flight = int(_native.load().rocco_hip_buffer_growths()) - grown_before
+        if keep_blocks and not lent and first_error is None:
+            # (`keep_blocks`: the pipelines' big blocks stay for `borrow_batch_blocks` and the next call; otherwise -- and after
+            # any error -- they go back to the allocator's cache here, whole, where the next call finds them again)
+            _batch_blocks[device.index] = list(arenas) + [t for t in scratches if t is not None]
         del arenas, scratches
-        if not keep_blocks and not lent:
-            # (`keep_blocks`: the pipelines' big blocks stay for `borrow_batch_blocks` and the next call; otherwise they go
-            # back to the allocator's cache here, whole, where the next call finds them again)
-            _batch_blocks.pop(device.index, None)
         if first_error is not None:
             raise first_error
         return result
