@@ -717,29 +717,31 @@ def _estimates_side_by_side(ready: list, plan, estimate, streams: int) -> list:
             # least -- a quarter of the workgroups, each of which holds a CU's registers while its rows' chains run: estimates
             # of a K = 100 genome 5.0 -> 4.5 s)
             solver.set("rolling_group_min", 4)
-            while True:
-                with lock:
-                    i = next(order, None)
-                if i is None:
-                    break
-                name, starts, scores, details, centred = ready[i]
-                for t in (centred, _dp._resident_tensor(scores)):
-                    if t is not None:
-                        t.record_stream(stream)
-                try:
-                    out[i] = estimate(scores, details, centred)
-                except (torch.OutOfMemoryError, MemoryError):
-                    # (a fragmented cache: whole free segments go back to the runtime, the estimate -- a function of its
-                    # arguments, its generators seeded per draw -- runs once more)
-                    stream.synchronize()
-                    torch.cuda.empty_cache()
-                    out[i] = estimate(scores, details, centred)
-                del centred
-                ready[i] = (name, starts, scores, details, None)
-                logger.info("Budget null %s: %s draws", name, out[i][1].get("num_null_draws"))
-            stream.synchronize()
-            _budget.set_null_workspace(None)
-            solver.set("rolling_group_min", 1)
+            try:
+                while True:
+                    with lock:
+                        i = next(order, None)
+                    if i is None:
+                        break
+                    name, starts, scores, details, centred = ready[i]
+                    for t in (centred, _dp._resident_tensor(scores)):
+                        if t is not None:
+                            t.record_stream(stream)
+                    try:
+                        out[i] = estimate(scores, details, centred)
+                    except (torch.OutOfMemoryError, MemoryError):
+                        # (a fragmented cache: whole free segments go back to the runtime, the estimate -- a function of its
+                        # arguments, its generators seeded per draw -- runs once more)
+                        stream.synchronize()
+                        torch.cuda.empty_cache()
+                        out[i] = estimate(scores, details, centred)
+                    del centred
+                    ready[i] = (name, starts, scores, details, None)
+                    logger.info("Budget null %s: %s draws", name, out[i][1].get("num_null_draws"))
+                stream.synchronize()
+            finally:
+                _budget.set_null_workspace(None)
+                solver.set("rolling_group_min", 1)
 
     # Count matrices: how many draws an estimate computes together is a question of memory (a draw holds three K x n
     # blocks), asked ONCE here for all the estimates that are about to run side by side: estimates that each ask what is
