@@ -494,7 +494,7 @@ int rocco_hip_pcg64_standard_normal_f64(rocco_hip_solver *solver, unsigned long 
     if (count == 0) {
         return ROCCO_HIP_OK;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     hipStream_t stream = (hipStream_t)stream_;
     // a value takes 1.022 raw draws on average; 3 % + a chunk's worth of slack, and the fill checks that it sufficed
     const long long raws = (long long)((double)count * 1.03) + 16 * kZigChunk;
@@ -622,7 +622,7 @@ int rocco_hip_bartlett_multipliers_f64(rocco_hip_solver *solver, const double *i
         rows == 0 || n == 0 || n_taps == 0 || n_taps > (size_t)0x7FFFFFFF || rows > 65535) {
         return ROCCO_HIP_EINVAL;
     }
-    ROCCO_HIP_TRY(hipSetDevice(solver->device));
+    ROCCO_HIP_TRY(hipSetDevice(solver->device)); (void)hipGetLastError();  // (no other library's stale error for this call's launch checks)
     hipStream_t stream = (hipStream_t)stream_;
     const int segments = (int)((n + kMomentSegment - 1) / kMomentSegment);
     size_t off = 0;
