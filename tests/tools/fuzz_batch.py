@@ -7,6 +7,7 @@ import pyoracle as po
 from rocco_amd import pipeline
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t_end = time.time() + seconds
+t_said = time.time()
 it = bad = chroms = 0
 while time.time() < t_end:
     rng = np.random.default_rng(990000 + it)
@@ -36,4 +37,6 @@ while time.time() < t_end:
         if not ok:
             bad += 1; print(f"MISMATCH it={it} chrom={r['name']} n={n} budget={budget} gamma={gamma}", flush=True)
     it += 1
+    if time.time() - t_said > 60.0:  # (a GPU box takes a command that says nothing for minutes to be hung)
+        t_said = time.time(); print(f"... {it} iterations so far", flush=True)
 print(f"{it} batches, {chroms} chromosomes, {bad} mismatches")

@@ -7,6 +7,7 @@ import pyoracle as po
 from rocco_amd import inference
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t_end = time.time() + seconds
+t_said = time.time()
 it = bad = 0
 counts = {}
 while time.time() < t_end:
@@ -70,5 +71,7 @@ while time.time() < t_end:
     if not ok:
         bad += 1; print(f"MISMATCH it={it} K={K} n={n} {which}", flush=True)
     it += 1
+    if time.time() - t_said > 60.0:  # (a GPU box takes a command that says nothing for minutes to be hung)
+        t_said = time.time(); print(f"... {it} cases, {bad} mismatches so far", flush=True)
 from rocco_amd import _native
 print(f"{it} cases, {bad} mismatches; {sorted(counts.items())}; seams repaired along the way: {int(_native.load().rocco_hip_whittaker_seam_repairs())}")

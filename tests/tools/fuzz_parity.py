@@ -8,6 +8,7 @@ from rocco_amd import dp
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + seconds
+t_said = time.time()
 it = bad = 0
 kinds = {}
 while time.time() < t_end:
@@ -52,4 +53,6 @@ while time.time() < t_end:
         bad += 1
         print(f"MISMATCH it={it} n={n} kind={kind} gamma={gamma} vec={use_vec} mode={mode}", flush=True)
     it += 1
+    if time.time() - t_said > 60.0:  # (a GPU box takes a command that says nothing for minutes to be hung)
+        t_said = time.time(); print(f"... {it} iterations so far", flush=True)
 print(f"{it} cases, {bad} mismatches; by (mode, kind): {sorted(kinds.items())}")
