@@ -714,6 +714,10 @@ def main():
                 "gpu_values_per_s": round(K * total_loci / t_batch, 1),
                 "hbm_floor": {"bytes": int(passes_bytes), "achieved_GBps": round(passes_bytes / t_batch / 1e9, 1),
                               "frac_of_peak": round(passes_bytes / t_batch / 1e9 / HBM_PEAK_GBS, 4),
+                              "traffic_bytes_per_value": 223.8,
+                              "traffic_source": "profiles/r05_pmc_count_path.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over "
+                                                "the same call with one pipeline: 1.38 TB per call; above the passes' count by the sweeps' "
+                                                "warm-up re-reads, +12 B, and the row medians' later passes, +13 B)",
                               "note": "192 B per value over the passes the path makes today (round 4: 248); ~16 B per value is "
                                       "compulsory (matrix in, centred matrix out). The baseline sweeps run in verified segments "
                                       "since round 5 and are bandwidth-bound; the rolling sums remain one sequential chain per row "
